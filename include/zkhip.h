@@ -1,0 +1,90 @@
+/* libzkhip -- MI355X (gfx950) kernels behind the halo2 prover's MSM / NTT boundary.  C ABI.
+ *
+ * Each entry point replaces one function of the un-vendored halo2-axiom crate [DEP] that the reference
+ * reaches through `create_proof` (/root/reference/aggregator/src/wrapper.rs:129), `keygen_vk`/`keygen_pk`
+ * (wrapper.rs:107-108) and `halo2_base::utils::testing::gen_proof`
+ * (/root/reference/aggregator/benches/wrapper_circuit.rs:140).  SURVEY.md section 8(b) is the contract.
+ *
+ * Memory formats are exactly the Rust in-memory formats, so a Rust host passes slices through unchanged:
+ *   Fr / Fq   : 4 x u64 little-endian limbs, Montgomery form (x * 2^256 mod p)            32 bytes
+ *   G1Affine  : x || y  (identity = all-zero)                                             64 bytes
+ *   G1        : x || y || z Jacobian (identity z = 0)                                     96 bytes
+ * All buffers are caller-owned and borrowed for the duration of the call (registered bases: until
+ * unregistered).  Every function returns ZKHIP_OK (0) or a negative ZKHIP_E* code and never aborts;
+ * zkhip_last_error() describes the last failure on the calling thread.  There is no CPU fallback: without a
+ * usable HIP device every compute entry point fails with ZKHIP_ENODEV.
+ */
+#ifndef ZKHIP_H
+#define ZKHIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZKHIP_OK 0
+#define ZKHIP_EINVAL (-1)  /* bad argument */
+#define ZKHIP_ENODEV (-2)  /* no HIP device / init failed */
+#define ZKHIP_EHIP (-3)    /* HIP runtime error, see zkhip_last_error() */
+#define ZKHIP_ENOMEM (-4)  /* device allocation failed */
+
+/* ---- lifecycle ----------------------------------------------------------------------------------- */
+/* Select the HIP device this process drives (one process per GPU).  devices == NULL: device 0 (or
+ * $ZKHIP_DEVICE).  Lazy init on first use is allowed.  ndev > 1 is rejected: multi-GPU = multi-process. */
+int zkhip_init(const int *devices, int ndev);
+void zkhip_shutdown(void);
+const char *zkhip_last_error(void);
+/* library / device identification, for logs: writes a NUL-terminated string */
+int zkhip_device_name(char *buf, size_t len);
+
+/* ---- MSM: replaces `best_multiexp(coeffs: &[Fr], bases: &[G1Affine]) -> G1` ------------------------- */
+/* [DEP] halo2_proofs/src/arithmetic.rs; called by ParamsKZG::commit / commit_lagrange.  n may be any value
+ * (n == 0 gives the identity).  out_xyz: Jacobian, canonical Montgomery limbs, any valid representative. */
+int zkhip_msm_g1(const uint64_t *scalars, const uint64_t *bases, size_t n, uint64_t out_xyz[12]);
+
+/* Residency for `ParamsKZG::{g, g_lagrange}` (static per params object): upload once; zkhip_msm_g1
+ * recognises `bases` pointers inside a registered range and skips the upload. */
+int zkhip_register_bases(const uint64_t *bases, size_t n);
+int zkhip_unregister_bases(const uint64_t *bases);
+
+/* ---- NTT: replaces `best_fft(a: &mut [Fr], omega: Fr, log_n: u32)` --------------------------------- */
+/* In place, natural order in and out: a[i] <- sum_j a[j] * omega^(i j).  log_n <= 28. */
+int zkhip_ntt_fr(uint64_t *a, const uint64_t omega[4], uint32_t log_n);
+
+/* ---- EvaluationDomain pieces ([DEP] halo2_proofs/src/poly/domain.rs), host buffers ----------------- */
+/* `EvaluationDomain::ifft`: best_fft with omega_inv, then every element times `divisor`. */
+int zkhip_ifft_scaled(uint64_t *a, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4]);
+/* `coeff_to_extended`: a (2^k coeffs) -> out (2^ext_k evaluations on the coset zeta * <ext_omega>):
+ * distribute_powers_zeta(into_coset) (a[i] *= {1, zeta, zeta^2}[i % 3]), zero-pad, best_fft. */
+int zkhip_coeff_to_extended(const uint64_t *a, uint32_t k, uint64_t *out, uint32_t ext_k, const uint64_t ext_omega[4],
+                            const uint64_t zeta[4]);
+/* `extended_to_coeff`: ifft on the extended domain, distribute_powers_zeta(out of coset), truncate to
+ * out_len elements (= n * quotient_poly_degree).  `a` is consumed (overwritten). */
+int zkhip_extended_to_coeff(uint64_t *a, uint32_t ext_k, const uint64_t ext_omega_inv[4], const uint64_t ext_divisor[4],
+                            const uint64_t zeta[4], uint64_t *out, size_t out_len);
+/* `divide_by_vanishing_poly`: a[i] *= table[i % period] (table = inverted t_evaluations). */
+int zkhip_mul_periodic(uint64_t *a, size_t n, const uint64_t *table, uint32_t period);
+
+/* ---- device-resident variants (pointers are HIP device pointers; stream is a hipStream_t or NULL) --- */
+/* Used by the pipeline / bench so that polynomials and scalars stay in HBM between calls. */
+int zkhip_msm_g1_device(const void *d_scalars, const void *d_bases, size_t n, void *d_out_xyz, void *stream);
+/* window-size override for experiments (0 = automatic) */
+int zkhip_msm_g1_device_c(const void *d_scalars, const void *d_bases, size_t n, void *d_out_xyz, int window_bits, void *stream);
+int zkhip_ntt_fr_device(void *d_a, const uint64_t omega[4], uint32_t log_n, void *stream);
+int zkhip_ifft_scaled_device(void *d_a, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4], void *stream);
+int zkhip_mul_periodic_device(void *d_a, size_t n, const void *d_table, uint32_t period, void *stream);
+/* out = sum of m Jacobian points (multi-GPU: fold of the gathered per-rank partial sums) */
+int zkhip_g1_sum_device(const void *d_points_xyz, int m, void *d_out_xyz, void *stream);
+int zkhip_g1_sum(const uint64_t *points_xyz, int m, uint64_t out_xyz[12]);
+int zkhip_msm_window_bits(size_t n);
+
+/* ---- parity hooks for the field / curve layer (rows a1/a2 of SURVEY.md section 8) ------------------ */
+/* field: 0 = Fq, 1 = Fr.  op: 0 mul, 1 add, 2 sub, 3 square (b ignored).  Elementwise on n elements. */
+int zkhip_test_field_op(int field, int op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
+/* op: 0 = affine a[i] + affine b[i], 1 = 2 * a[i], 2 = a[i] + (-b[i]).  out: n Jacobian points. */
+int zkhip_test_g1_op(int op, const uint64_t *a, const uint64_t *b, uint64_t *out_xyz, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKHIP_H */

@@ -1,0 +1,425 @@
+"""BN254 big-integer oracle for the MSM / NTT hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this
+module; the product path (`zksnap_circuits_halo2_amd/`, `libzkhip.so`) never does.
+
+PARITY UNPINNED by the reference: `/root/reference` holds no golden vector, KAT or fixture at the
+`best_multiexp` / `best_fft` boundary and its arithmetic lives in un-vendored,
+un-pinned git dependencies (`halo2-axiom` / `halo2curves-axiom`, reached from
+`aggregator/src/wrapper.rs:129` `create_proof`, `aggregator/Cargo.toml:7-21`).  This model restates
+the *published* algorithms of those crates [DEP] and is pinned instead by (a) public constants and
+known answers (EIP-196 `2*G`, `r*G = O`, `(r-1)*G = -G`), (b) self-consistency identities
+(`MSM(a, s^i G) = [sum a_i s^i] G`, `iNTT(NTT(a)) = a`, NTT == O(n^2) DFT).
+
+Memory formats restated:
+  * `bn256::Fr` / `bn256::Fq`: four little-endian u64 limbs in Montgomery form (x*2^256 mod p).
+  * `G1Affine`: x||y (8 limbs), identity = (0, 0).   `G1`: Jacobian x||y||z (12 limbs), identity z = 0.
+"""
+from __future__ import annotations
+
+import math
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+# ----------------------------------------------------------------------------------------------
+# Field constants (every derived constant is re-derived in the tests)
+# ----------------------------------------------------------------------------------------------
+R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B97091_43E1F593F0000001  # Fr modulus r
+Q_MOD = 0x30644E72E131A029B85045B68181585D97816A916871CA8D_3C208C16D87CFD47  # Fq modulus q
+MONT_BITS = 256
+MONT_R = 1 << MONT_BITS
+MASK64 = (1 << 64) - 1
+
+FR_S = 28                      # 2-adicity of r - 1
+FR_GENERATOR = 7               # multiplicative generator used by halo2curves [DEP]
+FR_ROOT_OF_UNITY = pow(FR_GENERATOR, (R_MOD - 1) >> FR_S, R_MOD)   # primitive 2^28-th root
+# halo2curves `Fr::ZETA` [DEP]; any primitive cube root works, the library takes it as an argument.
+FR_ZETA = 0x30644E72E131A029048B6E193FD84104CC37A73FEC2BC5E9B8CA0B2D36636F23
+CURVE_B = 3
+G1_GEN = (1, 2)
+
+
+def mont_inv64(p: int) -> int:
+    """-p^{-1} mod 2^64 (the `INV` constant of a 4x64 Montgomery implementation)."""
+    return (-pow(p, -1, 1 << 64)) & MASK64
+
+
+def to_mont(x: int, p: int) -> int:
+    return (x % p) * MONT_R % p
+
+
+def from_mont(x: int, p: int) -> int:
+    return x * pow(MONT_R, -1, p) % p
+
+
+def limbs4(x: int) -> List[int]:
+    return [(x >> (64 * i)) & MASK64 for i in range(4)]
+
+
+def from_limbs(l: Sequence[int]) -> int:
+    v = 0
+    for i, w in enumerate(l):
+        v |= int(w) << (64 * i)
+    return v
+
+
+# ----------------------------------------------------------------------------------------------
+# G1: y^2 = x^3 + 3 over Fq.  Affine points are (x, y) tuples of canonical ints; None = identity.
+# ----------------------------------------------------------------------------------------------
+Affine = Optional[Tuple[int, int]]
+Jac = Tuple[int, int, int]
+JAC_ID: Jac = (0, 1, 0)
+
+
+def on_curve(P: Affine) -> bool:
+    if P is None:
+        return True
+    x, y = P
+    return (y * y - x * x * x - CURVE_B) % Q_MOD == 0
+
+
+def neg(P: Affine) -> Affine:
+    return None if P is None else (P[0], (-P[1]) % Q_MOD)
+
+
+def jac_double(P: Jac) -> Jac:
+    X, Y, Z = P
+    if Z == 0 or Y == 0:
+        return JAC_ID
+    A = X * X % Q_MOD
+    B = Y * Y % Q_MOD
+    C = B * B % Q_MOD
+    D = 2 * ((X + B) * (X + B) - A - C) % Q_MOD
+    E = 3 * A % Q_MOD
+    F = E * E % Q_MOD
+    X3 = (F - 2 * D) % Q_MOD
+    Y3 = (E * (D - X3) - 8 * C) % Q_MOD
+    Z3 = 2 * Y * Z % Q_MOD
+    return (X3, Y3, Z3)
+
+
+def jac_add(P: Jac, Q: Jac) -> Jac:
+    X1, Y1, Z1 = P
+    X2, Y2, Z2 = Q
+    if Z1 == 0:
+        return Q
+    if Z2 == 0:
+        return P
+    Z1Z1 = Z1 * Z1 % Q_MOD
+    Z2Z2 = Z2 * Z2 % Q_MOD
+    U1 = X1 * Z2Z2 % Q_MOD
+    U2 = X2 * Z1Z1 % Q_MOD
+    S1 = Y1 * Z2 * Z2Z2 % Q_MOD
+    S2 = Y2 * Z1 * Z1Z1 % Q_MOD
+    if U1 == U2:
+        return jac_double(P) if S1 == S2 else JAC_ID
+    H = (U2 - U1) % Q_MOD
+    Rr = (S2 - S1) % Q_MOD
+    HH = H * H % Q_MOD
+    HHH = H * HH % Q_MOD
+    V = U1 * HH % Q_MOD
+    X3 = (Rr * Rr - HHH - 2 * V) % Q_MOD
+    Y3 = (Rr * (V - X3) - S1 * HHH) % Q_MOD
+    Z3 = Z1 * Z2 * H % Q_MOD
+    return (X3, Y3, Z3)
+
+
+def to_jac(P: Affine) -> Jac:
+    return JAC_ID if P is None else (P[0], P[1], 1)
+
+
+def to_affine(P: Jac) -> Affine:
+    X, Y, Z = P
+    if Z == 0:
+        return None
+    zi = pow(Z, -1, Q_MOD)
+    zi2 = zi * zi % Q_MOD
+    return (X * zi2 % Q_MOD, Y * zi2 * zi % Q_MOD)
+
+
+def add(P: Affine, Q: Affine) -> Affine:
+    return to_affine(jac_add(to_jac(P), to_jac(Q)))
+
+
+def scalar_mul(k: int, P: Affine) -> Affine:
+    k %= R_MOD
+    acc = JAC_ID
+    base = to_jac(P)
+    while k:
+        if k & 1:
+            acc = jac_add(acc, base)
+        base = jac_double(base)
+        k >>= 1
+    return to_affine(acc)
+
+
+def batch_to_affine(points: Sequence[Jac]) -> List[Affine]:
+    """Montgomery-trick normalisation (one inversion for the whole list)."""
+    prefix, acc = [], 1
+    for (_, _, Z) in points:
+        prefix.append(acc)
+        if Z:
+            acc = acc * Z % Q_MOD
+    inv = pow(acc, -1, Q_MOD)
+    out: List[Affine] = [None] * len(points)
+    for i in range(len(points) - 1, -1, -1):
+        X, Y, Z = points[i]
+        if Z == 0:
+            continue
+        zi = inv * prefix[i] % Q_MOD
+        inv = inv * Z % Q_MOD
+        zi2 = zi * zi % Q_MOD
+        out[i] = (X * zi2 % Q_MOD, Y * zi2 * zi % Q_MOD)
+    return out
+
+
+def structured_srs(s: int, n: int) -> List[Affine]:
+    """g[i] = s^i * G (a KZG monomial SRS with a *known* trapdoor)."""
+    jac, cur = [], 1
+    # fixed-base comb: G * cur via double-and-add is O(n * 254); fine for the small n used in tests
+    for _ in range(n):
+        jac.append(to_jac(scalar_mul(cur, G1_GEN)))
+        cur = cur * s % R_MOD
+    return batch_to_affine(jac)
+
+
+# ----------------------------------------------------------------------------------------------
+# MSM.  `msm_naive` is the mathematical definition; `multiexp_serial` / `best_multiexp` restate
+# the published halo2-axiom algorithm [DEP] `halo2_proofs/src/arithmetic.rs` (not under
+# /root/reference; entered from aggregator/src/wrapper.rs:129 and
+# aggregator/benches/wrapper_circuit.rs:140).
+# ----------------------------------------------------------------------------------------------
+def msm_naive(scalars: Sequence[int], bases: Sequence[Affine]) -> Affine:
+    assert len(scalars) == len(bases)
+    acc = JAC_ID
+    for k, P in zip(scalars, bases):
+        acc = jac_add(acc, to_jac(scalar_mul(k, P)))
+    return to_affine(acc)
+
+
+def window_bits(n: int) -> int:
+    """`c` of multiexp_serial: 1 (n<4) / 3 (n<32) / ceil(ln n)."""
+    if n < 4:
+        return 1
+    if n < 32:
+        return 3
+    return math.ceil(math.log(n))
+
+
+def _get_at(segment: int, c: int, k: int) -> int:
+    skip_bits = segment * c
+    if skip_bits // 8 >= 32:
+        return 0
+    return (k >> skip_bits) & ((1 << c) - 1) if skip_bits < 256 else 0
+
+
+def multiexp_serial(scalars: Sequence[int], bases: Sequence[Affine], acc: Jac = JAC_ID) -> Jac:
+    c = window_bits(len(bases))
+    segments = 256 // c + 1
+    for seg in range(segments - 1, -1, -1):
+        for _ in range(c):
+            acc = jac_double(acc)
+        buckets: List[Jac] = [JAC_ID] * ((1 << c) - 1)
+        for k, P in zip(scalars, bases):
+            d = _get_at(seg, c, k % R_MOD)
+            if d:
+                buckets[d - 1] = jac_add(buckets[d - 1], to_jac(P))
+        running = JAC_ID
+        for b in reversed(buckets):
+            running = jac_add(running, b)
+            acc = jac_add(acc, running)
+    return acc
+
+
+def best_multiexp(scalars: Sequence[int], bases: Sequence[Affine], threads: int = 1) -> Affine:
+    assert len(scalars) == len(bases)
+    n = len(scalars)
+    if n > threads:
+        chunk = n // threads
+        parts = [multiexp_serial(scalars[i:i + chunk], bases[i:i + chunk]) for i in range(0, n, chunk)]
+        acc = JAC_ID
+        for p in parts:
+            acc = jac_add(acc, p)
+        return to_affine(acc)
+    return to_affine(multiexp_serial(scalars, bases))
+
+
+# ----------------------------------------------------------------------------------------------
+# NTT over Fr.  `dft_naive` is the definition a[i] <- sum_j a[j] w^(ij); `best_fft` restates the
+# published halo2-axiom radix-2 algorithm [DEP] (bit-reverse, twiddle table w^0..w^(n/2-1), DIT).
+# ----------------------------------------------------------------------------------------------
+def omega_for(log_n: int) -> int:
+    assert 0 <= log_n <= FR_S
+    return pow(FR_ROOT_OF_UNITY, 1 << (FR_S - log_n), R_MOD)
+
+
+def dft_naive(a: Sequence[int], omega: int) -> List[int]:
+    n = len(a)
+    out = []
+    for i in range(n):
+        wi = pow(omega, i, R_MOD)
+        acc, w = 0, 1
+        for j in range(n):
+            acc = (acc + a[j] * w) % R_MOD
+            w = w * wi % R_MOD
+        out.append(acc)
+    return out
+
+
+def bitreverse(x: int, bits: int) -> int:
+    r = 0
+    for _ in range(bits):
+        r = (r << 1) | (x & 1)
+        x >>= 1
+    return r
+
+
+def best_fft(a: Sequence[int], omega: int, log_n: int) -> List[int]:
+    n = 1 << log_n
+    assert len(a) == n
+    a = [x % R_MOD for x in a]
+    for k in range(n):
+        rk = bitreverse(k, log_n)
+        if k < rk:
+            a[k], a[rk] = a[rk], a[k]
+    tw, w = [], 1
+    for _ in range(n // 2):
+        tw.append(w)
+        w = w * omega % R_MOD
+    chunk, tchunk = 2, n // 2
+    for _ in range(log_n):
+        half = chunk // 2
+        for base in range(0, n, chunk):
+            for i in range(half):
+                t = a[base + half + i] * tw[i * tchunk] % R_MOD
+                u = a[base + i]
+                a[base + i] = (u + t) % R_MOD
+                a[base + half + i] = (u - t) % R_MOD
+        chunk *= 2
+        tchunk //= 2
+    return a
+
+
+# ----------------------------------------------------------------------------------------------
+# EvaluationDomain restatement [DEP] `halo2_proofs/src/poly/domain.rs`.
+# ----------------------------------------------------------------------------------------------
+class EvaluationDomain:
+    """`EvaluationDomain::new(j, k)`: j = constraint-system degree, n = 2^k, coset generator zeta."""
+
+    def __init__(self, j: int, k: int, zeta: int = FR_ZETA):
+        self.k = k
+        self.n = 1 << k
+        self.quotient_poly_degree = j - 1
+        ek = k
+        while (1 << ek) < self.n * self.quotient_poly_degree:
+            ek += 1
+        self.extended_k = ek
+        self.extended_omega = omega_for(ek)
+        self.extended_omega_inv = pow(self.extended_omega, -1, R_MOD)
+        self.omega = pow(self.extended_omega, 1 << (ek - k), R_MOD)
+        self.omega_inv = pow(self.omega, -1, R_MOD)
+        self.g_coset = zeta
+        self.g_coset_inv = zeta * zeta % R_MOD
+        self.ifft_divisor = pow(self.n, -1, R_MOD)
+        self.extended_ifft_divisor = pow(1 << ek, -1, R_MOD)
+        # t(X) = X^n - 1 on the coset zeta * <extended_omega>: periodic with period 2^(ek-k); stored inverted
+        orig = pow(zeta, self.n, R_MOD)
+        step = pow(self.extended_omega, self.n, R_MOD)
+        t, cur = [], orig
+        while True:
+            t.append(cur)
+            cur = cur * step % R_MOD
+            if cur == orig:
+                break
+        assert len(t) == 1 << (ek - k)
+        self.t_evaluations = [pow((v - 1) % R_MOD, -1, R_MOD) for v in t]
+
+    def extended_len(self) -> int:
+        return 1 << self.extended_k
+
+    def ifft(self, a, omega_inv, log_n, divisor):
+        return [x * divisor % R_MOD for x in best_fft(a, omega_inv, log_n)]
+
+    def lagrange_to_coeff(self, a):
+        assert len(a) == self.n
+        return self.ifft(a, self.omega_inv, self.k, self.ifft_divisor)
+
+    def coeff_to_lagrange(self, a):
+        assert len(a) == self.n
+        return best_fft(a, self.omega, self.k)
+
+    def distribute_powers_zeta(self, a, into_coset: bool):
+        p = [self.g_coset, self.g_coset_inv] if into_coset else [self.g_coset_inv, self.g_coset]
+        return [x if i % 3 == 0 else x * p[i % 3 - 1] % R_MOD for i, x in enumerate(a)]
+
+    def coeff_to_extended(self, a):
+        assert len(a) == self.n
+        a = self.distribute_powers_zeta(a, True) + [0] * (self.extended_len() - self.n)
+        return best_fft(a, self.extended_omega, self.extended_k)
+
+    def extended_to_coeff(self, a):
+        assert len(a) == self.extended_len()
+        a = self.ifft(a, self.extended_omega_inv, self.extended_k, self.extended_ifft_divisor)
+        a = self.distribute_powers_zeta(a, False)
+        return a[: self.n * self.quotient_poly_degree]
+
+    def divide_by_vanishing_poly(self, a):
+        assert len(a) == self.extended_len()
+        m = len(self.t_evaluations)
+        return [x * self.t_evaluations[i % m] % R_MOD for i, x in enumerate(a)]
+
+
+# ----------------------------------------------------------------------------------------------
+# Deterministic input generators shared by tests / bench / C oracle
+# ----------------------------------------------------------------------------------------------
+class SplitMix64:
+    def __init__(self, seed: int):
+        self.s = seed & MASK64
+
+    def next(self) -> int:
+        self.s = (self.s + 0x9E3779B97F4A7C15) & MASK64
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & MASK64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & MASK64
+        return z ^ (z >> 31)
+
+    def fr(self) -> int:
+        return from_limbs([self.next() for _ in range(4)]) % R_MOD
+
+
+def witness_like_scalars(seed: int, n: int) -> List[int]:
+    """60 % zero, 30 % uniform < 2^88, 10 % uniform Fr."""
+    g = SplitMix64(seed)
+    out = []
+    for _ in range(n):
+        sel = g.next() % 10
+        v = g.fr()
+        out.append(0 if sel < 6 else (v & ((1 << 88) - 1)) if sel < 9 else v)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# Byte/limb encodings of the drop-in boundary (same memory as &[Fr], &[G1Affine], G1)
+# ----------------------------------------------------------------------------------------------
+def fr_to_limbs(x: int) -> List[int]:
+    return limbs4(to_mont(x, R_MOD))
+
+
+def fr_from_limbs(l: Sequence[int]) -> int:
+    return from_mont(from_limbs(l), R_MOD)
+
+
+def affine_to_limbs(P: Affine) -> List[int]:
+    if P is None:
+        return [0] * 8
+    return limbs4(to_mont(P[0], Q_MOD)) + limbs4(to_mont(P[1], Q_MOD))
+
+
+def affine_from_limbs(l: Sequence[int]) -> Affine:
+    x, y = from_limbs(l[0:4]), from_limbs(l[4:8])
+    if x == 0 and y == 0:
+        return None
+    return (from_mont(x, Q_MOD), from_mont(y, Q_MOD))
+
+
+def jac_from_limbs(l: Sequence[int]) -> Jac:
+    return tuple(from_mont(from_limbs(l[4 * i:4 * i + 4]), Q_MOD) for i in range(3))  # type: ignore

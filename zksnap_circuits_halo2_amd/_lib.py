@@ -1,0 +1,69 @@
+"""ctypes binding of libzkhip.so (include/zkhip.h).  Fails loudly when the library is missing: there is no
+CPU fallback anywhere in this package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzkhip.so")
+
+# every symbol include/zkhip.h declares (tests check the export list against the header)
+_SIGS = {
+    "zkhip_init": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
+    "zkhip_shutdown": (None, []),
+    "zkhip_last_error": (C.c_char_p, []),
+    "zkhip_device_name": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "zkhip_msm_g1": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "zkhip_register_bases": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "zkhip_unregister_bases": (C.c_int, [C.c_void_p]),
+    "zkhip_ntt_fr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    "zkhip_ifft_scaled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "zkhip_coeff_to_extended": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "zkhip_extended_to_coeff": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "zkhip_mul_periodic": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32]),
+    "zkhip_msm_g1_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "zkhip_msm_g1_device_c": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),
+    "zkhip_ntt_fr_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "zkhip_ifft_scaled_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "zkhip_mul_periodic_device": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "zkhip_g1_sum_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "zkhip_g1_sum": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "zkhip_msm_window_bits": (C.c_int, [C.c_size_t]),
+    "zkhip_test_field_op": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "zkhip_test_g1_op": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+}
+
+_lib = None
+
+
+class ZkhipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libzkhip error {code}: {msg}")
+        self.code = code
+
+
+def load() -> C.CDLL:
+    """Load libzkhip.so (built in-tree by `__graft_entry__.build()` / csrc/Makefile)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc, gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise ZkhipError(rc, load().zkhip_last_error().decode(errors="replace"))

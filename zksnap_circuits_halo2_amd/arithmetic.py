@@ -1,0 +1,35 @@
+"""`halo2_proofs::arithmetic` mirror: `best_multiexp`, `best_fft` [DEP halo2-axiom] -- the two free functions
+the reference reaches through `create_proof` (/root/reference/aggregator/src/wrapper.rs:129).  Same names and
+argument meaning; arrays are numpy uint64 views of the Rust memory formats."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data
+
+
+def best_multiexp(coeffs: np.ndarray, bases: np.ndarray) -> np.ndarray:
+    """sum_i coeffs[i] * bases[i].  coeffs: (n,4) uint64 Fr, bases: (n,8) uint64 G1Affine -> (12,) uint64 G1."""
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+    if not (isinstance(bases, np.ndarray) and bases.dtype == np.uint64 and bases.flags.c_contiguous):
+        bases = np.ascontiguousarray(bases, dtype=np.uint64)
+    bases2 = bases.reshape(-1, 8)
+    # same contract as the reference: `assert_eq!(coeffs.len(), bases.len())`
+    assert coeffs.shape[0] == bases2.shape[0], "coeffs.len() != bases.len()"
+    out = np.zeros(12, dtype=np.uint64)
+    lib = _lib.load()
+    _lib.check(lib.zkhip_msm_g1(_ptr(coeffs), _ptr(bases2), coeffs.shape[0], _ptr(out)))
+    return out
+
+
+def best_fft(a: np.ndarray, omega: np.ndarray, log_n: int) -> None:
+    """In-place NTT of a ((2^log_n, 4) uint64 Fr) with the (4,) uint64 root `omega`."""
+    assert a.dtype == np.uint64 and a.flags.c_contiguous
+    assert a.size == 4 << log_n, "a.len() != 1 << log_n"
+    omega = np.ascontiguousarray(omega, dtype=np.uint64).reshape(4)
+    lib = _lib.load()
+    _lib.check(lib.zkhip_ntt_fr(_ptr(a), _ptr(omega), log_n))

@@ -1,0 +1,372 @@
+// C ABI of libzkhip.so (include/zkhip.h): context, device buffers, registered-base residency, and the host-buffer
+// wrappers around the device paths in msm.hip / ntt.hip.  No CPU arithmetic lives here.
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include "zkhip_internal.hpp"
+
+namespace zkhip {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int ntt_transform(const uint32_t* d_in, uint32_t in_len, uint32_t* d_out, uint32_t out_len, uint32_t L,
+                  const uint32_t omega_ext[8], const uint32_t* in_scale, uint32_t in_period, const uint32_t* out_scale,
+                  uint32_t out_period, hipStream_t stream);
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s failed: %s", #x, hipGetErrorString(e_)); return ZKHIP_EHIP; } } while (0)
+
+struct dev_buf {       // grow-only device scratch
+  void* p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return ZKHIP_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    size_t want = bytes + bytes / 8;
+    if (hipMalloc(&p, want) != hipSuccess) {
+      if (hipMalloc(&p, bytes) != hipSuccess) { set_error("hipMalloc(%zu) failed", bytes); p = nullptr; return ZKHIP_ENOMEM; }
+      want = bytes;
+    }
+    cap = want;
+    return ZKHIP_OK;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct context {
+  bool ready = false;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  dev_buf ws, scalars, bases, poly, poly2, small;
+  std::map<const void*, std::pair<void*, size_t>> registered;   // host ptr -> (device ptr, n points)
+};
+
+static std::recursive_mutex g_mu;
+static context g_ctx;
+
+static int ensure_init() {
+  if (g_ctx.ready) return ZKHIP_OK;
+  return zkhip_init(nullptr, 0);
+}
+
+// device pointer for `bases` if it lies inside a registered range with room for n points
+static const uint32_t* find_registered(const uint64_t* bases, size_t n) {
+  for (auto& kv : g_ctx.registered) {
+    const char* lo = (const char*)kv.first;
+    const char* hi = lo + kv.second.second * 64;
+    const char* q = (const char*)bases;
+    if (q >= lo && q + n * 64 <= hi && ((q - lo) % 64) == 0) return (const uint32_t*)((char*)kv.second.first + (q - lo));
+  }
+  return nullptr;
+}
+
+}  // namespace zkhip
+
+using namespace zkhip;
+typedef std::lock_guard<std::recursive_mutex> guard_t;
+
+extern "C" {
+
+int zkhip_init(const int* devices, int ndev) {
+  guard_t g(g_mu);
+  if (ndev > 1) { set_error("zkhip_init: one process drives one GPU (ndev = %d)", ndev); return ZKHIP_EINVAL; }
+  int dev = 0;
+  if (devices && ndev == 1) dev = devices[0];
+  else if (const char* e = getenv("ZKHIP_DEVICE")) dev = atoi(e);
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0) { set_error("no HIP device available"); return ZKHIP_ENODEV; }
+  if (dev < 0 || dev >= count) { set_error("device %d out of range (%d devices)", dev, count); return ZKHIP_EINVAL; }
+  if (g_ctx.ready && g_ctx.device == dev) return ZKHIP_OK;
+  if (g_ctx.ready) zkhip_shutdown();
+  if (hipSetDevice(dev) != hipSuccess) { set_error("hipSetDevice(%d) failed", dev); return ZKHIP_ENODEV; }
+  if (hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); return ZKHIP_ENODEV; }
+  g_ctx.device = dev;
+  g_ctx.ready = true;
+  return ZKHIP_OK;
+}
+
+void zkhip_shutdown(void) {
+  guard_t g(g_mu);
+  if (!g_ctx.ready) return;
+  (void)hipSetDevice(g_ctx.device);
+  (void)hipStreamSynchronize(g_ctx.stream);
+  ntt_clear_cache();
+  for (auto& kv : g_ctx.registered) (void)hipFree(kv.second.first);
+  g_ctx.registered.clear();
+  g_ctx.ws.release(); g_ctx.scalars.release(); g_ctx.bases.release(); g_ctx.poly.release(); g_ctx.poly2.release(); g_ctx.small.release();
+  (void)hipStreamDestroy(g_ctx.stream);
+  g_ctx.stream = nullptr;
+  g_ctx.ready = false;
+}
+
+const char* zkhip_last_error(void) { return g_err; }
+
+int zkhip_device_name(char* buf, size_t len) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, g_ctx.device));
+  snprintf(buf, len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  return ZKHIP_OK;
+}
+
+int zkhip_msm_window_bits(size_t n) { return msm_pick_window(n); }
+
+// ---- MSM -----------------------------------------------------------------------------------------
+int zkhip_msm_g1_device_c(const void* d_scalars, const void* d_bases, size_t n, void* d_out_xyz, int window_bits, void* stream) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (!d_out_xyz || (n && (!d_scalars || !d_bases))) { set_error("msm: null pointer"); return ZKHIP_EINVAL; }
+  const int c = window_bits > 0 ? window_bits : msm_pick_window(n ? n : 1);
+  const size_t need = n ? msm_workspace_bytes(n, c) : 0;
+  if ((rc = g_ctx.ws.reserve(need)) != ZKHIP_OK) return rc;
+  hipStream_t s = stream ? (hipStream_t)stream : g_ctx.stream;
+  return msm_g1_device((const uint32_t*)d_scalars, (const uint32_t*)d_bases, n, (uint32_t*)d_out_xyz, g_ctx.ws.p, g_ctx.ws.cap, c, s);
+}
+
+int zkhip_msm_g1_device(const void* d_scalars, const void* d_bases, size_t n, void* d_out_xyz, void* stream) {
+  return zkhip_msm_g1_device_c(d_scalars, d_bases, n, d_out_xyz, 0, stream);
+}
+
+int zkhip_msm_g1(const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t out_xyz[12]) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (!out_xyz || (n && (!scalars || !bases))) { set_error("msm: null pointer"); return ZKHIP_EINVAL; }
+  hipStream_t s = g_ctx.stream;
+  if ((rc = g_ctx.small.reserve(4096)) != ZKHIP_OK) return rc;
+  const uint32_t* d_bases = nullptr;
+  if (n) {
+    if ((rc = g_ctx.scalars.reserve(n * 32)) != ZKHIP_OK) return rc;
+    HIPCHK(hipMemcpyAsync(g_ctx.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, s));
+    d_bases = find_registered(bases, n);
+    if (!d_bases) {
+      if ((rc = g_ctx.bases.reserve(n * 64)) != ZKHIP_OK) return rc;
+      HIPCHK(hipMemcpyAsync(g_ctx.bases.p, bases, n * 64, hipMemcpyHostToDevice, s));
+      d_bases = (const uint32_t*)g_ctx.bases.p;
+    }
+  }
+  rc = zkhip_msm_g1_device_c(g_ctx.scalars.p, d_bases, n, g_ctx.small.p, 0, s);
+  if (rc != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(out_xyz, g_ctx.small.p, 96, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return ZKHIP_OK;
+}
+
+int zkhip_register_bases(const uint64_t* bases, size_t n) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (!bases || n == 0) { set_error("register_bases: empty"); return ZKHIP_EINVAL; }
+  if (g_ctx.registered.count(bases)) zkhip_unregister_bases(bases);
+  void* d = nullptr;
+  if (hipMalloc(&d, n * 64) != hipSuccess) { set_error("register_bases: hipMalloc(%zu) failed", n * 64); return ZKHIP_ENOMEM; }
+  if (hipMemcpy(d, bases, n * 64, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); set_error("register_bases: upload failed"); return ZKHIP_EHIP; }
+  g_ctx.registered[bases] = std::make_pair(d, n);
+  return ZKHIP_OK;
+}
+
+int zkhip_unregister_bases(const uint64_t* bases) {
+  guard_t g(g_mu);
+  auto it = g_ctx.registered.find(bases);
+  if (it == g_ctx.registered.end()) { set_error("unregister_bases: pointer not registered"); return ZKHIP_EINVAL; }
+  (void)hipStreamSynchronize(g_ctx.stream);
+  (void)hipFree(it->second.first);
+  g_ctx.registered.erase(it);
+  return ZKHIP_OK;
+}
+
+int zkhip_g1_sum_device(const void* d_points_xyz, int m, void* d_out_xyz, void* stream) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (m < 0 || !d_out_xyz || (m && !d_points_xyz)) { set_error("g1_sum: bad argument"); return ZKHIP_EINVAL; }
+  return sum_jacobian_device((const uint32_t*)d_points_xyz, m, (uint32_t*)d_out_xyz, stream ? (hipStream_t)stream : g_ctx.stream);
+}
+
+int zkhip_g1_sum(const uint64_t* points_xyz, int m, uint64_t out_xyz[12]) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (m < 0 || !out_xyz || (m && !points_xyz)) { set_error("g1_sum: bad argument"); return ZKHIP_EINVAL; }
+  if ((rc = g_ctx.small.reserve(4096 + (size_t)m * 96)) != ZKHIP_OK) return rc;
+  char* d = (char*)g_ctx.small.p;
+  if (m) HIPCHK(hipMemcpyAsync(d + 4096, points_xyz, (size_t)m * 96, hipMemcpyHostToDevice, g_ctx.stream));
+  if ((rc = sum_jacobian_device((const uint32_t*)(d + 4096), m, (uint32_t*)d, g_ctx.stream)) != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(out_xyz, d, 96, hipMemcpyDeviceToHost, g_ctx.stream));
+  HIPCHK(hipStreamSynchronize(g_ctx.stream));
+  return ZKHIP_OK;
+}
+
+// ---- NTT / domain ----------------------------------------------------------------------------------
+int zkhip_ntt_fr_device(void* d_a, const uint64_t omega[4], uint32_t log_n, void* stream) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (!d_a || !omega) { set_error("ntt: null pointer"); return ZKHIP_EINVAL; }
+  return ntt_fr_device((uint32_t*)d_a, (const uint32_t*)omega, log_n, stream ? (hipStream_t)stream : g_ctx.stream);
+}
+
+int zkhip_ifft_scaled_device(void* d_a, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4], void* stream) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (!d_a || !omega_inv || !divisor) { set_error("ifft: null pointer"); return ZKHIP_EINVAL; }
+  return ntt_fr_device_ex((uint32_t*)d_a, (const uint32_t*)omega_inv, log_n, (const uint32_t*)divisor, stream ? (hipStream_t)stream : g_ctx.stream);
+}
+
+int zkhip_mul_periodic_device(void* d_a, size_t n, const void* d_table, uint32_t period, void* stream) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if ((n && !d_a) || !d_table) { set_error("mul_periodic: null pointer"); return ZKHIP_EINVAL; }
+  return fr_mul_periodic_device((uint32_t*)d_a, n, (const uint32_t*)d_table, period, stream ? (hipStream_t)stream : g_ctx.stream);
+}
+
+static int host_transform(const uint64_t* in, size_t in_len, uint64_t* out, size_t out_len, uint32_t log_n, const uint64_t* omega,
+                          const uint32_t* in_scale, uint32_t in_period, const uint32_t* out_scale, uint32_t out_period) {
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (log_n > 28) { set_error("ntt: log_n = %u > 28", log_n); return ZKHIP_EINVAL; }
+  if (!in || !out || !omega) { set_error("ntt: null pointer"); return ZKHIP_EINVAL; }
+  const size_t N = (size_t)1 << log_n;
+  if (in_len > N || out_len > N) { set_error("ntt: length exceeds domain"); return ZKHIP_EINVAL; }
+  hipStream_t s = g_ctx.stream;
+  if ((rc = g_ctx.poly.reserve(N * 32)) != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(g_ctx.poly.p, in, in_len * 32, hipMemcpyHostToDevice, s));
+  rc = ntt_transform((const uint32_t*)g_ctx.poly.p, (uint32_t)in_len, (uint32_t*)g_ctx.poly.p, (uint32_t)out_len, log_n,
+                     (const uint32_t*)omega, in_scale, in_period, out_scale, out_period, s);
+  if (rc != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(out, g_ctx.poly.p, out_len * 32, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return ZKHIP_OK;
+}
+
+int zkhip_ntt_fr(uint64_t* a, const uint64_t omega[4], uint32_t log_n) {
+  guard_t g(g_mu);
+  const size_t N = (size_t)1 << (log_n > 28 ? 0 : log_n);
+  return host_transform(a, N, a, N, log_n, omega, nullptr, 0, nullptr, 0);
+}
+
+int zkhip_ifft_scaled(uint64_t* a, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4]) {
+  guard_t g(g_mu);
+  if (!divisor) { set_error("ifft: null divisor"); return ZKHIP_EINVAL; }
+  const size_t N = (size_t)1 << (log_n > 28 ? 0 : log_n);
+  return host_transform(a, N, a, N, log_n, omega_inv, nullptr, 0, (const uint32_t*)divisor, 1);
+}
+
+// c[0] = base, c[1] = base * z, c[2] = base * z^2 computed on the device through the periodic-multiply kernel
+static int zeta_powers(const uint64_t* base, const uint64_t* z1, const uint64_t* z2, uint32_t out[24]) {
+  // out = {base, base*z1, base*z2}: uses mul hook on 2 elements
+  uint64_t a[8], b[8], r[8];
+  memcpy(a, base, 32); memcpy(a + 4, base, 32);
+  memcpy(b, z1, 32); memcpy(b + 4, z2, 32);
+  int rc = zkhip_test_field_op(1, 0, a, b, r, 2);
+  if (rc != ZKHIP_OK) return rc;
+  memcpy(out, base, 32); memcpy(out + 8, r, 64);
+  return ZKHIP_OK;
+}
+
+int zkhip_coeff_to_extended(const uint64_t* a, uint32_t k, uint64_t* out, uint32_t ext_k, const uint64_t ext_omega[4], const uint64_t zeta[4]) {
+  guard_t g(g_mu);
+  if (!a || !out || !ext_omega || !zeta || k > ext_k || ext_k > 28) { set_error("coeff_to_extended: bad argument"); return ZKHIP_EINVAL; }
+  // in-scale {1, zeta, zeta^2}: zeta^2 via one device multiply; "1" in Montgomery form = zeta^3, obtained the same way
+  uint64_t zz[8], z3[4];
+  uint64_t za[8], zb[8];
+  memcpy(za, zeta, 32); memcpy(za + 4, zeta, 32);
+  memcpy(zb, zeta, 32); memcpy(zb + 4, zeta, 32);
+  int rc = zkhip_test_field_op(1, 0, za, zb, zz, 1);          // zz[0..4) = zeta^2
+  if (rc != ZKHIP_OK) return rc;
+  rc = zkhip_test_field_op(1, 0, zz, zeta, z3, 1);            // zeta^3 (= 1 for a cube root of unity)
+  if (rc != ZKHIP_OK) return rc;
+  uint32_t sc[24];
+  memcpy(sc, z3, 32); memcpy(sc + 8, zeta, 32); memcpy(sc + 16, zz, 32);
+  return host_transform(a, (size_t)1 << k, out, (size_t)1 << ext_k, ext_k, ext_omega, sc, 3, nullptr, 0);
+}
+
+int zkhip_extended_to_coeff(uint64_t* a, uint32_t ext_k, const uint64_t ext_omega_inv[4], const uint64_t ext_divisor[4],
+                            const uint64_t zeta[4], uint64_t* out, size_t out_len) {
+  guard_t g(g_mu);
+  if (!a || !out || !ext_omega_inv || !ext_divisor || !zeta || ext_k > 28) { set_error("extended_to_coeff: bad argument"); return ZKHIP_EINVAL; }
+  // out-scale divisor * {1, zeta^2, zeta}   (distribute_powers_zeta(.., false) uses [g_coset_inv, g_coset] = [zeta^2, zeta])
+  uint64_t zz[4];
+  int rc = zkhip_test_field_op(1, 0, zeta, zeta, zz, 1);
+  if (rc != ZKHIP_OK) return rc;
+  uint32_t sc[24];
+  rc = zeta_powers(ext_divisor, zz, zeta, sc);
+  if (rc != ZKHIP_OK) return rc;
+  return host_transform(a, (size_t)1 << ext_k, out, out_len, ext_k, ext_omega_inv, nullptr, 0, sc, 3);
+}
+
+int zkhip_mul_periodic(uint64_t* a, size_t n, const uint64_t* table, uint32_t period) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if ((n && !a) || !table || period == 0) { set_error("mul_periodic: bad argument"); return ZKHIP_EINVAL; }
+  if (n == 0) return ZKHIP_OK;
+  hipStream_t s = g_ctx.stream;
+  if ((rc = g_ctx.poly.reserve(n * 32)) != ZKHIP_OK) return rc;
+  if ((rc = g_ctx.poly2.reserve((size_t)period * 32)) != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(g_ctx.poly.p, a, n * 32, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(g_ctx.poly2.p, table, (size_t)period * 32, hipMemcpyHostToDevice, s));
+  if ((rc = fr_mul_periodic_device((uint32_t*)g_ctx.poly.p, n, (const uint32_t*)g_ctx.poly2.p, period, s)) != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(a, g_ctx.poly.p, n * 32, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return ZKHIP_OK;
+}
+
+// ---- parity hooks ----------------------------------------------------------------------------------
+int zkhip_test_field_op(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (field < 0 || field > 1 || op < 0 || op > 3 || (n && (!a || !b || !out))) { set_error("test_field_op: bad argument"); return ZKHIP_EINVAL; }
+  if (n == 0) return ZKHIP_OK;
+  hipStream_t s = g_ctx.stream;
+  dev_buf tmp;
+  if ((rc = tmp.reserve(n * 96)) != ZKHIP_OK) return rc;
+  char* d = (char*)tmp.p;
+  hipError_t e = hipMemcpyAsync(d, a, n * 32, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(d + n * 32, b, n * 32, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) rc = test_field_op(field, op, (uint32_t*)d, (uint32_t*)(d + n * 32), (uint32_t*)(d + n * 64), n, s);
+  if (e == hipSuccess && rc == ZKHIP_OK) e = hipMemcpyAsync(out, d + n * 64, n * 32, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  tmp.release();
+  if (e != hipSuccess) { set_error("test_field_op: %s", hipGetErrorString(e)); return ZKHIP_EHIP; }
+  return rc;
+}
+
+int zkhip_test_g1_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out_xyz, size_t n) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (op < 0 || op > 2 || (n && (!a || !b || !out_xyz))) { set_error("test_g1_op: bad argument"); return ZKHIP_EINVAL; }
+  if (n == 0) return ZKHIP_OK;
+  hipStream_t s = g_ctx.stream;
+  dev_buf tmp;
+  if ((rc = tmp.reserve(n * (64 + 64 + 96))) != ZKHIP_OK) return rc;
+  char* d = (char*)tmp.p;
+  hipError_t e = hipMemcpyAsync(d, a, n * 64, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(d + n * 64, b, n * 64, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) rc = test_g1_op(op, (uint32_t*)d, (uint32_t*)(d + n * 64), (uint32_t*)(d + n * 128), n, s);
+  if (e == hipSuccess && rc == ZKHIP_OK) e = hipMemcpyAsync(out_xyz, d + n * 128, n * 96, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  tmp.release();
+  if (e != hipSuccess) { set_error("test_g1_op: %s", hipGetErrorString(e)); return ZKHIP_EHIP; }
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,522 @@
+// BN254 G1 multi-scalar multiplication for MI355X (gfx950).
+//
+// Replaces halo2-axiom `best_multiexp` / `multiexp_serial` [DEP] (halo2_proofs/src/arithmetic.rs; reached
+// from /root/reference/aggregator/src/wrapper.rs:129 `create_proof`, :108 `keygen_pk` and
+// /root/reference/aggregator/benches/wrapper_circuit.rs:140 `gen_proof`).  Same mathematical result
+// (sum_i s_i * P_i), different algorithm: the reference chunks points over CPU threads and runs an
+// unsigned c = ceil(ln n) Pippenger per chunk; here one GPU runs a signed-digit Pippenger over all points:
+//
+//   1. digits      scalar -> canonical integer -> W signed c-bit digits (int16), window-major
+//   2. count       per (window, chunk) workgroup: histogram of |digit|-1 in LDS, merged into the global
+//                  per-bucket counts with *contiguous* atomics (one wave-instruction = 256 contiguous bytes)
+//   3. scan        exclusive scan of the counts -> bucket offsets
+//   4. scatter     same tiling: LDS histogram again, one ranged global atomicAdd per non-empty bucket reserves
+//                  the slot range, LDS cursors place (point index | sign<<31) -> counting sort by bucket
+//   5. tasks       buckets are cut into tasks of <= TASK_LEN entries (load balance independent of the
+//                  scalar distribution: a bucket holding 100k points becomes 100k/TASK_LEN tasks)
+//   6. accumulate  one thread per task, XYZZ accumulator in registers, mixed additions
+//   7. combine     per bucket: sum of its task partials (wave-cooperative for very heavy buckets)
+//   8. reduce      log-depth pyramid: sum_k (k+1) B_k = Tot + sum_l 2^l T_l,  T_l = sum of buckets with bit l
+//   9. fold        Horner over the T_l and over the windows
+//
+// HBM layout: digits int16 [W][n]; sorted refs u32 [W*n]; counts/offsets u32 [W*B+1]; XYZZ points are
+// 36 x u32 (9 limbs x 4 coordinates, 144 B) arrays-of-structs.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include "ec.hpp"
+#include "zkhip_internal.hpp"
+
+namespace zkhip {
+
+constexpr int TASK_LEN = 64;       // max entries per accumulate task
+constexpr int HEAVY_TASKS = 16;    // buckets with more task partials than this go to the wave-cooperative combine
+
+struct task_t {
+  uint32_t bucket, start, len;
+};
+
+// ------------------------------------------------------------------------------------------------
+// XYZZ <-> global memory (array of 36-word structs)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ xyzz load_xyzz(const uint32_t* base, size_t idx) {
+  const uint4* q = reinterpret_cast<const uint4*>(base + idx * 36);
+  uint32_t w[36];
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    uint4 v = q[i];
+    w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+  }
+  xyzz r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) { r.X.l[i] = w[i]; r.Y.l[i] = w[9 + i]; r.ZZ.l[i] = w[18 + i]; r.ZZZ.l[i] = w[27 + i]; }
+  return r;
+}
+
+__device__ __forceinline__ void store_xyzz(uint32_t* base, size_t idx, const xyzz& a) {
+  uint32_t w[36];
+#pragma unroll
+  for (int i = 0; i < 9; i++) { w[i] = a.X.l[i]; w[9 + i] = a.Y.l[i]; w[18 + i] = a.ZZ.l[i]; w[27 + i] = a.ZZZ.l[i]; }
+  uint4* q = reinterpret_cast<uint4*>(base + idx * 36);
+#pragma unroll
+  for (int i = 0; i < 9; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 1. digits
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, int16_t* __restrict__ digits,
+                                                uint32_t n, int c, int W) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[8];
+  load_words(scalars + (size_t)i * 8, w);
+  // Montgomery-256 -> plain integer: mont261(a*2^256, 2^5) = a
+  fe c32;
+#pragma unroll
+  for (int k = 0; k < NL; k++) c32.l[k] = FrParams::FROM_EXT_CANON[k];
+  fe s = fe_canon_lt2p<FrParams>(fe_mul<FrParams>(c32, fe_unpack<0>(w)));
+  fe_pack(s, w);
+  const uint32_t half = 1u << (c - 1), mask = (1u << c) - 1;
+  uint32_t carry = 0;
+  for (int win = 0; win < W; win++) {
+    int bit = win * c;
+    uint32_t v = 0;
+    if (bit < 256) {
+      int wi = bit >> 5, sh = bit & 31;
+      uint64_t two = w[wi];
+      if (wi + 1 < 8) two |= (uint64_t)w[wi + 1] << 32;
+      v = (uint32_t)(two >> sh) & mask;
+    }
+    v += carry;
+    int32_t d;
+    if (v >= half) { d = (int32_t)v - (int32_t)(1u << c); carry = 1; } else { d = (int32_t)v; carry = 0; }
+    digits[(size_t)win * n + i] = (int16_t)d;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2. count / 4. scatter: grid (chunks, W), LDS histogram of B = 2^(c-1) u32 counters
+// ------------------------------------------------------------------------------------------------
+template <bool SCATTER>
+__global__ void __launch_bounds__(1024) k_sort_pass(const int16_t* __restrict__ digits, uint32_t n, uint32_t chunk,
+                                                    int c, uint32_t* __restrict__ count_or_cursor,
+                                                    uint32_t* __restrict__ sorted) {
+  extern __shared__ uint32_t hist[];
+  const uint32_t B = 1u << (c - 1);
+  const int win = blockIdx.y;
+  const uint32_t lo = blockIdx.x * chunk;
+  const uint32_t hi = min(n, lo + chunk);
+  for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) hist[b] = 0;
+  __syncthreads();
+  const int16_t* dw = digits + (size_t)win * n;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    int d = dw[i];
+    if (d != 0) atomicAdd(&hist[(d < 0 ? -d : d) - 1], 1u);
+  }
+  __syncthreads();
+  uint32_t* g = count_or_cursor + (size_t)win * B;
+  if (!SCATTER) {
+    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) {
+      uint32_t v = hist[b];
+      if (v) atomicAdd(&g[b], v);
+    }
+  } else {
+    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) {
+      uint32_t v = hist[b];
+      hist[b] = v ? atomicAdd(&g[b], v) : 0u;   // reserve [pos, pos+v) in the bucket's slot range
+    }
+    __syncthreads();
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+      int d = dw[i];
+      if (d != 0) {
+        uint32_t pos = atomicAdd(&hist[(d < 0 ? -d : d) - 1], 1u);
+        sorted[pos] = i | (d < 0 ? 0x80000000u : 0u);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3. exclusive scan of u32 (three small kernels).  MODE 0: identity, MODE 1: ceil(x / TASK_LEN)
+// ------------------------------------------------------------------------------------------------
+constexpr int SCAN_BLOCK = 256, SCAN_PER_THREAD = 16, SCAN_TILE = SCAN_BLOCK * SCAN_PER_THREAD;
+
+template <int MODE>
+__device__ __forceinline__ uint32_t scan_xform(uint32_t v) {
+  return MODE == 0 ? v : (v + TASK_LEN - 1) / TASK_LEN;
+}
+
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds, uint32_t& total) {
+  // 256 threads; wave scan via shuffles then 4 wave totals through LDS
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t x = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    uint32_t y = __shfl_up(x, off, 64);
+    if (lane >= off) x += y;
+  }
+  if (lane == 63) lds[wave] = x;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_BLOCK / 64; i++) {
+    uint32_t t = lds[i];
+    if (i < wave) base += t;
+    tot += t;
+  }
+  __syncthreads();
+  total = tot;
+  return base + x - v;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_sums(const uint32_t* __restrict__ in, uint32_t n,
+                                                          uint32_t* __restrict__ block_sums) {
+  __shared__ uint32_t lds[4];
+  uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_PER_THREAD; i++) if (base + i < n) s += scan_xform<MODE>(in[base + i]);
+  uint32_t total;
+  block_exclusive_scan(s, lds, total);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_top(uint32_t* __restrict__ block_sums, uint32_t nb,
+                                                         uint32_t* __restrict__ total_out) {
+  __shared__ uint32_t lds[4];
+  uint32_t running = 0;
+  for (uint32_t base = 0; base < nb; base += SCAN_BLOCK) {
+    uint32_t i = base + threadIdx.x;
+    uint32_t v = i < nb ? block_sums[i] : 0, total;
+    uint32_t ex = block_exclusive_scan(v, lds, total);
+    if (i < nb) block_sums[i] = running + ex;
+    running += total;
+  }
+  if (threadIdx.x == 0) *total_out = running;
+}
+
+// out[i] = exclusive prefix; out2 (optional) gets a copy (used as the scatter cursor); out[n] = total
+template <int MODE>
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply(const uint32_t* __restrict__ in, uint32_t n,
+                                                           const uint32_t* __restrict__ block_sums,
+                                                           const uint32_t* __restrict__ total,
+                                                           uint32_t* __restrict__ out, uint32_t* __restrict__ out2) {
+  __shared__ uint32_t lds[4];
+  uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
+  uint32_t v[SCAN_PER_THREAD], s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_PER_THREAD; i++) { v[i] = base + i < n ? scan_xform<MODE>(in[base + i]) : 0; s += v[i]; }
+  uint32_t tot;
+  uint32_t ex = block_exclusive_scan(s, lds, tot) + block_sums[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < SCAN_PER_THREAD; i++) {
+    if (base + i < n) { out[base + i] = ex; if (out2) out2[base + i] = ex; }
+    ex += v[i];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = *total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 5. tasks: bucket k with cnt entries -> ceil(cnt/TASK_LEN) tasks; heavy buckets appended to a list
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_make_tasks(const uint32_t* __restrict__ offset, const uint32_t* __restrict__ task_off,
+                                                    uint32_t nbuckets, task_t* __restrict__ tasks,
+                                                    uint32_t* __restrict__ heavy_count, uint32_t* __restrict__ heavy_list) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nbuckets) return;
+  uint32_t s = offset[k], e = offset[k + 1], t = task_off[k], nt = task_off[k + 1] - t;
+  for (uint32_t j = 0; j < nt; j++) {
+    task_t tk;
+    tk.bucket = k;
+    tk.start = s + j * TASK_LEN;
+    tk.len = min((uint32_t)TASK_LEN, e - tk.start);
+    tasks[t + j] = tk;
+  }
+  if (nt > HEAVY_TASKS) heavy_list[atomicAdd(heavy_count, 1u)] = k;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 6. accumulate: one thread per task
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(128) k_accumulate(const task_t* __restrict__ tasks, const uint32_t* __restrict__ ntasks_p,
+                                                    const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ bases,
+                                                    uint32_t* __restrict__ partials) {
+  const uint32_t ntasks = *ntasks_p;
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < ntasks; t += gridDim.x * blockDim.x) {
+    task_t tk = tasks[t];
+    xyzz acc = xyzz_identity();
+    const uint32_t* refs = sorted + tk.start;
+    uint32_t ref = refs[0];
+    affine_words pt = load_affine(bases, ref & 0x7fffffffu);
+    for (uint32_t j = 0; j < tk.len; j++) {
+      affine_words cur = pt;
+      uint32_t cref = ref;
+      if (j + 1 < tk.len) {            // prefetch the next point under the current addition
+        ref = refs[j + 1];
+        pt = load_affine(bases, ref & 0x7fffffffu);
+      }
+      if (affine_is_identity(cur)) continue;
+      fe x2 = fe_from_ext_lazy(cur.x);   // < 32p
+      fe y2 = fe_from_ext_lazy(cur.y);
+      if (cref >> 31) y2 = fe_neg_red(y2, Fq::P64_S1);   // -y: 64p - y < 64p, limbs < 2^30
+      xyzz_madd(acc, x2, y2);
+    }
+    store_xyzz(partials, t, acc);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 7. combine task partials per bucket
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(128) k_combine_light(const uint32_t* __restrict__ task_off, uint32_t nbuckets,
+                                                       const uint32_t* __restrict__ partials, uint32_t* __restrict__ buckets) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nbuckets) return;
+  uint32_t t = task_off[k], nt = task_off[k + 1] - t;
+  if (nt > HEAVY_TASKS) return;   // k_combine_heavy owns this bucket
+  xyzz acc = xyzz_identity();
+  if (nt >= 1) acc = load_xyzz(partials, t);
+  for (uint32_t j = 1; j < nt; j++) acc = xyzz_add(acc, load_xyzz(partials, t + j));
+  store_xyzz(buckets, k, acc);
+}
+
+// one 256-thread workgroup per heavy bucket: strided serial sums, then an LDS tree
+__global__ void __launch_bounds__(256) k_combine_heavy(const uint32_t* __restrict__ task_off,
+                                                       const uint32_t* __restrict__ heavy_count,
+                                                       const uint32_t* __restrict__ heavy_list,
+                                                       const uint32_t* __restrict__ partials, uint32_t* __restrict__ buckets) {
+  __shared__ uint32_t lds[256 * 36];
+  const uint32_t nheavy = *heavy_count;
+  for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
+    uint32_t k = heavy_list[h];
+    uint32_t t = task_off[k], nt = task_off[k + 1] - t;
+    xyzz acc = xyzz_identity();
+    for (uint32_t j = threadIdx.x; j < nt; j += blockDim.x) acc = xyzz_add(acc, load_xyzz(partials, t + j));
+    store_xyzz(lds, threadIdx.x, acc);
+    __syncthreads();
+    for (int stride = 128; stride >= 1; stride >>= 1) {
+      if ((int)threadIdx.x < stride) {
+        xyzz a = load_xyzz(lds, threadIdx.x), b = load_xyzz(lds, threadIdx.x + stride);
+        store_xyzz(lds, threadIdx.x, xyzz_add(a, b));
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) store_xyzz(buckets, k, load_xyzz(lds, 0));
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 8. pyramid reduction.  Per window, state at the start of step s (1-based):
+//      X   : N elements            (N = B >> (s-1))
+//      Z^l : N/2 elements each, l = 0 .. s-2
+//    laid out contiguously [X | Z^0 | ... | Z^(s-2)], window stride = `in_stride` elements.
+//    Step s writes [X' (N/2) | Z'^0 .. Z'^(s-1) (N/4 each)]:
+//      X'[t]        = X[2t] + X[2t+1]
+//      Z'^l[u]      = Z^l[2u] + Z^l[2u+1]          (l <= s-2)
+//      Z'^(s-1)[u]  = X[4u+1] + X[4u+3]            (odd elements of X start their own tree)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(128) k_pyramid_step(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                      uint32_t N, int s, uint32_t in_stride, uint32_t out_stride) {
+  const uint32_t per_win = N / 2 + (uint32_t)s * (N / 4);
+  uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= per_win) return;
+  const int win = blockIdx.y;
+  const uint32_t* wi = in + (size_t)win * in_stride * 36;
+  uint32_t* wo = out + (size_t)win * out_stride * 36;
+  uint32_t ia, ib;
+  if (tid < N / 2) {
+    ia = 2 * tid; ib = 2 * tid + 1;
+  } else {
+    uint32_t r = tid - N / 2;
+    uint32_t l = r / (N / 4), u = r % (N / 4);
+    if ((int)l == s - 1) { ia = 4 * u + 1; ib = 4 * u + 3; }
+    else { ia = N + l * (N / 2) + 2 * u; ib = ia + 1; }
+  }
+  store_xyzz(wo, tid, xyzz_add(load_xyzz(wi, ia), load_xyzz(wi, ib)));
+}
+
+// 9a. per-window Horner.  Input state after the last pyramid step: X has 2 elements, Z^0..Z^(nz-1) one each.
+//     window sum = X0 + X1 + sum_l 2^l Z^l + 2^nz X1
+__global__ void __launch_bounds__(64) k_window_horner(const uint32_t* __restrict__ in, uint32_t in_stride, int nz,
+                                                      uint32_t* __restrict__ winsum, int W) {
+  int win = blockIdx.x * blockDim.x + threadIdx.x;
+  if (win >= W) return;
+  const uint32_t* wi = in + (size_t)win * in_stride * 36;
+  xyzz x0 = load_xyzz(wi, 0), x1 = load_xyzz(wi, 1);
+  xyzz acc = x1;
+  for (int l = nz - 1; l >= 0; l--) acc = xyzz_add(xyzz_dbl(acc), load_xyzz(wi, 2 + l));
+  acc = xyzz_add(acc, xyzz_add(x0, x1));
+  store_xyzz(winsum, win, acc);
+}
+
+// 9b. fold windows: result = sum_w 2^(c w) winsum[w]; writes the Jacobian result (24 words)
+__global__ void __launch_bounds__(64) k_fold(const uint32_t* __restrict__ winsum, int W, int c, uint32_t* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  xyzz acc = load_xyzz(winsum, W - 1);
+  for (int w = W - 2; w >= 0; w--) {
+    for (int i = 0; i < c; i++) acc = xyzz_dbl(acc);
+    acc = xyzz_add(acc, load_xyzz(winsum, w));
+  }
+  store_jacobian(acc, out);
+}
+
+// sum of `m` Jacobian points (multi-GPU partial fold): out = sum in[i]
+__global__ void __launch_bounds__(64) k_sum_jacobian(const uint32_t* __restrict__ in, int m, uint32_t* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  xyzz acc = xyzz_identity();
+  for (int i = 0; i < m; i++) acc = xyzz_add(acc, load_jacobian(in + (size_t)i * 24));
+  store_jacobian(acc, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host orchestration
+// ------------------------------------------------------------------------------------------------
+int msm_pick_window(size_t n) {
+  // cost model in field multiplications: W * (10 n + 2 * 14 * 2^(c-1)), W = ceil(256 / c); c <= 16 (int16 digits, 128 KiB LDS)
+  int best = 2;
+  double best_cost = 1e300;
+  for (int c = 2; c <= 16; c++) {
+    double W = (256 + c - 1) / c;
+    double cost = W * (10.0 * (double)n + 28.0 * (double)(1u << (c - 1)));
+    if (cost < best_cost) { best_cost = cost; best = c; }
+  }
+  return best;
+}
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+size_t msm_workspace_bytes(size_t n, int c) {
+  const size_t W = (256 + c - 1) / c, B = (size_t)1 << (c - 1), NB = W * B;
+  const size_t max_tasks = W * n / TASK_LEN + NB + 1;
+  size_t total = 0;
+  total += align_up(W * n * sizeof(int16_t), 256);          // digits
+  total += align_up(W * n * sizeof(uint32_t), 256);         // sorted
+  total += 4 * align_up((NB + 1) * sizeof(uint32_t), 256);  // count, offset, cursor, task_off
+  total += 2 * align_up((NB / SCAN_TILE + 2) * sizeof(uint32_t), 256);  // scan block sums x2
+  total += align_up(max_tasks * sizeof(task_t), 256);
+  total += align_up(max_tasks * 144, 256);                  // partials
+  total += align_up((NB + 1) * sizeof(uint32_t), 256);      // heavy list
+  total += 2 * align_up((size_t)W * B * 144, 256);          // pyramid ping-pong (state never exceeds B elements per window)
+  total += align_up(W * 144, 256);                          // window sums
+  total += 4096;                                            // counters + result
+  return total;
+}
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s failed: %s", #x, hipGetErrorString(e_)); return ZKHIP_EHIP; } } while (0)
+
+// d_scalars: n x 8 words, d_bases: n x 16 words, d_out: 24 words (device).  ws: workspace of msm_workspace_bytes.
+int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, uint32_t* d_out, void* ws, size_t ws_bytes,
+                  int c_override, hipStream_t stream) {
+  if (n == 0) {
+    hipLaunchKernelGGL(k_sum_jacobian, dim3(1), dim3(64), 0, stream, (const uint32_t*)nullptr, 0, d_out);
+    HIPCHK(hipGetLastError());
+    return ZKHIP_OK;
+  }
+  if (n >= (1ull << 31)) { set_error("msm: n = %zu too large", n); return ZKHIP_EINVAL; }
+  const int c = c_override > 0 ? c_override : msm_pick_window(n);
+  if (c < 2 || c > 16) { set_error("msm: window bits %d out of range [2,16]", c); return ZKHIP_EINVAL; }
+  const int W = (256 + c - 1) / c;
+  const uint32_t B = 1u << (c - 1);
+  const uint32_t NB = (uint32_t)W * B;
+  if ((size_t)W * n >= (1ull << 32)) { set_error("msm: W*n overflows 32-bit slot index"); return ZKHIP_EINVAL; }
+  if (ws_bytes < msm_workspace_bytes(n, c)) { set_error("msm: workspace too small"); return ZKHIP_EINVAL; }
+  const size_t max_tasks = (size_t)W * n / TASK_LEN + NB + 1;
+
+  char* p = (char*)ws;
+  auto carve = [&](size_t bytes) { void* r = p; p += align_up(bytes, 256); return r; };
+  int16_t* digits = (int16_t*)carve((size_t)W * n * sizeof(int16_t));
+  uint32_t* sorted = (uint32_t*)carve((size_t)W * n * sizeof(uint32_t));
+  uint32_t* count = (uint32_t*)carve((NB + 1) * sizeof(uint32_t));
+  uint32_t* offset = (uint32_t*)carve((NB + 1) * sizeof(uint32_t));
+  uint32_t* cursor = (uint32_t*)carve((NB + 1) * sizeof(uint32_t));
+  uint32_t* task_off = (uint32_t*)carve((NB + 1) * sizeof(uint32_t));
+  uint32_t* bsum1 = (uint32_t*)carve((NB / SCAN_TILE + 2) * sizeof(uint32_t));
+  uint32_t* bsum2 = (uint32_t*)carve((NB / SCAN_TILE + 2) * sizeof(uint32_t));
+  task_t* tasks = (task_t*)carve(max_tasks * sizeof(task_t));
+  uint32_t* partials = (uint32_t*)carve(max_tasks * 144);
+  uint32_t* heavy_list = (uint32_t*)carve((NB + 1) * sizeof(uint32_t));
+  const size_t pyr_elems = B;   // per window: N + (s-1) N/2 <= B at every step
+  uint32_t* pyrA = (uint32_t*)carve((size_t)W * pyr_elems * 144);
+  uint32_t* pyrB = (uint32_t*)carve((size_t)W * pyr_elems * 144);
+  uint32_t* winsum = (uint32_t*)carve((size_t)W * 144);
+  uint32_t* counters = (uint32_t*)carve(1024);   // [0] total entries, [1] total tasks, [2] heavy count
+
+  // 1. digits
+  hipLaunchKernelGGL(k_digits, dim3((n + 255) / 256), dim3(256), 0, stream, d_scalars, digits, (uint32_t)n, c, W);
+  // 2. count
+  HIPCHK(hipMemsetAsync(count, 0, (NB + 1) * sizeof(uint32_t), stream));
+  HIPCHK(hipMemsetAsync(counters, 0, 1024, stream));
+  uint32_t chunks = (uint32_t)((n + 65535) / 65536);
+  while (chunks * (uint32_t)W < 256 && chunks < (n + 4095) / 4096) chunks *= 2;   // fill the chip
+  if (chunks == 0) chunks = 1;
+  const uint32_t chunk = (uint32_t)((n + chunks - 1) / chunks);
+  const size_t lds = (size_t)B * sizeof(uint32_t);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIPCHK(hipFuncSetAttribute((const void*)k_sort_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)k_sort_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_sort_pass<false>, dim3(chunks, W), dim3(1024), lds, stream, digits, (uint32_t)n, chunk, c, count, (uint32_t*)nullptr);
+  // 3. scan counts -> offset (+ cursor copy)
+  const uint32_t nblk = (NB + SCAN_TILE - 1) / SCAN_TILE;
+  hipLaunchKernelGGL(k_scan_sums<0>, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, count, NB, bsum1);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_BLOCK), 0, stream, bsum1, nblk, counters + 0);
+  hipLaunchKernelGGL(k_scan_apply<0>, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, count, NB, bsum1, counters + 0, offset, cursor);
+  // 4. scatter
+  hipLaunchKernelGGL(k_sort_pass<true>, dim3(chunks, W), dim3(1024), lds, stream, digits, (uint32_t)n, chunk, c, cursor, sorted);
+  // 5. tasks
+  hipLaunchKernelGGL(k_scan_sums<1>, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, count, NB, bsum2);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_BLOCK), 0, stream, bsum2, nblk, counters + 1);
+  hipLaunchKernelGGL(k_scan_apply<1>, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, count, NB, bsum2, counters + 1, task_off, (uint32_t*)nullptr);
+  hipLaunchKernelGGL(k_make_tasks, dim3((NB + 255) / 256), dim3(256), 0, stream, offset, task_off, NB, tasks, counters + 2, heavy_list);
+  // 6. accumulate (grid-stride over the device-side task count)
+  {
+    uint32_t blocks = (uint32_t)((max_tasks + 127) / 128);
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(128), 0, stream, tasks, counters + 1, sorted, d_bases, partials);
+  }
+  // 7. combine
+  hipLaunchKernelGGL(k_combine_light, dim3((NB + 127) / 128), dim3(128), 0, stream, task_off, NB, partials, pyrA);
+  hipLaunchKernelGGL(k_combine_heavy, dim3(256), dim3(256), 0, stream, task_off, counters + 2, heavy_list, partials, pyrA);
+  // 8. pyramid: buckets were written with window stride B (dense).  Steps 1 .. c-2 leave X with 2 elements.
+  uint32_t* cur = pyrA;
+  uint32_t* nxt = pyrB;
+  uint32_t in_stride = B;
+  int nz = 0;
+  {
+    uint32_t N = B;
+    int s = 1;
+    while (N > 2) {
+      uint32_t per_win = N / 2 + (uint32_t)s * (N / 4);
+      uint32_t out_stride = per_win;
+      hipLaunchKernelGGL(k_pyramid_step, dim3((per_win + 127) / 128, W), dim3(128), 0, stream, cur, nxt, N, s, in_stride, out_stride);
+      uint32_t* t = cur; cur = nxt; nxt = t;
+      in_stride = out_stride;
+      N >>= 1;
+      s++;
+    }
+    nz = s - 1;   // number of Z rows, one element each (B == 2: none; B == 1 handled below)
+  }
+  // 9. Horner + fold
+  if (B == 1) {
+    // c == 1 is excluded (c >= 2), so B >= 2 always; keep the guard for clarity
+    set_error("msm: internal: B == 1");
+    return ZKHIP_EINVAL;
+  }
+  hipLaunchKernelGGL(k_window_horner, dim3((W + 63) / 64), dim3(64), 0, stream, cur, in_stride, nz, winsum, W);
+  hipLaunchKernelGGL(k_fold, dim3(1), dim3(64), 0, stream, winsum, W, c, d_out);
+  HIPCHK(hipGetLastError());
+  return ZKHIP_OK;
+}
+
+int sum_jacobian_device(const uint32_t* d_in, int m, uint32_t* d_out, hipStream_t stream) {
+  hipLaunchKernelGGL(k_sum_jacobian, dim3(1), dim3(64), 0, stream, d_in, m, d_out);
+  HIPCHK(hipGetLastError());
+  return ZKHIP_OK;
+}
+
+}  // namespace zkhip

@@ -1,0 +1,441 @@
+// Radix-2 NTT over BN254 Fr for MI355X (gfx950).
+//
+// Replaces halo2-axiom `best_fft` and the `EvaluationDomain` passes built on it [DEP]
+// (halo2_proofs/src/arithmetic.rs, poly/domain.rs; reached from /root/reference/aggregator/src/wrapper.rs:129
+// `create_proof` and wrapper.rs:107-108 keygen).  Same result a[i] <- sum_j a[j] w^(ij), natural order in and
+// out; the reference does bit-reverse + in-place radix-2 butterflies over CPU threads, here:
+//
+//   * Stockham autosort: pass p with Ns = prod(previous radices), R = 2^B reads  x_r = src[j + r N/R]
+//     (contiguous in j), multiplies by w_(Ns R)^(k r), k = j mod Ns, does an R-point DFT and writes
+//     dst[(j/Ns) Ns R + k + r Ns].  No bit-reversal pass, every pass streams coalesced runs.
+//   * One workgroup owns a tile of J consecutive j (J * R = 2048 elements, 72 KiB of LDS as 9-limb values):
+//     cooperative coalesced load -> LDS, <= 3 rounds of <= 3 radix-2 stages in registers (8 elements per
+//     thread), LDS exchange between rounds, cooperative coalesced store.
+//   * B <= 9 bits per pass: 2^24 is three passes.  Twiddles w_M^t come from an M-entry table when
+//     M <= 2^16 and from two 2^(log M / 2)-entry tables (one extra multiply) above that; all tables are
+//     L2-resident and cached per (omega, log_n).
+//   * Values stay lazily reduced inside a pass (fp29.hpp); each pass ends with one multiply that reduces
+//     them, which on the last pass is also the caller's output scale (ifft divisor, coset powers) -> free.
+//   * The external Montgomery-256 words are used as they are: x*2^256 is the radix-2^261 Montgomery form of
+//     x*2^-5, and the NTT is linear, so no format conversion multiply is needed on either side.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
+#include <array>
+#include "fp29.hpp"
+#include "zkhip_internal.hpp"
+
+namespace zkhip {
+
+using Fr = FrParams;
+constexpr uint32_t NTT_TILE = 2048;
+constexpr int NTT_MAX_BITS = 9;
+
+struct scale_arg {      // up to 3 external (Montgomery-256) constants applied as c[i % period]; period 0 = none
+  uint32_t w[3][8];
+  uint32_t period;
+};
+
+struct pass_args {
+  const uint32_t* src;
+  uint32_t* dst;
+  uint32_t L, S, B;               // log2 N, log2 Ns, log2 R
+  const uint32_t* tw_local;       // w_R^x, x < R/2              (internal 9-limb form)
+  const uint32_t* tw_lo;          // w_M^t, t < 2^h (or t < M when tw_hi == nullptr)
+  const uint32_t* tw_hi;          // w_M^(t 2^h)
+  uint32_t h;
+  uint32_t first, last;
+  uint32_t in_len;                // first pass: elements >= in_len read as zero
+  uint32_t out_len;               // last pass: elements >= out_len are not stored
+  scale_arg in_scale, out_scale;
+};
+
+__device__ __forceinline__ fe load_fe9(const uint32_t* p, uint32_t idx) {
+  fe r;
+  const uint32_t* q = p + (size_t)idx * 9;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = q[i];
+  return r;
+}
+__device__ __forceinline__ void store_fe9(uint32_t* p, uint32_t idx, const fe& a) {
+  uint32_t* q = p + (size_t)idx * 9;
+#pragma unroll
+  for (int i = 0; i < 9; i++) q[i] = a.l[i];
+}
+
+// external constant c*2^256 -> internal c*2^261 (reduced)
+__device__ __forceinline__ fe fr_ext_to_internal(const uint32_t (&w)[8]) {
+  fe k;
+#pragma unroll
+  for (int i = 0; i < NL; i++) k.l[i] = Fr::FROM_EXT[i];
+  return fe_mul<Fr>(k, fe_unpack<0>(w));
+}
+
+__device__ __forceinline__ fe scale_pick(const scale_arg& s, uint32_t idx) {
+  uint32_t sel = idx % 3u;   // period is 1 or 3
+  if (s.period == 1) sel = 0;
+  uint32_t w[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) w[i] = sel == 0 ? s.w[0][i] : (sel == 1 ? s.w[1][i] : s.w[2][i]);
+  return fr_ext_to_internal(w);
+}
+
+__global__ void __launch_bounds__(256, 2) k_ntt_pass(pass_args a) {
+  extern __shared__ uint32_t lds[];
+  const uint32_t B = a.B, R = 1u << B, L = a.L;
+  const uint32_t N = 1u << L;
+  const uint32_t tile = N < NTT_TILE ? N : NTT_TILE;
+  const uint32_t J = tile >> B;
+  const uint32_t logJ = 31 - __builtin_clz(J);
+  const uint32_t j0 = blockIdx.x * J;
+  const uint32_t NR = N >> B;
+  const uint32_t Ns = 1u << a.S;
+  const uint32_t nthreads = blockDim.x;
+
+  // ---- load: global order (r, jj) -> LDS position (bitrev(r), jj) --------------------------------
+  for (uint32_t idx = threadIdx.x; idx < tile; idx += nthreads) {
+    const uint32_t r = idx >> logJ, jj = idx & (J - 1);
+    const uint32_t j = j0 + jj;
+    const uint32_t g = j + r * NR;
+    fe x;
+    if (a.first) {
+      if (g < a.in_len) {
+        uint32_t w[8];
+        load_words(a.src + (size_t)g * 8, w);
+        x = fe_unpack<0>(w);
+        if (a.in_scale.period) x = fe_mul<Fr>(scale_pick(a.in_scale, g), x);
+      } else {
+        x = fe_zero();
+      }
+    } else {
+      uint32_t w[8];
+      load_words(a.src + (size_t)g * 8, w);
+      x = fe_unpack<0>(w);
+      const uint32_t t = (j & (Ns - 1)) * r;
+      fe tw;
+      if (a.tw_hi == nullptr) {
+        tw = load_fe9(a.tw_lo, t);
+      } else {
+        tw = fe_mul<Fr>(load_fe9(a.tw_lo, t & ((1u << a.h) - 1)), load_fe9(a.tw_hi, t >> a.h));
+      }
+      x = fe_mul<Fr>(tw, x);
+    }
+    const uint32_t i = __brev(r) >> (32 - B);
+    store_fe9(lds, i * J + jj, x);
+  }
+  __syncthreads();
+
+  // ---- rounds of <= 3 in-register stages ----------------------------------------------------------
+  {
+    const uint32_t jj = threadIdx.x & (J - 1), m = threadIdx.x >> logJ;
+    uint32_t s = 0;
+    while (s < B) {
+      const uint32_t v = (B - s) < 3 ? (B - s) : 3;
+      fe x[8];
+      uint32_t pos[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const uint32_t rest = (m << (3 - v)) | ((uint32_t)e >> v);
+        const uint32_t lo = rest & ((1u << s) - 1), hi = rest >> s;
+        pos[e] = (hi << (s + v)) | (((uint32_t)e & ((1u << v) - 1)) << s) | lo;
+        x[e] = load_fe9(lds, pos[e] * J + jj);
+      }
+#pragma unroll
+      for (int u = 0; u < 3; u++) {
+        if ((uint32_t)u < v) {
+          const uint32_t st = s + u;
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            if ((e >> u) & 1) continue;          // e is the upper element of a pair
+            const int f = e | (1 << u);
+            const uint32_t lo_i = pos[e] & ((1u << st) - 1);
+            fe t = fe_mul<Fr>(load_fe9(a.tw_local, lo_i << (B - 1 - st)), x[f]);   // N x (limbs < 2^31.5)
+            x[f] = fe_sub_red(x[e], t, Fr::P3_S1);                                   // x - t + 3p
+            x[e] = fe_add(x[e], t);
+          }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; e++) store_fe9(lds, pos[e] * J + jj, fe_norm(x[e]));
+      __syncthreads();
+      s += v;
+    }
+  }
+
+  // ---- store: destination order (a, r', b), b = jj mod q fastest, q = min(Ns, J) -------------------
+  const uint32_t q = Ns < J ? Ns : J;
+  const uint32_t logq = 31 - __builtin_clz(q);
+  fe one = fe_one<Fr>();
+  for (uint32_t idx = threadIdx.x; idx < tile; idx += nthreads) {
+    const uint32_t b = idx & (q - 1), rp = (idx >> logq) & (R - 1), aa = idx >> (logq + B);
+    const uint32_t jj = aa * q + b;
+    const uint32_t j = j0 + jj;
+    const uint32_t d = ((j >> a.S) << (a.S + B)) + (j & (Ns - 1)) + (rp << a.S);
+    fe x = load_fe9(lds, rp * J + jj);
+    uint32_t w[8];
+    if (a.last) {
+      if (d >= a.out_len) continue;
+      fe sc = a.out_scale.period ? scale_pick(a.out_scale, d) : one;
+      fe_pack(fe_canon_lt2p<Fr>(fe_mul<Fr>(sc, x)), w);
+    } else {
+      fe_pack(fe_mul<Fr>(one, x), w);            // < 2p < 2^256
+    }
+    store_words(a.dst + (size_t)d * 8, w);
+  }
+}
+
+// N <= 4: direct DFT by one thread
+__global__ void k_ntt_tiny(const uint32_t* src, uint32_t* dst, uint32_t L, const uint32_t* pw2, uint32_t in_len,
+                           uint32_t out_len, scale_arg in_scale, scale_arg out_scale) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const uint32_t N = 1u << L;
+  fe x[4], y[4];
+  fe one = fe_one<Fr>();
+  for (uint32_t i = 0; i < N; i++) {
+    if (i < in_len) {
+      uint32_t w[8];
+      load_words(src + (size_t)i * 8, w);
+      x[i] = fe_unpack<0>(w);
+      if (in_scale.period) x[i] = fe_mul<Fr>(scale_pick(in_scale, i), x[i]);
+    } else x[i] = fe_zero();
+  }
+  fe om = load_fe9(pw2, 0);   // omega
+  fe wi = one;                // omega^i
+  for (uint32_t i = 0; i < N; i++) {
+    fe acc = fe_zero(), wij = one;
+    for (uint32_t j = 0; j < N; j++) {
+      acc = fe_norm(fe_add(acc, fe_mul<Fr>(wij, x[j])));
+      wij = fe_mul<Fr>(wij, wi);
+    }
+    y[i] = acc;
+    wi = fe_mul<Fr>(wi, om);
+  }
+  for (uint32_t i = 0; i < N && i < out_len; i++) {
+    fe sc = out_scale.period ? scale_pick(out_scale, i) : one;
+    uint32_t w[8];
+    fe_pack(fe_canon_lt2p<Fr>(fe_mul<Fr>(sc, y[i])), w);
+    store_words(dst + (size_t)i * 8, w);
+  }
+}
+
+// pw2[e] = omega^(2^e), e = 0..L  (internal form)
+__global__ void k_ntt_pow2(const uint32_t* omega_ext_dev, uint32_t L, uint32_t* pw2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  uint32_t w[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) w[i] = omega_ext_dev[i];
+  fe x = fr_ext_to_internal(w);
+  for (uint32_t e = 0; e <= L; e++) {
+    store_fe9(pw2, e, x);
+    x = fe_sqr<Fr>(x);
+  }
+}
+
+// out[i] = (omega^(2^e0))^i for i < count, by square-and-multiply over the bits of i
+__global__ void __launch_bounds__(256) k_ntt_powers(const uint32_t* pw2, uint32_t e0, uint32_t count, uint32_t* out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  fe acc = fe_one<Fr>();
+  uint32_t bits = i, b = 0;
+  while (bits) {
+    if (bits & 1) acc = fe_mul<Fr>(acc, load_fe9(pw2, e0 + b));
+    bits >>= 1;
+    b++;
+  }
+  store_fe9(out, i, fe_canon_lt2p<Fr>(acc));
+}
+
+// a[i] *= table[i % period]   (table in external form, converted per element: elementwise passes are HBM-bound)
+__global__ void __launch_bounds__(256) k_mul_periodic(uint32_t* a, size_t n, const uint32_t* table, uint32_t period) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    uint32_t w[8], t[8];
+    load_words(a + i * 8, w);
+    load_words(table + (size_t)(i % period) * 8, t);
+    fe r = fe_mul<Fr>(fr_ext_to_internal(t), fe_unpack<0>(w));
+    fe_pack(fe_canon_lt2p<Fr>(r), w);
+    store_words(a + i * 8, w);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// plans: pass split + twiddle tables, cached per (omega, log_n)
+// ------------------------------------------------------------------------------------------------
+struct ntt_plan {
+  uint32_t L = 0;
+  int npass = 0;
+  uint32_t B[4] = {0, 0, 0, 0}, S[4] = {0, 0, 0, 0}, h[4] = {0, 0, 0, 0};
+  uint32_t* pw2 = nullptr;
+  uint32_t* tw_local[4] = {nullptr, nullptr, nullptr, nullptr};
+  uint32_t* tw_lo[4] = {nullptr, nullptr, nullptr, nullptr};
+  uint32_t* tw_hi[4] = {nullptr, nullptr, nullptr, nullptr};
+  uint32_t* tmp[2] = {nullptr, nullptr};
+  std::vector<void*> allocs;
+};
+
+static std::mutex g_plan_mu;
+static std::map<std::array<uint32_t, 9>, ntt_plan*> g_plans;
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s failed: %s", #x, hipGetErrorString(e_)); return ZKHIP_EHIP; } } while (0)
+
+static int plan_alloc(ntt_plan* p, uint32_t** out, size_t bytes) {
+  void* d = nullptr;
+  if (hipMalloc(&d, bytes) != hipSuccess) { set_error("ntt: hipMalloc(%zu) failed", bytes); return ZKHIP_ENOMEM; }
+  p->allocs.push_back(d);
+  *out = (uint32_t*)d;
+  return ZKHIP_OK;
+}
+
+static int build_plan(const uint32_t omega_ext[8], uint32_t L, hipStream_t stream, ntt_plan** out) {
+  ntt_plan* p = new ntt_plan();
+  p->L = L;
+  int rc;
+  uint32_t* d_omega = nullptr;
+  if ((rc = plan_alloc(p, &d_omega, 32)) != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(d_omega, omega_ext, 32, hipMemcpyHostToDevice, stream));
+  if ((rc = plan_alloc(p, &p->pw2, (size_t)(L + 1) * 36)) != ZKHIP_OK) return rc;
+  hipLaunchKernelGGL(k_ntt_pow2, dim3(1), dim3(64), 0, stream, d_omega, L, p->pw2);
+  if (L >= 3) {
+    p->npass = (int)((L + NTT_MAX_BITS - 1) / NTT_MAX_BITS);
+    uint32_t rem = L, s = 0;
+    for (int i = 0; i < p->npass; i++) {
+      uint32_t b = (rem + (p->npass - i) - 1) / (p->npass - i);
+      p->B[i] = b; p->S[i] = s;
+      s += b; rem -= b;
+    }
+    for (int i = 0; i < p->npass; i++) {
+      const uint32_t B = p->B[i], logM = p->S[i] + B;
+      // local twiddles w_R^x = omega^(x * N/R), x < R/2
+      const uint32_t cnt = 1u << (B - 1);
+      if ((rc = plan_alloc(p, &p->tw_local[i], (size_t)cnt * 36)) != ZKHIP_OK) return rc;
+      hipLaunchKernelGGL(k_ntt_powers, dim3((cnt + 255) / 256), dim3(256), 0, stream, p->pw2, L - B, cnt, p->tw_local[i]);
+      if (i == 0) continue;
+      // pass twiddles w_M^t = omega^(t * N/M), t < M
+      if (logM <= 16) {
+        const uint32_t M = 1u << logM;
+        p->h[i] = 0;
+        if ((rc = plan_alloc(p, &p->tw_lo[i], (size_t)M * 36)) != ZKHIP_OK) return rc;
+        hipLaunchKernelGGL(k_ntt_powers, dim3((M + 255) / 256), dim3(256), 0, stream, p->pw2, L - logM, M, p->tw_lo[i]);
+      } else {
+        const uint32_t h = (logM + 1) / 2, nlo = 1u << h, nhi = 1u << (logM - h);
+        p->h[i] = h;
+        if ((rc = plan_alloc(p, &p->tw_lo[i], (size_t)nlo * 36)) != ZKHIP_OK) return rc;
+        if ((rc = plan_alloc(p, &p->tw_hi[i], (size_t)nhi * 36)) != ZKHIP_OK) return rc;
+        hipLaunchKernelGGL(k_ntt_powers, dim3((nlo + 255) / 256), dim3(256), 0, stream, p->pw2, L - logM, nlo, p->tw_lo[i]);
+        hipLaunchKernelGGL(k_ntt_powers, dim3((nhi + 255) / 256), dim3(256), 0, stream, p->pw2, L - logM + h, nhi, p->tw_hi[i]);
+      }
+    }
+    if (p->npass >= 2) {
+      if ((rc = plan_alloc(p, &p->tmp[0], ((size_t)32) << L)) != ZKHIP_OK) return rc;
+      if (p->npass >= 3 && (rc = plan_alloc(p, &p->tmp[1], ((size_t)32) << L)) != ZKHIP_OK) return rc;
+    }
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(stream));   // tables are shared by later calls on any stream
+  *out = p;
+  return ZKHIP_OK;
+}
+
+static int get_plan(const uint32_t omega_ext[8], uint32_t L, hipStream_t stream, ntt_plan** out) {
+  std::array<uint32_t, 9> key;
+  for (int i = 0; i < 8; i++) key[i] = omega_ext[i];
+  key[8] = L;
+  std::lock_guard<std::mutex> g(g_plan_mu);
+  auto it = g_plans.find(key);
+  if (it != g_plans.end()) { *out = it->second; return ZKHIP_OK; }
+  ntt_plan* p = nullptr;
+  int rc = build_plan(omega_ext, L, stream, &p);
+  if (rc != ZKHIP_OK) {
+    if (p) { for (void* d : p->allocs) (void)hipFree(d); delete p; }
+    return rc;
+  }
+  g_plans[key] = p;
+  *out = p;
+  return ZKHIP_OK;
+}
+
+void ntt_clear_cache() {
+  std::lock_guard<std::mutex> g(g_plan_mu);
+  for (auto& kv : g_plans) {
+    for (void* d : kv.second->allocs) (void)hipFree(d);
+    delete kv.second;
+  }
+  g_plans.clear();
+}
+
+static scale_arg make_scale(const uint32_t* ext, uint32_t period) {
+  scale_arg s;
+  memset(&s, 0, sizeof(s));
+  s.period = period;
+  for (uint32_t k = 0; k < period && k < 3; k++) memcpy(s.w[k], ext + 8 * k, 32);
+  return s;
+}
+
+// Generic transform: out[i] = out_scale[i % op] * sum_j (in_scale[j % ip] * in[j]) omega^(ij), j < in_len (zero above),
+// i < out_len.  d_in may equal d_out.  Scales are host arrays of `period` external-form constants (period 0, 1 or 3).
+int ntt_transform(const uint32_t* d_in, uint32_t in_len, uint32_t* d_out, uint32_t out_len, uint32_t L,
+                  const uint32_t omega_ext[8], const uint32_t* in_scale, uint32_t in_period, const uint32_t* out_scale,
+                  uint32_t out_period, hipStream_t stream) {
+  if (L > 28) { set_error("ntt: log_n = %u > 28", L); return ZKHIP_EINVAL; }
+  if ((in_period != 0 && in_period != 1 && in_period != 3) || (out_period != 0 && out_period != 1 && out_period != 3)) {
+    set_error("ntt: scale period must be 0, 1 or 3");
+    return ZKHIP_EINVAL;
+  }
+  ntt_plan* p = nullptr;
+  int rc = get_plan(omega_ext, L, stream, &p);
+  if (rc != ZKHIP_OK) return rc;
+  const uint32_t N = 1u << L;
+  if (in_len > N) in_len = N;
+  if (out_len > N) out_len = N;
+  scale_arg is = make_scale(in_scale, in_scale ? in_period : 0), os = make_scale(out_scale, out_scale ? out_period : 0);
+  if (L < 3) {
+    hipLaunchKernelGGL(k_ntt_tiny, dim3(1), dim3(64), 0, stream, d_in, d_out, L, p->pw2, in_len, out_len, is, os);
+    HIPCHK(hipGetLastError());
+    return ZKHIP_OK;
+  }
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [] {
+    (void)hipFuncSetAttribute((const void*)k_ntt_pass, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_TILE * 36);
+  });
+  const uint32_t tile = N < NTT_TILE ? N : NTT_TILE;
+  for (int i = 0; i < p->npass; i++) {
+    pass_args a;
+    memset(&a, 0, sizeof(a));
+    a.L = L; a.S = p->S[i]; a.B = p->B[i];
+    a.tw_local = p->tw_local[i]; a.tw_lo = p->tw_lo[i]; a.tw_hi = p->tw_hi[i]; a.h = p->h[i];
+    a.first = i == 0; a.last = i == p->npass - 1;
+    a.in_len = in_len; a.out_len = out_len;
+    a.in_scale = is; a.out_scale = os;
+    // buffer chain: in -> tmp0 -> tmp1 -> tmp0 -> ... -> out
+    a.src = i == 0 ? d_in : p->tmp[(i - 1) & 1];
+    a.dst = a.last ? d_out : p->tmp[i & 1];
+    hipLaunchKernelGGL(k_ntt_pass, dim3(N / tile), dim3(tile / 8), (size_t)tile * 36, stream, a);
+  }
+  HIPCHK(hipGetLastError());
+  return ZKHIP_OK;
+}
+
+int ntt_fr_device_ex(uint32_t* d_a, const uint32_t omega_ext[8], uint32_t log_n, const uint32_t* scale_ext, hipStream_t stream) {
+  const uint32_t N = 1u << log_n;
+  return ntt_transform(d_a, N, d_a, N, log_n, omega_ext, nullptr, 0, scale_ext, scale_ext ? 1 : 0, stream);
+}
+
+int ntt_fr_device(uint32_t* d_a, const uint32_t omega_ext[8], uint32_t log_n, hipStream_t stream) {
+  return ntt_fr_device_ex(d_a, omega_ext, log_n, nullptr, stream);
+}
+
+int fr_mul_periodic_device(uint32_t* d_a, size_t n, const uint32_t* d_table_ext, uint32_t period, hipStream_t stream) {
+  if (period == 0) { set_error("mul_periodic: period 0"); return ZKHIP_EINVAL; }
+  if (n == 0) return ZKHIP_OK;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(k_mul_periodic, dim3((uint32_t)blocks), dim3(256), 0, stream, d_a, n, d_table_ext, period);
+  HIPCHK(hipGetLastError());
+  return ZKHIP_OK;
+}
+
+}  // namespace zkhip

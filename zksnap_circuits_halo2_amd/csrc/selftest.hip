@@ -1,0 +1,61 @@
+// Elementwise field / curve kernels behind the zkhip_test_* parity hooks:
+// they expose the device arithmetic of fp29.hpp / ec.hpp in the external memory format so tests can diff it
+// against the oracle.  Not used by the MSM / NTT paths themselves.
+#include <hip/hip_runtime.h>
+#include "ec.hpp"
+#include "zkhip_internal.hpp"
+
+namespace zkhip {
+
+template <class P>
+__global__ void __launch_bounds__(256) k_field_op(int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t wa[8], wb[8], wo[8];
+  load_words(a + i * 8, wa);
+  load_words(b + i * 8, wb);
+  fe one = fe_one<P>();
+  fe x = fe_mul<P>(one, fe_from_ext_lazy(wa));   // x * 2^261, reduced
+  fe y = fe_mul<P>(one, fe_from_ext_lazy(wb));
+  fe r;
+  switch (op) {
+    case 0: r = fe_mul<P>(x, y); break;
+    case 1: r = fe_add(x, y); break;
+    case 2: r = fe_sub_red(x, y, P::P3_S1); break;
+    default: r = fe_sqr<P>(x); break;
+  }
+  fe_to_ext<P>(r, wo);
+  store_words(out + i * 8, wo);
+}
+
+__global__ void __launch_bounds__(128) k_g1_op(int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  affine_words pa = load_affine(a, i), pb = load_affine(b, i);
+  xyzz acc = xyzz_identity();
+  if (!affine_is_identity(pa)) xyzz_madd(acc, fe_from_ext_lazy(pa.x), fe_from_ext_lazy(pa.y));
+  if (op == 1) {
+    acc = xyzz_dbl(acc);
+  } else if (!affine_is_identity(pb)) {
+    fe y2 = fe_from_ext_lazy(pb.y);
+    if (op == 2) y2 = fe_neg_red(y2, Fq::P64_S1);
+    xyzz_madd(acc, fe_from_ext_lazy(pb.x), y2);
+  }
+  store_jacobian(acc, out + i * 24);
+}
+
+int test_field_op(int field, int op, const uint32_t* d_a, const uint32_t* d_b, uint32_t* d_out, size_t n, hipStream_t stream) {
+  if (n == 0) return ZKHIP_OK;
+  dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  if (field == 0) hipLaunchKernelGGL(k_field_op<FqParams>, grid, block, 0, stream, op, d_a, d_b, d_out, n);
+  else hipLaunchKernelGGL(k_field_op<FrParams>, grid, block, 0, stream, op, d_a, d_b, d_out, n);
+  return hipGetLastError() == hipSuccess ? ZKHIP_OK : ZKHIP_EHIP;
+}
+
+int test_g1_op(int op, const uint32_t* d_a, const uint32_t* d_b, uint32_t* d_out, size_t n, hipStream_t stream) {
+  if (n == 0) return ZKHIP_OK;
+  hipLaunchKernelGGL(k_g1_op, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, stream, op, d_a, d_b, d_out, n);
+  return hipGetLastError() == hipSuccess ? ZKHIP_OK : ZKHIP_EHIP;
+}
+
+}  // namespace zkhip

@@ -1,0 +1,31 @@
+// Internal declarations shared by the translation units of libzkhip.so (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+#include "../../include/zkhip.h"
+
+namespace zkhip {
+
+void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+
+// msm.hip
+int msm_pick_window(size_t n);
+size_t msm_workspace_bytes(size_t n, int c);
+int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, uint32_t* d_out, void* ws, size_t ws_bytes,
+                  int c_override, hipStream_t stream);
+int sum_jacobian_device(const uint32_t* d_in, int m, uint32_t* d_out, hipStream_t stream);
+
+// ntt.hip
+int ntt_fr_device(uint32_t* d_a, const uint32_t omega_ext[8], uint32_t log_n, hipStream_t stream);
+int ntt_fr_device_ex(uint32_t* d_a, const uint32_t omega_ext[8], uint32_t log_n, const uint32_t* scale_ext,
+                     hipStream_t stream);
+int fr_mul_periodic_device(uint32_t* d_a, size_t n, const uint32_t* d_table_ext, uint32_t period, hipStream_t stream);
+int fr_scale_device(uint32_t* d_a, size_t n, const uint32_t scale_ext[8], hipStream_t stream);
+void ntt_clear_cache();
+
+// selftest.hip
+int test_field_op(int field, int op, const uint32_t* d_a, const uint32_t* d_b, uint32_t* d_out, size_t n, hipStream_t stream);
+int test_g1_op(int op, const uint32_t* d_a, const uint32_t* d_b, uint32_t* d_out, size_t n, hipStream_t stream);
+
+}  // namespace zkhip
