@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""bench.py -- BN254 G1 MSM throughput on MI355X (BASELINE.json metric, configs[1]: 2^20 random points/scalars).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = one MSM over the rank's shard (2^20 points per GPU, weak scaling: the N-GPU job is one 2^20*N-point MSM
+sharded by point range) + the partial-sum exchange (all_gather of 96-byte Jacobian partials over RCCL, folded on
+device).  Scalars and bases are resident in HBM before the timed region; prints ONE JSON line on rank 0.
+Extra keys: "roofline" (dominant kernel = bucket accumulation, HIP-event timed inside the library on the launch
+stream), "cpu_baseline" (oracle/cpu_ref.c = restatement of the reference's best_multiexp on the host cores),
+"phases_ms", "ntt" and "wrapper_replay" (MSM+NTT call mix of one wrapper-circuit proof at k = 22, device-resident).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+R_TOP = 0x30644E72E131A029  # top limb of r: limbs with top < R_TOP are canonical Fr values
+
+
+def synth_scalars(n: int, seed: int, kind: str = "uniform") -> np.ndarray:
+    """(n,4) uint64 canonical limbs = uniformly random Fr elements in the Montgomery memory format (a uniformly random
+    canonical limb pattern is the Montgomery form of a uniformly random field element).  No oracle involved."""
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
+    a[:, 3] = rng.integers(0, R_TOP, size=n, dtype=np.uint64)
+    if kind == "witness":  # 60 % zero, 30 % small (< 2^88 as *integers*: needs Montgomery conversion, done on host bigints for a sample only)
+        sel = rng.integers(0, 10, size=n)
+        a[sel < 6] = 0
+    return a
+
+
+def profile_read(lib):
+    ms = (C.c_double * 32)()
+    names = ((C.c_char * 64) * 32)()
+    k = lib.zkhip_profile_read(ms, names, 32)
+    return [(names[i].value.decode(), ms[i]) for i in range(max(k, 0))]
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log-n", type=int, default=20, help="log2 points per GPU (BASELINE configs[1] = 20)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the NTT / wrapper-replay extras")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from zksnap_circuits_halo2_amd import _lib, fields as F
+
+    lib = _lib.load()
+    devs = (C.c_int * 1)(local_rank)
+    _lib.check(lib.zkhip_init(devs, 1))
+    stream = torch.cuda.current_stream().cuda_stream
+
+    n = 1 << args.log_n
+    # ---- inputs, resident in HBM --------------------------------------------------------------------------
+    t0 = F.fr_encode([0x5A4B534E41500002 + 7919 * rank])[0]
+    dd = F.fr_encode([0x9E3779B97F4A7C15F39CC0605CEDC835])[0]
+    d_bases = torch.empty(n * 8, dtype=torch.int64, device=dev)
+    _lib.check(lib.zkhip_g1_gen_walk_device(t0.ctypes.data, dd.ctypes.data, n, d_bases.data_ptr(), stream))
+    d_scalars = torch.from_numpy(synth_scalars(n, 0x5A4B534E41500003 + rank).view(np.int64)).to(dev)
+    d_out = torch.zeros(16, dtype=torch.int64, device=dev)          # 96-byte result in a 128-byte slot
+    d_gather = torch.zeros(16 * world, dtype=torch.int64, device=dev)
+    d_final = torch.zeros(16, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        _lib.check(lib.zkhip_msm_g1_device(d_scalars.data_ptr(), d_bases.data_ptr(), n, d_out.data_ptr(), stream))
+        if world > 1:
+            dist.all_gather_into_tensor(d_gather, d_out)
+            # every rank folds the gathered partials (slots are 16 x int64; compact to 12 first)
+            parts = d_gather.view(world, 16)[:, :12].contiguous()
+            _lib.check(lib.zkhip_g1_sum_device(parts.data_ptr(), world, d_final.data_ptr(), stream))
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    mpoints = world * n * args.steps / elapsed / 1e6
+
+    result = {
+        "metric": "BN254 G1 MSM Mpoints/sec",
+        "value": round(mpoints, 3),
+        "unit": "Mpoints/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32x9 (254-bit modular integer, radix 2^29)",
+        "data": "synthetic",
+        "config": {"workload": f"BN254 G1 MSM, 2^{args.log_n} random points/scalars per GPU (BASELINE configs[1]), "
+                               f"point-range sharded x{world}, inputs resident in HBM",
+                   "points_per_gpu": n, "window_bits": int(lib.zkhip_msm_window_bits(n)),
+                   "parallelism": f"point-range shard x{world} + all_gather(96 B) + fold"},
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel (bucket accumulation), HIP events on the launch stream ---------
+        lib.zkhip_profile_enable(1)
+        acc = {}
+        reps = 5
+        for _ in range(reps):
+            _lib.check(lib.zkhip_msm_g1_device(d_scalars.data_ptr(), d_bases.data_ptr(), n, d_out.data_ptr(), stream))
+            for name, ms in profile_read(lib):
+                acc[name] = acc.get(name, 0.0) + ms / reps
+        lib.zkhip_profile_enable(0)
+        t_acc = acc.get("accumulate", float("nan"))
+        alg_bytes = 96.0 * n                                       # 64 B affine base + 32 B scalar per point
+        achieved = alg_bytes / (t_acc * 1e-3) / 1e9
+        result["roofline"] = {"bound": "hbm", "kernel": "k_accumulate", "achieved": round(achieved, 2), "peak": 8000.0,
+                              "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": None,
+                              "avg_launch_ms": round(t_acc, 4), "algorithmic_bytes_per_launch": alg_bytes,
+                              "whole_msm_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / 8000.0, 5),
+                              "note": "256-bit modular-integer work: ALU-bound, not HBM-bound (DESIGN.md)"}
+        result["phases_ms"] = {k: round(v, 4) for k, v in acc.items()}
+
+    if rank == 0 and world == 1 and not args.no_extras:
+        result.update(extras(lib, _lib, F, torch, dev, stream))
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args.log_n, d_scalars, d_bases, d_out, n)
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def extras(lib, _lib, F, torch, dev, stream) -> dict:
+    """NTT throughput at the wrapper sizes and the MSM+NTT call mix of one wrapper-circuit proof (SURVEY.md 3.2 / 8d
+    config 4: 18 MSM 2^22 + 13 iNTT 2^22 + 13 NTT 2^24 + 1 iNTT 2^24), everything device-resident."""
+    out = {}
+    from zksnap_circuits_halo2_amd.fields import R_MOD, omega_for
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / reps * 1e3
+
+    ntt = {}
+    bufs = {}
+    for L in (22, 24):
+        N = 1 << L
+        a = torch.from_numpy(synth_scalars(N, 1000 + L).view(np.int64)).to(dev)
+        bufs[L] = a
+        om = F.fr_encode([omega_for(L)])[0]
+        ms = timed(lambda: _lib.check(lib.zkhip_ntt_fr_device(a.data_ptr(), om.ctypes.data, L, stream)), 5)
+        ntt[f"2^{L}"] = {"ms": round(ms, 4), "Melem_per_s": round(N / ms / 1e3, 1),
+                         "hbm_frac_algorithmic": round(64.0 * N / (ms * 1e-3) / 8e12, 5)}
+    out["ntt"] = ntt
+
+    k = 22
+    n = 1 << k
+    t0 = F.fr_encode([12345])[0]
+    dd = F.fr_encode([0x9E3779B97F4A7C15])[0]
+    g = torch.empty(n * 8, dtype=torch.int64, device=dev)
+    _lib.check(lib.zkhip_g1_gen_walk_device(t0.ctypes.data, dd.ctypes.data, n, g.data_ptr(), stream))
+    sc = bufs[22]
+    res = torch.zeros(16, dtype=torch.int64, device=dev)
+    om22i = F.fr_encode([pow(omega_for(22), -1, R_MOD)])[0]
+    div22 = F.fr_encode([pow(n, -1, R_MOD)])[0]
+    om24 = F.fr_encode([omega_for(24)])[0]
+    om24i = F.fr_encode([pow(omega_for(24), -1, R_MOD)])[0]
+    div24 = F.fr_encode([pow(1 << 24, -1, R_MOD)])[0]
+    ext = bufs[24]
+
+    def replay():
+        for _ in range(18):
+            _lib.check(lib.zkhip_msm_g1_device(sc.data_ptr(), g.data_ptr(), n, res.data_ptr(), stream))
+        for _ in range(13):
+            _lib.check(lib.zkhip_ifft_scaled_device(sc.data_ptr(), om22i.ctypes.data, 22, div22.ctypes.data, stream))
+        for _ in range(13):
+            _lib.check(lib.zkhip_ntt_fr_device(ext.data_ptr(), om24.ctypes.data, 24, stream))
+        _lib.check(lib.zkhip_ifft_scaled_device(ext.data_ptr(), om24i.ctypes.data, 24, div24.ctypes.data, stream))
+
+    ms_msm22 = timed(lambda: _lib.check(lib.zkhip_msm_g1_device(sc.data_ptr(), g.data_ptr(), n, res.data_ptr(), stream)), 3)
+    ms = timed(replay, 2)
+    out["msm_2^22"] = {"ms": round(ms_msm22, 3), "Mpoints_per_s": round(n / ms_msm22 / 1e3, 1)}
+    out["wrapper_replay"] = {"workload": "k=22: 18 MSM 2^22 + 13 iNTT 2^22 + 13 NTT 2^24 + 1 iNTT 2^24, device-resident",
+                             "ms": round(ms, 2), "proofs_per_s_msm_ntt_portion": round(1e3 / ms, 3),
+                             "note": "MSM+NTT portion only; the Rust host (witness, evaluate_h, transcript) cannot run here"}
+    return out
+
+
+def cpu_baseline(log_n, d_scalars, d_bases, d_out, n) -> dict:
+    """The reference's algorithm (oracle/cpu_ref.c restatement of best_multiexp) on the host cores, same inputs."""
+    from oracle import cpu_ref as Cr
+
+    threads = os.cpu_count() or 1
+    log_s = min(log_n, 20)
+    m = 1 << log_s
+    sc = np.ascontiguousarray(d_scalars.cpu().numpy().view(np.uint64).reshape(-1, 4)[:m])
+    bs = np.ascontiguousarray(d_bases.cpu().numpy().view(np.uint64).reshape(-1, 8)[:m])
+    t = time.perf_counter()
+    ref = Cr.best_multiexp(sc, bs, threads)
+    dt = time.perf_counter() - t
+    agree = None
+    if m == n:
+        got = d_out.cpu().numpy().view(np.uint64)[:12]
+        agree = bool(np.array_equal(Cr.jac_to_affine(np.ascontiguousarray(got)), Cr.jac_to_affine(ref)))
+    return {"value": round(m / dt / 1e6, 4), "unit": "Mpoints/s", "cores": threads, "kind": "port",
+            "sample": f"one 2^{log_s}-point MSM, same inputs as the GPU run, {threads} threads, {dt:.2f} s wall",
+            "gpu_result_matches": agree}
+
+
+if __name__ == "__main__":
+    main()

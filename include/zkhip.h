@@ -78,6 +78,17 @@ int zkhip_g1_sum_device(const void *d_points_xyz, int m, void *d_out_xyz, void *
 int zkhip_g1_sum(const uint64_t *points_xyz, int m, uint64_t out_xyz[12]);
 int zkhip_msm_window_bits(size_t n);
 
+/* ---- synthetic inputs + per-phase timing (bench / large tests) ------------------------------------- */
+/* d_out[i] = (t0 + i*d) * G as G1Affine, i < n, written to device memory: a seeded stand-in for an SRS whose
+ * discrete logs are known, so MSM(a, out) = [sum a_i (t0 + i d)] G can be checked with one scalar multiplication.
+ * t0, d: Fr in the usual Montgomery memory format. */
+int zkhip_g1_gen_walk_device(const uint64_t t0[4], const uint64_t d[4], size_t n, void *d_out, void *stream);
+/* Per-phase timing with HIP events on the stream the kernels run on.  enable(1), run one call, then
+ * zkhip_profile_read synchronises and returns the number of phases of the last profiled call, writing up to
+ * `max` durations (milliseconds) and names (63 chars + NUL each). */
+int zkhip_profile_enable(int on);
+int zkhip_profile_read(double *ms, char (*names)[64], int max);
+
 /* ---- parity hooks for the field / curve layer (rows a1/a2 of SURVEY.md section 8) ------------------ */
 /* field: 0 = Fq, 1 = Fr.  op: 0 mul, 1 add, 2 sub, 3 square (b ignored).  Elementwise on n elements. */
 int zkhip_test_field_op(int field, int op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);

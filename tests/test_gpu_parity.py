@@ -1,0 +1,284 @@
+"""GPU (-m gpu): parity of the HIP path (through the C ABI) with the oracle.  Bit-exact: field / NTT outputs are
+compared limb for limb, MSM outputs after affine normalisation (Jacobian representatives are not unique)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import zksnap_circuits_halo2_amd as Z
+from oracle import bn254 as O
+from zksnap_circuits_halo2_amd import _lib, fields as F
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+unhex = lambda s: [int(s[i:i + 16], 16) for i in range(0, len(s), 16)]
+
+
+def aff(cref, xyz):
+    """canonical affine limbs of a Jacobian result (also checks the limbs are canonical Montgomery values)."""
+    return cref.jac_to_affine(np.ascontiguousarray(xyz))
+
+
+def structured_expect(cref, sc, t0, d):
+    return cref.jac_to_affine(cref.scalar_mul(cref.expected_scalar(sc, t0, d), cref.generator()))
+
+
+# ---------------------------------------------------------------- rows a1 / a2: field and curve layer
+@pytest.mark.parametrize("field", [0, 1])
+def test_field_ops_vs_oracle(lib, cref, field):
+    p = O.Q_MOD if field == 0 else O.R_MOD
+    n = 1 << 16
+    g = O.SplitMix64(17 + field)
+    a = np.array([O.limbs4(g.fr() % p) for _ in range(n)], dtype=np.uint64)   # arbitrary canonical limb patterns
+    b = np.array([O.limbs4(g.fr() % p) for _ in range(n)], dtype=np.uint64)
+    edge = [0, 1, p - 1, p - 2, (p - 1) // 2, O.to_mont(1, p), O.to_mont(p - 1, p), (1 << 253) % p]
+    for i, e in enumerate(edge):
+        a[i] = O.limbs4(e)
+        b[i] = O.limbs4(edge[(3 * i + 1) % len(edge)])
+    for op in range(4):
+        out = np.zeros_like(a)
+        _lib.check(lib.zkhip_test_field_op(field, op, a.ctypes.data, b.ctypes.data, out.ctypes.data, n))
+        assert np.array_equal(out, cref.field_op(field, op, a, b)), f"field {field} op {op}"
+
+
+def test_curve_ops_vs_oracle(lib, cref):
+    n = 2048
+    A, _, _ = cref.gen_bases(5, n)
+    B, _, _ = cref.gen_bases(6, n)
+    A[3] = 0; B[4] = 0; A[5] = 0; B[5] = 0          # identities on either / both sides
+    B[6] = A[6]                                      # doubling through the mixed add
+    B[7] = A[7]; B[7, 4:8] = F.g1_encode([O.neg(O.affine_from_limbs([int(x) for x in A[7]]))])[0, 4:8]   # P + (-P)
+    pts = lambda M: [O.affine_from_limbs([int(x) for x in r]) for r in M[:64]]
+    for op, f in ((0, lambda P, Q: O.add(P, Q)), (1, lambda P, Q: O.add(P, P)), (2, lambda P, Q: O.add(P, O.neg(Q)))):
+        out = np.zeros((n, 12), dtype=np.uint64)
+        _lib.check(lib.zkhip_test_g1_op(op, A.ctypes.data, B.ctypes.data, out.ctypes.data, n))
+        got = [F.g1_decode_jacobian(out[i]) for i in range(64)]
+        assert got == [f(P, Q) for P, Q in zip(pts(A), pts(B))], f"g1 op {op}"
+        # the rest against the C oracle: G1Affine -> G1 (z = 1), then jac_add / doubling
+        one = np.array(O.limbs4(O.to_mont(1, O.Q_MOD)), dtype=np.uint64)
+        tojac = lambda r: np.concatenate([r, one]) if r.any() else np.zeros(12, dtype=np.uint64)
+        for i in range(64, n, 7):
+            ja, jb = tojac(A[i]), tojac(B[i])
+            if op == 1:
+                jb = ja
+            elif op == 2 and jb.any():
+                jb = jb.copy()
+                jb[4:8] = cref.field_op(0, 2, np.zeros((1, 4), dtype=np.uint64), jb[4:8].reshape(1, 4))[0]
+            assert np.array_equal(cref.jac_to_affine(out[i]), cref.jac_to_affine(cref.jac_add(ja, jb))), (op, i)
+        assert F.g1_decode_jacobian(out[5]) is None or op == 1
+
+
+# ---------------------------------------------------------------- row a3: best_multiexp
+def test_msm_golden_vectors(cref):
+    data = json.load(open(os.path.join(GOLD, "msm_g1.json")))
+    for case in data["msm"]:
+        sc = np.array([unhex(s) for s in case["scalars"]], dtype=np.uint64).reshape(-1, 4)
+        bs = np.array([unhex(s) for s in case["bases"]], dtype=np.uint64).reshape(-1, 8)
+        got = aff(cref, Z.best_multiexp(sc, bs))
+        assert [int(x) for x in got] == unhex(case["expected_affine"]), case["name"]
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 4, 31, 32, 33, 100, 257, 1000, 4097, 1 << 13, (1 << 15) + 5, 1 << 16])
+@pytest.mark.parametrize("kind", [0, 1])
+def test_msm_vs_reference_algorithm(cref, n, kind):
+    """same seeded inputs through the HIP path and through the C restatement of best_multiexp (8 threads)."""
+    bases, t0, d = cref.gen_bases(100 + n, n)
+    sc = cref.gen_scalars(200 + n + kind, n, kind)
+    if n >= 100:
+        sc[3] = 0; sc[4] = F.fr_encode([1])[0]; sc[5] = F.fr_encode([O.R_MOD - 1])[0]; sc[6] = F.fr_encode([1 << 253])[0]
+        bases[9] = 0                                   # identity base with a non-zero scalar
+        bases[11] = bases[10]; sc[11] = sc[10]         # repeated (base, scalar): forces a doubling inside a bucket
+    got = aff(cref, Z.best_multiexp(sc, bases))
+    assert np.array_equal(got, aff(cref, cref.best_multiexp(sc, bases, 8)))
+    if n < 100:
+        assert np.array_equal(got, structured_expect(cref, sc, t0, d))
+
+
+def test_msm_rejects_length_mismatch():
+    with pytest.raises(AssertionError):
+        Z.best_multiexp(np.zeros((3, 4), dtype=np.uint64), np.zeros((4, 8), dtype=np.uint64))
+
+
+@pytest.mark.parametrize("c", list(range(2, 17)))
+def test_msm_every_window_size(lib, cref, c):
+    import torch
+
+    n = 3000
+    bases, t0, d = cref.gen_bases(7, n)
+    sc = cref.gen_scalars(8 + c, n, c % 2)
+    dsc = torch.from_numpy(sc.view(np.int64)).cuda()
+    dbs = torch.from_numpy(bases.view(np.int64)).cuda()
+    dout = torch.zeros(12, dtype=torch.int64, device="cuda")
+    _lib.check(lib.zkhip_msm_g1_device_c(dsc.data_ptr(), dbs.data_ptr(), n, dout.data_ptr(), c, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    got = aff(cref, dout.cpu().numpy().view(np.uint64))
+    assert np.array_equal(got, structured_expect(cref, sc, t0, d))
+
+
+def test_msm_heavy_buckets_and_degenerate_inputs(cref):
+    n = 1 << 15
+    bases, t0, d = cref.gen_bases(31, 64)
+    bases = np.ascontiguousarray(np.tile(bases, (n // 64, 1)))      # every base repeated 512 times
+    one = F.fr_encode([1])[0]
+    for name, sc in (("all ones", np.tile(one, (n, 1))), ("all equal", np.tile(cref.gen_scalars(1, 1, 0), (n, 1))),
+                     ("witness-like", cref.gen_scalars(9, n, 1)), ("all zero", np.zeros((n, 4), dtype=np.uint64))):
+        sc = np.ascontiguousarray(sc, dtype=np.uint64)
+        got = aff(cref, Z.best_multiexp(sc, bases))
+        assert np.array_equal(got, aff(cref, cref.best_multiexp(sc, bases, 8))), name
+    # all bases identity
+    got = Z.best_multiexp(cref.gen_scalars(2, 500, 0), np.zeros((500, 8), dtype=np.uint64))
+    assert F.g1_decode_jacobian(got) is None
+
+
+def test_msm_registered_bases_and_subranges(lib, cref):
+    n = 5000
+    bases, t0, d = cref.gen_bases(77, n)
+    params = Z.ParamsKZG(13, np.ascontiguousarray(np.vstack([bases, np.zeros((8192 - n, 8), dtype=np.uint64)])))
+    try:
+        sc = cref.gen_scalars(78, n, 0)
+        full = aff(cref, params.commit(sc))
+        assert np.array_equal(full, structured_expect(cref, sc, t0, d))
+        # prefix of the registered array (commit of a shorter polynomial) and an interior slice
+        assert np.array_equal(aff(cref, params.commit(sc[:1234])), aff(cref, cref.best_multiexp(sc[:1234], bases[:1234], 4)))
+        sl = params.get_g()[100:900]
+        assert np.array_equal(aff(cref, Z.best_multiexp(sc[:800], sl)), aff(cref, cref.best_multiexp(sc[:800], np.ascontiguousarray(bases[100:900]), 4)))
+    finally:
+        params.close()
+
+
+def test_msm_2pow20_structured_identity_and_linearity(lib, cref):
+    """BASELINE config 2 size: MSM(a, (t0 + i d) G) = [sum a_i (t0 + i d)] G, and MSM(a) + MSM(b) = MSM(a + b)."""
+    n = 1 << 20
+    bases, t0, d = cref.gen_bases(0x5A4B534E41500002, n)
+    a = cref.gen_scalars(0x5A4B534E41500003, n, 0)
+    b = cref.gen_scalars(0x5A4B534E41500004, n, 1)
+    lib.zkhip_register_bases(bases.ctypes.data, n)
+    try:
+        ra, rb = Z.best_multiexp(a, bases), Z.best_multiexp(b, bases)
+        assert np.array_equal(aff(cref, ra), structured_expect(cref, a, t0, d))
+        assert np.array_equal(aff(cref, rb), structured_expect(cref, b, t0, d))
+        ab = cref.field_op(1, 1, a, b)
+        assert np.array_equal(aff(cref, Z.best_multiexp(ab, bases)), aff(cref, cref.jac_add(ra, rb)))
+    finally:
+        lib.zkhip_unregister_bases(bases.ctypes.data)
+
+
+# ---------------------------------------------------------------- rows a4 / a5: best_fft and EvaluationDomain
+def test_ntt_golden_vectors():
+    data = json.load(open(os.path.join(GOLD, "ntt_fr.json")))
+    for case in data["ntt"]:
+        a = np.array([unhex(s) for s in case["input"]], dtype=np.uint64).reshape(-1, 4)
+        Z.best_fft(a, np.array(unhex(case["omega"]), dtype=np.uint64), case["log_n"])
+        assert a.tolist() == [unhex(s) for s in case["expected"]], case["log_n"]
+    dcase = data["domain"]
+    dom = Z.EvaluationDomain(dcase["j"], dcase["k"])
+    H = lambda key: np.array([unhex(s) for s in dcase[key]], dtype=np.uint64).reshape(-1, 4)
+    coeffs, ext = H("coeffs"), H("coeff_to_extended")
+    assert np.array_equal(dom.lagrange_to_coeff(coeffs), H("lagrange_to_coeff"))
+    assert np.array_equal(dom.coeff_to_extended(coeffs), ext)
+    assert np.array_equal(dom.divide_by_vanishing_poly(ext), H("divide_by_vanishing_poly"))
+    assert np.array_equal(dom.extended_to_coeff(ext), H("extended_to_coeff"))
+
+
+@pytest.mark.parametrize("log_n", list(range(0, 21)))
+def test_ntt_vs_reference_algorithm(cref, log_n):
+    a = cref.gen_scalars(300 + log_n, 1 << log_n, log_n % 2)
+    omega = F.fr_encode([O.omega_for(log_n)])[0]
+    ref = a.copy()
+    cref.best_fft(ref, omega, log_n, 8)
+    Z.best_fft(a, omega, log_n)
+    assert np.array_equal(a, ref)
+
+
+@pytest.mark.parametrize("log_n", [22, 24])
+def test_ntt_large_round_trip_and_spot_check(cref, log_n):
+    """BASELINE sizes: iNTT(NTT(a)) = a limb for limb; NTT(delta_1) = powers of omega; one full compare at 2^22."""
+    n = 1 << log_n
+    w = O.omega_for(log_n)
+    omega, omega_inv = F.fr_encode([w])[0], F.fr_encode([pow(w, -1, O.R_MOD)])[0]
+    a = cref.gen_scalars(400 + log_n, n, 0)
+    orig = a.copy()
+    Z.best_fft(a, omega, log_n)
+    if log_n == 22:
+        ref = orig.copy()
+        cref.best_fft(ref, omega, log_n, 16)
+        assert np.array_equal(a, ref)
+    dom_div = F.fr_encode([pow(n, -1, O.R_MOD)])[0]
+    _lib.check(_lib.load().zkhip_ifft_scaled(a.ctypes.data, omega_inv.ctypes.data, log_n, dom_div.ctypes.data))
+    assert np.array_equal(a, orig)
+    delta = np.zeros((n, 4), dtype=np.uint64)
+    delta[1] = F.fr_encode([1])[0]
+    Z.best_fft(delta, omega, log_n)
+    idx = [0, 1, 2, 12345, n // 2, n - 1]
+    assert F.fr_decode(delta[idx]) == [pow(w, i, O.R_MOD) for i in idx]
+
+
+@pytest.mark.parametrize("j,k", [(4, 3), (4, 7), (4, 10), (4, 13), (3, 9), (5, 8), (4, 15)])
+def test_evaluation_domain_vs_reference_algorithm(cref, j, k):
+    dom = Z.EvaluationDomain(j, k)
+    a = cref.gen_scalars(500 + k, dom.n, 0)
+    # lagrange_to_coeff = best_fft(omega_inv) then * ifft_divisor
+    ref = a.copy()
+    cref.best_fft(ref, dom.omega_inv, k, 4)
+    cref.scale(ref, dom.ifft_divisor)
+    assert np.array_equal(dom.lagrange_to_coeff(a), ref)
+    # coeff_to_extended = distribute_powers_zeta(into) + zero pad + best_fft(extended_omega)
+    ext = np.zeros((dom.extended_len(), 4), dtype=np.uint64)
+    ext[: dom.n] = a
+    cref.distribute_powers_zeta(ext[: dom.n], dom.g_coset, dom.g_coset_inv)
+    cref.best_fft(ext, dom.extended_omega, dom.extended_k, 4)
+    got_ext = dom.coeff_to_extended(a)
+    assert np.array_equal(got_ext, ext)
+    # divide_by_vanishing_poly
+    q = ext.copy()
+    cref.mul_periodic(q, dom.t_evaluations)
+    assert np.array_equal(dom.divide_by_vanishing_poly(got_ext), q)
+    # extended_to_coeff = ifft(extended) + distribute_powers_zeta(out of) + truncate
+    back = ext.copy()
+    cref.best_fft(back, dom.extended_omega_inv, dom.extended_k, 4)
+    cref.scale(back, dom.extended_ifft_divisor)
+    cref.distribute_powers_zeta(back, dom.g_coset_inv, dom.g_coset)
+    out = dom.extended_to_coeff(got_ext)
+    assert out.shape[0] == dom.n * dom.quotient_poly_degree
+    assert np.array_equal(out, back[: out.shape[0]])
+    assert np.array_equal(out[: dom.n], a) and not out[dom.n:].any()
+
+
+def test_commit_equals_evaluation_at_trapdoor(cref):
+    """KZG identity on a structured SRS g[i] = s^i G with known s: commit(p) = [p(s)] G."""
+    k, n = 10, 1 << 10
+    g = O.SplitMix64(0x5A4B534E41500001)
+    s = g.fr()
+    # s^i * G = (s^i) * G: build with the C oracle's scalar multiplication
+    Gp = cref.generator()
+    jac = [cref.scalar_mul(pow(s, i, O.R_MOD), Gp) for i in range(n)]
+    srs = np.array([cref.jac_to_affine(j) for j in jac], dtype=np.uint64)
+    params = Z.ParamsKZG(k, srs)
+    try:
+        p = cref.gen_scalars(11, n, 0)
+        coeffs = F.fr_decode(p)
+        ps = 0
+        for c in reversed(coeffs):
+            ps = (ps * s + c) % O.R_MOD
+        assert np.array_equal(aff(cref, params.commit(p)), cref.jac_to_affine(cref.scalar_mul(ps, Gp)))
+    finally:
+        params.close()
+
+
+def test_sharded_msm_single_rank_gpu_path(cref):
+    from zksnap_circuits_halo2_amd.multi_gpu import shard_range, sharded_msm
+
+    n = 10000
+    bases, t0, d = cref.gen_bases(41, n)
+    sc = cref.gen_scalars(42, n, 0)
+    # emulate 3 ranks sequentially on one GPU: partials + device fold
+    parts = []
+    for r in range(3):
+        lo, hi = shard_range(n, r, 3)
+        parts.append(Z.best_multiexp(np.ascontiguousarray(sc[lo:hi]), np.ascontiguousarray(bases[lo:hi])))
+    out = np.zeros(12, dtype=np.uint64)
+    stack = np.ascontiguousarray(np.vstack(parts))
+    _lib.check(_lib.load().zkhip_g1_sum(stack.ctypes.data, 3, out.ctypes.data))
+    assert np.array_equal(aff(cref, out), structured_expect(cref, sc, t0, d))
+    assert np.array_equal(aff(cref, sharded_msm(sc, bases)), structured_expect(cref, sc, t0, d))

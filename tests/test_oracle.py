@@ -1,0 +1,141 @@
+"""CPU: pins the oracle (oracle/bn254.py, oracle/cpu_ref.c) to public constants, known answers, the committed golden
+vectors and to each other.  The reference itself holds no vectors at this boundary (parity unpinned)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import bn254 as O
+from zksnap_circuits_halo2_amd import fields as F
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+unhex = lambda s: [int(s[i:i + 16], 16) for i in range(0, len(s), 16)]
+
+
+def test_field_constants_match_survey():
+    # Montgomery constants of halo2curves bn256::{Fr,Fq} [DEP]
+    assert O.limbs4(O.R_MOD) == [0x43e1f593f0000001, 0x2833e84879b97091, 0xb85045b68181585d, 0x30644e72e131a029]
+    assert O.limbs4(O.MONT_R % O.R_MOD) == [0xac96341c4ffffffb, 0x36fc76959f60cd29, 0x666ea36f7879462e, 0x0e0a77c19a07df2f]
+    assert O.limbs4(O.MONT_R ** 2 % O.R_MOD) == [0x1bb8e645ae216da7, 0x53fe3ab1e35c59e3, 0x8c49833d53bb8085, 0x0216d0b17f4e44a5]
+    assert O.mont_inv64(O.R_MOD) == 0xc2e1f593efffffff
+    assert O.limbs4(O.Q_MOD) == [0x3c208c16d87cfd47, 0x97816a916871ca8d, 0xb85045b68181585d, 0x30644e72e131a029]
+    assert O.limbs4(O.MONT_R % O.Q_MOD) == [0xd35d438dc58f0d9d, 0x0a78eb28f5c70b3d, 0x666ea36f7879462c, 0x0e0a77c19a07df2f]
+    assert O.limbs4(O.MONT_R ** 2 % O.Q_MOD) == [0xf32cfc5b538afa89, 0xb5e71911d44501fb, 0x47ab1eff0a417ff6, 0x06d89f71cab8351f]
+    assert O.mont_inv64(O.Q_MOD) == 0x87d20782e4866389
+
+
+def test_roots_of_unity():
+    assert O.FR_ROOT_OF_UNITY == 0x03ddb9f5166d18b798865ea93dd31f743215cf6dd39329c8d34f1ed960c37c9c
+    assert pow(O.FR_ROOT_OF_UNITY, 1 << 28, O.R_MOD) == 1 and pow(O.FR_ROOT_OF_UNITY, 1 << 27, O.R_MOD) != 1
+    assert O.omega_for(22) == 0x18c95f1ae6514e11a1b30fd7923947c5ffcec5347f16e91b4dd654168326bede
+    assert O.omega_for(24) == 0x1951441010b2b95a6e47a6075066a50a036f5ba978c050f2821df86636c0facb
+    assert pow(O.FR_ZETA, 3, O.R_MOD) == 1 and O.FR_ZETA != 1
+
+
+def test_curve_known_answers():
+    G = O.G1_GEN
+    assert O.on_curve(G)
+    # EIP-196 ecMul vector
+    assert O.scalar_mul(2, G) == (0x030644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd3,
+                                  0x15ed738c0e0a7c92e7845f96b2ae9c0a68a6a449e3538fc7ff3ebf7a5a18a2c4)
+    assert O.scalar_mul(O.R_MOD, G) is None
+    assert O.scalar_mul(O.R_MOD - 1, G) == (1, O.Q_MOD - 2)
+    assert O.scalar_mul(12345, G) == (0x1936f7b07be20ac4b7faac53aba252c44112b369f437c12d75b8157882b390aa,
+                                      0x055c38c27b1dc7fbbdfbb7b4795e92d0d838126c25b6771908f9a23c35c8921a)
+    assert O.add(G, O.neg(G)) is None and O.add(None, G) == G
+
+
+def test_python_oracle_identities():
+    g = O.SplitMix64(42)
+    s = g.fr()
+    srs = O.structured_srs(s, 24)
+    a = [g.fr() for _ in range(24)]
+    horner = sum(x * pow(s, i, O.R_MOD) for i, x in enumerate(a)) % O.R_MOD
+    assert O.best_multiexp(a, srs, threads=1) == O.best_multiexp(a, srs, threads=5) == O.scalar_mul(horner, O.G1_GEN)
+    for L in (0, 1, 4, 6):
+        v = [g.fr() for _ in range(1 << L)]
+        w = O.omega_for(L)
+        f = O.best_fft(v, w, L)
+        assert f == O.dft_naive(v, w)
+        ninv = pow(1 << L, -1, O.R_MOD)
+        assert [x * ninv % O.R_MOD for x in O.best_fft(f, pow(w, -1, O.R_MOD), L)] == v
+    assert O.best_fft([1] + [0] * 15, O.omega_for(4), 4) == [1] * 16
+    d = O.EvaluationDomain(4, 5)
+    p = [g.fr() for _ in range(d.n)]
+    assert d.extended_k == 7 and len(d.t_evaluations) == 4
+    assert d.extended_to_coeff(d.coeff_to_extended(p)) == p + [0] * (2 * d.n)
+    assert d.coeff_to_lagrange(d.lagrange_to_coeff(p)) == p
+
+
+def test_golden_msm_vs_both_oracles(cref):
+    data = json.load(open(os.path.join(GOLD, "msm_g1.json")))
+    assert unhex(data["kat"]["two_G"]) == O.affine_to_limbs(O.scalar_mul(2, O.G1_GEN))
+    for case in data["msm"]:
+        sc = np.array([unhex(s) for s in case["scalars"]], dtype=np.uint64).reshape(-1, 4)
+        bs = np.array([unhex(s) for s in case["bases"]], dtype=np.uint64).reshape(-1, 8)
+        exp = unhex(case["expected_affine"])
+        ints = [O.fr_from_limbs([int(x) for x in r]) for r in sc]
+        pts = [O.affine_from_limbs([int(x) for x in r]) for r in bs]
+        assert O.affine_to_limbs(O.msm_naive(ints, pts)) == exp, case["name"]
+        for threads in (1, 3):
+            got = cref.jac_to_affine(cref.best_multiexp(sc, bs, threads))
+            assert [int(x) for x in got] == exp, (case["name"], threads)
+
+
+def test_golden_ntt_vs_both_oracles(cref):
+    data = json.load(open(os.path.join(GOLD, "ntt_fr.json")))
+    for case in data["ntt"]:
+        L = case["log_n"]
+        a = np.array([unhex(s) for s in case["input"]], dtype=np.uint64).reshape(-1, 4)
+        exp = np.array([unhex(s) for s in case["expected"]], dtype=np.uint64).reshape(-1, 4)
+        omega = np.array(unhex(case["omega"]), dtype=np.uint64)
+        assert F.fr_encode(O.best_fft(F.fr_decode(a), F.fr_decode(omega)[0], L)).tolist() == exp.tolist()
+        for threads in (1, 4):
+            b = a.copy()
+            cref.best_fft(b, omega, L, threads)
+            assert np.array_equal(b, exp), (L, threads)
+
+
+@pytest.mark.parametrize("n,threads", [(1, 1), (2, 2), (33, 1), (100, 7), (1000, 8)])
+def test_c_oracle_msm_vs_structured_identity(cref, n, threads):
+    bases, t0, d = cref.gen_bases(1000 + n, n)
+    sc = cref.gen_scalars(2000 + n, n, n % 2)
+    got = cref.jac_to_affine(cref.best_multiexp(sc, bases, threads))
+    exp = cref.jac_to_affine(cref.scalar_mul(cref.expected_scalar(sc, t0, d), cref.generator()))
+    assert np.array_equal(got, exp)
+
+
+def test_c_oracle_matches_python_generators_and_fields(cref):
+    g = O.SplitMix64(77)
+    assert F.fr_decode(cref.gen_scalars(77, 50, 0)) == [g.fr() for _ in range(50)]
+    assert F.fr_decode(cref.gen_scalars(99, 300, 1)) == O.witness_like_scalars(99, 300)
+    bases, t0, d = cref.gen_bases(11, 12)
+    assert [O.affine_from_limbs([int(x) for x in r]) for r in bases] == [O.scalar_mul((t0 + i * d) % O.R_MOD, O.G1_GEN) for i in range(12)]
+    for field, p in ((0, O.Q_MOD), (1, O.R_MOD)):
+        a = [g.fr() % p for _ in range(64)] + [0, 1, p - 1]
+        b = [g.fr() % p for _ in range(64)] + [p - 1, p - 1, p - 1]
+        enc = lambda v: np.array([O.limbs4(O.to_mont(x, p)) for x in v], dtype=np.uint64)
+        for op, f in ((0, lambda x, y: x * y % p), (1, lambda x, y: (x + y) % p), (2, lambda x, y: (x - y) % p), (3, lambda x, y: x * x % p)):
+            assert np.array_equal(cref.field_op(field, op, enc(a), enc(b)), enc([f(x, y) for x, y in zip(a, b)]))
+
+
+def test_c_oracle_domain_passes(cref):
+    d = O.EvaluationDomain(4, 6)
+    g = O.SplitMix64(5)
+    p = [g.fr() for _ in range(d.n)]
+    a = F.fr_encode(p)
+    enc1 = lambda v: F.fr_encode([v])[0]
+    # coeff_to_extended = distribute_powers_zeta + pad + fft
+    ext = np.zeros((d.extended_len(), 4), dtype=np.uint64)
+    ext[: d.n] = a
+    cref.distribute_powers_zeta(ext[: d.n], enc1(d.g_coset), enc1(d.g_coset_inv))
+    cref.best_fft(ext, enc1(d.extended_omega), d.extended_k, 2)
+    assert F.fr_decode(ext) == d.coeff_to_extended(p)
+    q = ext.copy()
+    cref.mul_periodic(q, F.fr_encode(d.t_evaluations))
+    assert F.fr_decode(q) == d.divide_by_vanishing_poly(F.fr_decode(ext))
+    cref.best_fft(ext, enc1(d.extended_omega_inv), d.extended_k, 2)
+    cref.scale(ext, enc1(d.extended_ifft_divisor))
+    cref.distribute_powers_zeta(ext, enc1(d.g_coset_inv), enc1(d.g_coset))
+    assert F.fr_decode(ext[: 3 * d.n]) == p + [0] * (2 * d.n)

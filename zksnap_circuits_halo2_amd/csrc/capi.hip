@@ -20,6 +20,31 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// ---- profiler -------------------------------------------------------------------------------------
+static bool g_prof_on = false;
+static const int PROF_MAX = 32;
+static hipEvent_t g_prof_ev[PROF_MAX + 1];
+static bool g_prof_ev_ready = false;
+static int g_prof_n = 0;   // number of marks recorded after the begin event
+static char g_prof_names[PROF_MAX][64];
+
+void prof_begin(hipStream_t stream) {
+  if (!g_prof_on) return;
+  if (!g_prof_ev_ready) {
+    for (int i = 0; i <= PROF_MAX; i++) (void)hipEventCreate(&g_prof_ev[i]);
+    g_prof_ev_ready = true;
+  }
+  g_prof_n = 0;
+  (void)hipEventRecord(g_prof_ev[0], stream);
+}
+
+void prof_mark(hipStream_t stream, const char* name) {
+  if (!g_prof_on || !g_prof_ev_ready || g_prof_n >= PROF_MAX) return;
+  snprintf(g_prof_names[g_prof_n], 64, "%s", name);
+  g_prof_n++;
+  (void)hipEventRecord(g_prof_ev[g_prof_n], stream);
+}
+
 int ntt_transform(const uint32_t* d_in, uint32_t in_len, uint32_t* d_out, uint32_t out_len, uint32_t L,
                   const uint32_t omega_ext[8], const uint32_t* in_scale, uint32_t in_period, const uint32_t* out_scale,
                   uint32_t out_period, hipStream_t stream);
@@ -326,6 +351,36 @@ int zkhip_mul_periodic(uint64_t* a, size_t n, const uint64_t* table, uint32_t pe
   HIPCHK(hipMemcpyAsync(a, g_ctx.poly.p, n * 32, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   return ZKHIP_OK;
+}
+
+int zkhip_profile_enable(int on) {
+  guard_t g(g_mu);
+  g_prof_on = on != 0;
+  g_prof_n = 0;
+  return ZKHIP_OK;
+}
+
+int zkhip_profile_read(double* ms, char (*names)[64], int max) {
+  guard_t g(g_mu);
+  if (!g_prof_ev_ready || g_prof_n == 0) return 0;
+  if (hipEventSynchronize(g_prof_ev[g_prof_n]) != hipSuccess) { set_error("profile_read: event sync failed"); return ZKHIP_EHIP; }
+  for (int i = 0; i < g_prof_n && i < max; i++) {
+    float t = 0;
+    (void)hipEventElapsedTime(&t, g_prof_ev[i], g_prof_ev[i + 1]);
+    if (ms) ms[i] = t;
+    if (names) snprintf(names[i], 64, "%s", g_prof_names[i]);
+  }
+  return g_prof_n;
+}
+
+int zkhip_g1_gen_walk_device(const uint64_t t0[4], const uint64_t d[4], size_t n, void* d_out, void* stream) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (!t0 || !d || (n && !d_out)) { set_error("gen_walk: null pointer"); return ZKHIP_EINVAL; }
+  if ((rc = g_ctx.ws.reserve(g1_gen_walk_workspace(n))) != ZKHIP_OK) return rc;
+  return g1_gen_walk_device((const uint32_t*)t0, (const uint32_t*)d, n, (uint32_t*)d_out, g_ctx.ws.p, g_ctx.ws.cap,
+                            stream ? (hipStream_t)stream : g_ctx.stream);
 }
 
 // ---- parity hooks ----------------------------------------------------------------------------------

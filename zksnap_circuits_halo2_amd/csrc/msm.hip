@@ -24,10 +24,13 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include "ec.hpp"
 #include "zkhip_internal.hpp"
 
 namespace zkhip {
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 constexpr int TASK_LEN = 64;       // max entries per accumulate task
 constexpr int HEAVY_TASKS = 16;    // buckets with more task partials than this go to the wave-cooperative combine
@@ -60,6 +63,17 @@ __device__ __forceinline__ void store_xyzz(uint32_t* base, size_t idx, const xyz
   uint4* q = reinterpret_cast<uint4*>(base + idx * 36);
 #pragma unroll
   for (int i = 0; i < 9; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+
+__device__ __forceinline__ fe load_fe9_generic(const uint32_t* p, size_t idx) {
+  fe r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = p[idx * 9 + i];
+  return r;
+}
+__device__ __forceinline__ void store_fe9_generic(uint32_t* p, size_t idx, const fe& a) {
+#pragma unroll
+  for (int i = 0; i < 9; i++) p[idx * 9 + i] = a.l[i];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -386,7 +400,6 @@ int msm_pick_window(size_t n) {
   return best;
 }
 
-static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 size_t msm_workspace_bytes(size_t n, int c) {
   const size_t W = (256 + c - 1) / c, B = (size_t)1 << (c - 1), NB = W * B;
@@ -444,8 +457,10 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   uint32_t* winsum = (uint32_t*)carve((size_t)W * 144);
   uint32_t* counters = (uint32_t*)carve(1024);   // [0] total entries, [1] total tasks, [2] heavy count
 
+  prof_begin(stream);
   // 1. digits
   hipLaunchKernelGGL(k_digits, dim3((n + 255) / 256), dim3(256), 0, stream, d_scalars, digits, (uint32_t)n, c, W);
+  prof_mark(stream, "digits");
   // 2. count
   HIPCHK(hipMemsetAsync(count, 0, (NB + 1) * sizeof(uint32_t), stream));
   HIPCHK(hipMemsetAsync(counters, 0, 1024, stream));
@@ -461,27 +476,33 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
     attr_set = true;
   }
   hipLaunchKernelGGL(k_sort_pass<false>, dim3(chunks, W), dim3(1024), lds, stream, digits, (uint32_t)n, chunk, c, count, (uint32_t*)nullptr);
+  prof_mark(stream, "count");
   // 3. scan counts -> offset (+ cursor copy)
   const uint32_t nblk = (NB + SCAN_TILE - 1) / SCAN_TILE;
   hipLaunchKernelGGL(k_scan_sums<0>, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, count, NB, bsum1);
   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_BLOCK), 0, stream, bsum1, nblk, counters + 0);
   hipLaunchKernelGGL(k_scan_apply<0>, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, count, NB, bsum1, counters + 0, offset, cursor);
+  prof_mark(stream, "scan");
   // 4. scatter
   hipLaunchKernelGGL(k_sort_pass<true>, dim3(chunks, W), dim3(1024), lds, stream, digits, (uint32_t)n, chunk, c, cursor, sorted);
+  prof_mark(stream, "scatter");
   // 5. tasks
   hipLaunchKernelGGL(k_scan_sums<1>, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, count, NB, bsum2);
   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_BLOCK), 0, stream, bsum2, nblk, counters + 1);
   hipLaunchKernelGGL(k_scan_apply<1>, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, count, NB, bsum2, counters + 1, task_off, (uint32_t*)nullptr);
   hipLaunchKernelGGL(k_make_tasks, dim3((NB + 255) / 256), dim3(256), 0, stream, offset, task_off, NB, tasks, counters + 2, heavy_list);
+  prof_mark(stream, "tasks");
   // 6. accumulate (grid-stride over the device-side task count)
   {
     uint32_t blocks = (uint32_t)((max_tasks + 127) / 128);
     if (blocks > 256 * 64) blocks = 256 * 64;
     hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(128), 0, stream, tasks, counters + 1, sorted, d_bases, partials);
   }
+  prof_mark(stream, "accumulate");
   // 7. combine
   hipLaunchKernelGGL(k_combine_light, dim3((NB + 127) / 128), dim3(128), 0, stream, task_off, NB, partials, pyrA);
   hipLaunchKernelGGL(k_combine_heavy, dim3(256), dim3(256), 0, stream, task_off, counters + 2, heavy_list, partials, pyrA);
+  prof_mark(stream, "combine");
   // 8. pyramid: buckets were written with window stride B (dense).  Steps 1 .. c-2 leave X with 2 elements.
   uint32_t* cur = pyrA;
   uint32_t* nxt = pyrB;
@@ -501,6 +522,7 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
     }
     nz = s - 1;   // number of Z rows, one element each (B == 2: none; B == 1 handled below)
   }
+  prof_mark(stream, "pyramid");
   // 9. Horner + fold
   if (B == 1) {
     // c == 1 is excluded (c >= 2), so B >= 2 always; keep the guard for clarity
@@ -508,7 +530,120 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
     return ZKHIP_EINVAL;
   }
   hipLaunchKernelGGL(k_window_horner, dim3((W + 63) / 64), dim3(64), 0, stream, cur, in_stride, nz, winsum, W);
+  prof_mark(stream, "horner");
   hipLaunchKernelGGL(k_fold, dim3(1), dim3(64), 0, stream, winsum, W, c, d_out);
+  prof_mark(stream, "fold");
+  HIPCHK(hipGetLastError());
+  return ZKHIP_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// synthetic bases: out[i] = (t0 + i d) G.  Thread j owns GEN_CHUNK consecutive points: start = (t0 + j CH d) G by
+// double-and-add, then a walk of XYZZ additions of D = d G, then Montgomery-trick normalisation of its chunk.
+// ------------------------------------------------------------------------------------------------
+constexpr int GEN_CHUNK = 32;
+
+__device__ xyzz scalar_mul_affine(const fe& k_canon_packed_as_fe_unused, const uint32_t (&kw)[8], const fe& gx, const fe& gy) {
+  xyzz acc = xyzz_identity();
+  for (int bit = 255; bit >= 0; bit--) {
+    acc = xyzz_dbl(acc);
+    if ((kw[bit >> 5] >> (bit & 31)) & 1) xyzz_madd(acc, gx, gy);
+  }
+  return acc;
+}
+
+__device__ fe fq_inverse(const fe& a) {   // a^(q-2), a reduced (< 2p), result < 2p
+  // exponent q - 2 as 8 x u32 (little endian)
+  const uint32_t e[8] = {0xd87cfd45u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+  fe acc = fe_one<Fq>();
+  for (int bit = 253; bit >= 0; bit--) {
+    acc = fe_sqr<Fq>(acc);
+    if ((e[bit >> 5] >> (bit & 31)) & 1) acc = fe_mul<Fq>(acc, a);
+  }
+  return acc;
+}
+
+__global__ void __launch_bounds__(64) k_gen_walk(const uint32_t* __restrict__ t0_d /* 16 words: t0, d (Montgomery-256) */,
+                                                 uint32_t n, uint32_t* __restrict__ out, uint32_t* __restrict__ tmp_pts,
+                                                 uint32_t* __restrict__ tmp_pref) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lo = j * GEN_CHUNK;
+  if (lo >= n) return;
+  const uint32_t cnt = min((uint32_t)GEN_CHUNK, n - lo);
+  // scalars: k = t0 + lo * d in Fr
+  uint32_t w0[8], wd[8], kw[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) { w0[i] = t0_d[i]; wd[i] = t0_d[8 + i]; }
+  fe one_r = fe_one<FrParams>();
+  fe t0 = fe_mul<FrParams>(one_r, fe_from_ext_lazy(w0));          // t0 * 2^261
+  fe dd = fe_mul<FrParams>(one_r, fe_from_ext_lazy(wd));
+  fe lo_f = fe_zero();
+  lo_f.l[0] = lo & LMASK; lo_f.l[1] = lo >> LB;                   // plain integer lo
+  fe r2; 
+#pragma unroll
+  for (int i = 0; i < NL; i++) r2.l[i] = FrParams::R2[i];
+  fe lo_m = fe_mul<FrParams>(r2, lo_f);                           // lo * 2^261
+  fe k = fe_norm(fe_add(t0, fe_mul<FrParams>(lo_m, dd)));         // < 4p
+  fe raw1;
+#pragma unroll
+  for (int i = 0; i < NL; i++) raw1.l[i] = FrParams::RAW_ONE[i];
+  fe kc = fe_canon_lt2p<FrParams>(fe_mul<FrParams>(raw1, k));      // canonical integer
+  fe_pack(kc, kw);
+  fe dc = fe_canon_lt2p<FrParams>(fe_mul<FrParams>(raw1, dd));
+  uint32_t dw[8];
+  fe_pack(dc, dw);
+  // generator (1, 2) in internal Montgomery form
+  fe gx = fe_one<Fq>();
+  fe gy = fe_norm(fe_dbl(gx));
+  xyzz P = scalar_mul_affine(kc, kw, gx, gy);
+  xyzz D = scalar_mul_affine(dc, dw, gx, gy);
+  // walk + prefix products of w_i = ZZ_i * ZZZ_i (identity points contribute 1)
+  fe pref = fe_one<Fq>();
+  for (uint32_t i = 0; i < cnt; i++) {
+    store_xyzz(tmp_pts, lo + i, P);
+    store_fe9_generic(tmp_pref, lo + i, pref);
+    if (!xyzz_is_identity(P)) pref = fe_mul<Fq>(pref, fe_mul<Fq>(P.ZZ, P.ZZZ));
+    P = xyzz_add(P, D);
+  }
+  fe inv = fq_inverse(pref);
+  for (uint32_t ii = cnt; ii-- > 0;) {
+    xyzz Q = load_xyzz(tmp_pts, lo + ii);
+    uint32_t* o = out + (size_t)(lo + ii) * 16;
+    if (xyzz_is_identity(Q)) {
+#pragma unroll
+      for (int t = 0; t < 16; t++) o[t] = 0;
+      continue;
+    }
+    fe pre = load_fe9_generic(tmp_pref, lo + ii);
+    fe winv = fe_mul<Fq>(inv, pre);                               // 1 / (ZZ * ZZZ)
+    inv = fe_mul<Fq>(inv, fe_mul<Fq>(Q.ZZ, Q.ZZZ));
+    fe x = fe_mul<Fq>(fe_mul<Fq>(winv, Q.ZZZ), Q.X);              // X / ZZ
+    fe y = fe_mul<Fq>(fe_mul<Fq>(winv, Q.ZZ), Q.Y);               // Y / ZZZ
+    uint32_t wx[8], wy[8];
+    fe_to_ext<Fq>(x, wx);
+    fe_to_ext<Fq>(y, wy);
+#pragma unroll
+    for (int t = 0; t < 8; t++) { o[t] = wx[t]; o[8 + t] = wy[t]; }
+  }
+}
+
+size_t g1_gen_walk_workspace(size_t n) { return align_up(n * 144, 256) + align_up(n * 36, 256) + 256; }
+
+int g1_gen_walk_device(const uint32_t t0_ext[8], const uint32_t d_ext[8], size_t n, uint32_t* d_out, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (n == 0) return ZKHIP_OK;
+  if (n >= (1ull << 31)) { set_error("gen_walk: n too large"); return ZKHIP_EINVAL; }
+  if (ws_bytes < g1_gen_walk_workspace(n)) { set_error("gen_walk: workspace too small"); return ZKHIP_EINVAL; }
+  char* p = (char*)ws;
+  uint32_t* tmp_pts = (uint32_t*)p; p += align_up(n * 144, 256);
+  uint32_t* tmp_pref = (uint32_t*)p; p += align_up(n * 36, 256);
+  uint32_t* consts = (uint32_t*)p;
+  uint32_t h[16];
+  memcpy(h, t0_ext, 32); memcpy(h + 8, d_ext, 32);
+  HIPCHK(hipMemcpyAsync(consts, h, 64, hipMemcpyHostToDevice, stream));
+  HIPCHK(hipStreamSynchronize(stream));   // `h` is a stack buffer
+  const uint32_t threads = (uint32_t)((n + GEN_CHUNK - 1) / GEN_CHUNK);
+  hipLaunchKernelGGL(k_gen_walk, dim3((threads + 63) / 64), dim3(64), 0, stream, consts, (uint32_t)n, d_out, tmp_pts, tmp_pref);
   HIPCHK(hipGetLastError());
   return ZKHIP_OK;
 }

@@ -402,6 +402,7 @@ int ntt_transform(const uint32_t* d_in, uint32_t in_len, uint32_t* d_out, uint32
     (void)hipFuncSetAttribute((const void*)k_ntt_pass, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_TILE * 36);
   });
   const uint32_t tile = N < NTT_TILE ? N : NTT_TILE;
+  prof_begin(stream);
   for (int i = 0; i < p->npass; i++) {
     pass_args a;
     memset(&a, 0, sizeof(a));
@@ -414,6 +415,7 @@ int ntt_transform(const uint32_t* d_in, uint32_t in_len, uint32_t* d_out, uint32
     a.src = i == 0 ? d_in : p->tmp[(i - 1) & 1];
     a.dst = a.last ? d_out : p->tmp[i & 1];
     hipLaunchKernelGGL(k_ntt_pass, dim3(N / tile), dim3(tile / 8), (size_t)tile * 36, stream, a);
+    prof_mark(stream, i == 0 ? "ntt_pass0" : (i == 1 ? "ntt_pass1" : (i == 2 ? "ntt_pass2" : "ntt_pass3")));
   }
   HIPCHK(hipGetLastError());
   return ZKHIP_OK;

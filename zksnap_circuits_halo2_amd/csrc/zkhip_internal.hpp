@@ -9,7 +9,13 @@ namespace zkhip {
 
 void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 
+// profiler (capi.hip): when enabled, device paths drop named HIP events on their stream between phases
+void prof_begin(hipStream_t stream);
+void prof_mark(hipStream_t stream, const char* name);
+
 // msm.hip
+int g1_gen_walk_device(const uint32_t t0_ext[8], const uint32_t d_ext[8], size_t n, uint32_t* d_out, void* ws, size_t ws_bytes, hipStream_t stream);
+size_t g1_gen_walk_workspace(size_t n);
 int msm_pick_window(size_t n);
 size_t msm_workspace_bytes(size_t n, int c);
 int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, uint32_t* d_out, void* ws, size_t ws_bytes,
