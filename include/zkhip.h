@@ -42,8 +42,10 @@ int zkhip_device_name(char *buf, size_t len);
  * (n == 0 gives the identity).  out_xyz: Jacobian, canonical Montgomery limbs, any valid representative. */
 int zkhip_msm_g1(const uint64_t *scalars, const uint64_t *bases, size_t n, uint64_t out_xyz[12]);
 
-/* Residency for `ParamsKZG::{g, g_lagrange}` (static per params object): upload once; zkhip_msm_g1
- * recognises `bases` pointers inside a registered range and skips the upload. */
+/* Residency for `ParamsKZG::{g, g_lagrange}` (static per params object): upload once and build the prepared table
+ * (2^(c w) * P_i for every window w: W * 64 bytes per point of HBM, one-time ~25 ms per 2^20 points); zkhip_msm_g1
+ * recognises `bases` pointers inside a registered range (any sub-range), skips the upload and runs the prepared
+ * path: one shared bucket set, no window fold. */
 int zkhip_register_bases(const uint64_t *bases, size_t n);
 int zkhip_unregister_bases(const uint64_t *bases);
 
@@ -68,6 +70,10 @@ int zkhip_mul_periodic(uint64_t *a, size_t n, const uint64_t *table, uint32_t pe
 /* ---- device-resident variants (pointers are HIP device pointers; stream is a hipStream_t or NULL) --- */
 /* Used by the pipeline / bench so that polynomials and scalars stay in HBM between calls. */
 int zkhip_msm_g1_device(const void *d_scalars, const void *d_bases, size_t n, void *d_out_xyz, void *stream);
+/* prepared (fixed-base) path for device-resident bases: the handle owns the table until released */
+int zkhip_prepare_bases_device(const void *d_bases, size_t n, uint64_t *handle);
+int zkhip_release_bases(uint64_t handle);
+int zkhip_msm_g1_prepared_device(uint64_t handle, size_t offset, const void *d_scalars, size_t n, void *d_out_xyz, void *stream);
 /* window-size override for experiments (0 = automatic) */
 int zkhip_msm_g1_device_c(const void *d_scalars, const void *d_bases, size_t n, void *d_out_xyz, int window_bits, void *stream);
 int zkhip_ntt_fr_device(void *d_a, const uint64_t omega[4], uint32_t log_n, void *stream);

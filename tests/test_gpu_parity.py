@@ -147,6 +147,54 @@ def test_msm_registered_bases_and_subranges(lib, cref):
         params.close()
 
 
+@pytest.mark.parametrize("n", [1, 7, 300, 5000, 70001])
+def test_msm_prepared_device_path(lib, cref, n):
+    """fixed-base table path (zkhip_prepare_bases_device): full range, sub-ranges, identity entries, both scalar kinds."""
+    import ctypes as C
+
+    import torch
+
+    bases, t0, d = cref.gen_bases(900 + n, n)
+    if n > 100:
+        bases[17] = 0
+    dbs = torch.from_numpy(bases.view(np.int64)).cuda()
+    h = C.c_uint64(0)
+    _lib.check(lib.zkhip_prepare_bases_device(dbs.data_ptr(), n, C.byref(h)))
+    try:
+        for kind, (off, m) in enumerate([(0, n), (n // 3, n - n // 3), (0, max(1, n // 2))]):
+            sc = cref.gen_scalars(950 + n + kind, m, kind % 2)
+            dsc = torch.from_numpy(sc.view(np.int64)).cuda()
+            dout = torch.zeros(12, dtype=torch.int64, device="cuda")
+            _lib.check(lib.zkhip_msm_g1_prepared_device(h, off, dsc.data_ptr(), m, dout.data_ptr(), None))
+            torch.cuda.synchronize()
+            got = aff(cref, dout.cpu().numpy().view(np.uint64))
+            assert np.array_equal(got, aff(cref, cref.best_multiexp(sc, np.ascontiguousarray(bases[off:off + m]), 8))), (n, off, m)
+        if n > 1000:   # one bucket holding every entry: exercises the combine tree (n/64 partials in a single bucket)
+            sc = np.ascontiguousarray(np.tile(F.fr_encode([1])[0], (n, 1)))
+            dsc = torch.from_numpy(sc.view(np.int64)).cuda()
+            _lib.check(lib.zkhip_msm_g1_prepared_device(h, 0, dsc.data_ptr(), n, dout.data_ptr(), None))
+            torch.cuda.synchronize()
+            assert np.array_equal(aff(cref, dout.cpu().numpy().view(np.uint64)), aff(cref, cref.best_multiexp(sc, bases, 8)))
+        assert lib.zkhip_msm_g1_prepared_device(h, 1, dsc.data_ptr(), n, dout.data_ptr(), None) == -1   # range check
+    finally:
+        _lib.check(lib.zkhip_release_bases(h))
+
+
+def test_gen_walk_matches_oracle(lib, cref):
+    import torch
+
+    n = 3001
+    t0, d = 0x1234567, 0xABCDEF0123456789ABCDEF
+    out = torch.zeros(n * 8, dtype=torch.int64, device="cuda")
+    t0_m, d_m = F.fr_encode([t0])[0], F.fr_encode([d])[0]      # keep the arrays alive across the call
+    _lib.check(lib.zkhip_g1_gen_walk_device(t0_m.ctypes.data, d_m.ctypes.data, n, out.data_ptr(), None))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(np.uint64).reshape(n, 8)
+    for i in (0, 1, 31, 32, 33, 1000, n - 1):
+        exp = cref.jac_to_affine(cref.scalar_mul((t0 + i * d) % O.R_MOD, cref.generator()))
+        assert np.array_equal(got[i], exp), i
+
+
 def test_msm_2pow20_structured_identity_and_linearity(lib, cref):
     """BASELINE config 2 size: MSM(a, (t0 + i d) G) = [sum a_i (t0 + i d)] G, and MSM(a) + MSM(b) = MSM(a + b)."""
     n = 1 << 20

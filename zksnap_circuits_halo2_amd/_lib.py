@@ -23,6 +23,9 @@ _SIGS = {
     "zkhip_extended_to_coeff": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "zkhip_mul_periodic": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32]),
     "zkhip_msm_g1_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "zkhip_prepare_bases_device": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]),
+    "zkhip_release_bases": (C.c_int, [C.c_uint64]),
+    "zkhip_msm_g1_prepared_device": (C.c_int, [C.c_uint64, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "zkhip_msm_g1_device_c": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),
     "zkhip_ntt_fr_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "zkhip_ifft_scaled_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),

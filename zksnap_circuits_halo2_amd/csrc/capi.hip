@@ -74,7 +74,9 @@ struct context {
   int device = 0;
   hipStream_t stream = nullptr;
   dev_buf ws, scalars, bases, poly, poly2, small;
-  std::map<const void*, std::pair<void*, size_t>> registered;   // host ptr -> (device ptr, n points)
+  std::map<const void*, prepared_bases*> registered;   // host ptr -> prepared table (slice 0 of the table = the bases themselves)
+  std::map<uint64_t, prepared_bases*> handles;          // zkhip_prepare_bases_device handles
+  uint64_t next_handle = 1;
 };
 
 static std::recursive_mutex g_mu;
@@ -85,13 +87,13 @@ static int ensure_init() {
   return zkhip_init(nullptr, 0);
 }
 
-// device pointer for `bases` if it lies inside a registered range with room for n points
-static const uint32_t* find_registered(const uint64_t* bases, size_t n) {
+// prepared table + point offset for `bases` if it lies inside a registered range with room for n points
+static const prepared_bases* find_registered(const uint64_t* bases, size_t n, size_t* off) {
   for (auto& kv : g_ctx.registered) {
     const char* lo = (const char*)kv.first;
-    const char* hi = lo + kv.second.second * 64;
+    const char* hi = lo + kv.second->n * 64;
     const char* q = (const char*)bases;
-    if (q >= lo && q + n * 64 <= hi && ((q - lo) % 64) == 0) return (const uint32_t*)((char*)kv.second.first + (q - lo));
+    if (q >= lo && q + n * 64 <= hi && ((q - lo) % 64) == 0) { *off = (size_t)(q - lo) / 64; return kv.second; }
   }
   return nullptr;
 }
@@ -127,8 +129,10 @@ void zkhip_shutdown(void) {
   (void)hipSetDevice(g_ctx.device);
   (void)hipStreamSynchronize(g_ctx.stream);
   ntt_clear_cache();
-  for (auto& kv : g_ctx.registered) (void)hipFree(kv.second.first);
+  for (auto& kv : g_ctx.registered) release_prepared(kv.second);
   g_ctx.registered.clear();
+  for (auto& kv : g_ctx.handles) release_prepared(kv.second);
+  g_ctx.handles.clear();
   g_ctx.ws.release(); g_ctx.scalars.release(); g_ctx.bases.release(); g_ctx.poly.release(); g_ctx.poly2.release(); g_ctx.small.release();
   (void)hipStreamDestroy(g_ctx.stream);
   g_ctx.stream = nullptr;
@@ -174,17 +178,24 @@ int zkhip_msm_g1(const uint64_t* scalars, const uint64_t* bases, size_t n, uint6
   hipStream_t s = g_ctx.stream;
   if ((rc = g_ctx.small.reserve(4096)) != ZKHIP_OK) return rc;
   const uint32_t* d_bases = nullptr;
+  const prepared_bases* pb = nullptr;
+  size_t off = 0;
   if (n) {
     if ((rc = g_ctx.scalars.reserve(n * 32)) != ZKHIP_OK) return rc;
     HIPCHK(hipMemcpyAsync(g_ctx.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, s));
-    d_bases = find_registered(bases, n);
-    if (!d_bases) {
+    pb = find_registered(bases, n, &off);
+    if (!pb) {
       if ((rc = g_ctx.bases.reserve(n * 64)) != ZKHIP_OK) return rc;
       HIPCHK(hipMemcpyAsync(g_ctx.bases.p, bases, n * 64, hipMemcpyHostToDevice, s));
       d_bases = (const uint32_t*)g_ctx.bases.p;
     }
   }
-  rc = zkhip_msm_g1_device_c(g_ctx.scalars.p, d_bases, n, g_ctx.small.p, 0, s);
+  if (pb) {
+    if ((rc = g_ctx.ws.reserve(msm_workspace_bytes(n, pb->c))) != ZKHIP_OK) return rc;
+    rc = msm_g1_device((const uint32_t*)g_ctx.scalars.p, nullptr, n, (uint32_t*)g_ctx.small.p, g_ctx.ws.p, g_ctx.ws.cap, 0, s, pb, off);
+  } else {
+    rc = zkhip_msm_g1_device_c(g_ctx.scalars.p, d_bases, n, g_ctx.small.p, 0, s);
+  }
   if (rc != ZKHIP_OK) return rc;
   HIPCHK(hipMemcpyAsync(out_xyz, g_ctx.small.p, 96, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
@@ -197,11 +208,47 @@ int zkhip_register_bases(const uint64_t* bases, size_t n) {
   if (rc != ZKHIP_OK) return rc;
   if (!bases || n == 0) { set_error("register_bases: empty"); return ZKHIP_EINVAL; }
   if (g_ctx.registered.count(bases)) zkhip_unregister_bases(bases);
-  void* d = nullptr;
-  if (hipMalloc(&d, n * 64) != hipSuccess) { set_error("register_bases: hipMalloc(%zu) failed", n * 64); return ZKHIP_ENOMEM; }
-  if (hipMemcpy(d, bases, n * 64, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); set_error("register_bases: upload failed"); return ZKHIP_EHIP; }
-  g_ctx.registered[bases] = std::make_pair(d, n);
+  if ((rc = g_ctx.bases.reserve(n * 64)) != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(g_ctx.bases.p, bases, n * 64, hipMemcpyHostToDevice, g_ctx.stream));
+  prepared_bases* pb = nullptr;
+  if ((rc = prepare_bases_device((const uint32_t*)g_ctx.bases.p, n, g_ctx.stream, &pb)) != ZKHIP_OK) return rc;
+  g_ctx.registered[bases] = pb;
   return ZKHIP_OK;
+}
+
+int zkhip_prepare_bases_device(const void* d_bases, size_t n, uint64_t* handle) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (!d_bases || !handle || n == 0) { set_error("prepare_bases: bad argument"); return ZKHIP_EINVAL; }
+  prepared_bases* pb = nullptr;
+  if ((rc = prepare_bases_device((const uint32_t*)d_bases, n, g_ctx.stream, &pb)) != ZKHIP_OK) return rc;
+  *handle = g_ctx.next_handle++;
+  g_ctx.handles[*handle] = pb;
+  return ZKHIP_OK;
+}
+
+int zkhip_release_bases(uint64_t handle) {
+  guard_t g(g_mu);
+  auto it = g_ctx.handles.find(handle);
+  if (it == g_ctx.handles.end()) { set_error("release_bases: unknown handle"); return ZKHIP_EINVAL; }
+  (void)hipDeviceSynchronize();
+  release_prepared(it->second);
+  g_ctx.handles.erase(it);
+  return ZKHIP_OK;
+}
+
+int zkhip_msm_g1_prepared_device(uint64_t handle, size_t offset, const void* d_scalars, size_t n, void* d_out_xyz, void* stream) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  auto it = g_ctx.handles.find(handle);
+  if (it == g_ctx.handles.end()) { set_error("msm_prepared: unknown handle"); return ZKHIP_EINVAL; }
+  if (!d_out_xyz || (n && !d_scalars)) { set_error("msm_prepared: null pointer"); return ZKHIP_EINVAL; }
+  const prepared_bases* pb = it->second;
+  if ((rc = g_ctx.ws.reserve(n ? msm_workspace_bytes(n, pb->c) : 0)) != ZKHIP_OK) return rc;
+  return msm_g1_device((const uint32_t*)d_scalars, nullptr, n, (uint32_t*)d_out_xyz, g_ctx.ws.p, g_ctx.ws.cap, 0,
+                       stream ? (hipStream_t)stream : g_ctx.stream, pb, offset);
 }
 
 int zkhip_unregister_bases(const uint64_t* bases) {
@@ -209,7 +256,7 @@ int zkhip_unregister_bases(const uint64_t* bases) {
   auto it = g_ctx.registered.find(bases);
   if (it == g_ctx.registered.end()) { set_error("unregister_bases: pointer not registered"); return ZKHIP_EINVAL; }
   (void)hipStreamSynchronize(g_ctx.stream);
-  (void)hipFree(it->second.first);
+  release_prepared(it->second);
   g_ctx.registered.erase(it);
   return ZKHIP_OK;
 }

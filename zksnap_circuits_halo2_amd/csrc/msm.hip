@@ -12,10 +12,10 @@
 //   3. scan        exclusive scan of the counts -> bucket offsets
 //   4. scatter     same tiling: LDS histogram again, one ranged global atomicAdd per non-empty bucket reserves
 //                  the slot range, LDS cursors place (point index | sign<<31) -> counting sort by bucket
-//   5. tasks       buckets are cut into tasks of <= TASK_LEN entries (load balance independent of the
-//                  scalar distribution: a bucket holding 100k points becomes 100k/TASK_LEN tasks)
+//   5. tasks       buckets are cut into tasks of <= 2^task_shift entries (load balance independent of the
+//                  scalar distribution: a bucket holding 100k points becomes 100k / 2^task_shift tasks)
 //   6. accumulate  one thread per task, XYZZ accumulator in registers, mixed additions
-//   7. combine     per bucket: sum of its task partials (wave-cooperative for very heavy buckets)
+//   7. combine     per bucket: in-place radix-4 tree over its task partials (any skew)
 //   8. reduce      log-depth pyramid: sum_k (k+1) B_k = Tot + sum_l 2^l T_l,  T_l = sum of buckets with bit l
 //   9. fold        Horner over the T_l and over the windows
 //
@@ -25,6 +25,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include "ec.hpp"
 #include "zkhip_internal.hpp"
 
@@ -32,8 +33,9 @@ namespace zkhip {
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-constexpr int TASK_LEN = 64;       // max entries per accumulate task
-constexpr int HEAVY_TASKS = 16;    // buckets with more task partials than this go to the wave-cooperative combine
+constexpr int TASK_SHIFT = 6;           // 64 entries per accumulate task: short tasks keep the tail of the launch balanced
+                                        // (measured at 2^22: 5.9 ms with 64-entry tasks, 6.9 ms with 256, 8.1 ms with 512)
+constexpr int COMBINE_LEVELS = 8;       // tree levels above the 64 sequential partials: covers 64 * 4^8 partials per bucket
 
 struct task_t {
   uint32_t bucket, start, len;
@@ -115,7 +117,8 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ sca
 template <bool SCATTER>
 __global__ void __launch_bounds__(1024) k_sort_pass(const int16_t* __restrict__ digits, uint32_t n, uint32_t chunk,
                                                     int c, uint32_t* __restrict__ count_or_cursor,
-                                                    uint32_t* __restrict__ sorted) {
+                                                    uint32_t* __restrict__ sorted, uint32_t win_bucket_stride,
+                                                    uint32_t ref_base, uint32_t ref_stride) {
   extern __shared__ uint32_t hist[];
   const uint32_t B = 1u << (c - 1);
   const int win = blockIdx.y;
@@ -129,7 +132,8 @@ __global__ void __launch_bounds__(1024) k_sort_pass(const int16_t* __restrict__ 
     if (d != 0) atomicAdd(&hist[(d < 0 ? -d : d) - 1], 1u);
   }
   __syncthreads();
-  uint32_t* g = count_or_cursor + (size_t)win * B;
+  uint32_t* g = count_or_cursor + (size_t)win * win_bucket_stride;   // general: own bucket set per window; prepared: shared
+  const uint32_t rbase = ref_base + (uint32_t)win * ref_stride;            // prepared: window w reads table slice w
   if (!SCATTER) {
     for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) {
       uint32_t v = hist[b];
@@ -145,20 +149,20 @@ __global__ void __launch_bounds__(1024) k_sort_pass(const int16_t* __restrict__ 
       int d = dw[i];
       if (d != 0) {
         uint32_t pos = atomicAdd(&hist[(d < 0 ? -d : d) - 1], 1u);
-        sorted[pos] = i | (d < 0 ? 0x80000000u : 0u);
+        sorted[pos] = (rbase + i) | (d < 0 ? 0x80000000u : 0u);
       }
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// 3. exclusive scan of u32 (three small kernels).  MODE 0: identity, MODE 1: ceil(x / TASK_LEN)
+// 3. exclusive scan of u32 (three small kernels).  MODE 0: identity, MODE 1: ceil(x / 2^task_shift)
 // ------------------------------------------------------------------------------------------------
 constexpr int SCAN_BLOCK = 256, SCAN_PER_THREAD = 16, SCAN_TILE = SCAN_BLOCK * SCAN_PER_THREAD;
 
 template <int MODE>
-__device__ __forceinline__ uint32_t scan_xform(uint32_t v) {
-  return MODE == 0 ? v : (v + TASK_LEN - 1) / TASK_LEN;
+__device__ __forceinline__ uint32_t scan_xform(uint32_t v, uint32_t task_shift) {
+  return MODE == 0 ? v : (v + (1u << task_shift) - 1) >> task_shift;
 }
 
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds, uint32_t& total) {
@@ -186,12 +190,12 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* l
 
 template <int MODE>
 __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_sums(const uint32_t* __restrict__ in, uint32_t n,
-                                                          uint32_t* __restrict__ block_sums) {
+                                                          uint32_t* __restrict__ block_sums, uint32_t task_shift) {
   __shared__ uint32_t lds[4];
   uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
   uint32_t s = 0;
 #pragma unroll
-  for (int i = 0; i < SCAN_PER_THREAD; i++) if (base + i < n) s += scan_xform<MODE>(in[base + i]);
+  for (int i = 0; i < SCAN_PER_THREAD; i++) if (base + i < n) s += scan_xform<MODE>(in[base + i], task_shift);
   uint32_t total;
   block_exclusive_scan(s, lds, total);
   if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
@@ -216,12 +220,12 @@ template <int MODE>
 __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply(const uint32_t* __restrict__ in, uint32_t n,
                                                            const uint32_t* __restrict__ block_sums,
                                                            const uint32_t* __restrict__ total,
-                                                           uint32_t* __restrict__ out, uint32_t* __restrict__ out2) {
+                                                           uint32_t* __restrict__ out, uint32_t* __restrict__ out2, uint32_t task_shift) {
   __shared__ uint32_t lds[4];
   uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
   uint32_t v[SCAN_PER_THREAD], s = 0;
 #pragma unroll
-  for (int i = 0; i < SCAN_PER_THREAD; i++) { v[i] = base + i < n ? scan_xform<MODE>(in[base + i]) : 0; s += v[i]; }
+  for (int i = 0; i < SCAN_PER_THREAD; i++) { v[i] = base + i < n ? scan_xform<MODE>(in[base + i], task_shift) : 0; s += v[i]; }
   uint32_t tot;
   uint32_t ex = block_exclusive_scan(s, lds, tot) + block_sums[blockIdx.x];
 #pragma unroll
@@ -233,22 +237,28 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply(const uint32_t* __res
 }
 
 // ------------------------------------------------------------------------------------------------
-// 5. tasks: bucket k with cnt entries -> ceil(cnt/TASK_LEN) tasks; heavy buckets appended to a list
+// 5. tasks: bucket k with cnt entries -> ceil(cnt / 2^task_shift) tasks; max_parts = largest task count of any bucket
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_make_tasks(const uint32_t* __restrict__ offset, const uint32_t* __restrict__ task_off,
-                                                    uint32_t nbuckets, task_t* __restrict__ tasks,
-                                                    uint32_t* __restrict__ heavy_count, uint32_t* __restrict__ heavy_list) {
+                                                    uint32_t nbuckets, task_t* __restrict__ tasks, uint32_t task_shift,
+                                                    uint32_t* __restrict__ max_parts) {
   uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= nbuckets) return;
-  uint32_t s = offset[k], e = offset[k + 1], t = task_off[k], nt = task_off[k + 1] - t;
-  for (uint32_t j = 0; j < nt; j++) {
-    task_t tk;
-    tk.bucket = k;
-    tk.start = s + j * TASK_LEN;
-    tk.len = min((uint32_t)TASK_LEN, e - tk.start);
-    tasks[t + j] = tk;
+  uint32_t nt = 0;
+  if (k < nbuckets) {
+    uint32_t s = offset[k], e = offset[k + 1], t = task_off[k];
+    nt = task_off[k + 1] - t;
+    for (uint32_t j = 0; j < nt; j++) {
+      task_t tk;
+      tk.bucket = k;
+      tk.start = s + (j << task_shift);
+      tk.len = min(1u << task_shift, e - tk.start);
+      tasks[t + j] = tk;
+    }
   }
-  if (nt > HEAVY_TASKS) heavy_list[atomicAdd(heavy_count, 1u)] = k;
+  // block max -> one atomic per wave
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) nt = max(nt, (uint32_t)__shfl_xor((int)nt, off, 64));
+  if ((threadIdx.x & 63) == 0 && nt > 1) atomicMax(max_parts, nt);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -282,44 +292,54 @@ __global__ void __launch_bounds__(128) k_accumulate(const task_t* __restrict__ t
 }
 
 // ------------------------------------------------------------------------------------------------
-// 7. combine task partials per bucket
+// 7. combine task partials per bucket.  A bucket with m partials needs m - 1 additions; total work is ~1/64 of the
+//    accumulation, so what matters is robustness to skew and few launches:
+//      - tree levels (in place, radix 4) run only for buckets that still have more than SEQ_PARTS partials left:
+//        level l turns partial j, j % 4^(l+1) == 0, into the sum of j, j + 4^l, j + 2 4^l, j + 3 4^l.  With uniform
+//        scalars no bucket qualifies and every level exits on one scalar load.
+//      - k_combine_seq: one thread per bucket sums the <= SEQ_PARTS partials that are left (stride 4^levels) and
+//        writes the dense bucket array the pyramid reads.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(128) k_combine_light(const uint32_t* __restrict__ task_off, uint32_t nbuckets,
-                                                       const uint32_t* __restrict__ partials, uint32_t* __restrict__ buckets) {
-  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= nbuckets) return;
-  uint32_t t = task_off[k], nt = task_off[k + 1] - t;
-  if (nt > HEAVY_TASKS) return;   // k_combine_heavy owns this bucket
-  xyzz acc = xyzz_identity();
-  if (nt >= 1) acc = load_xyzz(partials, t);
-  for (uint32_t j = 1; j < nt; j++) acc = xyzz_add(acc, load_xyzz(partials, t + j));
-  store_xyzz(buckets, k, acc);
+constexpr uint32_t SEQ_PARTS = 64;
+
+__device__ __forceinline__ uint32_t tree_levels_for(uint32_t m) {   // smallest L with ceil(m / 4^L) <= SEQ_PARTS
+  uint32_t L = 0;
+  while (((m + (1u << (2 * L)) - 1) >> (2 * L)) > SEQ_PARTS) L++;
+  return L;
 }
 
-// one 256-thread workgroup per heavy bucket: strided serial sums, then an LDS tree
-__global__ void __launch_bounds__(256) k_combine_heavy(const uint32_t* __restrict__ task_off,
-                                                       const uint32_t* __restrict__ heavy_count,
-                                                       const uint32_t* __restrict__ heavy_list,
-                                                       const uint32_t* __restrict__ partials, uint32_t* __restrict__ buckets) {
-  __shared__ uint32_t lds[256 * 36];
-  const uint32_t nheavy = *heavy_count;
-  for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
-    uint32_t k = heavy_list[h];
-    uint32_t t = task_off[k], nt = task_off[k + 1] - t;
-    xyzz acc = xyzz_identity();
-    for (uint32_t j = threadIdx.x; j < nt; j += blockDim.x) acc = xyzz_add(acc, load_xyzz(partials, t + j));
-    store_xyzz(lds, threadIdx.x, acc);
-    __syncthreads();
-    for (int stride = 128; stride >= 1; stride >>= 1) {
-      if ((int)threadIdx.x < stride) {
-        xyzz a = load_xyzz(lds, threadIdx.x), b = load_xyzz(lds, threadIdx.x + stride);
-        store_xyzz(lds, threadIdx.x, xyzz_add(a, b));
-      }
-      __syncthreads();
+__global__ void __launch_bounds__(128) k_combine_tree(const task_t* __restrict__ tasks, const uint32_t* __restrict__ ntasks_p,
+                                                      const uint32_t* __restrict__ task_off, const uint32_t* __restrict__ max_parts,
+                                                      uint32_t* __restrict__ partials, int level) {
+  const uint32_t stride = 1u << (2 * level);
+  if (((*max_parts + stride - 1) >> (2 * level)) <= SEQ_PARTS) return;   // no bucket needs this level
+  const uint32_t ntasks = *ntasks_p;
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < ntasks; t += gridDim.x * blockDim.x) {
+    const uint32_t b = tasks[t].bucket;
+    const uint32_t first = task_off[b], m = task_off[b + 1] - first, j = t - first;
+    if ((j & (4 * stride - 1)) != 0 || (uint32_t)level >= tree_levels_for(m)) continue;
+    xyzz acc = load_xyzz(partials, t);
+#pragma unroll 1
+    for (uint32_t q = 1; q < 4; q++) {
+      if (j + q * stride < m) acc = xyzz_add(acc, load_xyzz(partials, t + q * stride));
     }
-    if (threadIdx.x == 0) store_xyzz(buckets, k, load_xyzz(lds, 0));
-    __syncthreads();
+    store_xyzz(partials, t, acc);
   }
+}
+
+__global__ void __launch_bounds__(128) k_combine_seq(const uint32_t* __restrict__ task_off, uint32_t nbuckets,
+                                                     const uint32_t* __restrict__ partials, uint32_t* __restrict__ buckets) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nbuckets) return;
+  const uint32_t t = task_off[k], m = task_off[k + 1] - t;
+  xyzz acc = xyzz_identity();
+  if (m) {
+    const uint32_t stride = 1u << (2 * tree_levels_for(m));
+    acc = load_xyzz(partials, t);
+#pragma unroll 1
+    for (uint32_t j = stride; j < m; j += stride) acc = xyzz_add(acc, load_xyzz(partials, t + j));
+  }
+  store_xyzz(buckets, k, acc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -401,9 +421,21 @@ int msm_pick_window(size_t n) {
 }
 
 
+int msm_pick_window_prepared(size_t n) {
+  // one shared bucket set: W * 10 n + 2 * 14 * 2^(c-1)
+  int best = 2;
+  double best_cost = 1e300;
+  for (int c = 2; c <= 16; c++) {
+    double W = (256 + c - 1) / c;
+    double cost = W * 10.0 * (double)n + 28.0 * (double)(1u << (c - 1));
+    if (cost < best_cost) { best_cost = cost; best = c; }
+  }
+  return best;
+}
+
 size_t msm_workspace_bytes(size_t n, int c) {
   const size_t W = (256 + c - 1) / c, B = (size_t)1 << (c - 1), NB = W * B;
-  const size_t max_tasks = W * n / TASK_LEN + NB + 1;
+  const size_t max_tasks = W * n / 16 + NB + 1;   // sized for the smallest task length the experiments knob allows
   size_t total = 0;
   total += align_up(W * n * sizeof(int16_t), 256);          // digits
   total += align_up(W * n * sizeof(uint32_t), 256);         // sorted
@@ -411,7 +443,6 @@ size_t msm_workspace_bytes(size_t n, int c) {
   total += 2 * align_up((NB / SCAN_TILE + 2) * sizeof(uint32_t), 256);  // scan block sums x2
   total += align_up(max_tasks * sizeof(task_t), 256);
   total += align_up(max_tasks * 144, 256);                  // partials
-  total += align_up((NB + 1) * sizeof(uint32_t), 256);      // heavy list
   total += 2 * align_up((size_t)W * B * 144, 256);          // pyramid ping-pong (state never exceeds B elements per window)
   total += align_up(W * 144, 256);                          // window sums
   total += 4096;                                            // counters + result
@@ -421,22 +452,31 @@ size_t msm_workspace_bytes(size_t n, int c) {
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s failed: %s", #x, hipGetErrorString(e_)); return ZKHIP_EHIP; } } while (0)
 
 // d_scalars: n x 8 words, d_bases: n x 16 words, d_out: 24 words (device).  ws: workspace of msm_workspace_bytes.
+// prepared != nullptr: d_bases is ignored, points come from the table (window w of point i at table[w * stride + off + i]).
 int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, uint32_t* d_out, void* ws, size_t ws_bytes,
-                  int c_override, hipStream_t stream) {
+                  int c_override, hipStream_t stream, const prepared_bases* prepared, size_t prepared_off) {
   if (n == 0) {
     hipLaunchKernelGGL(k_sum_jacobian, dim3(1), dim3(64), 0, stream, (const uint32_t*)nullptr, 0, d_out);
     HIPCHK(hipGetLastError());
     return ZKHIP_OK;
   }
   if (n >= (1ull << 31)) { set_error("msm: n = %zu too large", n); return ZKHIP_EINVAL; }
-  const int c = c_override > 0 ? c_override : msm_pick_window(n);
+  const int c = prepared ? prepared->c : (c_override > 0 ? c_override : msm_pick_window(n));
   if (c < 2 || c > 16) { set_error("msm: window bits %d out of range [2,16]", c); return ZKHIP_EINVAL; }
   const int W = (256 + c - 1) / c;
   const uint32_t B = 1u << (c - 1);
-  const uint32_t NB = (uint32_t)W * B;
+  const int WB = prepared ? 1 : W;                 // number of bucket sets
+  const uint32_t NB = (uint32_t)WB * B;
+  if (prepared) {
+    if (prepared_off + n > prepared->n) { set_error("msm: range exceeds the prepared bases"); return ZKHIP_EINVAL; }
+    if ((size_t)W * prepared->n >= (1ull << 31)) { set_error("msm: prepared table too large for 31-bit point references"); return ZKHIP_EINVAL; }
+    d_bases = prepared->table;
+  }
   if ((size_t)W * n >= (1ull << 32)) { set_error("msm: W*n overflows 32-bit slot index"); return ZKHIP_EINVAL; }
   if (ws_bytes < msm_workspace_bytes(n, c)) { set_error("msm: workspace too small"); return ZKHIP_EINVAL; }
-  const size_t max_tasks = (size_t)W * n / TASK_LEN + NB + 1;
+  const size_t max_tasks = (size_t)W * n / 16 + NB + 1;
+  uint32_t task_shift = TASK_SHIFT;
+  if (const char* e = getenv("ZKHIP_TASK_SHIFT")) { int v = atoi(e); if (v >= 4 && v <= 14) task_shift = (uint32_t)v; }   // experiments
 
   char* p = (char*)ws;
   auto carve = [&](size_t bytes) { void* r = p; p += align_up(bytes, 256); return r; };
@@ -450,12 +490,11 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   uint32_t* bsum2 = (uint32_t*)carve((NB / SCAN_TILE + 2) * sizeof(uint32_t));
   task_t* tasks = (task_t*)carve(max_tasks * sizeof(task_t));
   uint32_t* partials = (uint32_t*)carve(max_tasks * 144);
-  uint32_t* heavy_list = (uint32_t*)carve((NB + 1) * sizeof(uint32_t));
   const size_t pyr_elems = B;   // per window: N + (s-1) N/2 <= B at every step
   uint32_t* pyrA = (uint32_t*)carve((size_t)W * pyr_elems * 144);
   uint32_t* pyrB = (uint32_t*)carve((size_t)W * pyr_elems * 144);
   uint32_t* winsum = (uint32_t*)carve((size_t)W * 144);
-  uint32_t* counters = (uint32_t*)carve(1024);   // [0] total entries, [1] total tasks, [2] heavy count
+  uint32_t* counters = (uint32_t*)carve(1024);   // [0] total entries, [1] total tasks, [2] max task partials of one bucket
 
   prof_begin(stream);
   // 1. digits
@@ -475,22 +514,24 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
     HIPCHK(hipFuncSetAttribute((const void*)k_sort_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_sort_pass<false>, dim3(chunks, W), dim3(1024), lds, stream, digits, (uint32_t)n, chunk, c, count, (uint32_t*)nullptr);
+  const uint32_t wb_stride = prepared ? 0u : B;
+  const uint32_t ref_base = prepared ? (uint32_t)prepared_off : 0u, ref_stride = prepared ? (uint32_t)prepared->n : 0u;
+  hipLaunchKernelGGL(k_sort_pass<false>, dim3(chunks, W), dim3(1024), lds, stream, digits, (uint32_t)n, chunk, c, count, (uint32_t*)nullptr, wb_stride, ref_base, ref_stride);
   prof_mark(stream, "count");
   // 3. scan counts -> offset (+ cursor copy)
   const uint32_t nblk = (NB + SCAN_TILE - 1) / SCAN_TILE;
-  hipLaunchKernelGGL(k_scan_sums<0>, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, count, NB, bsum1);
+  hipLaunchKernelGGL(k_scan_sums<0>, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, count, NB, bsum1, 0u);
   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_BLOCK), 0, stream, bsum1, nblk, counters + 0);
-  hipLaunchKernelGGL(k_scan_apply<0>, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, count, NB, bsum1, counters + 0, offset, cursor);
+  hipLaunchKernelGGL(k_scan_apply<0>, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, count, NB, bsum1, counters + 0, offset, cursor, 0u);
   prof_mark(stream, "scan");
   // 4. scatter
-  hipLaunchKernelGGL(k_sort_pass<true>, dim3(chunks, W), dim3(1024), lds, stream, digits, (uint32_t)n, chunk, c, cursor, sorted);
+  hipLaunchKernelGGL(k_sort_pass<true>, dim3(chunks, W), dim3(1024), lds, stream, digits, (uint32_t)n, chunk, c, cursor, sorted, wb_stride, ref_base, ref_stride);
   prof_mark(stream, "scatter");
   // 5. tasks
-  hipLaunchKernelGGL(k_scan_sums<1>, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, count, NB, bsum2);
+  hipLaunchKernelGGL(k_scan_sums<1>, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, count, NB, bsum2, task_shift);
   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_BLOCK), 0, stream, bsum2, nblk, counters + 1);
-  hipLaunchKernelGGL(k_scan_apply<1>, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, count, NB, bsum2, counters + 1, task_off, (uint32_t*)nullptr);
-  hipLaunchKernelGGL(k_make_tasks, dim3((NB + 255) / 256), dim3(256), 0, stream, offset, task_off, NB, tasks, counters + 2, heavy_list);
+  hipLaunchKernelGGL(k_scan_apply<1>, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, count, NB, bsum2, counters + 1, task_off, (uint32_t*)nullptr, task_shift);
+  hipLaunchKernelGGL(k_make_tasks, dim3((NB + 255) / 256), dim3(256), 0, stream, offset, task_off, NB, tasks, task_shift, counters + 2);
   prof_mark(stream, "tasks");
   // 6. accumulate (grid-stride over the device-side task count)
   {
@@ -500,8 +541,13 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   }
   prof_mark(stream, "accumulate");
   // 7. combine
-  hipLaunchKernelGGL(k_combine_light, dim3((NB + 127) / 128), dim3(128), 0, stream, task_off, NB, partials, pyrA);
-  hipLaunchKernelGGL(k_combine_heavy, dim3(256), dim3(256), 0, stream, task_off, counters + 2, heavy_list, partials, pyrA);
+  {
+    uint32_t blocks = (uint32_t)((max_tasks + 127) / 128);
+    if (blocks > 2048) blocks = 2048;
+    for (int level = 0; level < COMBINE_LEVELS; level++)
+      hipLaunchKernelGGL(k_combine_tree, dim3(blocks), dim3(128), 0, stream, tasks, counters + 1, task_off, counters + 2, partials, level);
+  }
+  hipLaunchKernelGGL(k_combine_seq, dim3((NB + 127) / 128), dim3(128), 0, stream, task_off, NB, partials, pyrA);
   prof_mark(stream, "combine");
   // 8. pyramid: buckets were written with window stride B (dense).  Steps 1 .. c-2 leave X with 2 elements.
   uint32_t* cur = pyrA;
@@ -514,7 +560,7 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
     while (N > 2) {
       uint32_t per_win = N / 2 + (uint32_t)s * (N / 4);
       uint32_t out_stride = per_win;
-      hipLaunchKernelGGL(k_pyramid_step, dim3((per_win + 127) / 128, W), dim3(128), 0, stream, cur, nxt, N, s, in_stride, out_stride);
+      hipLaunchKernelGGL(k_pyramid_step, dim3((per_win + 127) / 128, WB), dim3(128), 0, stream, cur, nxt, N, s, in_stride, out_stride);
       uint32_t* t = cur; cur = nxt; nxt = t;
       in_stride = out_stride;
       N >>= 1;
@@ -529,9 +575,9 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
     set_error("msm: internal: B == 1");
     return ZKHIP_EINVAL;
   }
-  hipLaunchKernelGGL(k_window_horner, dim3((W + 63) / 64), dim3(64), 0, stream, cur, in_stride, nz, winsum, W);
+  hipLaunchKernelGGL(k_window_horner, dim3((WB + 63) / 64), dim3(64), 0, stream, cur, in_stride, nz, winsum, WB);
   prof_mark(stream, "horner");
-  hipLaunchKernelGGL(k_fold, dim3(1), dim3(64), 0, stream, winsum, W, c, d_out);
+  hipLaunchKernelGGL(k_fold, dim3(1), dim3(64), 0, stream, winsum, WB, c, d_out);   // prepared: WB == 1, just the format conversion
   prof_mark(stream, "fold");
   HIPCHK(hipGetLastError());
   return ZKHIP_OK;
@@ -544,7 +590,7 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
 // ------------------------------------------------------------------------------------------------
 constexpr int GEN_CHUNK = 32;
 
-__device__ xyzz scalar_mul_affine(const fe& k_canon_packed_as_fe_unused, const uint32_t (&kw)[8], const fe& gx, const fe& gy) {
+__device__ __forceinline__ xyzz scalar_mul_affine(const uint32_t (&kw)[8], const fe& gx, const fe& gy) {
   xyzz acc = xyzz_identity();
   for (int bit = 255; bit >= 0; bit--) {
     acc = xyzz_dbl(acc);
@@ -553,7 +599,7 @@ __device__ xyzz scalar_mul_affine(const fe& k_canon_packed_as_fe_unused, const u
   return acc;
 }
 
-__device__ fe fq_inverse(const fe& a) {   // a^(q-2), a reduced (< 2p), result < 2p
+__device__ __forceinline__ fe fq_inverse(const fe& a) {   // a^(q-2), a reduced (< 2p), result < 2p
   // exponent q - 2 as 8 x u32 (little endian)
   const uint32_t e[8] = {0xd87cfd45u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
   fe acc = fe_one<Fq>();
@@ -596,8 +642,8 @@ __global__ void __launch_bounds__(64) k_gen_walk(const uint32_t* __restrict__ t0
   // generator (1, 2) in internal Montgomery form
   fe gx = fe_one<Fq>();
   fe gy = fe_norm(fe_dbl(gx));
-  xyzz P = scalar_mul_affine(kc, kw, gx, gy);
-  xyzz D = scalar_mul_affine(dc, dw, gx, gy);
+  xyzz P = scalar_mul_affine(kw, gx, gy);
+  xyzz D = scalar_mul_affine(dw, gx, gy);
   // walk + prefix products of w_i = ZZ_i * ZZZ_i (identity points contribute 1)
   fe pref = fe_one<Fq>();
   for (uint32_t i = 0; i < cnt; i++) {
@@ -646,6 +692,83 @@ int g1_gen_walk_device(const uint32_t t0_ext[8], const uint32_t d_ext[8], size_t
   hipLaunchKernelGGL(k_gen_walk, dim3((threads + 63) / 64), dim3(64), 0, stream, consts, (uint32_t)n, d_out, tmp_pts, tmp_pref);
   HIPCHK(hipGetLastError());
   return ZKHIP_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// prepared bases: table[w * n + i] = 2^(c w) * P_i (affine, external format), w < W.  One thread per point walks the
+// doubling chain, parks the XYZZ multiples in `tmp`, then normalises its W-1 points with one inversion.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_build_table(const uint32_t* __restrict__ bases, uint32_t n, int c, int W,
+                                                    uint32_t* __restrict__ table, uint32_t* __restrict__ tmp_pts,
+                                                    uint32_t* __restrict__ tmp_pref) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  affine_words pt = load_affine(bases, i);
+  {
+    uint4* q = reinterpret_cast<uint4*>(table + (size_t)i * 16);
+    q[0] = make_uint4(pt.x[0], pt.x[1], pt.x[2], pt.x[3]); q[1] = make_uint4(pt.x[4], pt.x[5], pt.x[6], pt.x[7]);
+    q[2] = make_uint4(pt.y[0], pt.y[1], pt.y[2], pt.y[3]); q[3] = make_uint4(pt.y[4], pt.y[5], pt.y[6], pt.y[7]);
+  }
+  if (affine_is_identity(pt)) {
+    for (int w = 1; w < W; w++) {
+      uint4* q = reinterpret_cast<uint4*>(table + ((size_t)w * n + i) * 16);
+      q[0] = q[1] = q[2] = q[3] = make_uint4(0, 0, 0, 0);
+    }
+    return;
+  }
+  xyzz P = xyzz_identity();
+  xyzz_madd(P, fe_from_ext_lazy(pt.x), fe_from_ext_lazy(pt.y));
+  fe pref = fe_one<Fq>();
+  for (int w = 1; w < W; w++) {
+    for (int k = 0; k < c; k++) P = xyzz_dbl(P);
+    store_xyzz(tmp_pts, (size_t)(w - 1) * n + i, P);
+    store_fe9_generic(tmp_pref, (size_t)(w - 1) * n + i, pref);
+    pref = fe_mul<Fq>(pref, fe_mul<Fq>(P.ZZ, P.ZZZ));     // never zero: the group has odd prime order
+  }
+  fe inv = fq_inverse(pref);
+  for (int w = W - 1; w >= 1; w--) {
+    xyzz Q = load_xyzz(tmp_pts, (size_t)(w - 1) * n + i);
+    fe pre = load_fe9_generic(tmp_pref, (size_t)(w - 1) * n + i);
+    fe winv = fe_mul<Fq>(inv, pre);
+    inv = fe_mul<Fq>(inv, fe_mul<Fq>(Q.ZZ, Q.ZZZ));
+    fe x = fe_mul<Fq>(fe_mul<Fq>(winv, Q.ZZZ), Q.X);
+    fe y = fe_mul<Fq>(fe_mul<Fq>(winv, Q.ZZ), Q.Y);
+    uint32_t wx[8], wy[8];
+    fe_to_ext<Fq>(x, wx);
+    fe_to_ext<Fq>(y, wy);
+    uint4* q = reinterpret_cast<uint4*>(table + ((size_t)w * n + i) * 16);
+    q[0] = make_uint4(wx[0], wx[1], wx[2], wx[3]); q[1] = make_uint4(wx[4], wx[5], wx[6], wx[7]);
+    q[2] = make_uint4(wy[0], wy[1], wy[2], wy[3]); q[3] = make_uint4(wy[4], wy[5], wy[6], wy[7]);
+  }
+}
+
+// d_bases: n affine points on the device.  Allocates the table (W * n * 64 B) and a temporary (freed before returning).
+int prepare_bases_device(const uint32_t* d_bases, size_t n, hipStream_t stream, prepared_bases** out) {
+  if (n == 0 || n >= (1ull << 27)) { set_error("prepare_bases: n = %zu out of range", n); return ZKHIP_EINVAL; }
+  const int c = msm_pick_window_prepared(n);
+  const int W = (256 + c - 1) / c;
+  prepared_bases* pb = new prepared_bases();
+  pb->n = n; pb->c = c; pb->W = W; pb->table = nullptr;
+  void *table = nullptr, *tmp = nullptr;
+  const size_t tbytes = (size_t)W * n * 64, tmp_pts = align_up((size_t)(W - 1) * n * 144, 256), tmp_pref = align_up((size_t)(W - 1) * n * 36, 256);
+  if (hipMalloc(&table, tbytes) != hipSuccess) { delete pb; set_error("prepare_bases: hipMalloc(%zu) failed", tbytes); return ZKHIP_ENOMEM; }
+  if (hipMalloc(&tmp, tmp_pts + tmp_pref) != hipSuccess) { (void)hipFree(table); delete pb; set_error("prepare_bases: hipMalloc(%zu) failed", tmp_pts + tmp_pref); return ZKHIP_ENOMEM; }
+  hipLaunchKernelGGL(k_build_table, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_bases, (uint32_t)n, c, W, (uint32_t*)table,
+                     (uint32_t*)tmp, (uint32_t*)((char*)tmp + tmp_pts));
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  (void)hipFree(tmp);
+  if (e != hipSuccess) { (void)hipFree(table); delete pb; set_error("prepare_bases: %s", hipGetErrorString(e)); return ZKHIP_EHIP; }
+  pb->table = (uint32_t*)table;
+  *out = pb;
+  return ZKHIP_OK;
+}
+
+void release_prepared(prepared_bases* pb) {
+  if (!pb) return;
+  if (pb->table) (void)hipFree(pb->table);
+  delete pb;
 }
 
 int sum_jacobian_device(const uint32_t* d_in, int m, uint32_t* d_out, hipStream_t stream) {
