@@ -12,10 +12,12 @@
 //     cooperative coalesced load -> LDS, <= 3 rounds of <= 3 radix-2 stages in registers (8 elements per
 //     thread), LDS exchange between rounds, cooperative coalesced store.
 //   * B <= 9 bits per pass: 2^24 is three passes.  Twiddles w_M^t come from an M-entry table when
-//     M <= 2^16 and from two 2^(log M / 2)-entry tables (one extra multiply) above that; all tables are
-//     L2-resident and cached per (omega, log_n).
-//   * Values stay lazily reduced inside a pass (fp29.hpp); each pass ends with one multiply that reduces
-//     them, which on the last pass is also the caller's output scale (ifft divisor, coset powers) -> free.
+//     M <= 2^24 (HBM is plentiful: 36 B * M per (omega, log_n), cached) and from two 2^(log M / 2)-entry
+//     tables (one extra multiply) above that.
+//   * Values stay lazily reduced inside a pass (fp29.hpp); intermediate passes end with a ~50-instruction
+//     quotient-estimate reduction (fe_reduce_soft) so the value fits 32 bytes; the last pass ends with the
+//     caller's output scale (ifft divisor, coset powers) as its one multiply, or with a soft reduction and two
+//     conditional subtractions when there is no scale.
 //   * The external Montgomery-256 words are used as they are: x*2^256 is the radix-2^261 Montgomery form of
 //     x*2^-5, and the NTT is linear, so no format conversion multiply is needed on either side.
 #include <hip/hip_runtime.h>
@@ -33,6 +35,7 @@ namespace zkhip {
 using Fr = FrParams;
 constexpr uint32_t NTT_TILE = 2048;
 constexpr int NTT_MAX_BITS = 9;
+constexpr uint32_t NTT_DIRECT_TABLE_BITS = 24;   // pass twiddles w_M^t as one M-entry table up to M = 2^24 (604 MB), two-level above
 
 struct scale_arg {      // up to 3 external (Montgomery-256) constants applied as c[i % period]; period 0 = none
   uint32_t w[3][8];
@@ -143,18 +146,54 @@ __global__ void __launch_bounds__(256, 2) k_ntt_pass(pass_args a) {
         pos[e] = (hi << (s + v)) | (((uint32_t)e & ((1u << v) - 1)) << s) | lo;
         x[e] = load_fe9(lds, pos[e] * J + jj);
       }
+      if (s == 0) {
+        // First round (v == 3, lo == 0): twiddles depend only on the register index and 7 of the 12 are w^0 = 1, so
+        // those butterflies need no multiply.  Inputs are N-form < 2p.  Bounds (value / limb) are noted per stage.
+        const fe w4 = load_fe9(a.tw_local, 1u << (B - 2)), w8 = load_fe9(a.tw_local, 1u << (B - 3)),
+                 w83 = load_fe9(a.tw_local, 3u << (B - 3));
 #pragma unroll
-      for (int u = 0; u < 3; u++) {
-        if ((uint32_t)u < v) {
-          const uint32_t st = s + u;
+        for (int e = 0; e < 8; e += 2) {                    // stage 0: all trivial.  x' < 4p / 2^30, y' < 5p / 1.5*2^30
+          fe t = x[e + 1];
+          x[e + 1] = fe_sub_red(x[e], t, Fr::P3_S1);
+          x[e] = fe_add(x[e], t);
+        }
 #pragma unroll
-          for (int e = 0; e < 8; e++) {
-            if ((e >> u) & 1) continue;          // e is the upper element of a pair
-            const int f = e | (1 << u);
-            const uint32_t lo_i = pos[e] & ((1u << st) - 1);
-            fe t = fe_mul<Fr>(load_fe9(a.tw_local, lo_i << (B - 1 - st)), x[f]);   // N x (limbs < 2^31.5)
-            x[f] = fe_sub_red(x[e], t, Fr::P3_S1);                                   // x - t + 3p
-            x[e] = fe_add(x[e], t);
+        for (int e = 0; e < 8; e += 4) {                    // stage 1
+          fe t = fe_norm(x[e + 2]);                         // trivial pair (e, e+2): t < 4p, N
+          x[e + 2] = fe_sub_red(x[e], t, Fr::P6_S1);        // < 10p / 2^31
+          x[e] = fe_add(x[e], t);                           // < 8p / 1.5*2^30
+          fe u1 = fe_mul<Fr>(w4, x[e + 3]);                 // pair (e+1, e+3): input < 5p / 1.5*2^30
+          x[e + 3] = fe_sub_red(x[e + 1], u1, Fr::P3_S1);   // < 8p / 2.5*2^30
+          x[e + 1] = fe_add(x[e + 1], u1);                  // < 7p / 2^31
+        }
+        {                                                   // stage 2
+          fe t = fe_norm(x[4]);                             // trivial pair (0, 4): t < 8p, N
+          x[4] = fe_sub_red(x[0], t, Fr::P10_S1);           // < 18p / 2.5*2^30
+          x[0] = fe_add(x[0], t);                           // < 16p / 2^31
+          fe u1 = fe_mul<Fr>(w8, x[5]);                     // inputs: limbs <= 2.5*2^30 < 2^31.5
+          x[5] = fe_sub_red(x[1], u1, Fr::P3_S1);
+          x[1] = fe_add(x[1], u1);
+          fe u2 = fe_mul<Fr>(w4, x[6]);
+          x[6] = fe_sub_red(x[2], u2, Fr::P3_S1);
+          x[2] = fe_add(x[2], u2);
+          fe u3 = fe_mul<Fr>(w83, x[7]);
+          x[7] = fe_sub_red(x[3], u3, Fr::P3_S1);
+          x[3] = fe_add(x[3], u3);
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+          if ((uint32_t)u < v) {
+            const uint32_t st = s + u;
+  #pragma unroll
+            for (int e = 0; e < 8; e++) {
+              if ((e >> u) & 1) continue;          // e is the upper element of a pair
+              const int f = e | (1 << u);
+              const uint32_t lo_i = pos[e] & ((1u << st) - 1);
+              fe t = fe_mul<Fr>(load_fe9(a.tw_local, lo_i << (B - 1 - st)), x[f]);   // N x (limbs < 2^31.5)
+              x[f] = fe_sub_red(x[e], t, Fr::P3_S1);                                   // x - t + 3p
+              x[e] = fe_add(x[e], t);
+            }
           }
         }
       }
@@ -168,7 +207,6 @@ __global__ void __launch_bounds__(256, 2) k_ntt_pass(pass_args a) {
   // ---- store: destination order (a, r', b), b = jj mod q fastest, q = min(Ns, J) -------------------
   const uint32_t q = Ns < J ? Ns : J;
   const uint32_t logq = 31 - __builtin_clz(q);
-  fe one = fe_one<Fr>();
   for (uint32_t idx = threadIdx.x; idx < tile; idx += nthreads) {
     const uint32_t b = idx & (q - 1), rp = (idx >> logq) & (R - 1), aa = idx >> (logq + B);
     const uint32_t jj = aa * q + b;
@@ -178,10 +216,10 @@ __global__ void __launch_bounds__(256, 2) k_ntt_pass(pass_args a) {
     uint32_t w[8];
     if (a.last) {
       if (d >= a.out_len) continue;
-      fe sc = a.out_scale.period ? scale_pick(a.out_scale, d) : one;
-      fe_pack(fe_canon_lt2p<Fr>(fe_mul<Fr>(sc, x)), w);
+      if (a.out_scale.period) fe_pack(fe_canon_lt2p<Fr>(fe_mul<Fr>(scale_pick(a.out_scale, d), x)), w);
+      else fe_pack(fe_canon_lt3p<Fr>(fe_reduce_soft<Fr>(x)), w);   // x is N-form < 29p after the last round
     } else {
-      fe_pack(fe_mul<Fr>(one, x), w);            // < 2p < 2^256
+      fe_pack(fe_reduce_soft<Fr>(x), w);         // < 2p + 2^233 < 2^256: fits the 32-byte intermediate format
     }
     store_words(a.dst + (size_t)d * 8, w);
   }
@@ -315,7 +353,7 @@ static int build_plan(const uint32_t omega_ext[8], uint32_t L, hipStream_t strea
       hipLaunchKernelGGL(k_ntt_powers, dim3((cnt + 255) / 256), dim3(256), 0, stream, p->pw2, L - B, cnt, p->tw_local[i]);
       if (i == 0) continue;
       // pass twiddles w_M^t = omega^(t * N/M), t < M
-      if (logM <= 16) {
+      if (logM <= NTT_DIRECT_TABLE_BITS) {   // direct table: 36 B * M of HBM, saves the table-combining multiply
         const uint32_t M = 1u << logM;
         p->h[i] = 0;
         if ((rc = plan_alloc(p, &p->tw_lo[i], (size_t)M * 36)) != ZKHIP_OK) return rc;
