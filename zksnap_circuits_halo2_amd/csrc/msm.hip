@@ -82,9 +82,13 @@ __device__ __forceinline__ void store_fe9_generic(uint32_t* p, size_t idx, const
 // 1. digits
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, int16_t* __restrict__ digits,
-                                                uint32_t n, int c, int W) {
+                                                uint32_t n, uint32_t n_pad, int c, int W) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i >= n_pad) return;
+  if (i >= n) {                                   // padding entries: digit 0 = "no entry"
+    for (int win = 0; win < W; win++) digits[(size_t)win * n_pad + i] = 0;
+    return;
+  }
   uint32_t w[8];
   load_words(scalars + (size_t)i * 8, w);
   // Montgomery-256 -> plain integer: mont261(a*2^256, 2^5) = a
@@ -107,49 +111,69 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ sca
     v += carry;
     int32_t d;
     if (v >= half) { d = (int32_t)v - (int32_t)(1u << c); carry = 1; } else { d = (int32_t)v; carry = 0; }
-    digits[(size_t)win * n + i] = (int16_t)d;
+    digits[(size_t)win * n_pad + i] = (int16_t)d;
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 // 2. count / 4. scatter: grid (chunks, W), LDS histogram of B = 2^(c-1) u32 counters
 // ------------------------------------------------------------------------------------------------
+// Both passes are latency-bound if written naively (one 2-byte load per thread per iteration): digits are read 8 at a
+// time (16-byte loads; rows and chunks are padded to multiples of 8) and the returning global atomics of the reservation
+// step are issued in independent batches.
 template <bool SCATTER>
-__global__ void __launch_bounds__(1024) k_sort_pass(const int16_t* __restrict__ digits, uint32_t n, uint32_t chunk,
+__global__ void __launch_bounds__(1024) k_sort_pass(const int16_t* __restrict__ digits, uint32_t n_pad, uint32_t chunk,
                                                     int c, uint32_t* __restrict__ count_or_cursor,
                                                     uint32_t* __restrict__ sorted, uint32_t win_bucket_stride,
                                                     uint32_t ref_base, uint32_t ref_stride) {
   extern __shared__ uint32_t hist[];
   const uint32_t B = 1u << (c - 1);
   const int win = blockIdx.y;
-  const uint32_t lo = blockIdx.x * chunk;
-  const uint32_t hi = min(n, lo + chunk);
+  const uint32_t lo = blockIdx.x * chunk;                 // multiple of 8
+  const uint32_t hi = min(n_pad, lo + chunk);             // multiple of 8
   for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) hist[b] = 0;
   __syncthreads();
-  const int16_t* dw = digits + (size_t)win * n;
-  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-    int d = dw[i];
-    if (d != 0) atomicAdd(&hist[(d < 0 ? -d : d) - 1], 1u);
+  const uint4* dv = reinterpret_cast<const uint4*>(digits + (size_t)win * n_pad);
+  const uint32_t v_lo = lo >> 3, v_hi = hi >> 3;
+  for (uint32_t vi = v_lo + threadIdx.x; vi < v_hi; vi += blockDim.x) {
+    const uint4 q = dv[vi];
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int d = (int16_t)(w[k >> 1] >> ((k & 1) * 16));
+      if (d != 0) atomicAdd(&hist[(d < 0 ? -d : d) - 1], 1u);
+    }
   }
   __syncthreads();
   uint32_t* g = count_or_cursor + (size_t)win * win_bucket_stride;   // general: own bucket set per window; prepared: shared
-  const uint32_t rbase = ref_base + (uint32_t)win * ref_stride;            // prepared: window w reads table slice w
   if (!SCATTER) {
     for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) {
       uint32_t v = hist[b];
       if (v) atomicAdd(&g[b], v);
     }
   } else {
-    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) {
-      uint32_t v = hist[b];
-      hist[b] = v ? atomicAdd(&g[b], v) : 0u;   // reserve [pos, pos+v) in the bucket's slot range
+    // reserve [pos, pos + v) in each non-empty bucket's slot range: 8 independent returning atomics in flight per thread
+    for (uint32_t b0 = threadIdx.x; b0 < B; b0 += 8 * blockDim.x) {
+      uint32_t v[8], r[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) { const uint32_t b = b0 + k * blockDim.x; v[k] = b < B ? hist[b] : 0u; }
+#pragma unroll
+      for (int k = 0; k < 8; k++) r[k] = v[k] ? atomicAdd(&g[b0 + k * blockDim.x], v[k]) : 0u;
+#pragma unroll
+      for (int k = 0; k < 8; k++) { const uint32_t b = b0 + k * blockDim.x; if (b < B) hist[b] = r[k]; }
     }
     __syncthreads();
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-      int d = dw[i];
-      if (d != 0) {
-        uint32_t pos = atomicAdd(&hist[(d < 0 ? -d : d) - 1], 1u);
-        sorted[pos] = (rbase + i) | (d < 0 ? 0x80000000u : 0u);
+    const uint32_t rbase = ref_base + (uint32_t)win * ref_stride;       // prepared: window w reads table slice w
+    for (uint32_t vi = v_lo + threadIdx.x; vi < v_hi; vi += blockDim.x) {
+      const uint4 q = dv[vi];
+      const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int d = (int16_t)(w[k >> 1] >> ((k & 1) * 16));
+        if (d != 0) {
+          const uint32_t pos = atomicAdd(&hist[(d < 0 ? -d : d) - 1], 1u);
+          sorted[pos] = (rbase + vi * 8 + k) | (d < 0 ? 0x80000000u : 0u);
+        }
       }
     }
   }
@@ -437,7 +461,7 @@ size_t msm_workspace_bytes(size_t n, int c) {
   const size_t W = (256 + c - 1) / c, B = (size_t)1 << (c - 1), NB = W * B;
   const size_t max_tasks = W * n / 16 + NB + 1;   // sized for the smallest task length the experiments knob allows
   size_t total = 0;
-  total += align_up(W * n * sizeof(int16_t), 256);          // digits
+  total += align_up(W * (n + 8) * sizeof(int16_t), 256);    // digits (rows padded to a multiple of 8)
   total += align_up(W * n * sizeof(uint32_t), 256);         // sorted
   total += 4 * align_up((NB + 1) * sizeof(uint32_t), 256);  // count, offset, cursor, task_off
   total += 2 * align_up((NB / SCAN_TILE + 2) * sizeof(uint32_t), 256);  // scan block sums x2
@@ -480,7 +504,8 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
 
   char* p = (char*)ws;
   auto carve = [&](size_t bytes) { void* r = p; p += align_up(bytes, 256); return r; };
-  int16_t* digits = (int16_t*)carve((size_t)W * n * sizeof(int16_t));
+  const uint32_t n_pad = (uint32_t)((n + 7) & ~(size_t)7);
+  int16_t* digits = (int16_t*)carve((size_t)W * n_pad * sizeof(int16_t));
   uint32_t* sorted = (uint32_t*)carve((size_t)W * n * sizeof(uint32_t));
   uint32_t* count = (uint32_t*)carve((NB + 1) * sizeof(uint32_t));
   uint32_t* offset = (uint32_t*)carve((NB + 1) * sizeof(uint32_t));
@@ -498,7 +523,7 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
 
   prof_begin(stream);
   // 1. digits
-  hipLaunchKernelGGL(k_digits, dim3((n + 255) / 256), dim3(256), 0, stream, d_scalars, digits, (uint32_t)n, c, W);
+  hipLaunchKernelGGL(k_digits, dim3((n_pad + 255) / 256), dim3(256), 0, stream, d_scalars, digits, (uint32_t)n, n_pad, c, W);
   prof_mark(stream, "digits");
   // 2. count
   HIPCHK(hipMemsetAsync(count, 0, (NB + 1) * sizeof(uint32_t), stream));
@@ -506,7 +531,7 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   uint32_t chunks = (uint32_t)((n + 65535) / 65536);
   while (chunks * (uint32_t)W < 256 && chunks < (n + 4095) / 4096) chunks *= 2;   // fill the chip
   if (chunks == 0) chunks = 1;
-  const uint32_t chunk = (uint32_t)((n + chunks - 1) / chunks);
+  const uint32_t chunk = (uint32_t)((((n + chunks - 1) / chunks) + 7) & ~(size_t)7);   // multiple of 8 (vector loads)
   const size_t lds = (size_t)B * sizeof(uint32_t);
   static bool attr_set = false;
   if (!attr_set) {
@@ -516,7 +541,7 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   }
   const uint32_t wb_stride = prepared ? 0u : B;
   const uint32_t ref_base = prepared ? (uint32_t)prepared_off : 0u, ref_stride = prepared ? (uint32_t)prepared->n : 0u;
-  hipLaunchKernelGGL(k_sort_pass<false>, dim3(chunks, W), dim3(1024), lds, stream, digits, (uint32_t)n, chunk, c, count, (uint32_t*)nullptr, wb_stride, ref_base, ref_stride);
+  hipLaunchKernelGGL(k_sort_pass<false>, dim3(chunks, W), dim3(1024), lds, stream, digits, n_pad, chunk, c, count, (uint32_t*)nullptr, wb_stride, ref_base, ref_stride);
   prof_mark(stream, "count");
   // 3. scan counts -> offset (+ cursor copy)
   const uint32_t nblk = (NB + SCAN_TILE - 1) / SCAN_TILE;
@@ -525,7 +550,7 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   hipLaunchKernelGGL(k_scan_apply<0>, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, count, NB, bsum1, counters + 0, offset, cursor, 0u);
   prof_mark(stream, "scan");
   // 4. scatter
-  hipLaunchKernelGGL(k_sort_pass<true>, dim3(chunks, W), dim3(1024), lds, stream, digits, (uint32_t)n, chunk, c, cursor, sorted, wb_stride, ref_base, ref_stride);
+  hipLaunchKernelGGL(k_sort_pass<true>, dim3(chunks, W), dim3(1024), lds, stream, digits, n_pad, chunk, c, cursor, sorted, wb_stride, ref_base, ref_stride);
   prof_mark(stream, "scatter");
   // 5. tasks
   hipLaunchKernelGGL(k_scan_sums<1>, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, count, NB, bsum2, task_shift);
