@@ -167,8 +167,14 @@ def main() -> None:
         t_acc = acc.get("accumulate", float("nan"))
         alg_bytes = 96.0 * n                                       # 64 B affine base + 32 B scalar per point
         achieved = alg_bytes / (t_acc * 1e-3) / 1e9
+        traffic = None
+        try:   # PMC-measured HBM bytes of this kernel at this size (collected in separate rocprofv3 --pmc passes, committed)
+            if args.log_n == 20:
+                traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["k_accumulate"]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         result["roofline"] = {"bound": "hbm", "kernel": "k_accumulate", "achieved": round(achieved, 2), "peak": 8000.0,
-                              "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": None,
+                              "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic,
                               "avg_launch_ms": round(t_acc, 4), "algorithmic_bytes_per_launch": alg_bytes,
                               "whole_msm_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / 8000.0, 5),
                               "note": "256-bit modular-integer work: ALU-bound, not HBM-bound (DESIGN.md)"}

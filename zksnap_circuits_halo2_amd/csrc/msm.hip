@@ -35,7 +35,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 
 constexpr int TASK_SHIFT = 6;           // 64 entries per accumulate task: short tasks keep the tail of the launch balanced
                                         // (measured at 2^22: 5.9 ms with 64-entry tasks, 6.9 ms with 256, 8.1 ms with 512)
-constexpr int COMBINE_LEVELS = 8;       // tree levels above the 64 sequential partials: covers 64 * 4^8 partials per bucket
+constexpr int COMBINE_LEVELS = 9;       // radix-4 tree levels above the final step: covers 16 * 4^9 partials per bucket
 
 struct task_t {
   uint32_t bucket, start, len;
@@ -321,27 +321,27 @@ __global__ void __launch_bounds__(128) k_accumulate(const task_t* __restrict__ t
 //      - tree levels (in place, radix 4) run only for buckets that still have more than SEQ_PARTS partials left:
 //        level l turns partial j, j % 4^(l+1) == 0, into the sum of j, j + 4^l, j + 2 4^l, j + 3 4^l.  With uniform
 //        scalars no bucket qualifies and every level exits on one scalar load.
-//      - k_combine_seq: one thread per bucket sums the <= SEQ_PARTS partials that are left (stride 4^levels) and
-//        writes the dense bucket array the pyramid reads.
+//      - k_combine_seq: 8 lanes per bucket sum the <= SEQ_PARTS partials that are left (stride 4^levels), shuffle-reduce,
+//        and write the dense bucket array the pyramid reads.
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t SEQ_PARTS = 64;
-
-__device__ __forceinline__ uint32_t tree_levels_for(uint32_t m) {   // smallest L with ceil(m / 4^L) <= SEQ_PARTS
+// seq_parts: how many partials the final step may sum per bucket (256 when the MSM is throughput-bound, 16 when it is
+// latency-bound, where a skewed bucket -- e.g. from a short top window -- would otherwise be a long sequential chain)
+__device__ __forceinline__ uint32_t tree_levels_for(uint32_t m, uint32_t seq_parts) {   // smallest L with ceil(m / 4^L) <= seq_parts
   uint32_t L = 0;
-  while (((m + (1u << (2 * L)) - 1) >> (2 * L)) > SEQ_PARTS) L++;
+  while (((m + (1u << (2 * L)) - 1) >> (2 * L)) > seq_parts) L++;
   return L;
 }
 
 __global__ void __launch_bounds__(128) k_combine_tree(const task_t* __restrict__ tasks, const uint32_t* __restrict__ ntasks_p,
                                                       const uint32_t* __restrict__ task_off, const uint32_t* __restrict__ max_parts,
-                                                      uint32_t* __restrict__ partials, int level) {
+                                                      uint32_t* __restrict__ partials, int level, uint32_t seq_parts) {
   const uint32_t stride = 1u << (2 * level);
-  if (((*max_parts + stride - 1) >> (2 * level)) <= SEQ_PARTS) return;   // no bucket needs this level
+  if (((*max_parts + stride - 1) >> (2 * level)) <= seq_parts) return;   // no bucket needs this level
   const uint32_t ntasks = *ntasks_p;
   for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < ntasks; t += gridDim.x * blockDim.x) {
     const uint32_t b = tasks[t].bucket;
     const uint32_t first = task_off[b], m = task_off[b + 1] - first, j = t - first;
-    if ((j & (4 * stride - 1)) != 0 || (uint32_t)level >= tree_levels_for(m)) continue;
+    if ((j & (4 * stride - 1)) != 0 || (uint32_t)level >= tree_levels_for(m, seq_parts)) continue;
     xyzz acc = load_xyzz(partials, t);
 #pragma unroll 1
     for (uint32_t q = 1; q < 4; q++) {
@@ -351,19 +351,39 @@ __global__ void __launch_bounds__(128) k_combine_tree(const task_t* __restrict__
   }
 }
 
-__global__ void __launch_bounds__(128) k_combine_seq(const uint32_t* __restrict__ task_off, uint32_t nbuckets,
-                                                     const uint32_t* __restrict__ partials, uint32_t* __restrict__ buckets) {
-  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= nbuckets) return;
-  const uint32_t t = task_off[k], m = task_off[k + 1] - t;
-  xyzz acc = xyzz_identity();
-  if (m) {
-    const uint32_t stride = 1u << (2 * tree_levels_for(m));
-    acc = load_xyzz(partials, t);
-#pragma unroll 1
-    for (uint32_t j = stride; j < m; j += stride) acc = xyzz_add(acc, load_xyzz(partials, t + j));
+__device__ __forceinline__ xyzz xyzz_shfl_xor(const xyzz& a, int mask) {
+  xyzz r;
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    r.X.l[i] = (uint32_t)__shfl_xor((int)a.X.l[i], mask, 64);
+    r.Y.l[i] = (uint32_t)__shfl_xor((int)a.Y.l[i], mask, 64);
+    r.ZZ.l[i] = (uint32_t)__shfl_xor((int)a.ZZ.l[i], mask, 64);
+    r.ZZZ.l[i] = (uint32_t)__shfl_xor((int)a.ZZZ.l[i], mask, 64);
   }
-  store_xyzz(buckets, k, acc);
+  return r;
+}
+
+// LANES adjacent lanes per bucket: lane q sums the remaining partials q, q + LANES, ... (stride 4^levels apart), then
+// log2(LANES) xor-shuffle steps add the lane sums.  Depth m/LANES + log2(LANES) additions instead of m - 1.  The host
+// picks LANES from the expected partials per bucket (1 lane when buckets hold ~1-2 partials: the general path).
+template <int COMBINE_LANES>
+__global__ void __launch_bounds__(128) k_combine_seq(const uint32_t* __restrict__ task_off, uint32_t nbuckets,
+                                                     const uint32_t* __restrict__ partials, uint32_t* __restrict__ buckets,
+                                                     uint32_t seq_parts) {
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t k = gid / COMBINE_LANES, q = gid % COMBINE_LANES;
+  const bool live = k < nbuckets;                  // whole lane groups are live or dead together (128 % 8 == 0)
+  xyzz acc = xyzz_identity();
+  if (live) {
+    const uint32_t t = task_off[k], m = task_off[k + 1] - t;
+    const uint32_t stride = 1u << (2 * tree_levels_for(m, seq_parts));
+    const uint32_t left = (m + stride - 1) / stride;              // partials still to be summed
+#pragma unroll 1
+    for (uint32_t j = q; j < left; j += COMBINE_LANES) acc = xyzz_add(acc, load_xyzz(partials, t + j * stride));
+  }
+#pragma unroll 1
+  for (int mask = 1; mask < COMBINE_LANES; mask <<= 1) acc = xyzz_add(acc, xyzz_shfl_xor(acc, mask));
+  if (live && q == 0) store_xyzz(buckets, k, acc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -396,18 +416,27 @@ __global__ void __launch_bounds__(128) k_pyramid_step(const uint32_t* __restrict
   store_xyzz(wo, tid, xyzz_add(load_xyzz(wi, ia), load_xyzz(wi, ib)));
 }
 
-// 9a. per-window Horner.  Input state after the last pyramid step: X has 2 elements, Z^0..Z^(nz-1) one each.
-//     window sum = X0 + X1 + sum_l 2^l Z^l + 2^nz X1
+// 9a. per-window weighted sum.  Input state after the last pyramid step: X has 2 elements, Z^0..Z^(nz-1) one each.
+//     window sum = X0 + X1 + sum_l 2^l Z^l + 2^nz X1.  One 16-lane group per window: lane l < nz computes 2^l Z^l by l
+//     doublings, lane nz computes 2^nz X1, lane nz + 1 holds X0 + X1; a 4-step shuffle tree adds the terms.
+//     Depth nz doublings + 4 additions instead of nz (doubling + addition).  Needs nz + 2 <= 16, i.e. c <= 16.
 __global__ void __launch_bounds__(64) k_window_horner(const uint32_t* __restrict__ in, uint32_t in_stride, int nz,
                                                       uint32_t* __restrict__ winsum, int W) {
-  int win = blockIdx.x * blockDim.x + threadIdx.x;
-  if (win >= W) return;
-  const uint32_t* wi = in + (size_t)win * in_stride * 36;
-  xyzz x0 = load_xyzz(wi, 0), x1 = load_xyzz(wi, 1);
-  xyzz acc = x1;
-  for (int l = nz - 1; l >= 0; l--) acc = xyzz_add(xyzz_dbl(acc), load_xyzz(wi, 2 + l));
-  acc = xyzz_add(acc, xyzz_add(x0, x1));
-  store_xyzz(winsum, win, acc);
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int win = gid >> 4, lane = gid & 15;
+  xyzz acc = xyzz_identity();
+  if (win < W) {
+    const uint32_t* wi = in + (size_t)win * in_stride * 36;
+    int dbl = 0;
+    if (lane < nz) { acc = load_xyzz(wi, 2 + lane); dbl = lane; }
+    else if (lane == nz) { acc = load_xyzz(wi, 1); dbl = nz; }
+    else if (lane == nz + 1) acc = xyzz_add(load_xyzz(wi, 0), load_xyzz(wi, 1));
+#pragma unroll 1
+    for (int i = 0; i < dbl; i++) acc = xyzz_dbl(acc);
+  }
+#pragma unroll 1
+  for (int mask = 1; mask < 16; mask <<= 1) acc = xyzz_add(acc, xyzz_shfl_xor(acc, mask));
+  if (win < W && lane == 0) store_xyzz(winsum, win, acc);
 }
 
 // 9b. fold windows: result = sum_w 2^(c w) winsum[w]; writes the Jacobian result (24 words)
@@ -459,7 +488,8 @@ int msm_pick_window_prepared(size_t n) {
 
 size_t msm_workspace_bytes(size_t n, int c) {
   const size_t W = (256 + c - 1) / c, B = (size_t)1 << (c - 1), NB = W * B;
-  const size_t max_tasks = W * n / 16 + NB + 1;   // sized for the smallest task length the experiments knob allows
+  // 64-entry tasks when the chip is full, else as short as 4 entries (see the task-length choice in msm_g1_device)
+  const size_t max_tasks = ((W * n) >> TASK_SHIFT) >= ((size_t)1 << 17) ? ((W * n) >> TASK_SHIFT) + NB + 1 : W * n / 4 + NB + 1;
   size_t total = 0;
   total += align_up(W * (n + 8) * sizeof(int16_t), 256);    // digits (rows padded to a multiple of 8)
   total += align_up(W * n * sizeof(uint32_t), 256);         // sorted
@@ -498,9 +528,20 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   }
   if ((size_t)W * n >= (1ull << 32)) { set_error("msm: W*n overflows 32-bit slot index"); return ZKHIP_EINVAL; }
   if (ws_bytes < msm_workspace_bytes(n, c)) { set_error("msm: workspace too small"); return ZKHIP_EINVAL; }
-  const size_t max_tasks = (size_t)W * n / 16 + NB + 1;
+  const size_t max_tasks = (((size_t)W * n) >> TASK_SHIFT) >= ((size_t)1 << 17) ? (((size_t)W * n) >> TASK_SHIFT) + NB + 1 : (size_t)W * n / 4 + NB + 1;
+  // Task length.  With >= 2^17 tasks of 64 entries the chip is full and 64 is best (throughput-bound, see TASK_SHIFT).  Below
+  // that the MSM is latency-bound: a task of L entries is L sequential mixed adds (~5 us each at low occupancy) and a bucket
+  // of s entries leaves s/L partials to sum (~10 us each): pick L = 2^shift minimising 5 L + 10 (s/L - 1).
   uint32_t task_shift = TASK_SHIFT;
-  if (const char* e = getenv("ZKHIP_TASK_SHIFT")) { int v = atoi(e); if (v >= 4 && v <= 14) task_shift = (uint32_t)v; }   // experiments
+  if ((((size_t)W * n) >> TASK_SHIFT) < ((size_t)1 << 17)) {
+    const double occ = (double)W * (double)n / (double)NB;
+    double best = 1e300;
+    for (uint32_t sh = 2; sh <= (uint32_t)TASK_SHIFT; sh++) {
+      const double L = (double)(1u << sh), parts = occ / L;
+      const double est = 5.0 * L + 10.0 * (parts > 1.0 ? parts - 1.0 : 0.0);
+      if (est < best) { best = est; task_shift = sh; }
+    }
+  }
 
   char* p = (char*)ws;
   auto carve = [&](size_t bytes) { void* r = p; p += align_up(bytes, 256); return r; };
@@ -566,13 +607,20 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   }
   prof_mark(stream, "accumulate");
   // 7. combine
+  const uint32_t seq_parts = (((size_t)W * n) >> TASK_SHIFT) >= ((size_t)1 << 17) ? 256u : 16u;
   {
     uint32_t blocks = (uint32_t)((max_tasks + 127) / 128);
     if (blocks > 2048) blocks = 2048;
     for (int level = 0; level < COMBINE_LEVELS; level++)
-      hipLaunchKernelGGL(k_combine_tree, dim3(blocks), dim3(128), 0, stream, tasks, counters + 1, task_off, counters + 2, partials, level);
+      hipLaunchKernelGGL(k_combine_tree, dim3(blocks), dim3(128), 0, stream, tasks, counters + 1, task_off, counters + 2, partials, level, seq_parts);
   }
-  hipLaunchKernelGGL(k_combine_seq, dim3((NB + 127) / 128), dim3(128), 0, stream, task_off, NB, partials, pyrA);
+  {
+    const double parts = (double)W * (double)n / (double)NB / (double)(1u << task_shift);   // expected partials per bucket
+    if (parts <= 2.0) hipLaunchKernelGGL(k_combine_seq<1>, dim3((NB + 127) / 128), dim3(128), 0, stream, task_off, NB, partials, pyrA, seq_parts);
+    else if (parts <= 4.0) hipLaunchKernelGGL(k_combine_seq<2>, dim3((unsigned)(((size_t)NB * 2 + 127) / 128)), dim3(128), 0, stream, task_off, NB, partials, pyrA, seq_parts);
+    else if (parts <= 12.0) hipLaunchKernelGGL(k_combine_seq<4>, dim3((unsigned)(((size_t)NB * 4 + 127) / 128)), dim3(128), 0, stream, task_off, NB, partials, pyrA, seq_parts);
+    else hipLaunchKernelGGL(k_combine_seq<8>, dim3((unsigned)(((size_t)NB * 8 + 127) / 128)), dim3(128), 0, stream, task_off, NB, partials, pyrA, seq_parts);
+  }
   prof_mark(stream, "combine");
   // 8. pyramid: buckets were written with window stride B (dense).  Steps 1 .. c-2 leave X with 2 elements.
   uint32_t* cur = pyrA;
@@ -600,7 +648,7 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
     set_error("msm: internal: B == 1");
     return ZKHIP_EINVAL;
   }
-  hipLaunchKernelGGL(k_window_horner, dim3((WB + 63) / 64), dim3(64), 0, stream, cur, in_stride, nz, winsum, WB);
+  hipLaunchKernelGGL(k_window_horner, dim3((WB * 16 + 63) / 64), dim3(64), 0, stream, cur, in_stride, nz, winsum, WB);
   prof_mark(stream, "horner");
   hipLaunchKernelGGL(k_fold, dim3(1), dim3(64), 0, stream, winsum, WB, c, d_out);   // prepared: WB == 1, just the format conversion
   prof_mark(stream, "fold");
