@@ -67,6 +67,20 @@ int zkhip_extended_to_coeff(uint64_t *a, uint32_t ext_k, const uint64_t ext_omeg
 /* `divide_by_vanishing_poly`: a[i] *= table[i % period] (table = inverted t_evaluations). */
 int zkhip_mul_periodic(uint64_t *a, size_t n, const uint64_t *table, uint32_t period);
 
+/* ---- Fr-vector primitives of the prover besides the NTT ------------------------ */
+/* `eval_polynomial(poly, point)` [DEP arithmetic.rs]: out = sum poly[i] * point^i. */
+int zkhip_fr_eval_polynomial(const uint64_t *poly, size_t n, const uint64_t point[4], uint64_t out[4]);
+/* `kate_division(a, b)` [DEP arithmetic.rs]: quotient of a(X) by (X - b), remainder dropped; q has n - 1 elements. */
+int zkhip_fr_kate_division(const uint64_t *a, size_t n, const uint64_t b[4], uint64_t *q);
+/* `BatchInvert::batch_invert` [DEP ff]: in place, zeros stay zero. */
+int zkhip_fr_batch_invert(uint64_t *a, size_t n);
+/* grand-product running product [DEP plonk/permutation/prover.rs]: out[0] = 1, out[i] = v[0] * ... * v[i-1] (out may alias v). */
+int zkhip_fr_prefix_product(const uint64_t *v, size_t n, uint64_t *out);
+int zkhip_fr_eval_polynomial_device(const void *d_poly, size_t n, const uint64_t point[4], void *d_out, void *stream);
+int zkhip_fr_kate_division_device(const void *d_a, size_t n, const uint64_t b[4], void *d_q, void *stream);
+int zkhip_fr_batch_invert_device(void *d_a, size_t n, void *stream);
+int zkhip_fr_prefix_product_device(const void *d_v, size_t n, void *d_out, void *stream);
+
 /* ---- device-resident variants (pointers are HIP device pointers; stream is a hipStream_t or NULL) --- */
 /* Used by the pipeline / bench so that polynomials and scalars stay in HBM between calls. */
 int zkhip_msm_g1_device(const void *d_scalars, const void *d_bases, size_t n, void *d_out_xyz, void *stream);

@@ -369,6 +369,43 @@ class EvaluationDomain:
 
 
 # ----------------------------------------------------------------------------------------------
+# Row a7: eval_polynomial / kate_division [DEP halo2_proofs/src/arithmetic.rs], BatchInvert [DEP ff], and the
+# grand-product running product [DEP halo2_proofs/src/plonk/permutation/prover.rs]
+# ----------------------------------------------------------------------------------------------
+def eval_polynomial(poly: Sequence[int], point: int) -> int:
+    acc = 0
+    for c in reversed(poly):          # Horner, as the reference's serial `evaluate`
+        acc = (acc * point + c) % R_MOD
+    return acc
+
+
+def kate_division(a: Sequence[int], b: int) -> List[int]:
+    """Quotient of a(X) by (X - b); the remainder is dropped (the reference negates b and runs the same recurrence)."""
+    nb = (-b) % R_MOD
+    q = [0] * (len(a) - 1)
+    tmp = 0
+    for i in range(len(a) - 1, 0, -1):
+        lead = (a[i] - tmp) % R_MOD
+        q[i - 1] = lead
+        tmp = lead * nb % R_MOD
+    return q
+
+
+def batch_invert(a: Sequence[int]) -> List[int]:
+    """Elementwise inverse, zeros stay zero (ff::BatchInvert semantics)."""
+    return [pow(x, -1, R_MOD) if x % R_MOD else 0 for x in a]
+
+
+def prefix_product(v: Sequence[int]) -> List[int]:
+    """z[0] = 1, z[i+1] = z[i] * v[i]; returns z[0..n)."""
+    out, cur = [], 1
+    for x in v:
+        out.append(cur)
+        cur = cur * x % R_MOD
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
 # Deterministic input generators shared by tests / bench / C oracle (SURVEY.md section 8d)
 # ----------------------------------------------------------------------------------------------
 class SplitMix64:

@@ -463,6 +463,56 @@ void ref_mul_periodic(u64* a, size_t n, const u64* table, size_t period) { /* di
   for (size_t i = 0; i < n; i++) f_mul(&FR, a + 4 * i, a + 4 * i, table + 4 * (i % period));
 }
 
+/* ---------------------------------------------------------------- row a7 (serial restatements) */
+void ref_eval_polynomial(const u64* poly, size_t n, const u64 point[4], u64 out[4]) { /* `evaluate`: Horner from the top */
+  u64 acc[4] = {0, 0, 0, 0};
+  for (size_t i = n; i-- > 0;) {
+    f_mul(&FR, acc, acc, point);
+    f_add(&FR, acc, acc, poly + 4 * i);
+  }
+  memcpy(out, acc, 32);
+}
+void ref_kate_division(const u64* a, size_t n, const u64 b[4], u64* q) { /* b = -b; q[i-1] = a[i] - tmp; tmp = q[i-1] * b */
+  if (n < 2) return;
+  u64 nb[4], zero[4] = {0, 0, 0, 0}, tmp[4] = {0, 0, 0, 0};
+  f_sub(&FR, nb, zero, b);
+  for (size_t i = n - 1; i >= 1; i--) {
+    u64 lead[4];
+    f_sub(&FR, lead, a + 4 * i, tmp);
+    memcpy(q + 4 * (i - 1), lead, 32);
+    f_mul(&FR, tmp, lead, nb);
+  }
+}
+void ref_batch_invert(u64* a, size_t n) { /* ff::BatchInvert: zeros are skipped and stay zero */
+  u64* pref = (u64*)malloc((n + 1) * 32);
+  u64 acc[4];
+  memcpy(acc, FR.one, 32);
+  for (size_t i = 0; i < n; i++) {
+    memcpy(pref + 4 * i, acc, 32);
+    if (!f_is_zero(a + 4 * i)) f_mul(&FR, acc, acc, a + 4 * i);
+  }
+  u64 inv[4];
+  f_inv(&FR, inv, acc);
+  for (size_t i = n; i-- > 0;) {
+    if (f_is_zero(a + 4 * i)) continue;
+    u64 t[4];
+    f_mul(&FR, t, inv, pref + 4 * i);
+    f_mul(&FR, inv, inv, a + 4 * i);
+    memcpy(a + 4 * i, t, 32);
+  }
+  free(pref);
+}
+void ref_prefix_product(const u64* v, size_t n, u64* out) { /* z[0] = 1; z[i+1] = z[i] * v[i] */
+  u64 cur[4];
+  memcpy(cur, FR.one, 32);
+  for (size_t i = 0; i < n; i++) {
+    u64 t[4];
+    memcpy(t, v + 4 * i, 32);
+    memcpy(out + 4 * i, cur, 32);
+    f_mul(&FR, cur, cur, t);
+  }
+}
+
 /* ---------------------------------------------------------------- elementwise hooks + generators */
 void ref_field_op(int field, int op, const u64* a, const u64* b, u64* out, size_t n) {
   const field_t* F = field == 0 ? &FQ : &FR;

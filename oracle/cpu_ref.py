@@ -61,6 +61,28 @@ def mul_periodic(a: np.ndarray, table: np.ndarray) -> None:
     load().ref_mul_periodic(_p(a), C.c_size_t(a.shape[0]), _p(table), C.c_size_t(table.shape[0]))
 
 
+def eval_polynomial(poly: np.ndarray, point: np.ndarray) -> np.ndarray:
+    out = np.zeros(4, dtype=np.uint64)
+    load().ref_eval_polynomial(_p(poly), C.c_size_t(poly.shape[0]), _p(point), _p(out))
+    return out
+
+
+def kate_division(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    q = np.zeros((max(a.shape[0] - 1, 0), 4), dtype=np.uint64)
+    load().ref_kate_division(_p(a), C.c_size_t(a.shape[0]), _p(b), _p(q))
+    return q
+
+
+def batch_invert(a: np.ndarray) -> None:
+    load().ref_batch_invert(_p(a), C.c_size_t(a.shape[0]))
+
+
+def prefix_product(v: np.ndarray) -> np.ndarray:
+    out = np.zeros_like(v)
+    load().ref_prefix_product(_p(v), C.c_size_t(v.shape[0]), _p(out))
+    return out
+
+
 def jac_to_affine(xyz: np.ndarray) -> np.ndarray:
     out = np.zeros(8, dtype=np.uint64)
     load().ref_jac_to_affine(_p(np.ascontiguousarray(xyz, dtype=np.uint64)), _p(out))

@@ -330,3 +330,40 @@ def test_sharded_msm_single_rank_gpu_path(cref):
     _lib.check(_lib.load().zkhip_g1_sum(stack.ctypes.data, 3, out.ctypes.data))
     assert np.array_equal(aff(cref, out), structured_expect(cref, sc, t0, d))
     assert np.array_equal(aff(cref, sharded_msm(sc, bases)), structured_expect(cref, sc, t0, d))
+
+
+# ---------------------------------------------------------------- row a7: eval_polynomial, kate_division, batch_invert, grand product
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 1000, 1025, 32 * 32 + 1, 70000, 1 << 20])
+def test_row_a7_vs_reference_algorithm(cref, n):
+    from zksnap_circuits_halo2_amd import arithmetic as A
+
+    a = cref.gen_scalars(700 + n, n, n % 2)
+    x = cref.gen_scalars(800 + n, 1, 0)[0]
+    assert np.array_equal(A.eval_polynomial(a, x), cref.eval_polynomial(a, x))
+    assert np.array_equal(A.kate_division(a, x), cref.kate_division(a, x))
+    assert np.array_equal(A.prefix_product(a), cref.prefix_product(a))
+    b, ref = a.copy(), a.copy()
+    A.batch_invert(b)
+    cref.batch_invert(ref)
+    assert np.array_equal(b, ref)
+    if n >= 31:   # zeros stay zero / all zero
+        assert not b[(a == 0).all(axis=1)].any()
+    z = np.zeros((min(n, 100), 4), dtype=np.uint64)
+    A.batch_invert(z)
+    assert not z.any()
+    assert np.array_equal(A.eval_polynomial(z, x), np.zeros(4, dtype=np.uint64))
+
+
+def test_row_a7_golden_small():
+    from zksnap_circuits_halo2_amd import arithmetic as A
+
+    g = O.SplitMix64(2024)
+    a = [g.fr() for _ in range(77)]
+    x = g.fr()
+    Aenc, X = F.fr_encode(a), F.fr_encode([x])[0]
+    assert F.fr_decode(A.eval_polynomial(Aenc, X))[0] == O.eval_polynomial(a, x)
+    assert F.fr_decode(A.kate_division(Aenc, X)) == O.kate_division(a, x)
+    assert F.fr_decode(A.prefix_product(Aenc)) == O.prefix_product(a)
+    B = Aenc.copy()
+    A.batch_invert(B)
+    assert F.fr_decode(B) == O.batch_invert(a)

@@ -139,3 +139,27 @@ def test_c_oracle_domain_passes(cref):
     cref.scale(ext, enc1(d.extended_ifft_divisor))
     cref.distribute_powers_zeta(ext, enc1(d.g_coset_inv), enc1(d.g_coset))
     assert F.fr_decode(ext[: 3 * d.n]) == p + [0] * (2 * d.n)
+
+
+def test_row_a7_oracles_agree(cref):
+    """eval_polynomial / kate_division / batch_invert / prefix_product: C restatement == big-int model, plus identities."""
+    g = O.SplitMix64(31)
+    for n in (1, 2, 5, 33, 200):
+        a = [g.fr() for _ in range(n)]
+        x = g.fr()
+        A, X = F.fr_encode(a), F.fr_encode([x])[0]
+        assert F.fr_decode(cref.eval_polynomial(A, X))[0] == O.eval_polynomial(a, x) == sum(c * pow(x, i, O.R_MOD) for i, c in enumerate(a)) % O.R_MOD
+        q = O.kate_division(a, x)
+        assert F.fr_decode(cref.kate_division(A, X)) == q
+        if n > 1:   # a(X) = q(X) (X - x) + a(x): check at a random point
+            y = g.fr()
+            assert (O.eval_polynomial(q, y) * (y - x) + O.eval_polynomial(a, x)) % O.R_MOD == O.eval_polynomial(a, y)
+        v = list(a)
+        if n > 3:
+            v[1] = 0
+        V = F.fr_encode(v)
+        assert F.fr_decode(cref.prefix_product(V)) == O.prefix_product(v)
+        W = V.copy()
+        cref.batch_invert(W)
+        inv = F.fr_decode(W)
+        assert inv == O.batch_invert(v) and all((p * q_) % O.R_MOD == (1 if p else 0) for p, q_ in zip(v, inv))

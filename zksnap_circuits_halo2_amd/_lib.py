@@ -22,6 +22,14 @@ _SIGS = {
     "zkhip_coeff_to_extended": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "zkhip_extended_to_coeff": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "zkhip_mul_periodic": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32]),
+    "zkhip_fr_eval_polynomial": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "zkhip_fr_kate_division": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "zkhip_fr_batch_invert": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "zkhip_fr_prefix_product": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "zkhip_fr_eval_polynomial_device": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "zkhip_fr_kate_division_device": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "zkhip_fr_batch_invert_device": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "zkhip_fr_prefix_product_device": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "zkhip_msm_g1_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "zkhip_prepare_bases_device": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]),
     "zkhip_release_bases": (C.c_int, [C.c_uint64]),

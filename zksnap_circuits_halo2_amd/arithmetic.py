@@ -33,3 +33,35 @@ def best_fft(a: np.ndarray, omega: np.ndarray, log_n: int) -> None:
     omega = np.ascontiguousarray(omega, dtype=np.uint64).reshape(4)
     lib = _lib.load()
     _lib.check(lib.zkhip_ntt_fr(_ptr(a), _ptr(omega), log_n))
+
+
+def eval_polynomial(poly: np.ndarray, point: np.ndarray) -> np.ndarray:
+    """sum poly[i] * point^i  ((n,4) uint64 Fr, (4,) uint64 Fr) -> (4,) uint64 Fr."""
+    poly = np.ascontiguousarray(poly, dtype=np.uint64).reshape(-1, 4)
+    point = np.ascontiguousarray(point, dtype=np.uint64).reshape(4)
+    out = np.zeros(4, dtype=np.uint64)
+    _lib.check(_lib.load().zkhip_fr_eval_polynomial(_ptr(poly), poly.shape[0], _ptr(point), _ptr(out)))
+    return out
+
+
+def kate_division(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """Quotient of a(X) by (X - b), remainder dropped: (n,4) -> (n-1,4)."""
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+    b = np.ascontiguousarray(b, dtype=np.uint64).reshape(4)
+    q = np.zeros((max(a.shape[0] - 1, 0), 4), dtype=np.uint64)
+    _lib.check(_lib.load().zkhip_fr_kate_division(_ptr(a), a.shape[0], _ptr(b), _ptr(q)))
+    return q
+
+
+def batch_invert(a: np.ndarray) -> None:
+    """In-place elementwise inversion; zeros stay zero (ff::BatchInvert)."""
+    assert a.dtype == np.uint64 and a.flags.c_contiguous
+    _lib.check(_lib.load().zkhip_fr_batch_invert(_ptr(a), a.size // 4))
+
+
+def prefix_product(v: np.ndarray) -> np.ndarray:
+    """Grand-product running product: out[0] = 1, out[i] = v[0] * ... * v[i-1]."""
+    v = np.ascontiguousarray(v, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros_like(v)
+    _lib.check(_lib.load().zkhip_fr_prefix_product(_ptr(v), v.shape[0], _ptr(out)))
+    return out

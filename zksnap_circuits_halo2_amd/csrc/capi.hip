@@ -400,6 +400,92 @@ int zkhip_mul_periodic(uint64_t* a, size_t n, const uint64_t* table, uint32_t pe
   return ZKHIP_OK;
 }
 
+// ---- row a7: Fr-vector primitives ---------------------------------------------------------------------
+int zkhip_fr_eval_polynomial_device(const void* d_poly, size_t n, const uint64_t point[4], void* d_out, void* stream) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (!point || !d_out || (n && !d_poly)) { set_error("eval_polynomial: null pointer"); return ZKHIP_EINVAL; }
+  if ((rc = g_ctx.ws.reserve(poly_workspace_bytes(n))) != ZKHIP_OK) return rc;
+  return fr_eval_polynomial_device((const uint32_t*)d_poly, n, (const uint32_t*)point, (uint32_t*)d_out, g_ctx.ws.p, g_ctx.ws.cap,
+                                   stream ? (hipStream_t)stream : g_ctx.stream);
+}
+
+int zkhip_fr_kate_division_device(const void* d_a, size_t n, const uint64_t b[4], void* d_q, void* stream) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (!b || (n > 1 && (!d_a || !d_q))) { set_error("kate_division: null pointer"); return ZKHIP_EINVAL; }
+  if ((rc = g_ctx.ws.reserve(poly_workspace_bytes(n))) != ZKHIP_OK) return rc;
+  return fr_kate_division_device((const uint32_t*)d_a, n, (const uint32_t*)b, (uint32_t*)d_q, g_ctx.ws.p, g_ctx.ws.cap,
+                                 stream ? (hipStream_t)stream : g_ctx.stream);
+}
+
+int zkhip_fr_batch_invert_device(void* d_a, size_t n, void* stream) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (n && !d_a) { set_error("batch_invert: null pointer"); return ZKHIP_EINVAL; }
+  if ((rc = g_ctx.ws.reserve(poly_workspace_bytes(n))) != ZKHIP_OK) return rc;
+  return fr_batch_invert_device((uint32_t*)d_a, n, g_ctx.ws.p, g_ctx.ws.cap, stream ? (hipStream_t)stream : g_ctx.stream);
+}
+
+int zkhip_fr_prefix_product_device(const void* d_v, size_t n, void* d_out, void* stream) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (n && (!d_v || !d_out)) { set_error("prefix_product: null pointer"); return ZKHIP_EINVAL; }
+  if ((rc = g_ctx.ws.reserve(poly_workspace_bytes(n))) != ZKHIP_OK) return rc;
+  return fr_prefix_product_device((const uint32_t*)d_v, n, (uint32_t*)d_out, g_ctx.ws.p, g_ctx.ws.cap, stream ? (hipStream_t)stream : g_ctx.stream);
+}
+
+// host-buffer wrappers: upload to the poly scratch, run, download
+static int host_vec_op(int op, const uint64_t* in, size_t n_in, const uint64_t* c, uint64_t* out, size_t n_out) {
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  hipStream_t s = g_ctx.stream;
+  if ((rc = g_ctx.poly.reserve((n_in + 1) * 32)) != ZKHIP_OK) return rc;
+  if ((rc = g_ctx.poly2.reserve((n_out + 1) * 32)) != ZKHIP_OK) return rc;
+  if (n_in) HIPCHK(hipMemcpyAsync(g_ctx.poly.p, in, n_in * 32, hipMemcpyHostToDevice, s));
+  switch (op) {
+    case 0: rc = zkhip_fr_eval_polynomial_device(g_ctx.poly.p, n_in, c, g_ctx.poly2.p, s); break;
+    case 1: rc = zkhip_fr_kate_division_device(g_ctx.poly.p, n_in, c, g_ctx.poly2.p, s); break;
+    case 2: rc = zkhip_fr_batch_invert_device(g_ctx.poly.p, n_in, s); break;
+    default: rc = zkhip_fr_prefix_product_device(g_ctx.poly.p, n_in, g_ctx.poly2.p, s); break;
+  }
+  if (rc != ZKHIP_OK) return rc;
+  if (n_out) HIPCHK(hipMemcpyAsync(out, op == 2 ? g_ctx.poly.p : g_ctx.poly2.p, n_out * 32, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return ZKHIP_OK;
+}
+
+int zkhip_fr_eval_polynomial(const uint64_t* poly, size_t n, const uint64_t point[4], uint64_t out[4]) {
+  guard_t g(g_mu);
+  if (!point || !out || (n && !poly)) { set_error("eval_polynomial: null pointer"); return ZKHIP_EINVAL; }
+  return host_vec_op(0, poly, n, point, out, 1);
+}
+
+int zkhip_fr_kate_division(const uint64_t* a, size_t n, const uint64_t b[4], uint64_t* q) {
+  guard_t g(g_mu);
+  if (!b || (n > 1 && (!a || !q))) { set_error("kate_division: null pointer"); return ZKHIP_EINVAL; }
+  if (n < 2) return ZKHIP_OK;
+  return host_vec_op(1, a, n, b, q, n - 1);
+}
+
+int zkhip_fr_batch_invert(uint64_t* a, size_t n) {
+  guard_t g(g_mu);
+  if (n && !a) { set_error("batch_invert: null pointer"); return ZKHIP_EINVAL; }
+  if (n == 0) return ZKHIP_OK;
+  return host_vec_op(2, a, n, nullptr, a, n);
+}
+
+int zkhip_fr_prefix_product(const uint64_t* v, size_t n, uint64_t* out) {
+  guard_t g(g_mu);
+  if (n && (!v || !out)) { set_error("prefix_product: null pointer"); return ZKHIP_EINVAL; }
+  if (n == 0) return ZKHIP_OK;
+  return host_vec_op(3, v, n, nullptr, out, n);
+}
+
 int zkhip_profile_enable(int on) {
   guard_t g(g_mu);
   g_prof_on = on != 0;

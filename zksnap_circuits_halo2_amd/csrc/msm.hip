@@ -67,6 +67,18 @@ __device__ __forceinline__ void store_xyzz(uint32_t* base, size_t idx, const xyz
   for (int i = 0; i < 9; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
 
+__device__ __forceinline__ xyzz xyzz_shfl_xor(const xyzz& a, int mask) {
+  xyzz r;
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    r.X.l[i] = (uint32_t)__shfl_xor((int)a.X.l[i], mask, 64);
+    r.Y.l[i] = (uint32_t)__shfl_xor((int)a.Y.l[i], mask, 64);
+    r.ZZ.l[i] = (uint32_t)__shfl_xor((int)a.ZZ.l[i], mask, 64);
+    r.ZZZ.l[i] = (uint32_t)__shfl_xor((int)a.ZZZ.l[i], mask, 64);
+  }
+  return r;
+}
+
 __device__ __forceinline__ fe load_fe9_generic(const uint32_t* p, size_t idx) {
   fe r;
 #pragma unroll
@@ -351,18 +363,6 @@ __global__ void __launch_bounds__(128) k_combine_tree(const task_t* __restrict__
   }
 }
 
-__device__ __forceinline__ xyzz xyzz_shfl_xor(const xyzz& a, int mask) {
-  xyzz r;
-#pragma unroll
-  for (int i = 0; i < NL; i++) {
-    r.X.l[i] = (uint32_t)__shfl_xor((int)a.X.l[i], mask, 64);
-    r.Y.l[i] = (uint32_t)__shfl_xor((int)a.Y.l[i], mask, 64);
-    r.ZZ.l[i] = (uint32_t)__shfl_xor((int)a.ZZ.l[i], mask, 64);
-    r.ZZZ.l[i] = (uint32_t)__shfl_xor((int)a.ZZZ.l[i], mask, 64);
-  }
-  return r;
-}
-
 // LANES adjacent lanes per bucket: lane q sums the remaining partials q, q + LANES, ... (stride 4^levels apart), then
 // log2(LANES) xor-shuffle steps add the lane sums.  Depth m/LANES + log2(LANES) additions instead of m - 1.  The host
 // picks LANES from the expected partials per bucket (1 lane when buckets hold ~1-2 partials: the general path).
@@ -450,12 +450,18 @@ __global__ void __launch_bounds__(64) k_fold(const uint32_t* __restrict__ winsum
   store_jacobian(acc, out);
 }
 
-// sum of `m` Jacobian points (multi-GPU partial fold): out = sum in[i]
+// sum of `m` Jacobian points (multi-GPU partial fold): out = sum in[i].  One wave: lane l sums points l, l + 64, ...,
+// then a 6-step shuffle tree (8 GPUs: depth 3 additions instead of 8 sequential ones).
 __global__ void __launch_bounds__(64) k_sum_jacobian(const uint32_t* __restrict__ in, int m, uint32_t* __restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (blockIdx.x != 0) return;
   xyzz acc = xyzz_identity();
-  for (int i = 0; i < m; i++) acc = xyzz_add(acc, load_jacobian(in + (size_t)i * 24));
-  store_jacobian(acc, out);
+  for (int i = threadIdx.x; i < m; i += 64) acc = xyzz_add(acc, load_jacobian(in + (size_t)i * 24));
+#pragma unroll 1
+  for (int mask = 1; mask < 64; mask <<= 1) {
+    if (mask >= m && mask > 1) break;          // lanes >= m hold the identity: higher steps add nothing
+    acc = xyzz_add(acc, xyzz_shfl_xor(acc, mask));
+  }
+  if (threadIdx.x == 0) store_jacobian(acc, out);
 }
 
 // ------------------------------------------------------------------------------------------------

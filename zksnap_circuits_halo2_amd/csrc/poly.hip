@@ -1,0 +1,297 @@
+// Fr-vector primitives of the prover besides the NTT: `eval_polynomial`, `kate_division`
+// ([DEP] halo2-axiom halo2_proofs/src/arithmetic.rs), `BatchInvert::batch_invert` ([DEP] ff crate, used by the
+// permutation / lookup grand products) and the grand-product running product itself ([DEP] plonk/permutation/prover.rs:
+// z[i+1] = z[i] * v[i]); all reached from create_proof, /root/reference/aggregator/src/wrapper.rs:129.
+//
+// All four are chunked linear recurrences: a thread owns CH consecutive elements, a first pass produces one aggregate
+// per chunk, the aggregates are processed recursively (1/CH of the work), a second pass re-runs each chunk with its
+// incoming carry.  2 multiplies per element, O(log_CH n) launches.
+//   suffix Horner scan  out[i] = a[i] + b * out[i+1]           (kate_division; eval_polynomial is out[0])
+//   prefix product      out[0] = 1, out[i+1] = out[i] * v[i]
+//   batch inversion     Montgomery's trick per chunk with one Fermat inversion per thread
+// Values are kept in the external Montgomery-256 domain throughout: x*2^256 is the radix-2^261 form of x*2^-5 and the
+// recurrences are linear in the data, so only the constant multiplier is converted (fp29.hpp).
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "fp29.hpp"
+#include "zkhip_internal.hpp"
+
+namespace zkhip {
+
+using Fr = FrParams;
+constexpr uint32_t POLY_CH = 32;   // elements per thread
+
+struct fe_arg {   // a field constant passed by value (external words)
+  uint32_t w[8];
+};
+
+__device__ __forceinline__ fe fr_const_internal(const fe_arg& c) {   // c * 2^256 -> c * 2^261, reduced
+  fe k;
+#pragma unroll
+  for (int i = 0; i < NL; i++) k.l[i] = Fr::FROM_EXT[i];
+  uint32_t w[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) w[i] = c.w[i];
+  return fe_mul<Fr>(k, fe_unpack<0>(w));
+}
+
+__device__ __forceinline__ fe load_ext(const uint32_t* p, size_t i) {
+  uint32_t w[8];
+  load_words(p + i * 8, w);
+  return fe_unpack<0>(w);
+}
+__device__ __forceinline__ void store_canon(uint32_t* p, size_t i, const fe& x_lt3p) {
+  uint32_t w[8];
+  fe_pack(fe_canon_lt3p<Fr>(x_lt3p), w);
+  store_words(p + i * 8, w);
+}
+
+__device__ __forceinline__ fe fr_pow_u32(fe base, uint32_t e) {   // base^e, base internal & reduced
+  fe acc = fe_one<Fr>();
+  while (e) {
+    if (e & 1) acc = fe_mul<Fr>(acc, base);
+    base = fe_sqr<Fr>(base);
+    e >>= 1;
+  }
+  return acc;
+}
+
+// ---- suffix Horner scan ---------------------------------------------------------------------------
+// pass A: agg[t] = sum_{i in chunk t} a[i] b^(i - lo)          (the chunk's scan value at its first element, carry-in 0)
+__global__ void __launch_bounds__(256) k_horner_agg(const uint32_t* __restrict__ a, size_t n, const fe_arg* __restrict__ b_dev, uint32_t* __restrict__ agg) {
+  const fe_arg b_ext = *b_dev;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t lo = t * POLY_CH;
+  if (lo >= n) return;
+  const size_t hi = lo + POLY_CH < n ? lo + POLY_CH : n;
+  const fe b = fr_const_internal(b_ext);
+  fe q = fe_zero();
+  for (size_t i = hi; i-- > lo;) q = fe_norm(fe_add(load_ext(a, i), fe_mul<Fr>(b, q)));   // < 3p, N
+  store_canon(agg, t, q);
+}
+
+// pass B: out[i] = a[i] + b * out[i+1] with carry-in carry[t+1] (the full scan value at the next chunk's first element)
+__global__ void __launch_bounds__(256) k_horner_apply(const uint32_t* __restrict__ a, size_t n, const fe_arg* __restrict__ b_dev,
+                                                      const uint32_t* __restrict__ carry, size_t ncarry, uint32_t* __restrict__ out,
+                                                      size_t out_shift) {
+  const fe_arg b_ext = *b_dev;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t lo = t * POLY_CH;
+  if (lo >= n) return;
+  const size_t hi = lo + POLY_CH < n ? lo + POLY_CH : n;
+  const fe b = fr_const_internal(b_ext);
+  fe q = (carry != nullptr && t + 1 < ncarry) ? load_ext(carry, t + 1) : fe_zero();
+  for (size_t i = hi; i-- > lo;) {
+    q = fe_norm(fe_add(load_ext(a, i), fe_mul<Fr>(b, q)));
+    if (i >= out_shift) store_canon(out, i - out_shift, q);     // kate_division drops the scan value at index 0
+  }
+}
+
+// b^CH for the next recursion level (single thread)
+__global__ void k_pow_const(const fe_arg* __restrict__ b_dev, uint32_t e, uint32_t* __restrict__ out_ext) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const fe_arg b_ext = *b_dev;
+  fe r = fr_pow_u32(fr_const_internal(b_ext), e);             // b^e * 2^261
+  fe k;
+#pragma unroll
+  for (int i = 0; i < NL; i++) k.l[i] = Fr::TO_EXT[i];
+  uint32_t w[8];
+  fe_pack(fe_canon_lt2p<Fr>(fe_mul<Fr>(k, r)), w);             // b^e * 2^256
+#pragma unroll
+  for (int i = 0; i < 8; i++) out_ext[i] = w[i];
+}
+
+// ---- prefix product --------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_prod_agg(const uint32_t* __restrict__ v, size_t n, uint32_t* __restrict__ agg) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t lo = t * POLY_CH;
+  if (lo >= n) return;
+  const size_t hi = lo + POLY_CH < n ? lo + POLY_CH : n;
+  uint32_t w[8];
+  load_words(v + lo * 8, w);
+  fe acc = fe_unpack<0>(w);                                   // x * 2^256 (external domain)
+  for (size_t i = lo + 1; i < hi; i++) {
+    load_words(v + i * 8, w);
+    acc = fe_mul<Fr>(acc, fe_from_ext_lazy(w));               // ext-domain value times internal-form factor stays in the ext domain
+  }
+  store_canon(agg, t, acc);
+}
+
+// out[i] = carry[t] * prod_{lo <= j < i} v[j]   (exclusive); carry == nullptr: carry is 1
+__global__ void __launch_bounds__(256) k_prod_apply(const uint32_t* __restrict__ v, size_t n, const uint32_t* __restrict__ carry,
+                                                    uint32_t* __restrict__ out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t lo = t * POLY_CH;
+  if (lo >= n) return;
+  const size_t hi = lo + POLY_CH < n ? lo + POLY_CH : n;
+  fe cur;
+  if (carry) cur = load_ext(carry, t);
+  else {                                                      // 1 in the external domain = 2^256 mod r
+#pragma unroll
+    for (int i = 0; i < NL; i++) cur.l[i] = Fr::TO_EXT[i];
+  }
+  uint32_t w[8];
+  for (size_t i = lo; i < hi; i++) {
+    load_words(v + i * 8, w);                                 // read before the store: v and out may alias
+    const fe f = fe_from_ext_lazy(w);
+    store_canon(out, i, cur);
+    cur = fe_mul<Fr>(cur, f);
+  }
+}
+
+// ---- batch inversion (zeros stay zero, like ff::BatchInvert) ------------------------------------------
+__device__ __forceinline__ fe fr_inverse(const fe& a) {   // a^(r-2); a internal & reduced
+  const uint32_t e[8] = {0xefffffffu, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+  fe acc = fe_one<Fr>();
+  for (int bit = 253; bit >= 0; bit--) {
+    acc = fe_sqr<Fr>(acc);
+    if ((e[bit >> 5] >> (bit & 31)) & 1) acc = fe_mul<Fr>(acc, a);
+  }
+  return acc;
+}
+
+__global__ void __launch_bounds__(128) k_batch_invert(uint32_t* __restrict__ a, size_t n, uint32_t* __restrict__ scratch) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t lo = t * POLY_CH;
+  if (lo >= n) return;
+  const size_t hi = lo + POLY_CH < n ? lo + POLY_CH : n;
+  // x*2^256 read as the internal form of x' = x*2^-5.  prefix products of the non-zero x' (internal form), parked in scratch
+  const fe one = fe_one<Fr>();
+  fe pref = one;
+  uint32_t w[8];
+  for (size_t i = lo; i < hi; i++) {
+    load_words(a + i * 8, w);
+    uint32_t o = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) o |= w[k];
+#pragma unroll
+    for (int k = 0; k < NL; k++) scratch[i * 9 + k] = pref.l[k];
+    if (o) pref = fe_mul<Fr>(pref, fe_unpack<0>(w));
+  }
+  // inverse of the product, rescaled once so that the outputs come out in the external domain:
+  // x'^-1 (internal) = x^-1 * 2^266; times 2^251 (Montgomery) -> x^-1 * 2^256
+  fe c251 = fe_zero();
+  c251.l[8] = 1u << (251 - 232);
+  fe inv = fe_mul<Fr>(fr_inverse(pref), c251);
+  for (size_t i = hi; i-- > lo;) {
+    load_words(a + i * 8, w);
+    uint32_t o = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) o |= w[k];
+    if (!o) continue;
+    fe pre;
+#pragma unroll
+    for (int k = 0; k < NL; k++) pre.l[k] = scratch[i * 9 + k];
+    fe out = fe_mul<Fr>(inv, pre);
+    inv = fe_mul<Fr>(inv, fe_unpack<0>(w));
+    uint32_t wo[8];
+    fe_pack(fe_canon_lt2p<Fr>(out), wo);
+    store_words(a + i * 8, wo);
+  }
+}
+
+// ---- host orchestration ------------------------------------------------------------------------------
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s failed: %s", #x, hipGetErrorString(e_)); return ZKHIP_EHIP; } } while (0)
+
+static inline size_t chunks_of(size_t n) { return (n + POLY_CH - 1) / POLY_CH; }
+static inline dim3 grid_for(size_t threads, int block) { return dim3((unsigned)((threads + block - 1) / block)); }
+
+size_t poly_workspace_bytes(size_t n) {   // aggregate arrays of every recursion level + constants + batch-invert scratch
+  size_t total = 8192, m = n;
+  while (m > 1) { m = chunks_of(m); total += ((m * 32 + 255) / 256) * 256 + 256; }
+  return total + ((n * 36 + 255) / 256) * 256;
+}
+
+// out[i - out_shift] = sum_{j >= i} a[j] b^(j-i) for i >= out_shift (out may be nullptr: only the value at index 0 is
+// wanted and is written to d_result).  b: the multiplier in device memory (8 external words).  ws: scratch.
+static int horner_scan(const uint32_t* d_a, size_t n, const fe_arg* b, uint32_t* d_out, size_t out_shift,
+                       uint32_t* d_result, char* ws, hipStream_t stream) {
+  if (n <= POLY_CH) {   // one chunk
+    if (d_out) hipLaunchKernelGGL(k_horner_apply, dim3(1), dim3(256), 0, stream, d_a, n, b, (const uint32_t*)nullptr, (size_t)0, d_out, out_shift);
+    if (d_result) hipLaunchKernelGGL(k_horner_agg, dim3(1), dim3(256), 0, stream, d_a, n, b, d_result);
+    HIPCHK(hipGetLastError());
+    return ZKHIP_OK;
+  }
+  const size_t m = chunks_of(n);
+  uint32_t* agg = (uint32_t*)ws;
+  char* next_ws = ws + ((m * 32 + 255) / 256) * 256;
+  fe_arg* bpow = (fe_arg*)next_ws;
+  next_ws += 256;
+  hipLaunchKernelGGL(k_horner_agg, grid_for(m, 256), dim3(256), 0, stream, d_a, n, b, agg);
+  hipLaunchKernelGGL(k_pow_const, dim3(1), dim3(64), 0, stream, b, POLY_CH, (uint32_t*)bpow);
+  // recursion: scan the aggregates in place with multiplier b^CH; its value at index 0 is the overall result
+  int rc = horner_scan(agg, m, bpow, d_out ? agg : nullptr, 0, d_result, next_ws, stream);
+  if (rc != ZKHIP_OK) return rc;
+  if (d_out) hipLaunchKernelGGL(k_horner_apply, grid_for(m, 256), dim3(256), 0, stream, d_a, n, b, (const uint32_t*)agg, m, d_out, out_shift);
+  HIPCHK(hipGetLastError());
+  return ZKHIP_OK;
+}
+
+// the multiplier arrives from the host: park it in the last 256 bytes of the workspace
+static int stage_const(const uint32_t host[8], char* ws, size_t ws_bytes, hipStream_t stream, fe_arg** out) {
+  fe_arg* d = (fe_arg*)(ws + ws_bytes - 256);
+  HIPCHK(hipMemcpyAsync(d, host, 32, hipMemcpyHostToDevice, stream));
+  HIPCHK(hipStreamSynchronize(stream));   // `host` may be a caller stack buffer
+  *out = d;
+  return ZKHIP_OK;
+}
+
+// eval_polynomial: result (8 words, device) = sum a[i] x^i
+int fr_eval_polynomial_device(const uint32_t* d_a, size_t n, const uint32_t x_host[8], uint32_t* d_result, void* ws, size_t ws_bytes,
+                              hipStream_t stream) {
+  if (n == 0) { HIPCHK(hipMemsetAsync(d_result, 0, 32, stream)); return ZKHIP_OK; }
+  if (ws_bytes < poly_workspace_bytes(n)) { set_error("eval_polynomial: workspace too small"); return ZKHIP_EINVAL; }
+  fe_arg* b = nullptr;
+  int rc = stage_const(x_host, (char*)ws, ws_bytes, stream, &b);
+  if (rc != ZKHIP_OK) return rc;
+  return horner_scan(d_a, n, b, nullptr, 0, d_result, (char*)ws, stream);
+}
+
+// kate_division: q[i] = a[i+1] + b q[i+1], i < n-1  (quotient of a(X) by (X - b), remainder dropped)
+int fr_kate_division_device(const uint32_t* d_a, size_t n, const uint32_t b_host[8], uint32_t* d_q, void* ws, size_t ws_bytes,
+                            hipStream_t stream) {
+  if (n < 2) return ZKHIP_OK;
+  if (ws_bytes < poly_workspace_bytes(n)) { set_error("kate_division: workspace too small"); return ZKHIP_EINVAL; }
+  fe_arg* b = nullptr;
+  int rc = stage_const(b_host, (char*)ws, ws_bytes, stream, &b);
+  if (rc != ZKHIP_OK) return rc;
+  // the suffix Horner scan of a at index i+1 is q[i]: scan everything, drop index 0
+  return horner_scan(d_a, n, b, d_q, 1, nullptr, (char*)ws, stream);
+}
+
+static int prefix_product_rec(const uint32_t* d_v, size_t n, const uint32_t* carry, uint32_t* d_out, char* ws, hipStream_t stream);
+
+// exclusive prefix product: out[0] = 1, out[i] = v[0] ... v[i-1]   (out may alias v)
+int fr_prefix_product_device(const uint32_t* d_v, size_t n, uint32_t* d_out, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (n == 0) return ZKHIP_OK;
+  if (ws_bytes < poly_workspace_bytes(n)) { set_error("prefix_product: workspace too small"); return ZKHIP_EINVAL; }
+  return prefix_product_rec(d_v, n, nullptr, d_out, (char*)ws, stream);
+}
+
+static int prefix_product_rec(const uint32_t* d_v, size_t n, const uint32_t* carry_unused, uint32_t* d_out, char* ws, hipStream_t stream) {
+  (void)carry_unused;
+  if (n <= POLY_CH) {
+    hipLaunchKernelGGL(k_prod_apply, dim3(1), dim3(256), 0, stream, d_v, n, (const uint32_t*)nullptr, d_out);
+    HIPCHK(hipGetLastError());
+    return ZKHIP_OK;
+  }
+  const size_t m = chunks_of(n);
+  uint32_t* agg = (uint32_t*)ws;
+  char* next_ws = ws + ((m * 32 + 255) / 256) * 256 + 256;
+  hipLaunchKernelGGL(k_prod_agg, grid_for(m, 256), dim3(256), 0, stream, d_v, n, agg);
+  int rc = prefix_product_rec(agg, m, nullptr, agg, next_ws, stream);   // exclusive prefix products of the chunk products, in place
+  if (rc != ZKHIP_OK) return rc;
+  hipLaunchKernelGGL(k_prod_apply, grid_for(m, 256), dim3(256), 0, stream, d_v, n, (const uint32_t*)agg, d_out);
+  HIPCHK(hipGetLastError());
+  return ZKHIP_OK;
+}
+
+int fr_batch_invert_device(uint32_t* d_a, size_t n, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (n == 0) return ZKHIP_OK;
+  if (ws_bytes < poly_workspace_bytes(n)) { set_error("batch_invert: workspace too small"); return ZKHIP_EINVAL; }
+  hipLaunchKernelGGL(k_batch_invert, grid_for(chunks_of(n), 128), dim3(128), 0, stream, d_a, n, (uint32_t*)ws);
+  HIPCHK(hipGetLastError());
+  return ZKHIP_OK;
+}
+
+}  // namespace zkhip

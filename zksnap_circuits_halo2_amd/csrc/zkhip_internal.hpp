@@ -38,6 +38,13 @@ int fr_mul_periodic_device(uint32_t* d_a, size_t n, const uint32_t* d_table_ext,
 int fr_scale_device(uint32_t* d_a, size_t n, const uint32_t scale_ext[8], hipStream_t stream);
 void ntt_clear_cache();
 
+// poly.hip
+size_t poly_workspace_bytes(size_t n);
+int fr_eval_polynomial_device(const uint32_t* d_a, size_t n, const uint32_t x_host[8], uint32_t* d_result, void* ws, size_t ws_bytes, hipStream_t stream);
+int fr_kate_division_device(const uint32_t* d_a, size_t n, const uint32_t b_host[8], uint32_t* d_q, void* ws, size_t ws_bytes, hipStream_t stream);
+int fr_prefix_product_device(const uint32_t* d_v, size_t n, uint32_t* d_out, void* ws, size_t ws_bytes, hipStream_t stream);
+int fr_batch_invert_device(uint32_t* d_a, size_t n, void* ws, size_t ws_bytes, hipStream_t stream);
+
 // selftest.hip
 int test_field_op(int field, int op, const uint32_t* d_a, const uint32_t* d_b, uint32_t* d_out, size_t n, hipStream_t stream);
 int test_g1_op(int op, const uint32_t* d_a, const uint32_t* d_b, uint32_t* d_out, size_t n, hipStream_t stream);
