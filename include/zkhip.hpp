@@ -1,0 +1,263 @@
+// C++ host-side mirror of the reference's prover interface for the MSM / NTT path, header-only over the C ABI (zkhip.h).
+//
+// The reference is Rust and reaches this path through the un-vendored halo2-axiom crate [DEP]
+// (`halo2_base::halo2_proofs`, /root/reference/aggregator/src/wrapper.rs:3-24).  This header gives a C++ host the same
+// names, argument meaning and error behaviour:
+//     halo2_proofs::arithmetic::{best_multiexp, best_fft, eval_polynomial, kate_division}
+//     halo2_proofs::poly::EvaluationDomain::{new, lagrange_to_coeff, coeff_to_extended, extended_to_coeff,
+//                                           divide_by_vanishing_poly, extended_len, get_omega, ...}
+//     halo2_proofs::poly::kzg::commitment::ParamsKZG::{commit, commit_lagrange, get_g, k, n}
+// Types are the Rust memory layouts (Montgomery limbs), so buffers can be shared with a Rust host unchanged.
+// The reference's functions are infallible (`assert!` / `unwrap()`): here a failing call throws std::runtime_error with
+// zkhip_last_error(), and length mismatches throw std::invalid_argument (the `assert_eq!` of best_multiexp / best_fft).
+// Only scalar constants are computed on the host (what `EvaluationDomain::new` does); every vector operation runs in
+// libzkhip.so on the GPU.  There is no CPU fallback.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "zkhip.h"
+
+namespace zkhip {
+namespace halo2 {
+
+struct Fr {
+  uint64_t l[4];  // Montgomery form, little-endian limbs (= halo2curves bn256::Fr)
+  bool operator==(const Fr& o) const { return std::memcmp(l, o.l, 32) == 0; }
+};
+struct G1Affine {
+  uint64_t x[4], y[4];  // identity = all zero
+};
+struct G1 {
+  uint64_t x[4], y[4], z[4];  // Jacobian, identity z = 0
+};
+static_assert(sizeof(Fr) == 32 && sizeof(G1Affine) == 64 && sizeof(G1) == 96, "layouts must match the Rust types");
+
+inline void check(int rc, const char* what) {
+  if (rc != ZKHIP_OK) throw std::runtime_error(std::string(what) + ": " + zkhip_last_error());
+}
+
+// ---- scalar Fr arithmetic for domain constants (host; 4 x 64-bit Montgomery like the reference's Fr) ---------------
+namespace detail {
+typedef unsigned __int128 u128;
+constexpr uint64_t R_MOD[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+constexpr uint64_t R_INV = 0xc2e1f593efffffffULL;  // -r^-1 mod 2^64
+constexpr uint64_t R_ONE[4] = {0xac96341c4ffffffbULL, 0x36fc76959f60cd29ULL, 0x666ea36f7879462eULL, 0x0e0a77c19a07df2fULL};
+constexpr uint64_t R_R2[4] = {0x1bb8e645ae216da7ULL, 0x53fe3ab1e35c59e3ULL, 0x8c49833d53bb8085ULL, 0x0216d0b17f4e44a5ULL};
+
+inline bool geq(const uint64_t a[4], const uint64_t b[4]) {
+  for (int i = 3; i >= 0; i--) {
+    if (a[i] != b[i]) return a[i] > b[i];
+  }
+  return true;
+}
+inline void sub(uint64_t r[4], const uint64_t a[4], const uint64_t b[4]) {
+  uint64_t borrow = 0;
+  for (int i = 0; i < 4; i++) {
+    u128 d = (u128)a[i] - b[i] - borrow;
+    r[i] = (uint64_t)d;
+    borrow = (uint64_t)(d >> 64) & 1;
+  }
+}
+inline Fr mul(const Fr& a, const Fr& b) {
+  uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; i++) {
+    uint64_t carry = 0;
+    for (int j = 0; j < 4; j++) {
+      u128 s = (u128)a.l[j] * b.l[i] + t[j] + carry;
+      t[j] = (uint64_t)s;
+      carry = (uint64_t)(s >> 64);
+    }
+    u128 s = (u128)t[4] + carry;
+    t[4] = (uint64_t)s;
+    t[5] = (uint64_t)(s >> 64);
+    const uint64_t m = t[0] * R_INV;
+    s = (u128)m * R_MOD[0] + t[0];
+    carry = (uint64_t)(s >> 64);
+    for (int j = 1; j < 4; j++) {
+      s = (u128)m * R_MOD[j] + t[j] + carry;
+      t[j - 1] = (uint64_t)s;
+      carry = (uint64_t)(s >> 64);
+    }
+    s = (u128)t[4] + carry;
+    t[3] = (uint64_t)s;
+    t[4] = t[5] + (uint64_t)(s >> 64);
+  }
+  Fr r;
+  if (t[4] || geq(t, R_MOD)) sub(r.l, t, R_MOD); else std::memcpy(r.l, t, 32);
+  return r;
+}
+inline Fr one() { Fr r; std::memcpy(r.l, R_ONE, 32); return r; }
+inline Fr from_u64(uint64_t v) { Fr raw{{v, 0, 0, 0}}, r2; std::memcpy(r2.l, R_R2, 32); return mul(raw, r2); }
+inline Fr from_raw(const uint64_t v[4]) { Fr raw, r2; std::memcpy(raw.l, v, 32); std::memcpy(r2.l, R_R2, 32); return mul(raw, r2); }
+inline Fr sub_fr(const Fr& a, const Fr& b) {
+  Fr r;
+  if (geq(a.l, b.l)) sub(r.l, a.l, b.l);
+  else { uint64_t t[4]; sub(t, b.l, a.l); sub(r.l, R_MOD, t); }
+  return r;
+}
+inline Fr pow(Fr base, const uint64_t e[4]) {
+  Fr acc = one();
+  for (int i = 0; i < 256; i++) {
+    if ((e[i >> 6] >> (i & 63)) & 1) acc = mul(acc, base);
+    base = mul(base, base);
+  }
+  return acc;
+}
+inline Fr pow_u64(const Fr& base, uint64_t e) { const uint64_t ee[4] = {e, 0, 0, 0}; return pow(base, ee); }
+inline Fr invert(const Fr& a) {
+  uint64_t e[4];
+  const uint64_t two[4] = {2, 0, 0, 0};
+  sub(e, R_MOD, two);
+  return pow(a, e);
+}
+}  // namespace detail
+
+// `Fr::S`, `Fr::ROOT_OF_UNITY` (= 7^((r-1)/2^28)), `Fr::ZETA` of halo2curves bn256 [DEP]
+constexpr uint32_t FR_S = 28;
+inline Fr fr_root_of_unity() {
+  const uint64_t raw[4] = {0xd34f1ed960c37c9cULL, 0x3215cf6dd39329c8ULL, 0x98865ea93dd31f74ULL, 0x03ddb9f5166d18b7ULL};
+  return detail::from_raw(raw);
+}
+inline Fr fr_zeta() {
+  const uint64_t raw[4] = {0xb8ca0b2d36636f23ULL, 0xcc37a73fec2bc5e9ULL, 0x048b6e193fd84104ULL, 0x30644e72e131a029ULL};
+  return detail::from_raw(raw);
+}
+
+// ---- halo2_proofs::arithmetic ----------------------------------------------------------------------------------
+inline G1 best_multiexp(const Fr* coeffs, size_t coeffs_len, const G1Affine* bases, size_t bases_len) {
+  if (coeffs_len != bases_len) throw std::invalid_argument("best_multiexp: coeffs.len() != bases.len()");
+  G1 out;
+  check(zkhip_msm_g1(coeffs->l, bases->x, coeffs_len, out.x), "best_multiexp");
+  return out;
+}
+inline G1 best_multiexp(const std::vector<Fr>& coeffs, const std::vector<G1Affine>& bases) {
+  static const Fr dummy_s{};
+  static const G1Affine dummy_b{};
+  return best_multiexp(coeffs.empty() ? &dummy_s : coeffs.data(), coeffs.size(), bases.empty() ? &dummy_b : bases.data(), bases.size());
+}
+inline void best_fft(std::vector<Fr>& a, const Fr& omega, uint32_t log_n) {
+  if (a.size() != ((size_t)1 << log_n)) throw std::invalid_argument("best_fft: a.len() != 1 << log_n");
+  check(zkhip_ntt_fr(a.data()->l, omega.l, log_n), "best_fft");
+}
+inline Fr eval_polynomial(const std::vector<Fr>& poly, const Fr& point) {
+  Fr out;
+  static const Fr dummy{};
+  check(zkhip_fr_eval_polynomial(poly.empty() ? dummy.l : poly.data()->l, poly.size(), point.l, out.l), "eval_polynomial");
+  return out;
+}
+inline std::vector<Fr> kate_division(const std::vector<Fr>& a, const Fr& b) {
+  std::vector<Fr> q(a.empty() ? 0 : a.size() - 1);
+  if (a.size() > 1) check(zkhip_fr_kate_division(a.data()->l, a.size(), b.l, q.data()->l), "kate_division");
+  return q;
+}
+
+// ---- halo2_proofs::poly::EvaluationDomain -----------------------------------------------------------------------
+class EvaluationDomain {
+ public:
+  // `EvaluationDomain::new(j, k)`: j = degree of the constraint system, n = 2^k
+  EvaluationDomain(uint32_t j, uint32_t k) : k_(k), n_((uint64_t)1 << k), quotient_poly_degree_(j - 1) {
+    extended_k_ = k;
+    while (((uint64_t)1 << extended_k_) < n_ * quotient_poly_degree_) extended_k_++;
+    if (extended_k_ > FR_S) throw std::invalid_argument("EvaluationDomain: extended_k exceeds the field's 2-adicity");
+    extended_omega_ = fr_root_of_unity();
+    for (uint32_t i = extended_k_; i < FR_S; i++) extended_omega_ = detail::mul(extended_omega_, extended_omega_);
+    omega_ = extended_omega_;
+    for (uint32_t i = k; i < extended_k_; i++) omega_ = detail::mul(omega_, omega_);
+    omega_inv_ = detail::invert(omega_);
+    extended_omega_inv_ = detail::invert(extended_omega_);
+    g_coset_ = fr_zeta();
+    g_coset_inv_ = detail::mul(g_coset_, g_coset_);
+    ifft_divisor_ = detail::invert(detail::from_u64(n_));
+    extended_ifft_divisor_ = detail::invert(detail::from_u64((uint64_t)1 << extended_k_));
+    // t(X) = X^n - 1 on the coset zeta * <extended_omega>, period 2^(extended_k - k); stored inverted
+    const Fr orig = detail::pow_u64(g_coset_, n_), step = detail::pow_u64(extended_omega_, n_);
+    Fr cur = orig;
+    do {
+      t_evaluations_.push_back(detail::invert(detail::sub_fr(cur, detail::one())));
+      cur = detail::mul(cur, step);
+    } while (!(cur == orig));
+  }
+
+  uint32_t k() const { return k_; }
+  uint32_t extended_k() const { return extended_k_; }
+  size_t extended_len() const { return (size_t)1 << extended_k_; }
+  uint64_t get_quotient_poly_degree() const { return quotient_poly_degree_; }
+  const Fr& get_omega() const { return omega_; }
+  const Fr& get_omega_inv() const { return omega_inv_; }
+  const Fr& get_extended_omega() const { return extended_omega_; }
+
+  // Lagrange (evaluations over <omega>) -> coefficients: ifft(omega_inv) then * 1/n
+  std::vector<Fr> lagrange_to_coeff(std::vector<Fr> a) const {
+    if (a.size() != n_) throw std::invalid_argument("lagrange_to_coeff: wrong length");
+    check(zkhip_ifft_scaled(a.data()->l, omega_inv_.l, k_, ifft_divisor_.l), "lagrange_to_coeff");
+    return a;
+  }
+  std::vector<Fr> coeff_to_extended(const std::vector<Fr>& a) const {
+    if (a.size() != n_) throw std::invalid_argument("coeff_to_extended: wrong length");
+    std::vector<Fr> out(extended_len());
+    check(zkhip_coeff_to_extended(a.data()->l, k_, out.data()->l, extended_k_, extended_omega_.l, g_coset_.l), "coeff_to_extended");
+    return out;
+  }
+  std::vector<Fr> extended_to_coeff(std::vector<Fr> a) const {
+    if (a.size() != extended_len()) throw std::invalid_argument("extended_to_coeff: wrong length");
+    std::vector<Fr> out((size_t)(n_ * quotient_poly_degree_));
+    check(zkhip_extended_to_coeff(a.data()->l, extended_k_, extended_omega_inv_.l, extended_ifft_divisor_.l, g_coset_.l,
+                                  out.data()->l, out.size()), "extended_to_coeff");
+    return out;
+  }
+  std::vector<Fr> divide_by_vanishing_poly(std::vector<Fr> a) const {
+    if (a.size() != extended_len()) throw std::invalid_argument("divide_by_vanishing_poly: wrong length");
+    check(zkhip_mul_periodic(a.data()->l, a.size(), t_evaluations_.data()->l, (uint32_t)t_evaluations_.size()), "divide_by_vanishing_poly");
+    return a;
+  }
+
+ private:
+  uint32_t k_, extended_k_;
+  uint64_t n_, quotient_poly_degree_;
+  Fr omega_, omega_inv_, extended_omega_, extended_omega_inv_, g_coset_, g_coset_inv_, ifft_divisor_, extended_ifft_divisor_;
+  std::vector<Fr> t_evaluations_;
+};
+
+// ---- halo2_proofs::poly::kzg::commitment::ParamsKZG (commit surface) ----------------------------------------------
+class ParamsKZG {
+ public:
+  // takes ownership of the SRS arrays and pins them in HBM (prepared fixed-base tables)
+  ParamsKZG(uint32_t k, std::vector<G1Affine> g, std::vector<G1Affine> g_lagrange = {})
+      : k_(k), n_((uint64_t)1 << k), g_(std::move(g)), g_lagrange_(std::move(g_lagrange)) {
+    if (g_.size() != n_ || (!g_lagrange_.empty() && g_lagrange_.size() != n_)) throw std::invalid_argument("ParamsKZG: SRS length != 2^k");
+    check(zkhip_register_bases(g_.data()->x, g_.size()), "ParamsKZG::register g");
+    if (!g_lagrange_.empty()) check(zkhip_register_bases(g_lagrange_.data()->x, g_lagrange_.size()), "ParamsKZG::register g_lagrange");
+  }
+  ~ParamsKZG() {
+    zkhip_unregister_bases(g_.data()->x);
+    if (!g_lagrange_.empty()) zkhip_unregister_bases(g_lagrange_.data()->x);
+  }
+  ParamsKZG(const ParamsKZG&) = delete;
+  ParamsKZG& operator=(const ParamsKZG&) = delete;
+
+  uint32_t k() const { return k_; }
+  uint64_t n() const { return n_; }
+  const std::vector<G1Affine>& get_g() const { return g_; }
+  // commit(poly) = best_multiexp(poly.coeffs, g[..len]); blinding is ignored for KZG, as in the reference
+  G1 commit(const std::vector<Fr>& poly) const {
+    if (poly.size() > n_) throw std::invalid_argument("commit: polynomial longer than the SRS");
+    return best_multiexp(poly.data(), poly.size(), g_.data(), poly.size());
+  }
+  G1 commit_lagrange(const std::vector<Fr>& poly) const {
+    if (g_lagrange_.empty()) throw std::invalid_argument("commit_lagrange: no Lagrange basis");
+    if (poly.size() > n_) throw std::invalid_argument("commit_lagrange: polynomial longer than the SRS");
+    return best_multiexp(poly.data(), poly.size(), g_lagrange_.data(), poly.size());
+  }
+
+ private:
+  uint32_t k_;
+  uint64_t n_;
+  std::vector<G1Affine> g_, g_lagrange_;
+};
+
+}  // namespace halo2
+}  // namespace zkhip

@@ -1,0 +1,57 @@
+// Drives the C++ host mirror (include/zkhip.hpp) the way a compiled host of the reference would use it; run by
+// tests/test_gpu_parity.py::test_cpp_host_mirror, which supplies the inputs and checks every output against the oracle.
+//   usage: host_mirror_driver <in.bin> <out.bin>
+//   in : u32 j, u32 k, then 2^k Fr (polynomial), 2^k G1Affine (SRS g)
+//   out: omega, extended_omega (Fr each), commit (G1), best_fft(poly, omega), lagrange_to_coeff(poly), coeff_to_extended(poly),
+//        divide_by_vanishing_poly(ext), extended_to_coeff(ext), eval_polynomial(poly, omega), kate_division(poly, omega)
+#include <cstdio>
+#include <vector>
+#include "zkhip.hpp"
+
+using namespace zkhip::halo2;
+
+template <class T>
+static void put(FILE* f, const std::vector<T>& v) { fwrite(v.data(), sizeof(T), v.size(), f); }
+
+int main(int argc, char** argv) {
+  if (argc != 3) return 2;
+  FILE* in = fopen(argv[1], "rb");
+  if (!in) return 2;
+  uint32_t jk[2];
+  if (fread(jk, 4, 2, in) != 2) return 2;
+  const uint32_t j = jk[0], k = jk[1];
+  const size_t n = (size_t)1 << k;
+  std::vector<Fr> poly(n);
+  std::vector<G1Affine> g(n);
+  if (fread(poly.data(), sizeof(Fr), n, in) != n || fread(g.data(), sizeof(G1Affine), n, in) != n) return 2;
+  fclose(in);
+  try {
+    EvaluationDomain domain(j, k);
+    ParamsKZG params(k, g);
+    FILE* out = fopen(argv[2], "wb");
+    fwrite(&domain.get_omega(), sizeof(Fr), 1, out);
+    fwrite(&domain.get_extended_omega(), sizeof(Fr), 1, out);
+    G1 c = params.commit(poly);
+    fwrite(&c, sizeof(G1), 1, out);
+    std::vector<Fr> f = poly;
+    best_fft(f, domain.get_omega(), k);
+    put(out, f);
+    put(out, domain.lagrange_to_coeff(poly));
+    std::vector<Fr> ext = domain.coeff_to_extended(poly);
+    put(out, ext);
+    put(out, domain.divide_by_vanishing_poly(ext));
+    put(out, domain.extended_to_coeff(ext));
+    Fr e = eval_polynomial(poly, domain.get_omega());
+    fwrite(&e, sizeof(Fr), 1, out);
+    put(out, kate_division(poly, domain.get_omega()));
+    fclose(out);
+    // error behaviour: the reference's assert_eq!(coeffs.len(), bases.len())
+    bool threw = false;
+    try { best_multiexp(poly.data(), n, g.data(), n - 1); } catch (const std::invalid_argument&) { threw = true; }
+    if (!threw) return 3;
+  } catch (const std::exception& e) {
+    fprintf(stderr, "host_mirror_driver: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

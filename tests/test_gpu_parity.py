@@ -367,3 +367,51 @@ def test_row_a7_golden_small():
     B = Aenc.copy()
     A.batch_invert(B)
     assert F.fr_decode(B) == O.batch_invert(a)
+
+
+# ---------------------------------------------------------------- C++ host mirror (include/zkhip.hpp)
+def test_cpp_host_mirror(cref, tmp_path):
+    """The compiled-host mirror of the reference interface (EvaluationDomain, ParamsKZG, best_fft, ...) end to end."""
+    import struct
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    drv = os.path.join(root, "tests", "cpp", "host_mirror_driver")
+    assert os.path.exists(drv), "build it with __graft_entry__.build()"
+    j, k = 4, 11
+    n = 1 << k
+    poly = cref.gen_scalars(4242, n, 0)
+    g, t0, d = cref.gen_bases(4243, n)
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(fin, "wb") as f:
+        f.write(struct.pack("<II", j, k))
+        f.write(poly.tobytes())
+        f.write(g.tobytes())
+    subprocess.check_call([drv, str(fin), str(fout)], timeout=300)
+    raw = np.fromfile(fout, dtype=np.uint64)
+    pos = 0
+
+    def take(count, width):
+        nonlocal pos
+        out = raw[pos:pos + count * width].reshape(count, width)
+        pos += count * width
+        return out
+
+    dom = O.EvaluationDomain(j, k)
+    assert F.fr_decode(take(1, 4))[0] == dom.omega and F.fr_decode(take(1, 4))[0] == dom.extended_omega
+    assert np.array_equal(aff(cref, take(1, 12)[0]), structured_expect(cref, poly, t0, d))
+    enc1 = lambda v: F.fr_encode([v])[0]
+    ref = poly.copy(); cref.best_fft(ref, enc1(dom.omega), k, 4)
+    assert np.array_equal(take(n, 4), ref)
+    ref = poly.copy(); cref.best_fft(ref, enc1(dom.omega_inv), k, 4); cref.scale(ref, enc1(dom.ifft_divisor))
+    assert np.array_equal(take(n, 4), ref)
+    ext = np.zeros((dom.extended_len(), 4), dtype=np.uint64); ext[:n] = poly
+    cref.distribute_powers_zeta(ext[:n], enc1(dom.g_coset), enc1(dom.g_coset_inv)); cref.best_fft(ext, enc1(dom.extended_omega), dom.extended_k, 4)
+    assert np.array_equal(take(dom.extended_len(), 4), ext)
+    q = ext.copy(); cref.mul_periodic(q, F.fr_encode(dom.t_evaluations))
+    assert np.array_equal(take(dom.extended_len(), 4), q)
+    back = take(3 * n, 4)
+    assert np.array_equal(back[:n], poly) and not back[n:].any()
+    assert np.array_equal(take(1, 4)[0], cref.eval_polynomial(poly, enc1(dom.omega)))
+    assert np.array_equal(take(n - 1, 4), cref.kate_division(poly, enc1(dom.omega)))
+    assert pos == raw.size
