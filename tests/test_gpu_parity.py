@@ -369,6 +369,65 @@ def test_row_a7_golden_small():
     assert F.fr_decode(B) == O.batch_invert(a)
 
 
+@pytest.mark.parametrize("log_n,kind", [(22, 0), (22, 1), (24, 1)])
+def test_msm_wrapper_sizes_structured_identity(lib, cref, log_n, kind):
+    """wrapper-circuit sizes (k = 22, and k = 24 with witness-like scalars): bases generated on the device,
+    MSM(a, (t0 + i d) G) = [sum a_i (t0 + i d)] G checked with the oracle's scalar arithmetic."""
+    import ctypes as C
+
+    import torch
+
+    n = 1 << log_n
+    T0, D = 0x5A4B534E41500002 + log_n, 0x9E3779B97F4A7C15F39CC0605CEDC835
+    t0m, dm = F.fr_encode([T0])[0], F.fr_encode([D])[0]
+    bases = torch.empty(n * 8, dtype=torch.int64, device="cuda")
+    _lib.check(lib.zkhip_g1_gen_walk_device(t0m.ctypes.data, dm.ctypes.data, n, bases.data_ptr(), None))
+    h = C.c_uint64(0)
+    _lib.check(lib.zkhip_prepare_bases_device(bases.data_ptr(), n, C.byref(h)))
+    try:
+        sc = cref.gen_scalars(6000 + log_n + kind, n, kind)
+        dsc = torch.from_numpy(sc.view(np.int64)).cuda()
+        out = torch.zeros(12, dtype=torch.int64, device="cuda")
+        _lib.check(lib.zkhip_msm_g1_prepared_device(h, 0, dsc.data_ptr(), n, out.data_ptr(), None))
+        torch.cuda.synchronize()
+        exp = cref.jac_to_affine(cref.scalar_mul(cref.expected_scalar(sc, T0, D), cref.generator()))
+        assert np.array_equal(aff(cref, out.cpu().numpy().view(np.uint64)), exp)
+    finally:
+        _lib.check(lib.zkhip_release_bases(h))
+
+
+def test_concurrent_host_calls_are_serialised_correctly(cref):
+    """best_multiexp / best_fft called from several host threads at once (rayon-style callers): the library serialises
+    them internally; every result must still be right."""
+    import threading
+
+    n = 3000
+    bases, t0, d = cref.gen_bases(71, n)
+    results, errors = {}, []
+
+    def work(tid):
+        try:
+            for rep in range(4):
+                sc = cref.gen_scalars(7100 + 10 * tid + rep, n, rep % 2)
+                got = aff(cref, Z.best_multiexp(sc, bases))
+                ok = np.array_equal(got, structured_expect(cref, sc, t0, d))
+                a = cref.gen_scalars(7200 + 10 * tid + rep, 1 << 10, 0)
+                ref = a.copy()
+                om = F.fr_encode([O.omega_for(10)])[0]
+                cref.best_fft(ref, om, 10, 1)
+                Z.best_fft(a, om, 10)
+                results[(tid, rep)] = ok and np.array_equal(a, ref)
+        except Exception as e:   # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors and len(results) == 16 and all(results.values())
+
+
 # ---------------------------------------------------------------- C++ host mirror (include/zkhip.hpp)
 def test_cpp_host_mirror(cref, tmp_path):
     """The compiled-host mirror of the reference interface (EvaluationDomain, ParamsKZG, best_fft, ...) end to end."""
