@@ -86,6 +86,8 @@ int zkhip_fr_prefix_product_device(const void *d_v, size_t n, void *d_out, void 
 int zkhip_msm_g1_device(const void *d_scalars, const void *d_bases, size_t n, void *d_out_xyz, void *stream);
 /* prepared (fixed-base) path for device-resident bases: the handle owns the table until released */
 int zkhip_prepare_bases_device(const void *d_bases, size_t n, uint64_t *handle);
+/* same with an explicit window size (2..20; 0 = automatic) -- experiments and tests of the wide-window path */
+int zkhip_prepare_bases_device_c(const void *d_bases, size_t n, int window_bits, uint64_t *handle);
 int zkhip_release_bases(uint64_t handle);
 int zkhip_msm_g1_prepared_device(uint64_t handle, size_t offset, const void *d_scalars, size_t n, void *d_out_xyz, void *stream);
 /* window-size override for experiments (0 = automatic) */

@@ -180,6 +180,34 @@ def test_msm_prepared_device_path(lib, cref, n):
         _lib.check(lib.zkhip_release_bases(h))
 
 
+@pytest.mark.parametrize("c", [3, 9, 13, 16, 17, 18, 19, 20])
+def test_msm_prepared_every_window_including_wide(lib, cref, c):
+    """prepared path with an explicit window size; c > 16 takes the two-level (coarse groups + fine LDS histogram) sort."""
+    import ctypes as C
+
+    import torch
+
+    n = 20011
+    bases, t0, d = cref.gen_bases(1200 + c, n)
+    bases[5] = 0
+    dbs = torch.from_numpy(bases.view(np.int64)).cuda()
+    h = C.c_uint64(0)
+    _lib.check(lib.zkhip_prepare_bases_device_c(dbs.data_ptr(), n, c, C.byref(h)))
+    try:
+        one = F.fr_encode([1])[0]
+        cases = [cref.gen_scalars(1300 + c, n, 0), cref.gen_scalars(1400 + c, n, 1), np.ascontiguousarray(np.tile(one, (n, 1))),
+                 np.ascontiguousarray(np.tile(F.fr_encode([O.R_MOD - 1])[0], (n, 1)))]
+        for sc in cases:
+            dsc = torch.from_numpy(sc.view(np.int64)).cuda()
+            dout = torch.zeros(12, dtype=torch.int64, device="cuda")
+            _lib.check(lib.zkhip_msm_g1_prepared_device(h, 0, dsc.data_ptr(), n, dout.data_ptr(), None))
+            torch.cuda.synchronize()
+            assert np.array_equal(aff(cref, dout.cpu().numpy().view(np.uint64)), aff(cref, cref.best_multiexp(sc, bases, 8)))
+    finally:
+        _lib.check(lib.zkhip_release_bases(h))
+    assert lib.zkhip_prepare_bases_device_c(dbs.data_ptr(), n, 21, C.byref(h)) == -1
+
+
 def test_gen_walk_matches_oracle(lib, cref):
     import torch
 

@@ -191,7 +191,7 @@ int zkhip_msm_g1(const uint64_t* scalars, const uint64_t* bases, size_t n, uint6
     }
   }
   if (pb) {
-    if ((rc = g_ctx.ws.reserve(msm_workspace_bytes(n, pb->c))) != ZKHIP_OK) return rc;
+    if ((rc = g_ctx.ws.reserve(msm_workspace_bytes(n, pb->c, true))) != ZKHIP_OK) return rc;
     rc = msm_g1_device((const uint32_t*)g_ctx.scalars.p, nullptr, n, (uint32_t*)g_ctx.small.p, g_ctx.ws.p, g_ctx.ws.cap, 0, s, pb, off);
   } else {
     rc = zkhip_msm_g1_device_c(g_ctx.scalars.p, d_bases, n, g_ctx.small.p, 0, s);
@@ -217,12 +217,16 @@ int zkhip_register_bases(const uint64_t* bases, size_t n) {
 }
 
 int zkhip_prepare_bases_device(const void* d_bases, size_t n, uint64_t* handle) {
+  return zkhip_prepare_bases_device_c(d_bases, n, 0, handle);
+}
+
+int zkhip_prepare_bases_device_c(const void* d_bases, size_t n, int window_bits, uint64_t* handle) {
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
   if (!d_bases || !handle || n == 0) { set_error("prepare_bases: bad argument"); return ZKHIP_EINVAL; }
   prepared_bases* pb = nullptr;
-  if ((rc = prepare_bases_device((const uint32_t*)d_bases, n, g_ctx.stream, &pb)) != ZKHIP_OK) return rc;
+  if ((rc = prepare_bases_device((const uint32_t*)d_bases, n, g_ctx.stream, &pb, window_bits)) != ZKHIP_OK) return rc;
   *handle = g_ctx.next_handle++;
   g_ctx.handles[*handle] = pb;
   return ZKHIP_OK;
@@ -246,7 +250,7 @@ int zkhip_msm_g1_prepared_device(uint64_t handle, size_t offset, const void* d_s
   if (it == g_ctx.handles.end()) { set_error("msm_prepared: unknown handle"); return ZKHIP_EINVAL; }
   if (!d_out_xyz || (n && !d_scalars)) { set_error("msm_prepared: null pointer"); return ZKHIP_EINVAL; }
   const prepared_bases* pb = it->second;
-  if ((rc = g_ctx.ws.reserve(n ? msm_workspace_bytes(n, pb->c) : 0)) != ZKHIP_OK) return rc;
+  if ((rc = g_ctx.ws.reserve(n ? msm_workspace_bytes(n, pb->c, true) : 0)) != ZKHIP_OK) return rc;
   return msm_g1_device((const uint32_t*)d_scalars, nullptr, n, (uint32_t*)d_out_xyz, g_ctx.ws.p, g_ctx.ws.cap, 0,
                        stream ? (hipStream_t)stream : g_ctx.stream, pb, offset);
 }

@@ -35,7 +35,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 
 constexpr int TASK_SHIFT = 6;           // 64 entries per accumulate task: short tasks keep the tail of the launch balanced
                                         // (measured at 2^22: 5.9 ms with 64-entry tasks, 6.9 ms with 256, 8.1 ms with 512)
-constexpr int COMBINE_LEVELS = 9;       // radix-4 tree levels above the final step: covers 16 * 4^9 partials per bucket
+constexpr int COMBINE_LEVELS = 10;      // radix-4 tree levels above the final step: covers 16 * 4^10 partials per bucket
 
 struct task_t {
   uint32_t bucket, start, len;
@@ -93,7 +93,8 @@ __device__ __forceinline__ void store_fe9_generic(uint32_t* p, size_t idx, const
 // ------------------------------------------------------------------------------------------------
 // 1. digits
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, int16_t* __restrict__ digits,
+template <typename DIGIT>   // int16_t for c <= 16, int32_t for the wide windows of the prepared path
+__global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, DIGIT* __restrict__ digits,
                                                 uint32_t n, uint32_t n_pad, int c, int W) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_pad) return;
@@ -123,7 +124,7 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ sca
     v += carry;
     int32_t d;
     if (v >= half) { d = (int32_t)v - (int32_t)(1u << c); carry = 1; } else { d = (int32_t)v; carry = 0; }
-    digits[(size_t)win * n_pad + i] = (int16_t)d;
+    digits[(size_t)win * n_pad + i] = (DIGIT)d;
   }
 }
 
@@ -188,6 +189,131 @@ __global__ void __launch_bounds__(1024) k_sort_pass(const int16_t* __restrict__ 
         }
       }
     }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// 2'/4'. wide windows (16 < c <= 21, prepared path only).  Fewer windows = fewer additions (c = 20: 13 instead of 16),
+//     but 2^(c-1) buckets no longer fit an LDS histogram.  Two levels:
+//       coarse  bucket >> 15 selects one of G = 2^(c-16) groups; a (window, chunk) workgroup counts / places its entries
+//               per group (G LDS counters, one ranged global atomic per group) into a staging array (ref u32 + fine u16);
+//       fine    per group, the 2^15 "fine" buckets are handled exactly like the one-level path: LDS histogram, contiguous
+//               atomics into the global counts, scan, reservation, placement.
+// ------------------------------------------------------------------------------------------------
+constexpr int FINE_BITS = 15;
+constexpr uint32_t FINE_CHUNK = 65536;
+constexpr int MAX_GROUPS = 32;
+
+// (Recomputing the digits from the scalars in both passes instead of storing them as int32 was tried and measured slower:
+// 0.139 vs 0.117 ms at 2^20, 1.75 vs 1.3 ms at 2^24.)
+template <bool SCATTER>
+__global__ void __launch_bounds__(1024) k_coarse_pass(const int32_t* __restrict__ digits, uint32_t n_pad, uint32_t chunk,
+                                                      uint32_t* __restrict__ gcount_or_cursor, uint32_t* __restrict__ stage_ref,
+                                                      uint16_t* __restrict__ stage_fine, uint32_t ref_base, uint32_t ref_stride) {
+  __shared__ uint32_t cnt[MAX_GROUPS];
+  const int win = blockIdx.y;
+  const uint32_t lo = blockIdx.x * chunk, hi = min(n_pad, lo + chunk);   // multiples of 8
+  if (threadIdx.x < MAX_GROUPS) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const uint4* dv = reinterpret_cast<const uint4*>(digits + (size_t)win * n_pad);
+  const uint32_t v_lo = lo >> 2, v_hi = hi >> 2;
+  for (uint32_t vi = v_lo + threadIdx.x; vi < v_hi; vi += blockDim.x) {
+    const uint4 q = dv[vi];
+    const int32_t d4[4] = {(int32_t)q.x, (int32_t)q.y, (int32_t)q.z, (int32_t)q.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int32_t d = d4[k];
+      if (d != 0) atomicAdd(&cnt[((uint32_t)(d < 0 ? -d : d) - 1) >> FINE_BITS], 1u);
+    }
+  }
+  __syncthreads();
+  if (!SCATTER) {
+    if (threadIdx.x < MAX_GROUPS && cnt[threadIdx.x]) atomicAdd(&gcount_or_cursor[threadIdx.x], cnt[threadIdx.x]);
+    return;
+  }
+  if (threadIdx.x < MAX_GROUPS) {
+    const uint32_t v = cnt[threadIdx.x];
+    cnt[threadIdx.x] = v ? atomicAdd(&gcount_or_cursor[threadIdx.x], v) : 0u;
+  }
+  __syncthreads();
+  const uint32_t rbase = ref_base + (uint32_t)win * ref_stride;
+  for (uint32_t vi = v_lo + threadIdx.x; vi < v_hi; vi += blockDim.x) {
+    const uint4 q = dv[vi];
+    const int32_t d4[4] = {(int32_t)q.x, (int32_t)q.y, (int32_t)q.z, (int32_t)q.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int32_t d = d4[k];
+      if (d != 0) {
+        const uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1;
+        const uint32_t pos = atomicAdd(&cnt[b >> FINE_BITS], 1u);
+        stage_ref[pos] = (rbase + vi * 4 + k) | (d < 0 ? 0x80000000u : 0u);
+        stage_fine[pos] = (uint16_t)(b & ((1u << FINE_BITS) - 1));
+      }
+    }
+  }
+}
+
+// goff[g] = start of group g in the staging array (exclusive scan of the group counts), gcursor = copy
+__global__ void k_group_offsets(const uint32_t* __restrict__ gcount, int G, uint32_t* __restrict__ goff, uint32_t* __restrict__ gcursor) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  uint32_t run = 0;
+  for (int g = 0; g < G; g++) { goff[g] = run; gcursor[g] = run; run += gcount[g]; }
+  goff[G] = run;
+}
+
+template <bool SCATTER>
+__global__ void __launch_bounds__(1024) k_fine_pass(const uint16_t* __restrict__ stage_fine, const uint32_t* __restrict__ stage_ref,
+                                                    const uint32_t* __restrict__ goff, uint32_t* __restrict__ count_or_cursor,
+                                                    uint32_t* __restrict__ sorted) {
+  extern __shared__ uint32_t hist[];
+  constexpr uint32_t FB = 1u << FINE_BITS;
+  const uint32_t g = blockIdx.y;
+  const uint32_t gend = goff[g + 1];
+  const uint64_t start64 = (uint64_t)goff[g] + (uint64_t)blockIdx.x * FINE_CHUNK;
+  if (start64 >= gend) return;
+  const uint32_t start = (uint32_t)start64, end = (uint32_t)min((uint64_t)gend, start64 + FINE_CHUNK);
+  for (uint32_t b = threadIdx.x; b < FB; b += blockDim.x) hist[b] = 0;
+  __syncthreads();
+  // [start, end) = unaligned head | 8-entry vectors | tail
+  const uint32_t a_lo = min(end, (start + 7) & ~7u), a_hi = max(a_lo, end & ~7u);
+  const uint4* fv = reinterpret_cast<const uint4*>(stage_fine);
+  for (uint32_t p = start + threadIdx.x; p < a_lo; p += blockDim.x) atomicAdd(&hist[stage_fine[p]], 1u);
+  for (uint32_t p = a_hi + threadIdx.x; p < end; p += blockDim.x) atomicAdd(&hist[stage_fine[p]], 1u);
+  for (uint32_t vi = (a_lo >> 3) + threadIdx.x; vi < (a_hi >> 3); vi += blockDim.x) {
+    const uint4 q = fv[vi];
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 8; k++) atomicAdd(&hist[(w[k >> 1] >> ((k & 1) * 16)) & 0xffffu], 1u);
+  }
+  __syncthreads();
+  uint32_t* gl = count_or_cursor + (size_t)g * FB;
+  if (!SCATTER) {
+    for (uint32_t b = threadIdx.x; b < FB; b += blockDim.x) {
+      const uint32_t v = hist[b];
+      if (v) atomicAdd(&gl[b], v);
+    }
+    return;
+  }
+  for (uint32_t b0 = threadIdx.x; b0 < FB; b0 += 8 * blockDim.x) {
+    uint32_t v[8], r[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const uint32_t b = b0 + k * blockDim.x; v[k] = b < FB ? hist[b] : 0u; }
+#pragma unroll
+    for (int k = 0; k < 8; k++) r[k] = v[k] ? atomicAdd(&gl[b0 + k * blockDim.x], v[k]) : 0u;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const uint32_t b = b0 + k * blockDim.x; if (b < FB) hist[b] = r[k]; }
+  }
+  __syncthreads();
+  for (uint32_t p = start + threadIdx.x; p < a_lo; p += blockDim.x) sorted[atomicAdd(&hist[stage_fine[p]], 1u)] = stage_ref[p];
+  for (uint32_t p = a_hi + threadIdx.x; p < end; p += blockDim.x) sorted[atomicAdd(&hist[stage_fine[p]], 1u)] = stage_ref[p];
+  const uint4* rv = reinterpret_cast<const uint4*>(stage_ref);
+  for (uint32_t vi = (a_lo >> 3) + threadIdx.x; vi < (a_hi >> 3); vi += blockDim.x) {
+    const uint4 q = fv[vi], r0 = rv[2 * vi], r1 = rv[2 * vi + 1];
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+    const uint32_t r[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+    for (int k = 0; k < 8; k++) sorted[atomicAdd(&hist[(w[k >> 1] >> ((k & 1) * 16)) & 0xffffu], 1u)] = r[k];
   }
 }
 
@@ -275,9 +401,15 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply(const uint32_t* __res
 // ------------------------------------------------------------------------------------------------
 // 5. tasks: bucket k with cnt entries -> ceil(cnt / 2^task_shift) tasks; max_parts = largest task count of any bucket
 // ------------------------------------------------------------------------------------------------
+// One thread per bucket.  (A thread-per-task variant with a binary search for the bucket is robust against a bucket that
+// holds a large share of all entries, but measured 2-5x slower in the common case: 0.28 vs 0.05 ms at 2^22; a degenerate
+// input -- every scalar equal -- costs this version ~1-2 ms of serial task records, which is acceptable.)
 __global__ void __launch_bounds__(256) k_make_tasks(const uint32_t* __restrict__ offset, const uint32_t* __restrict__ task_off,
                                                     uint32_t nbuckets, task_t* __restrict__ tasks, uint32_t task_shift,
-                                                    uint32_t* __restrict__ max_parts) {
+                                                    uint32_t* __restrict__ max_parts, uint32_t* __restrict__ len_count) {
+  __shared__ uint32_t lh[65];
+  if (threadIdx.x < 65) lh[threadIdx.x] = 0;
+  __syncthreads();
   uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t nt = 0;
   if (k < nbuckets) {
@@ -290,21 +422,65 @@ __global__ void __launch_bounds__(256) k_make_tasks(const uint32_t* __restrict__
       tk.len = min(1u << task_shift, e - tk.start);
       tasks[t + j] = tk;
     }
+    if (nt) {   // nt - 1 full tasks and one of the remaining length
+      if (nt > 1) atomicAdd(&lh[1u << task_shift], nt - 1);
+      atomicAdd(&lh[(e - s) - ((nt - 1) << task_shift)], 1u);
+    }
   }
+  __syncthreads();
+  if (threadIdx.x < 65 && lh[threadIdx.x]) atomicAdd(&len_count[threadIdx.x], lh[threadIdx.x]);
   // block max -> one atomic per wave
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) nt = max(nt, (uint32_t)__shfl_xor((int)nt, off, 64));
   if ((threadIdx.x & 63) == 0 && nt > 1) atomicMax(max_parts, nt);
 }
 
+// Execution order of the tasks: longest first, so that the 64 tasks of a wave have equal length (a wave runs as long as its
+// longest task) and the launch tail consists of short tasks.  len_cursor[L] = first slot of length L.
+__global__ void k_order_offsets(const uint32_t* __restrict__ len_count, uint32_t* __restrict__ len_cursor) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  uint32_t run = 0;
+  for (int L = 64; L >= 1; L--) { len_cursor[L] = run; run += len_count[L]; }
+}
+
+__global__ void __launch_bounds__(256) k_make_order(const uint32_t* __restrict__ offset, const uint32_t* __restrict__ task_off,
+                                                    uint32_t nbuckets, uint32_t task_shift, uint32_t* __restrict__ len_cursor,
+                                                    uint32_t* __restrict__ order) {
+  __shared__ uint32_t lh[65];
+  if (threadIdx.x < 65) lh[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t nt = 0, t = 0, full = 1u << task_shift, rem = 0;
+  if (k < nbuckets) {
+    t = task_off[k];
+    nt = task_off[k + 1] - t;
+    if (nt) {
+      rem = (offset[k + 1] - offset[k]) - ((nt - 1) << task_shift);
+      if (nt > 1) atomicAdd(&lh[full], nt - 1);
+      atomicAdd(&lh[rem], 1u);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 65) { const uint32_t v = lh[threadIdx.x]; lh[threadIdx.x] = v ? atomicAdd(&len_cursor[threadIdx.x], v) : 0u; }
+  __syncthreads();
+  if (nt) {
+    if (nt > 1) {
+      const uint32_t pos = atomicAdd(&lh[full], nt - 1);
+      for (uint32_t j = 0; j + 1 < nt; j++) order[pos + j] = t + j;
+    }
+    order[atomicAdd(&lh[rem], 1u)] = t + nt - 1;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // 6. accumulate: one thread per task
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(128) k_accumulate(const task_t* __restrict__ tasks, const uint32_t* __restrict__ ntasks_p,
-                                                    const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ bases,
-                                                    uint32_t* __restrict__ partials) {
+                                                    const uint32_t* __restrict__ order, const uint32_t* __restrict__ sorted,
+                                                    const uint32_t* __restrict__ bases, uint32_t* __restrict__ partials) {
   const uint32_t ntasks = *ntasks_p;
-  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < ntasks; t += gridDim.x * blockDim.x) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ntasks; i += gridDim.x * blockDim.x) {
+    const uint32_t t = order[i];           // tasks run longest-first; partial t stays in bucket order
     task_t tk = tasks[t];
     xyzz acc = xyzz_identity();
     const uint32_t* refs = sorted + tk.start;
@@ -336,8 +512,7 @@ __global__ void __launch_bounds__(128) k_accumulate(const task_t* __restrict__ t
 //      - k_combine_seq: 8 lanes per bucket sum the <= SEQ_PARTS partials that are left (stride 4^levels), shuffle-reduce,
 //        and write the dense bucket array the pyramid reads.
 // ------------------------------------------------------------------------------------------------
-// seq_parts: how many partials the final step may sum per bucket (256 when the MSM is throughput-bound, 16 when it is
-// latency-bound, where a skewed bucket -- e.g. from a short top window -- would otherwise be a long sequential chain)
+// seq_parts: how many partials the final step may sum per bucket (16 per lane of k_combine_seq)
 __device__ __forceinline__ uint32_t tree_levels_for(uint32_t m, uint32_t seq_parts) {   // smallest L with ceil(m / 4^L) <= seq_parts
   uint32_t L = 0;
   while (((m + (1u << (2 * L)) - 1) >> (2 * L)) > seq_parts) L++;
@@ -417,13 +592,13 @@ __global__ void __launch_bounds__(128) k_pyramid_step(const uint32_t* __restrict
 }
 
 // 9a. per-window weighted sum.  Input state after the last pyramid step: X has 2 elements, Z^0..Z^(nz-1) one each.
-//     window sum = X0 + X1 + sum_l 2^l Z^l + 2^nz X1.  One 16-lane group per window: lane l < nz computes 2^l Z^l by l
+//     window sum = X0 + X1 + sum_l 2^l Z^l + 2^nz X1.  One 32-lane group per window: lane l < nz computes 2^l Z^l by l
 //     doublings, lane nz computes 2^nz X1, lane nz + 1 holds X0 + X1; a 4-step shuffle tree adds the terms.
-//     Depth nz doublings + 4 additions instead of nz (doubling + addition).  Needs nz + 2 <= 16, i.e. c <= 16.
+//     Depth nz doublings + 5 additions instead of nz (doubling + addition).  Needs nz + 2 <= 32 (c <= 21: nz = c - 2).
 __global__ void __launch_bounds__(64) k_window_horner(const uint32_t* __restrict__ in, uint32_t in_stride, int nz,
                                                       uint32_t* __restrict__ winsum, int W) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int win = gid >> 4, lane = gid & 15;
+  const int win = gid >> 5, lane = gid & 31;
   xyzz acc = xyzz_identity();
   if (win < W) {
     const uint32_t* wi = in + (size_t)win * in_stride * 36;
@@ -435,7 +610,7 @@ __global__ void __launch_bounds__(64) k_window_horner(const uint32_t* __restrict
     for (int i = 0; i < dbl; i++) acc = xyzz_dbl(acc);
   }
 #pragma unroll 1
-  for (int mask = 1; mask < 16; mask <<= 1) acc = xyzz_add(acc, xyzz_shfl_xor(acc, mask));
+  for (int mask = 1; mask < 32; mask <<= 1) acc = xyzz_add(acc, xyzz_shfl_xor(acc, mask));
   if (win < W && lane == 0) store_xyzz(winsum, win, acc);
 }
 
@@ -480,30 +655,37 @@ int msm_pick_window(size_t n) {
 }
 
 
+constexpr int MAX_WINDOW_PREPARED = 20;   // 2^19 buckets = 16 groups of 2^15
+
 int msm_pick_window_prepared(size_t n) {
-  // one shared bucket set: W * 10 n + 2 * 14 * 2^(c-1)
+  // one shared bucket set: W * 10 n multiplications of accumulation + 2 * 14 * 2^(c-1) of bucket reduction.  Windows above
+  // 16 bits add a partition pass over the entries (~1 multiplication-equivalent each) and are only worth it for large n.
   int best = 2;
   double best_cost = 1e300;
-  for (int c = 2; c <= 16; c++) {
+  for (int c = 2; c <= MAX_WINDOW_PREPARED; c++) {
     double W = (256 + c - 1) / c;
-    double cost = W * 10.0 * (double)n + 28.0 * (double)(1u << (c - 1));
+    double cost = W * 10.0 * (double)n + 28.0 * (double)(1u << (c - 1)) + (c > 16 ? W * 1.0 * (double)n : 0.0);
+    if (c > 16 && n < ((size_t)1 << 21)) continue;   // measured: c = 20 ties at 2^20 (2.07 vs 2.05 ms), wins from 2^21 (3.57 vs 3.71 ms)
     if (cost < best_cost) { best_cost = cost; best = c; }
   }
+  if (const char* e = getenv("ZKHIP_MAX_WINDOW")) { int m = atoi(e); if (m >= 2 && best > m) best = m; }   // A/B knob
   return best;
 }
 
-size_t msm_workspace_bytes(size_t n, int c) {
-  const size_t W = (256 + c - 1) / c, B = (size_t)1 << (c - 1), NB = W * B;
+size_t msm_workspace_bytes(size_t n, int c, bool prepared) {
+  const size_t W = (256 + c - 1) / c, B = (size_t)1 << (c - 1), WB = prepared ? 1 : W, NB = WB * B;
   // 64-entry tasks when the chip is full, else as short as 4 entries (see the task-length choice in msm_g1_device)
   const size_t max_tasks = ((W * n) >> TASK_SHIFT) >= ((size_t)1 << 17) ? ((W * n) >> TASK_SHIFT) + NB + 1 : W * n / 4 + NB + 1;
   size_t total = 0;
-  total += align_up(W * (n + 8) * sizeof(int16_t), 256);    // digits (rows padded to a multiple of 8)
+  total += align_up(W * (n + 8) * (c > 16 ? sizeof(int32_t) : sizeof(int16_t)), 256);    // digits (rows padded to a multiple of 8)
+  if (c > 16) total += align_up(W * n * sizeof(uint32_t), 256) + align_up(W * n * sizeof(uint16_t), 256) + 1024;   // staging (ref, fine) + group counters
   total += align_up(W * n * sizeof(uint32_t), 256);         // sorted
   total += 4 * align_up((NB + 1) * sizeof(uint32_t), 256);  // count, offset, cursor, task_off
   total += 2 * align_up((NB / SCAN_TILE + 2) * sizeof(uint32_t), 256);  // scan block sums x2
   total += align_up(max_tasks * sizeof(task_t), 256);
+  total += align_up(max_tasks * sizeof(uint32_t), 256);     // execution order
   total += align_up(max_tasks * 144, 256);                  // partials
-  total += 2 * align_up((size_t)W * B * 144, 256);          // pyramid ping-pong (state never exceeds B elements per window)
+  total += 2 * align_up((size_t)WB * B * 144, 256);         // pyramid ping-pong (state never exceeds B elements per bucket set)
   total += align_up(W * 144, 256);                          // window sums
   total += 4096;                                            // counters + result
   return total;
@@ -522,7 +704,8 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   }
   if (n >= (1ull << 31)) { set_error("msm: n = %zu too large", n); return ZKHIP_EINVAL; }
   const int c = prepared ? prepared->c : (c_override > 0 ? c_override : msm_pick_window(n));
-  if (c < 2 || c > 16) { set_error("msm: window bits %d out of range [2,16]", c); return ZKHIP_EINVAL; }
+  const bool wide = c > 16;                         // two-level bucket sort, int32 digits: prepared path only
+  if (c < 2 || c > (prepared ? MAX_WINDOW_PREPARED : 16)) { set_error("msm: window bits %d out of range", c); return ZKHIP_EINVAL; }
   const int W = (256 + c - 1) / c;
   const uint32_t B = 1u << (c - 1);
   const int WB = prepared ? 1 : W;                 // number of bucket sets
@@ -533,7 +716,7 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
     d_bases = prepared->table;
   }
   if ((size_t)W * n >= (1ull << 32)) { set_error("msm: W*n overflows 32-bit slot index"); return ZKHIP_EINVAL; }
-  if (ws_bytes < msm_workspace_bytes(n, c)) { set_error("msm: workspace too small"); return ZKHIP_EINVAL; }
+  if (ws_bytes < msm_workspace_bytes(n, c, prepared != nullptr)) { set_error("msm: workspace too small"); return ZKHIP_EINVAL; }
   const size_t max_tasks = (((size_t)W * n) >> TASK_SHIFT) >= ((size_t)1 << 17) ? (((size_t)W * n) >> TASK_SHIFT) + NB + 1 : (size_t)W * n / 4 + NB + 1;
   // Task length.  With >= 2^17 tasks of 64 entries the chip is full and 64 is best (throughput-bound, see TASK_SHIFT).  Below
   // that the MSM is latency-bound: a task of L entries is L sequential mixed adds (~5 us each at low occupancy) and a bucket
@@ -552,7 +735,10 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   char* p = (char*)ws;
   auto carve = [&](size_t bytes) { void* r = p; p += align_up(bytes, 256); return r; };
   const uint32_t n_pad = (uint32_t)((n + 7) & ~(size_t)7);
-  int16_t* digits = (int16_t*)carve((size_t)W * n_pad * sizeof(int16_t));
+  void* digits = carve((size_t)W * n_pad * (wide ? sizeof(int32_t) : sizeof(int16_t)));
+  uint32_t* stage_ref = wide ? (uint32_t*)carve((size_t)W * n * sizeof(uint32_t)) : nullptr;
+  uint16_t* stage_fine = wide ? (uint16_t*)carve((size_t)W * n * sizeof(uint16_t)) : nullptr;
+  uint32_t* gcounters = wide ? (uint32_t*)carve(1024) : nullptr;   // [0..32) group counts, [32..65) group offsets, [96..128) group cursors
   uint32_t* sorted = (uint32_t*)carve((size_t)W * n * sizeof(uint32_t));
   uint32_t* count = (uint32_t*)carve((NB + 1) * sizeof(uint32_t));
   uint32_t* offset = (uint32_t*)carve((NB + 1) * sizeof(uint32_t));
@@ -561,16 +747,19 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   uint32_t* bsum1 = (uint32_t*)carve((NB / SCAN_TILE + 2) * sizeof(uint32_t));
   uint32_t* bsum2 = (uint32_t*)carve((NB / SCAN_TILE + 2) * sizeof(uint32_t));
   task_t* tasks = (task_t*)carve(max_tasks * sizeof(task_t));
+  uint32_t* order = (uint32_t*)carve(max_tasks * sizeof(uint32_t));
   uint32_t* partials = (uint32_t*)carve(max_tasks * 144);
   const size_t pyr_elems = B;   // per window: N + (s-1) N/2 <= B at every step
-  uint32_t* pyrA = (uint32_t*)carve((size_t)W * pyr_elems * 144);
-  uint32_t* pyrB = (uint32_t*)carve((size_t)W * pyr_elems * 144);
+  uint32_t* pyrA = (uint32_t*)carve((size_t)WB * pyr_elems * 144);
+  uint32_t* pyrB = (uint32_t*)carve((size_t)WB * pyr_elems * 144);
   uint32_t* winsum = (uint32_t*)carve((size_t)W * 144);
-  uint32_t* counters = (uint32_t*)carve(1024);   // [0] total entries, [1] total tasks, [2] max task partials of one bucket
+  uint32_t* counters = (uint32_t*)carve(1024);   // [0] total entries, [1] total tasks, [2] max task partials of one bucket,
+                                                 // [64..129) task-length histogram, [160..225) its cursors
 
   prof_begin(stream);
   // 1. digits
-  hipLaunchKernelGGL(k_digits, dim3((n_pad + 255) / 256), dim3(256), 0, stream, d_scalars, digits, (uint32_t)n, n_pad, c, W);
+  if (wide) hipLaunchKernelGGL(k_digits<int32_t>, dim3((n_pad + 255) / 256), dim3(256), 0, stream, d_scalars, (int32_t*)digits, (uint32_t)n, n_pad, c, W);
+  else hipLaunchKernelGGL(k_digits<int16_t>, dim3((n_pad + 255) / 256), dim3(256), 0, stream, d_scalars, (int16_t*)digits, (uint32_t)n, n_pad, c, W);
   prof_mark(stream, "digits");
   // 2. count
   HIPCHK(hipMemsetAsync(count, 0, (NB + 1) * sizeof(uint32_t), stream));
@@ -579,16 +768,31 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   while (chunks * (uint32_t)W < 256 && chunks < (n + 4095) / 4096) chunks *= 2;   // fill the chip
   if (chunks == 0) chunks = 1;
   const uint32_t chunk = (uint32_t)((((n + chunks - 1) / chunks) + 7) & ~(size_t)7);   // multiple of 8 (vector loads)
-  const size_t lds = (size_t)B * sizeof(uint32_t);
+  const size_t lds = wide ? ((size_t)4 << FINE_BITS) : (size_t)B * sizeof(uint32_t);
   static bool attr_set = false;
   if (!attr_set) {
     HIPCHK(hipFuncSetAttribute((const void*)k_sort_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)k_sort_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)k_fine_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)k_fine_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     attr_set = true;
   }
+  const int G = wide ? (int)(B >> FINE_BITS) : 1;                      // coarse groups
+  const uint32_t fine_chunks = (uint32_t)(((size_t)W * n + FINE_CHUNK - 1) / FINE_CHUNK);   // worst case: one group holds everything
   const uint32_t wb_stride = prepared ? 0u : B;
   const uint32_t ref_base = prepared ? (uint32_t)prepared_off : 0u, ref_stride = prepared ? (uint32_t)prepared->n : 0u;
-  hipLaunchKernelGGL(k_sort_pass<false>, dim3(chunks, W), dim3(1024), lds, stream, digits, n_pad, chunk, c, count, (uint32_t*)nullptr, wb_stride, ref_base, ref_stride);
+  if (wide) {
+    HIPCHK(hipMemsetAsync(gcounters, 0, 1024, stream));
+    hipLaunchKernelGGL(k_coarse_pass<false>, dim3(chunks, W), dim3(1024), 0, stream, (const int32_t*)digits, n_pad, chunk, gcounters, (uint32_t*)nullptr,
+                       (uint16_t*)nullptr, ref_base, ref_stride);
+    hipLaunchKernelGGL(k_group_offsets, dim3(1), dim3(64), 0, stream, gcounters, G, gcounters + 32, gcounters + 96);
+    hipLaunchKernelGGL(k_coarse_pass<true>, dim3(chunks, W), dim3(1024), 0, stream, (const int32_t*)digits, n_pad, chunk, gcounters + 96, stage_ref,
+                       stage_fine, ref_base, ref_stride);
+    prof_mark(stream, "coarse");
+    hipLaunchKernelGGL(k_fine_pass<false>, dim3(fine_chunks, G), dim3(1024), lds, stream, stage_fine, stage_ref, gcounters + 32, count, (uint32_t*)nullptr);
+  } else {
+    hipLaunchKernelGGL(k_sort_pass<false>, dim3(chunks, W), dim3(1024), lds, stream, (const int16_t*)digits, n_pad, chunk, c, count, (uint32_t*)nullptr, wb_stride, ref_base, ref_stride);
+  }
   prof_mark(stream, "count");
   // 3. scan counts -> offset (+ cursor copy)
   const uint32_t nblk = (NB + SCAN_TILE - 1) / SCAN_TILE;
@@ -597,23 +801,30 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   hipLaunchKernelGGL(k_scan_apply<0>, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, count, NB, bsum1, counters + 0, offset, cursor, 0u);
   prof_mark(stream, "scan");
   // 4. scatter
-  hipLaunchKernelGGL(k_sort_pass<true>, dim3(chunks, W), dim3(1024), lds, stream, digits, n_pad, chunk, c, cursor, sorted, wb_stride, ref_base, ref_stride);
+  if (wide) hipLaunchKernelGGL(k_fine_pass<true>, dim3(fine_chunks, G), dim3(1024), lds, stream, stage_fine, stage_ref, gcounters + 32, cursor, sorted);
+  else hipLaunchKernelGGL(k_sort_pass<true>, dim3(chunks, W), dim3(1024), lds, stream, (const int16_t*)digits, n_pad, chunk, c, cursor, sorted, wb_stride, ref_base, ref_stride);
   prof_mark(stream, "scatter");
   // 5. tasks
   hipLaunchKernelGGL(k_scan_sums<1>, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, count, NB, bsum2, task_shift);
   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_BLOCK), 0, stream, bsum2, nblk, counters + 1);
   hipLaunchKernelGGL(k_scan_apply<1>, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, count, NB, bsum2, counters + 1, task_off, (uint32_t*)nullptr, task_shift);
-  hipLaunchKernelGGL(k_make_tasks, dim3((NB + 255) / 256), dim3(256), 0, stream, offset, task_off, NB, tasks, task_shift, counters + 2);
+  hipLaunchKernelGGL(k_make_tasks, dim3((NB + 255) / 256), dim3(256), 0, stream, offset, task_off, NB, tasks, task_shift, counters + 2, counters + 64);
+  hipLaunchKernelGGL(k_order_offsets, dim3(1), dim3(64), 0, stream, counters + 64, counters + 160);
+  hipLaunchKernelGGL(k_make_order, dim3((NB + 255) / 256), dim3(256), 0, stream, offset, task_off, NB, task_shift, counters + 160, order);
   prof_mark(stream, "tasks");
   // 6. accumulate (grid-stride over the device-side task count)
   {
     uint32_t blocks = (uint32_t)((max_tasks + 127) / 128);
     if (blocks > 256 * 64) blocks = 256 * 64;
-    hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(128), 0, stream, tasks, counters + 1, sorted, d_bases, partials);
+    hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(128), 0, stream, tasks, counters + 1, order, sorted, d_bases, partials);
   }
   prof_mark(stream, "accumulate");
   // 7. combine
-  const uint32_t seq_parts = (((size_t)W * n) >> TASK_SHIFT) >= ((size_t)1 << 17) ? 256u : 16u;
+  // expected partials per bucket decide how many lanes sum a bucket in the final step; the tree handles any bucket with more
+  // than 16 partials per lane, so a skewed bucket (e.g. from a short top window) never becomes a long sequential chain
+  const double parts_avg = (double)W * (double)n / (double)NB / (double)(1u << task_shift);
+  const int combine_lanes = parts_avg <= 2.0 ? 1 : (parts_avg <= 4.0 ? 2 : (parts_avg <= 12.0 ? 4 : 8));
+  const uint32_t seq_parts = 16u * (uint32_t)combine_lanes;
   {
     uint32_t blocks = (uint32_t)((max_tasks + 127) / 128);
     if (blocks > 2048) blocks = 2048;
@@ -621,10 +832,9 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
       hipLaunchKernelGGL(k_combine_tree, dim3(blocks), dim3(128), 0, stream, tasks, counters + 1, task_off, counters + 2, partials, level, seq_parts);
   }
   {
-    const double parts = (double)W * (double)n / (double)NB / (double)(1u << task_shift);   // expected partials per bucket
-    if (parts <= 2.0) hipLaunchKernelGGL(k_combine_seq<1>, dim3((NB + 127) / 128), dim3(128), 0, stream, task_off, NB, partials, pyrA, seq_parts);
-    else if (parts <= 4.0) hipLaunchKernelGGL(k_combine_seq<2>, dim3((unsigned)(((size_t)NB * 2 + 127) / 128)), dim3(128), 0, stream, task_off, NB, partials, pyrA, seq_parts);
-    else if (parts <= 12.0) hipLaunchKernelGGL(k_combine_seq<4>, dim3((unsigned)(((size_t)NB * 4 + 127) / 128)), dim3(128), 0, stream, task_off, NB, partials, pyrA, seq_parts);
+    if (combine_lanes == 1) hipLaunchKernelGGL(k_combine_seq<1>, dim3((NB + 127) / 128), dim3(128), 0, stream, task_off, NB, partials, pyrA, seq_parts);
+    else if (combine_lanes == 2) hipLaunchKernelGGL(k_combine_seq<2>, dim3((unsigned)(((size_t)NB * 2 + 127) / 128)), dim3(128), 0, stream, task_off, NB, partials, pyrA, seq_parts);
+    else if (combine_lanes == 4) hipLaunchKernelGGL(k_combine_seq<4>, dim3((unsigned)(((size_t)NB * 4 + 127) / 128)), dim3(128), 0, stream, task_off, NB, partials, pyrA, seq_parts);
     else hipLaunchKernelGGL(k_combine_seq<8>, dim3((unsigned)(((size_t)NB * 8 + 127) / 128)), dim3(128), 0, stream, task_off, NB, partials, pyrA, seq_parts);
   }
   prof_mark(stream, "combine");
@@ -654,7 +864,7 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
     set_error("msm: internal: B == 1");
     return ZKHIP_EINVAL;
   }
-  hipLaunchKernelGGL(k_window_horner, dim3((WB * 16 + 63) / 64), dim3(64), 0, stream, cur, in_stride, nz, winsum, WB);
+  hipLaunchKernelGGL(k_window_horner, dim3((WB * 32 + 63) / 64), dim3(64), 0, stream, cur, in_stride, nz, winsum, WB);
   prof_mark(stream, "horner");
   hipLaunchKernelGGL(k_fold, dim3(1), dim3(64), 0, stream, winsum, WB, c, d_out);   // prepared: WB == 1, just the format conversion
   prof_mark(stream, "fold");
@@ -823,9 +1033,10 @@ __global__ void __launch_bounds__(64) k_build_table(const uint32_t* __restrict__
 }
 
 // d_bases: n affine points on the device.  Allocates the table (W * n * 64 B) and a temporary (freed before returning).
-int prepare_bases_device(const uint32_t* d_bases, size_t n, hipStream_t stream, prepared_bases** out) {
+int prepare_bases_device(const uint32_t* d_bases, size_t n, hipStream_t stream, prepared_bases** out, int c_override) {
   if (n == 0 || n >= (1ull << 27)) { set_error("prepare_bases: n = %zu out of range", n); return ZKHIP_EINVAL; }
-  const int c = msm_pick_window_prepared(n);
+  const int c = c_override > 0 ? c_override : msm_pick_window_prepared(n);
+  if (c < 2 || c > MAX_WINDOW_PREPARED) { set_error("prepare_bases: window bits %d out of range [2,%d]", c, MAX_WINDOW_PREPARED); return ZKHIP_EINVAL; }
   const int W = (256 + c - 1) / c;
   prepared_bases* pb = new prepared_bases();
   pb->n = n; pb->c = c; pb->W = W; pb->table = nullptr;
