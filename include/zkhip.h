@@ -95,6 +95,11 @@ int zkhip_msm_g1_device_c(const void *d_scalars, const void *d_bases, size_t n, 
 int zkhip_ntt_fr_device(void *d_a, const uint64_t omega[4], uint32_t log_n, void *stream);
 int zkhip_ifft_scaled_device(void *d_a, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4], void *stream);
 int zkhip_mul_periodic_device(void *d_a, size_t n, const void *d_table, uint32_t period, void *stream);
+/* `batch` polynomials of 2^log_n elements, polynomial b at d_a + b * stride elements (stride >= 2^log_n), one launch set:
+ * many small transforms (voter / state-transition columns at k = 13..17) run at large-transform throughput */
+int zkhip_ntt_fr_batch_device(void *d_a, const uint64_t omega[4], uint32_t log_n, uint32_t batch, size_t stride, void *stream);
+int zkhip_ifft_scaled_batch_device(void *d_a, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4], uint32_t batch,
+                                   size_t stride, void *stream);
 /* out = sum of m Jacobian points (multi-GPU: fold of the gathered per-rank partial sums) */
 int zkhip_g1_sum_device(const void *d_points_xyz, int m, void *d_out_xyz, void *stream);
 int zkhip_g1_sum(const uint64_t *points_xyz, int m, uint64_t out_xyz[12]);

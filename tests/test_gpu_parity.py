@@ -267,6 +267,39 @@ def test_ntt_vs_reference_algorithm(cref, log_n):
     assert np.array_equal(a, ref)
 
 
+@pytest.mark.parametrize("log_n,batch,pad", [(2, 5, 0), (6, 7, 3), (9, 4, 0), (10, 9, 5), (13, 33, 0), (15, 6, 8), (19, 3, 0)])
+def test_ntt_batched_vs_reference_algorithm(lib, cref, log_n, batch, pad):
+    """K polynomials in one launch set (strided layout), forward and scaled inverse, each checked against best_fft."""
+    import torch
+
+    n = 1 << log_n
+    stride = n + pad
+    w = O.omega_for(log_n)
+    omega, omega_inv = F.fr_encode([w])[0], F.fr_encode([pow(w, -1, O.R_MOD)])[0]
+    div = F.fr_encode([pow(n, -1, O.R_MOD)])[0]
+    host = np.zeros((batch * stride, 4), dtype=np.uint64)
+    polys = []
+    for b in range(batch):
+        a = cref.gen_scalars(9000 + 31 * log_n + b, n, b % 2)
+        polys.append(a)
+        host[b * stride:b * stride + n] = a
+        host[b * stride + n:(b + 1) * stride] = 0xDEADBEEF      # padding must stay untouched
+    d = torch.from_numpy(host.view(np.int64)).cuda()
+    _lib.check(lib.zkhip_ntt_fr_batch_device(d.data_ptr(), omega.ctypes.data, log_n, batch, stride, None))
+    torch.cuda.synchronize()
+    got = d.cpu().numpy().view(np.uint64).reshape(-1, 4)
+    for b in range(batch):
+        ref = polys[b].copy()
+        cref.best_fft(ref, omega, log_n, 4)
+        assert np.array_equal(got[b * stride:b * stride + n], ref), b
+        assert (got[b * stride + n:(b + 1) * stride] == 0xDEADBEEF).all()
+    _lib.check(lib.zkhip_ifft_scaled_batch_device(d.data_ptr(), omega_inv.ctypes.data, log_n, div.ctypes.data, batch, stride, None))
+    torch.cuda.synchronize()
+    back = d.cpu().numpy().view(np.uint64).reshape(-1, 4)
+    for b in range(batch):
+        assert np.array_equal(back[b * stride:b * stride + n], polys[b]), b
+
+
 @pytest.mark.parametrize("log_n", [22, 24])
 def test_ntt_large_round_trip_and_spot_check(cref, log_n):
     """BASELINE sizes: iNTT(NTT(a)) = a limb for limb; NTT(delta_1) = powers of omega; one full compare at 2^22."""

@@ -37,6 +37,8 @@ _SIGS = {
     "zkhip_msm_g1_prepared_device": (C.c_int, [C.c_uint64, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "zkhip_msm_g1_device_c": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),
     "zkhip_ntt_fr_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "zkhip_ntt_fr_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_size_t, C.c_void_p]),
+    "zkhip_ifft_scaled_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_size_t, C.c_void_p]),
     "zkhip_ifft_scaled_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "zkhip_mul_periodic_device": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_void_p]),
     "zkhip_g1_sum_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

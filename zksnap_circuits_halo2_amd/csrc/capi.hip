@@ -45,9 +45,6 @@ void prof_mark(hipStream_t stream, const char* name) {
   (void)hipEventRecord(g_prof_ev[g_prof_n], stream);
 }
 
-int ntt_transform(const uint32_t* d_in, uint32_t in_len, uint32_t* d_out, uint32_t out_len, uint32_t L,
-                  const uint32_t omega_ext[8], const uint32_t* in_scale, uint32_t in_period, const uint32_t* out_scale,
-                  uint32_t out_period, hipStream_t stream);
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s failed: %s", #x, hipGetErrorString(e_)); return ZKHIP_EHIP; } } while (0)
 
@@ -73,7 +70,7 @@ struct context {
   bool ready = false;
   int device = 0;
   hipStream_t stream = nullptr;
-  dev_buf ws, scalars, bases, poly, poly2, small;
+  dev_buf ws, scalars, bases, poly, poly2, small, ntt_tmp;
   std::map<const void*, prepared_bases*> registered;   // host ptr -> prepared table (slice 0 of the table = the bases themselves)
   std::map<uint64_t, prepared_bases*> handles;          // zkhip_prepare_bases_device handles
   uint64_t next_handle = 1;
@@ -133,7 +130,7 @@ void zkhip_shutdown(void) {
   g_ctx.registered.clear();
   for (auto& kv : g_ctx.handles) release_prepared(kv.second);
   g_ctx.handles.clear();
-  g_ctx.ws.release(); g_ctx.scalars.release(); g_ctx.bases.release(); g_ctx.poly.release(); g_ctx.poly2.release(); g_ctx.small.release();
+  g_ctx.ws.release(); g_ctx.scalars.release(); g_ctx.bases.release(); g_ctx.poly.release(); g_ctx.poly2.release(); g_ctx.small.release(); g_ctx.ntt_tmp.release();
   (void)hipStreamDestroy(g_ctx.stream);
   g_ctx.stream = nullptr;
   g_ctx.ready = false;
@@ -288,12 +285,52 @@ int zkhip_g1_sum(const uint64_t* points_xyz, int m, uint64_t out_xyz[12]) {
 }
 
 // ---- NTT / domain ----------------------------------------------------------------------------------
+// runs ntt_transform with scratch from the context (two buffers of batch * 2^L elements when the transform is multi-pass)
+static int run_transform(const uint32_t* d_in, uint32_t in_len, uint32_t in_stride, uint32_t* d_out, uint32_t out_len, uint32_t out_stride,
+                         uint32_t batch, uint32_t L, const uint32_t* omega, const uint32_t* in_scale, uint32_t in_period,
+                         const uint32_t* out_scale, uint32_t out_period, hipStream_t s) {
+  if (L > 28) { set_error("ntt: log_n = %u > 28", L); return ZKHIP_EINVAL; }
+  const int np = ntt_passes(L);
+  const size_t one = (size_t)batch << L;   // elements
+  uint32_t *t0 = nullptr, *t1 = nullptr;
+  if (np >= 2) {
+    int rc = g_ctx.ntt_tmp.reserve(one * 32 * (np >= 3 ? 2 : 1));
+    if (rc != ZKHIP_OK) return rc;
+    t0 = (uint32_t*)g_ctx.ntt_tmp.p;
+    if (np >= 3) t1 = t0 + one * 8;
+  }
+  return ntt_transform(d_in, in_len, in_stride, d_out, out_len, out_stride, batch, L, omega, in_scale, in_period, out_scale, out_period, t0, t1, s);
+}
+
+int zkhip_ntt_fr_batch_device(void* d_a, const uint64_t omega[4], uint32_t log_n, uint32_t batch, size_t stride, void* stream) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (!d_a || !omega || log_n > 28 || stride < ((size_t)1 << log_n) || stride >= ((size_t)1 << 32)) { set_error("ntt_batch: bad argument"); return ZKHIP_EINVAL; }
+  const uint32_t N = 1u << log_n;
+  return run_transform((const uint32_t*)d_a, N, (uint32_t)stride, (uint32_t*)d_a, N, (uint32_t)stride, batch, log_n, (const uint32_t*)omega, nullptr, 0,
+                       nullptr, 0, stream ? (hipStream_t)stream : g_ctx.stream);
+}
+
+int zkhip_ifft_scaled_batch_device(void* d_a, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4], uint32_t batch, size_t stride,
+                                   void* stream) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (!d_a || !omega_inv || !divisor || log_n > 28 || stride < ((size_t)1 << log_n) || stride >= ((size_t)1 << 32)) { set_error("ifft_batch: bad argument"); return ZKHIP_EINVAL; }
+  const uint32_t N = 1u << log_n;
+  return run_transform((const uint32_t*)d_a, N, (uint32_t)stride, (uint32_t*)d_a, N, (uint32_t)stride, batch, log_n, (const uint32_t*)omega_inv, nullptr, 0,
+                       (const uint32_t*)divisor, 1, stream ? (hipStream_t)stream : g_ctx.stream);
+}
+
 int zkhip_ntt_fr_device(void* d_a, const uint64_t omega[4], uint32_t log_n, void* stream) {
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
   if (!d_a || !omega) { set_error("ntt: null pointer"); return ZKHIP_EINVAL; }
-  return ntt_fr_device((uint32_t*)d_a, (const uint32_t*)omega, log_n, stream ? (hipStream_t)stream : g_ctx.stream);
+  if (log_n > 28) { set_error("ntt: log_n = %u > 28", log_n); return ZKHIP_EINVAL; }
+  const uint32_t N = 1u << log_n;
+  return run_transform((const uint32_t*)d_a, N, N, (uint32_t*)d_a, N, N, 1, log_n, (const uint32_t*)omega, nullptr, 0, nullptr, 0, stream ? (hipStream_t)stream : g_ctx.stream);
 }
 
 int zkhip_ifft_scaled_device(void* d_a, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4], void* stream) {
@@ -301,7 +338,10 @@ int zkhip_ifft_scaled_device(void* d_a, const uint64_t omega_inv[4], uint32_t lo
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
   if (!d_a || !omega_inv || !divisor) { set_error("ifft: null pointer"); return ZKHIP_EINVAL; }
-  return ntt_fr_device_ex((uint32_t*)d_a, (const uint32_t*)omega_inv, log_n, (const uint32_t*)divisor, stream ? (hipStream_t)stream : g_ctx.stream);
+  if (log_n > 28) { set_error("ifft: log_n = %u > 28", log_n); return ZKHIP_EINVAL; }
+  const uint32_t N = 1u << log_n;
+  return run_transform((const uint32_t*)d_a, N, N, (uint32_t*)d_a, N, N, 1, log_n, (const uint32_t*)omega_inv, nullptr, 0, (const uint32_t*)divisor, 1,
+                       stream ? (hipStream_t)stream : g_ctx.stream);
 }
 
 int zkhip_mul_periodic_device(void* d_a, size_t n, const void* d_table, uint32_t period, void* stream) {
@@ -323,7 +363,7 @@ static int host_transform(const uint64_t* in, size_t in_len, uint64_t* out, size
   hipStream_t s = g_ctx.stream;
   if ((rc = g_ctx.poly.reserve(N * 32)) != ZKHIP_OK) return rc;
   HIPCHK(hipMemcpyAsync(g_ctx.poly.p, in, in_len * 32, hipMemcpyHostToDevice, s));
-  rc = ntt_transform((const uint32_t*)g_ctx.poly.p, (uint32_t)in_len, (uint32_t*)g_ctx.poly.p, (uint32_t)out_len, log_n,
+  rc = run_transform((const uint32_t*)g_ctx.poly.p, (uint32_t)in_len, (uint32_t)N, (uint32_t*)g_ctx.poly.p, (uint32_t)out_len, (uint32_t)N, 1, log_n,
                      (const uint32_t*)omega, in_scale, in_period, out_scale, out_period, s);
   if (rc != ZKHIP_OK) return rc;
   HIPCHK(hipMemcpyAsync(out, g_ctx.poly.p, out_len * 32, hipMemcpyDeviceToHost, s));

@@ -45,6 +45,7 @@ struct scale_arg {      // up to 3 external (Montgomery-256) constants applied a
 struct pass_args {
   const uint32_t* src;
   uint32_t* dst;
+  uint32_t src_stride, dst_stride; // batch: elements between consecutive polynomials (blockIdx.y selects the polynomial)
   uint32_t L, S, B;               // log2 N, log2 Ns, log2 R
   const uint32_t* tw_local;       // w_R^x, x < R/2              (internal 9-limb form)
   const uint32_t* tw_lo;          // w_M^t, t < 2^h (or t < M when tw_hi == nullptr)
@@ -97,6 +98,8 @@ __global__ void __launch_bounds__(256, 2) k_ntt_pass(pass_args a) {
   const uint32_t NR = N >> B;
   const uint32_t Ns = 1u << a.S;
   const uint32_t nthreads = blockDim.x;
+  const uint32_t* const src = a.src + (size_t)blockIdx.y * a.src_stride * 8;
+  uint32_t* const dst = a.dst + (size_t)blockIdx.y * a.dst_stride * 8;
 
   // ---- load: global order (r, jj) -> LDS position (bitrev(r), jj) --------------------------------
   for (uint32_t idx = threadIdx.x; idx < tile; idx += nthreads) {
@@ -107,7 +110,7 @@ __global__ void __launch_bounds__(256, 2) k_ntt_pass(pass_args a) {
     if (a.first) {
       if (g < a.in_len) {
         uint32_t w[8];
-        load_words(a.src + (size_t)g * 8, w);
+        load_words(src + (size_t)g * 8, w);
         x = fe_unpack<0>(w);
         if (a.in_scale.period) x = fe_mul<Fr>(scale_pick(a.in_scale, g), x);
       } else {
@@ -115,7 +118,7 @@ __global__ void __launch_bounds__(256, 2) k_ntt_pass(pass_args a) {
       }
     } else {
       uint32_t w[8];
-      load_words(a.src + (size_t)g * 8, w);
+      load_words(src + (size_t)g * 8, w);
       x = fe_unpack<0>(w);
       const uint32_t t = (j & (Ns - 1)) * r;
       fe tw;
@@ -221,14 +224,16 @@ __global__ void __launch_bounds__(256, 2) k_ntt_pass(pass_args a) {
     } else {
       fe_pack(fe_reduce_soft<Fr>(x), w);         // < 2p + 2^233 < 2^256: fits the 32-byte intermediate format
     }
-    store_words(a.dst + (size_t)d * 8, w);
+    store_words(dst + (size_t)d * 8, w);
   }
 }
 
 // N <= 4: direct DFT by one thread
-__global__ void k_ntt_tiny(const uint32_t* src, uint32_t* dst, uint32_t L, const uint32_t* pw2, uint32_t in_len,
-                           uint32_t out_len, scale_arg in_scale, scale_arg out_scale) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ void k_ntt_tiny(const uint32_t* src0, uint32_t* dst0, uint32_t L, const uint32_t* pw2, uint32_t in_len,
+                           uint32_t out_len, scale_arg in_scale, scale_arg out_scale, uint32_t src_stride, uint32_t dst_stride) {
+  if (threadIdx.x != 0) return;
+  const uint32_t* src = src0 + (size_t)blockIdx.x * src_stride * 8;
+  uint32_t* dst = dst0 + (size_t)blockIdx.x * dst_stride * 8;
   const uint32_t N = 1u << L;
   fe x[4], y[4];
   fe one = fe_one<Fr>();
@@ -311,7 +316,6 @@ struct ntt_plan {
   uint32_t* tw_local[4] = {nullptr, nullptr, nullptr, nullptr};
   uint32_t* tw_lo[4] = {nullptr, nullptr, nullptr, nullptr};
   uint32_t* tw_hi[4] = {nullptr, nullptr, nullptr, nullptr};
-  uint32_t* tmp[2] = {nullptr, nullptr};
   std::vector<void*> allocs;
 };
 
@@ -367,10 +371,6 @@ static int build_plan(const uint32_t omega_ext[8], uint32_t L, hipStream_t strea
         hipLaunchKernelGGL(k_ntt_powers, dim3((nhi + 255) / 256), dim3(256), 0, stream, p->pw2, L - logM + h, nhi, p->tw_hi[i]);
       }
     }
-    if (p->npass >= 2) {
-      if ((rc = plan_alloc(p, &p->tmp[0], ((size_t)32) << L)) != ZKHIP_OK) return rc;
-      if (p->npass >= 3 && (rc = plan_alloc(p, &p->tmp[1], ((size_t)32) << L)) != ZKHIP_OK) return rc;
-    }
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(stream));   // tables are shared by later calls on any stream
@@ -413,11 +413,17 @@ static scale_arg make_scale(const uint32_t* ext, uint32_t period) {
   return s;
 }
 
-// Generic transform: out[i] = out_scale[i % op] * sum_j (in_scale[j % ip] * in[j]) omega^(ij), j < in_len (zero above),
-// i < out_len.  d_in may equal d_out.  Scales are host arrays of `period` external-form constants (period 0, 1 or 3).
-int ntt_transform(const uint32_t* d_in, uint32_t in_len, uint32_t* d_out, uint32_t out_len, uint32_t L,
-                  const uint32_t omega_ext[8], const uint32_t* in_scale, uint32_t in_period, const uint32_t* out_scale,
-                  uint32_t out_period, hipStream_t stream) {
+int ntt_passes(uint32_t L) { return L < 3 ? 0 : (int)((L + NTT_MAX_BITS - 1) / NTT_MAX_BITS); }
+
+// Generic transform of `batch` polynomials (polynomial b at d_in + b * in_stride elements, result at d_out + b * out_stride):
+// out[i] = out_scale[i % op] * sum_j (in_scale[j % ip] * in[j]) omega^(ij), j < in_len (zero above), i < out_len.
+// d_in may equal d_out.  Scales are host arrays of `period` external-form constants (period 0, 1 or 3).
+// tmp0 / tmp1: scratch of batch * 2^L elements each, needed when the transform has >= 2 / >= 3 passes (ntt_passes).
+int ntt_transform(const uint32_t* d_in, uint32_t in_len, uint32_t in_stride, uint32_t* d_out, uint32_t out_len, uint32_t out_stride,
+                  uint32_t batch, uint32_t L, const uint32_t omega_ext[8], const uint32_t* in_scale, uint32_t in_period,
+                  const uint32_t* out_scale, uint32_t out_period, uint32_t* tmp0, uint32_t* tmp1, hipStream_t stream) {
+  if (batch == 0) return ZKHIP_OK;
+  if (batch > 65535) { set_error("ntt: batch %u > 65535", batch); return ZKHIP_EINVAL; }
   if (L > 28) { set_error("ntt: log_n = %u > 28", L); return ZKHIP_EINVAL; }
   if ((in_period != 0 && in_period != 1 && in_period != 3) || (out_period != 0 && out_period != 1 && out_period != 3)) {
     set_error("ntt: scale period must be 0, 1 or 3");
@@ -431,7 +437,7 @@ int ntt_transform(const uint32_t* d_in, uint32_t in_len, uint32_t* d_out, uint32
   if (out_len > N) out_len = N;
   scale_arg is = make_scale(in_scale, in_scale ? in_period : 0), os = make_scale(out_scale, out_scale ? out_period : 0);
   if (L < 3) {
-    hipLaunchKernelGGL(k_ntt_tiny, dim3(1), dim3(64), 0, stream, d_in, d_out, L, p->pw2, in_len, out_len, is, os);
+    hipLaunchKernelGGL(k_ntt_tiny, dim3(batch), dim3(64), 0, stream, d_in, d_out, L, p->pw2, in_len, out_len, is, os, in_stride, out_stride);
     HIPCHK(hipGetLastError());
     return ZKHIP_OK;
   }
@@ -440,6 +446,8 @@ int ntt_transform(const uint32_t* d_in, uint32_t in_len, uint32_t* d_out, uint32
     (void)hipFuncSetAttribute((const void*)k_ntt_pass, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_TILE * 36);
   });
   const uint32_t tile = N < NTT_TILE ? N : NTT_TILE;
+  if ((p->npass >= 2 && !tmp0) || (p->npass >= 3 && !tmp1)) { set_error("ntt: missing scratch buffer"); return ZKHIP_EINVAL; }
+  uint32_t* tmp[2] = {tmp0, tmp1};
   prof_begin(stream);
   for (int i = 0; i < p->npass; i++) {
     pass_args a;
@@ -450,23 +458,17 @@ int ntt_transform(const uint32_t* d_in, uint32_t in_len, uint32_t* d_out, uint32
     a.in_len = in_len; a.out_len = out_len;
     a.in_scale = is; a.out_scale = os;
     // buffer chain: in -> tmp0 -> tmp1 -> tmp0 -> ... -> out
-    a.src = i == 0 ? d_in : p->tmp[(i - 1) & 1];
-    a.dst = a.last ? d_out : p->tmp[i & 1];
-    hipLaunchKernelGGL(k_ntt_pass, dim3(N / tile), dim3(tile / 8), (size_t)tile * 36, stream, a);
+    a.src = i == 0 ? d_in : tmp[(i - 1) & 1];
+    a.dst = a.last ? d_out : tmp[i & 1];
+    a.src_stride = i == 0 ? in_stride : N;
+    a.dst_stride = a.last ? out_stride : N;
+    hipLaunchKernelGGL(k_ntt_pass, dim3(N / tile, batch), dim3(tile / 8), (size_t)tile * 36, stream, a);
     prof_mark(stream, i == 0 ? "ntt_pass0" : (i == 1 ? "ntt_pass1" : (i == 2 ? "ntt_pass2" : "ntt_pass3")));
   }
   HIPCHK(hipGetLastError());
   return ZKHIP_OK;
 }
 
-int ntt_fr_device_ex(uint32_t* d_a, const uint32_t omega_ext[8], uint32_t log_n, const uint32_t* scale_ext, hipStream_t stream) {
-  const uint32_t N = 1u << log_n;
-  return ntt_transform(d_a, N, d_a, N, log_n, omega_ext, nullptr, 0, scale_ext, scale_ext ? 1 : 0, stream);
-}
-
-int ntt_fr_device(uint32_t* d_a, const uint32_t omega_ext[8], uint32_t log_n, hipStream_t stream) {
-  return ntt_fr_device_ex(d_a, omega_ext, log_n, nullptr, stream);
-}
 
 int fr_mul_periodic_device(uint32_t* d_a, size_t n, const uint32_t* d_table_ext, uint32_t period, hipStream_t stream) {
   if (period == 0) { set_error("mul_periodic: period 0"); return ZKHIP_EINVAL; }

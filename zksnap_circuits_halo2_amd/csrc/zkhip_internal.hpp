@@ -31,9 +31,10 @@ void release_prepared(prepared_bases* pb);
 int sum_jacobian_device(const uint32_t* d_in, int m, uint32_t* d_out, hipStream_t stream);
 
 // ntt.hip
-int ntt_fr_device(uint32_t* d_a, const uint32_t omega_ext[8], uint32_t log_n, hipStream_t stream);
-int ntt_fr_device_ex(uint32_t* d_a, const uint32_t omega_ext[8], uint32_t log_n, const uint32_t* scale_ext,
-                     hipStream_t stream);
+int ntt_passes(uint32_t L);
+int ntt_transform(const uint32_t* d_in, uint32_t in_len, uint32_t in_stride, uint32_t* d_out, uint32_t out_len, uint32_t out_stride,
+                  uint32_t batch, uint32_t L, const uint32_t omega_ext[8], const uint32_t* in_scale, uint32_t in_period,
+                  const uint32_t* out_scale, uint32_t out_period, uint32_t* tmp0, uint32_t* tmp1, hipStream_t stream);
 int fr_mul_periodic_device(uint32_t* d_a, size_t n, const uint32_t* d_table_ext, uint32_t period, hipStream_t stream);
 int fr_scale_device(uint32_t* d_a, size_t n, const uint32_t scale_ext[8], hipStream_t stream);
 void ntt_clear_cache();
