@@ -90,6 +90,11 @@ int zkhip_prepare_bases_device(const void *d_bases, size_t n, uint64_t *handle);
 int zkhip_prepare_bases_device_c(const void *d_bases, size_t n, int window_bits, uint64_t *handle);
 int zkhip_release_bases(uint64_t handle);
 int zkhip_msm_g1_prepared_device(uint64_t handle, size_t offset, const void *d_scalars, size_t n, void *d_out_xyz, void *stream);
+/* `batch` scalar vectors (vector k at d_scalars + k * scalar_stride elements) against the same prepared bases in one launch
+ * set -- e.g. all advice columns of a circuit: small MSMs (k = 13..17) then run at large-MSM throughput.  d_out_xyz: batch
+ * Jacobian results, 96 bytes each. */
+int zkhip_msm_g1_prepared_batch_device(uint64_t handle, size_t offset, const void *d_scalars, size_t n, size_t batch, size_t scalar_stride,
+                                       void *d_out_xyz, void *stream);
 /* window-size override for experiments (0 = automatic) */
 int zkhip_msm_g1_device_c(const void *d_scalars, const void *d_bases, size_t n, void *d_out_xyz, int window_bits, void *stream);
 int zkhip_ntt_fr_device(void *d_a, const uint64_t omega[4], uint32_t log_n, void *stream);

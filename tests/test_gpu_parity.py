@@ -208,6 +208,42 @@ def test_msm_prepared_every_window_including_wide(lib, cref, c):
     assert lib.zkhip_prepare_bases_device_c(dbs.data_ptr(), n, 21, C.byref(h)) == -1
 
 
+@pytest.mark.parametrize("n,batch,pad", [(1, 3, 0), (100, 5, 7), (4096, 9, 0), (8192, 40, 16), (70001, 3, 1)])
+def test_msm_prepared_batch_vs_reference_algorithm(lib, cref, n, batch, pad):
+    """K scalar vectors against one prepared SRS in one launch set; every result against the reference algorithm."""
+    import ctypes as C
+
+    import torch
+
+    bases, t0, d = cref.gen_bases(1500 + n, n)
+    if n > 50:
+        bases[7] = 0
+    dbs = torch.from_numpy(bases.view(np.int64)).cuda()
+    h = C.c_uint64(0)
+    _lib.check(lib.zkhip_prepare_bases_device(dbs.data_ptr(), n, C.byref(h)))
+    try:
+        stride = n + pad
+        host = np.zeros((batch * stride, 4), dtype=np.uint64)
+        vecs = []
+        for k in range(batch):
+            sc = cref.gen_scalars(1600 + 17 * n + k, n, k % 2)
+            if k == 1:
+                sc[:] = 0                                   # an all-zero column
+            if k == 2 and n > 1:
+                sc[:] = F.fr_encode([1])[0]                 # an all-ones column (one heavy bucket)
+            vecs.append(sc)
+            host[k * stride:k * stride + n] = sc
+        dsc = torch.from_numpy(host.view(np.int64)).cuda()
+        dout = torch.zeros(batch * 12, dtype=torch.int64, device="cuda")
+        _lib.check(lib.zkhip_msm_g1_prepared_batch_device(h, 0, dsc.data_ptr(), n, batch, stride, dout.data_ptr(), None))
+        torch.cuda.synchronize()
+        got = dout.cpu().numpy().view(np.uint64).reshape(batch, 12)
+        for k in range(batch):
+            assert np.array_equal(aff(cref, got[k]), aff(cref, cref.best_multiexp(vecs[k], bases, 8))), k
+    finally:
+        _lib.check(lib.zkhip_release_bases(h))
+
+
 def test_gen_walk_matches_oracle(lib, cref):
     import torch
 

@@ -35,6 +35,7 @@ _SIGS = {
     "zkhip_prepare_bases_device_c": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint64)]),
     "zkhip_release_bases": (C.c_int, [C.c_uint64]),
     "zkhip_msm_g1_prepared_device": (C.c_int, [C.c_uint64, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "zkhip_msm_g1_prepared_batch_device": (C.c_int, [C.c_uint64, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]),
     "zkhip_msm_g1_device_c": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),
     "zkhip_ntt_fr_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "zkhip_ntt_fr_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_size_t, C.c_void_p]),

@@ -262,6 +262,29 @@ int zkhip_unregister_bases(const uint64_t* bases) {
   return ZKHIP_OK;
 }
 
+int zkhip_msm_g1_prepared_batch_device(uint64_t handle, size_t offset, const void* d_scalars, size_t n, size_t batch, size_t scalar_stride,
+                                       void* d_out_xyz, void* stream) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  auto it = g_ctx.handles.find(handle);
+  if (it == g_ctx.handles.end()) { set_error("msm_prepared_batch: unknown handle"); return ZKHIP_EINVAL; }
+  if (!d_out_xyz || (n && batch && !d_scalars) || (batch > 1 && scalar_stride < n)) { set_error("msm_prepared_batch: bad argument"); return ZKHIP_EINVAL; }
+  const prepared_bases* pb = it->second;
+  hipStream_t s = stream ? (hipStream_t)stream : g_ctx.stream;
+  // tables built for wide windows (n >= 2^21) do not batch: those MSMs are throughput-bound one at a time
+  size_t group = (pb->c > 16 || batch <= 1) ? 1 : batch;
+  while (group > 1 && ((size_t)((256 + pb->c - 1) / pb->c) * n * group >= (1ull << 31) || (group << (pb->c - 1)) > (1ull << 22))) group = (group + 1) / 2;   // <= 4 Mi buckets per launch set
+  for (size_t k0 = 0; k0 < batch; k0 += group) {
+    const size_t kk = batch - k0 < group ? batch - k0 : group;
+    if ((rc = g_ctx.ws.reserve(n ? msm_workspace_bytes(n, pb->c, true, kk) : 0)) != ZKHIP_OK) return rc;
+    rc = msm_g1_device((const uint32_t*)d_scalars + k0 * scalar_stride * 8, nullptr, n, (uint32_t*)d_out_xyz + k0 * 24, g_ctx.ws.p, g_ctx.ws.cap, 0, s, pb,
+                       offset, kk, scalar_stride);
+    if (rc != ZKHIP_OK) return rc;
+  }
+  return ZKHIP_OK;
+}
+
 int zkhip_g1_sum_device(const void* d_points_xyz, int m, void* d_out_xyz, void* stream) {
   guard_t g(g_mu);
   int rc = ensure_init();

@@ -95,15 +95,19 @@ __device__ __forceinline__ void store_fe9_generic(uint32_t* p, size_t idx, const
 // ------------------------------------------------------------------------------------------------
 template <typename DIGIT>   // int16_t for c <= 16, int32_t for the wide windows of the prepared path
 __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, DIGIT* __restrict__ digits,
-                                                uint32_t n, uint32_t n_pad, int c, int W) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_pad) return;
+                                                uint32_t n, uint32_t n_pad, int c, int W, uint32_t K, size_t scalar_stride) {
+  // batch: K scalar vectors (vector k at scalars + k * scalar_stride elements); digits are laid out [W][K][n_pad]
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)K * n_pad) return;
+  const uint32_t kb = (uint32_t)(idx / n_pad), i = (uint32_t)(idx % n_pad);
+  digits += (size_t)kb * n_pad;
+  const size_t row = (size_t)K * n_pad;
   if (i >= n) {                                   // padding entries: digit 0 = "no entry"
-    for (int win = 0; win < W; win++) digits[(size_t)win * n_pad + i] = 0;
+    for (int win = 0; win < W; win++) digits[(size_t)win * row + i] = 0;
     return;
   }
   uint32_t w[8];
-  load_words(scalars + (size_t)i * 8, w);
+  load_words(scalars + ((size_t)kb * scalar_stride + i) * 8, w);
   // Montgomery-256 -> plain integer: mont261(a*2^256, 2^5) = a
   fe c32;
 #pragma unroll
@@ -124,7 +128,7 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ sca
     v += carry;
     int32_t d;
     if (v >= half) { d = (int32_t)v - (int32_t)(1u << c); carry = 1; } else { d = (int32_t)v; carry = 0; }
-    digits[(size_t)win * n_pad + i] = (DIGIT)d;
+    digits[(size_t)win * row + i] = (DIGIT)d;
   }
 }
 
@@ -142,11 +146,12 @@ __global__ void __launch_bounds__(1024) k_sort_pass(const int16_t* __restrict__ 
   extern __shared__ uint32_t hist[];
   const uint32_t B = 1u << (c - 1);
   const int win = blockIdx.y;
+  const uint32_t kb = blockIdx.z, K = gridDim.z;          // batch: MSM kb of K (own bucket set, same bases)
   const uint32_t lo = blockIdx.x * chunk;                 // multiple of 8
   const uint32_t hi = min(n_pad, lo + chunk);             // multiple of 8
   for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) hist[b] = 0;
   __syncthreads();
-  const uint4* dv = reinterpret_cast<const uint4*>(digits + (size_t)win * n_pad);
+  const uint4* dv = reinterpret_cast<const uint4*>(digits + ((size_t)win * K + kb) * n_pad);
   const uint32_t v_lo = lo >> 3, v_hi = hi >> 3;
   for (uint32_t vi = v_lo + threadIdx.x; vi < v_hi; vi += blockDim.x) {
     const uint4 q = dv[vi];
@@ -158,7 +163,8 @@ __global__ void __launch_bounds__(1024) k_sort_pass(const int16_t* __restrict__ 
     }
   }
   __syncthreads();
-  uint32_t* g = count_or_cursor + (size_t)win * win_bucket_stride;   // general: own bucket set per window; prepared: shared
+  // bucket set: general path (K = 1): one per window; prepared path: one per MSM of the batch, shared by its windows
+  uint32_t* g = count_or_cursor + (size_t)win * win_bucket_stride + (size_t)kb * B;
   if (!SCATTER) {
     for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) {
       uint32_t v = hist[b];
@@ -625,6 +631,12 @@ __global__ void __launch_bounds__(64) k_fold(const uint32_t* __restrict__ winsum
   store_jacobian(acc, out);
 }
 
+// batched prepared MSM: every bucket set's weighted sum is a final result
+__global__ void __launch_bounds__(64) k_store_results(const uint32_t* __restrict__ winsum, uint32_t K, uint32_t* __restrict__ out) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < K) store_jacobian(load_xyzz(winsum, k), out + (size_t)k * 24);
+}
+
 // sum of `m` Jacobian points (multi-GPU partial fold): out = sum in[i].  One wave: lane l sums points l, l + 64, ...,
 // then a 6-step shuffle tree (8 GPUs: depth 3 additions instead of 8 sequential ones).
 __global__ void __launch_bounds__(64) k_sum_jacobian(const uint32_t* __restrict__ in, int m, uint32_t* __restrict__ out) {
@@ -672,8 +684,9 @@ int msm_pick_window_prepared(size_t n) {
   return best;
 }
 
-size_t msm_workspace_bytes(size_t n, int c, bool prepared) {
-  const size_t W = (256 + c - 1) / c, B = (size_t)1 << (c - 1), WB = prepared ? 1 : W, NB = WB * B;
+size_t msm_workspace_bytes(size_t n_one, int c, bool prepared, size_t batch) {
+  const size_t n = n_one * batch + 8 * batch;   // entries scale with the batch (rows padded per MSM)
+  const size_t W = (256 + c - 1) / c, B = (size_t)1 << (c - 1), WB = prepared ? batch : W, NB = WB * B;
   // 64-entry tasks when the chip is full, else as short as 4 entries (see the task-length choice in msm_g1_device)
   const size_t max_tasks = ((W * n) >> TASK_SHIFT) >= ((size_t)1 << 17) ? ((W * n) >> TASK_SHIFT) + NB + 1 : W * n / 4 + NB + 1;
   size_t total = 0;
@@ -686,7 +699,7 @@ size_t msm_workspace_bytes(size_t n, int c, bool prepared) {
   total += align_up(max_tasks * sizeof(uint32_t), 256);     // execution order
   total += align_up(max_tasks * 144, 256);                  // partials
   total += 2 * align_up((size_t)WB * B * 144, 256);         // pyramid ping-pong (state never exceeds B elements per bucket set)
-  total += align_up(W * 144, 256);                          // window sums
+  total += align_up((W + batch) * 144, 256);                // window / bucket-set sums
   total += 4096;                                            // counters + result
   return total;
 }
@@ -695,35 +708,42 @@ size_t msm_workspace_bytes(size_t n, int c, bool prepared) {
 
 // d_scalars: n x 8 words, d_bases: n x 16 words, d_out: 24 words (device).  ws: workspace of msm_workspace_bytes.
 // prepared != nullptr: d_bases is ignored, points come from the table (window w of point i at table[w * stride + off + i]).
+// batch > 1 (prepared path, c <= 16 only): `batch` scalar vectors of n elements, vector k at d_scalars + k * scalar_stride
+// elements, all against the same bases; d_out receives `batch` results (24 words each).
 int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, uint32_t* d_out, void* ws, size_t ws_bytes,
-                  int c_override, hipStream_t stream, const prepared_bases* prepared, size_t prepared_off) {
+                  int c_override, hipStream_t stream, const prepared_bases* prepared, size_t prepared_off, size_t batch,
+                  size_t scalar_stride) {
+  if (batch == 0) return ZKHIP_OK;
   if (n == 0) {
-    hipLaunchKernelGGL(k_sum_jacobian, dim3(1), dim3(64), 0, stream, (const uint32_t*)nullptr, 0, d_out);
+    for (size_t k = 0; k < batch; k++) hipLaunchKernelGGL(k_sum_jacobian, dim3(1), dim3(64), 0, stream, (const uint32_t*)nullptr, 0, d_out + k * 24);
     HIPCHK(hipGetLastError());
     return ZKHIP_OK;
   }
+  if (batch > 1 && (!prepared || prepared->c > 16 || batch > 65535)) { set_error("msm: batch needs prepared bases with a window <= 16 bits"); return ZKHIP_EINVAL; }
+  const uint32_t K = (uint32_t)batch;
   if (n >= (1ull << 31)) { set_error("msm: n = %zu too large", n); return ZKHIP_EINVAL; }
   const int c = prepared ? prepared->c : (c_override > 0 ? c_override : msm_pick_window(n));
   const bool wide = c > 16;                         // two-level bucket sort, int32 digits: prepared path only
   if (c < 2 || c > (prepared ? MAX_WINDOW_PREPARED : 16)) { set_error("msm: window bits %d out of range", c); return ZKHIP_EINVAL; }
   const int W = (256 + c - 1) / c;
   const uint32_t B = 1u << (c - 1);
-  const int WB = prepared ? 1 : W;                 // number of bucket sets
+  const int WB = prepared ? (int)K : W;            // number of bucket sets
   const uint32_t NB = (uint32_t)WB * B;
   if (prepared) {
     if (prepared_off + n > prepared->n) { set_error("msm: range exceeds the prepared bases"); return ZKHIP_EINVAL; }
     if ((size_t)W * prepared->n >= (1ull << 31)) { set_error("msm: prepared table too large for 31-bit point references"); return ZKHIP_EINVAL; }
     d_bases = prepared->table;
   }
-  if ((size_t)W * n >= (1ull << 32)) { set_error("msm: W*n overflows 32-bit slot index"); return ZKHIP_EINVAL; }
-  if (ws_bytes < msm_workspace_bytes(n, c, prepared != nullptr)) { set_error("msm: workspace too small"); return ZKHIP_EINVAL; }
-  const size_t max_tasks = (((size_t)W * n) >> TASK_SHIFT) >= ((size_t)1 << 17) ? (((size_t)W * n) >> TASK_SHIFT) + NB + 1 : (size_t)W * n / 4 + NB + 1;
+  if ((size_t)W * n * K >= (1ull << 32) || (size_t)WB * B >= (1ull << 31)) { set_error("msm: W*n*batch overflows 32-bit slot index"); return ZKHIP_EINVAL; }
+  if (ws_bytes < msm_workspace_bytes(n, c, prepared != nullptr, K)) { set_error("msm: workspace too small"); return ZKHIP_EINVAL; }
+  const size_t nk = n * K;                          // scalars in the whole batch
+  const size_t max_tasks = (((size_t)W * nk) >> TASK_SHIFT) >= ((size_t)1 << 17) ? (((size_t)W * nk) >> TASK_SHIFT) + NB + 1 : (size_t)W * nk / 4 + NB + 1;
   // Task length.  With >= 2^17 tasks of 64 entries the chip is full and 64 is best (throughput-bound, see TASK_SHIFT).  Below
   // that the MSM is latency-bound: a task of L entries is L sequential mixed adds (~5 us each at low occupancy) and a bucket
   // of s entries leaves s/L partials to sum (~10 us each): pick L = 2^shift minimising 5 L + 10 (s/L - 1).
   uint32_t task_shift = TASK_SHIFT;
-  if ((((size_t)W * n) >> TASK_SHIFT) < ((size_t)1 << 17)) {
-    const double occ = (double)W * (double)n / (double)NB;
+  if ((((size_t)W * nk) >> TASK_SHIFT) < ((size_t)1 << 17)) {
+    const double occ = (double)W * (double)nk / (double)NB;
     double best = 1e300;
     for (uint32_t sh = 2; sh <= (uint32_t)TASK_SHIFT; sh++) {
       const double L = (double)(1u << sh), parts = occ / L;
@@ -735,11 +755,11 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   char* p = (char*)ws;
   auto carve = [&](size_t bytes) { void* r = p; p += align_up(bytes, 256); return r; };
   const uint32_t n_pad = (uint32_t)((n + 7) & ~(size_t)7);
-  void* digits = carve((size_t)W * n_pad * (wide ? sizeof(int32_t) : sizeof(int16_t)));
+  void* digits = carve((size_t)W * K * n_pad * (wide ? sizeof(int32_t) : sizeof(int16_t)));
   uint32_t* stage_ref = wide ? (uint32_t*)carve((size_t)W * n * sizeof(uint32_t)) : nullptr;
   uint16_t* stage_fine = wide ? (uint16_t*)carve((size_t)W * n * sizeof(uint16_t)) : nullptr;
   uint32_t* gcounters = wide ? (uint32_t*)carve(1024) : nullptr;   // [0..32) group counts, [32..65) group offsets, [96..128) group cursors
-  uint32_t* sorted = (uint32_t*)carve((size_t)W * n * sizeof(uint32_t));
+  uint32_t* sorted = (uint32_t*)carve((size_t)W * nk * sizeof(uint32_t));
   uint32_t* count = (uint32_t*)carve((NB + 1) * sizeof(uint32_t));
   uint32_t* offset = (uint32_t*)carve((NB + 1) * sizeof(uint32_t));
   uint32_t* cursor = (uint32_t*)carve((NB + 1) * sizeof(uint32_t));
@@ -752,20 +772,22 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   const size_t pyr_elems = B;   // per window: N + (s-1) N/2 <= B at every step
   uint32_t* pyrA = (uint32_t*)carve((size_t)WB * pyr_elems * 144);
   uint32_t* pyrB = (uint32_t*)carve((size_t)WB * pyr_elems * 144);
-  uint32_t* winsum = (uint32_t*)carve((size_t)W * 144);
+  uint32_t* winsum = (uint32_t*)carve((size_t)(W + K) * 144);
   uint32_t* counters = (uint32_t*)carve(1024);   // [0] total entries, [1] total tasks, [2] max task partials of one bucket,
                                                  // [64..129) task-length histogram, [160..225) its cursors
 
   prof_begin(stream);
   // 1. digits
-  if (wide) hipLaunchKernelGGL(k_digits<int32_t>, dim3((n_pad + 255) / 256), dim3(256), 0, stream, d_scalars, (int32_t*)digits, (uint32_t)n, n_pad, c, W);
-  else hipLaunchKernelGGL(k_digits<int16_t>, dim3((n_pad + 255) / 256), dim3(256), 0, stream, d_scalars, (int16_t*)digits, (uint32_t)n, n_pad, c, W);
+  const size_t sstride = K > 1 ? scalar_stride : n;
+  const unsigned dblocks = (unsigned)(((size_t)K * n_pad + 255) / 256);
+  if (wide) hipLaunchKernelGGL(k_digits<int32_t>, dim3(dblocks), dim3(256), 0, stream, d_scalars, (int32_t*)digits, (uint32_t)n, n_pad, c, W, K, sstride);
+  else hipLaunchKernelGGL(k_digits<int16_t>, dim3(dblocks), dim3(256), 0, stream, d_scalars, (int16_t*)digits, (uint32_t)n, n_pad, c, W, K, sstride);
   prof_mark(stream, "digits");
   // 2. count
   HIPCHK(hipMemsetAsync(count, 0, (NB + 1) * sizeof(uint32_t), stream));
   HIPCHK(hipMemsetAsync(counters, 0, 1024, stream));
   uint32_t chunks = (uint32_t)((n + 65535) / 65536);
-  while (chunks * (uint32_t)W < 256 && chunks < (n + 4095) / 4096) chunks *= 2;   // fill the chip
+  while (chunks * (uint32_t)W * K < 256 && chunks < (n + 4095) / 4096) chunks *= 2;   // fill the chip
   if (chunks == 0) chunks = 1;
   const uint32_t chunk = (uint32_t)((((n + chunks - 1) / chunks) + 7) & ~(size_t)7);   // multiple of 8 (vector loads)
   const size_t lds = wide ? ((size_t)4 << FINE_BITS) : (size_t)B * sizeof(uint32_t);
@@ -791,7 +813,7 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
     prof_mark(stream, "coarse");
     hipLaunchKernelGGL(k_fine_pass<false>, dim3(fine_chunks, G), dim3(1024), lds, stream, stage_fine, stage_ref, gcounters + 32, count, (uint32_t*)nullptr);
   } else {
-    hipLaunchKernelGGL(k_sort_pass<false>, dim3(chunks, W), dim3(1024), lds, stream, (const int16_t*)digits, n_pad, chunk, c, count, (uint32_t*)nullptr, wb_stride, ref_base, ref_stride);
+    hipLaunchKernelGGL(k_sort_pass<false>, dim3(chunks, W, K), dim3(1024), lds, stream, (const int16_t*)digits, n_pad, chunk, c, count, (uint32_t*)nullptr, wb_stride, ref_base, ref_stride);
   }
   prof_mark(stream, "count");
   // 3. scan counts -> offset (+ cursor copy)
@@ -802,7 +824,7 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   prof_mark(stream, "scan");
   // 4. scatter
   if (wide) hipLaunchKernelGGL(k_fine_pass<true>, dim3(fine_chunks, G), dim3(1024), lds, stream, stage_fine, stage_ref, gcounters + 32, cursor, sorted);
-  else hipLaunchKernelGGL(k_sort_pass<true>, dim3(chunks, W), dim3(1024), lds, stream, (const int16_t*)digits, n_pad, chunk, c, cursor, sorted, wb_stride, ref_base, ref_stride);
+  else hipLaunchKernelGGL(k_sort_pass<true>, dim3(chunks, W, K), dim3(1024), lds, stream, (const int16_t*)digits, n_pad, chunk, c, cursor, sorted, wb_stride, ref_base, ref_stride);
   prof_mark(stream, "scatter");
   // 5. tasks
   hipLaunchKernelGGL(k_scan_sums<1>, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, count, NB, bsum2, task_shift);
@@ -822,7 +844,7 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   // 7. combine
   // expected partials per bucket decide how many lanes sum a bucket in the final step; the tree handles any bucket with more
   // than 16 partials per lane, so a skewed bucket (e.g. from a short top window) never becomes a long sequential chain
-  const double parts_avg = (double)W * (double)n / (double)NB / (double)(1u << task_shift);
+  const double parts_avg = (double)W * (double)nk / (double)NB / (double)(1u << task_shift);
   const int combine_lanes = parts_avg <= 2.0 ? 1 : (parts_avg <= 4.0 ? 2 : (parts_avg <= 12.0 ? 4 : 8));
   const uint32_t seq_parts = 16u * (uint32_t)combine_lanes;
   {
@@ -866,7 +888,8 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   }
   hipLaunchKernelGGL(k_window_horner, dim3((WB * 32 + 63) / 64), dim3(64), 0, stream, cur, in_stride, nz, winsum, WB);
   prof_mark(stream, "horner");
-  hipLaunchKernelGGL(k_fold, dim3(1), dim3(64), 0, stream, winsum, WB, c, d_out);   // prepared: WB == 1, just the format conversion
+  if (prepared) hipLaunchKernelGGL(k_store_results, dim3((K + 63) / 64), dim3(64), 0, stream, winsum, K, d_out);   // one result per bucket set
+  else hipLaunchKernelGGL(k_fold, dim3(1), dim3(64), 0, stream, winsum, WB, c, d_out);
   prof_mark(stream, "fold");
   HIPCHK(hipGetLastError());
   return ZKHIP_OK;

@@ -17,7 +17,7 @@ void prof_mark(hipStream_t stream, const char* name);
 int g1_gen_walk_device(const uint32_t t0_ext[8], const uint32_t d_ext[8], size_t n, uint32_t* d_out, void* ws, size_t ws_bytes, hipStream_t stream);
 size_t g1_gen_walk_workspace(size_t n);
 int msm_pick_window(size_t n);
-size_t msm_workspace_bytes(size_t n, int c, bool prepared = false);
+size_t msm_workspace_bytes(size_t n, int c, bool prepared = false, size_t batch = 1);
 struct prepared_bases {   // table[w * n + i] = 2^(c w) * P_i, affine external format
   uint32_t* table;
   size_t n;
@@ -25,7 +25,8 @@ struct prepared_bases {   // table[w * n + i] = 2^(c w) * P_i, affine external f
 };
 int msm_pick_window_prepared(size_t n);
 int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, uint32_t* d_out, void* ws, size_t ws_bytes,
-                  int c_override, hipStream_t stream, const prepared_bases* prepared = nullptr, size_t prepared_off = 0);
+                  int c_override, hipStream_t stream, const prepared_bases* prepared = nullptr, size_t prepared_off = 0, size_t batch = 1,
+                  size_t scalar_stride = 0);
 int prepare_bases_device(const uint32_t* d_bases, size_t n, hipStream_t stream, prepared_bases** out, int c_override = 0);
 void release_prepared(prepared_bases* pb);
 int sum_jacobian_device(const uint32_t* d_in, int m, uint32_t* d_out, hipStream_t stream);
