@@ -249,10 +249,62 @@ def extras(lib, _lib, F, torch, dev, stream) -> dict:
     ms = timed(replay, 2)
     lib.zkhip_release_bases(h22)
     out["msm_2^22"] = {"ms": round(ms_msm22, 3), "Mpoints_per_s": round(n / ms_msm22 / 1e3, 1)}
+    del g, ext, sc
+    bufs.clear()
+    torch.cuda.empty_cache()
+    out["small_circuit_replays"] = small_replays(lib, _lib, F, torch, dev, stream, timed)
     out["wrapper_replay"] = {"workload": "k=22: 18 MSM 2^22 + 13 iNTT 2^22 + 13 NTT 2^24 + 1 iNTT 2^24, device-resident",
                              "ms": round(ms, 2), "proofs_per_s_msm_ntt_portion": round(1e3 / ms, 3),
                              "note": "MSM+NTT portion only; the Rust host (witness, evaluate_h, transcript) cannot run here"}
     return out
+
+
+def small_replays(lib, _lib, F, torch, dev, stream, timed) -> dict:
+    """MSM+NTT call mix of the small circuits (BASELINE configs[0] / [2]; column counts from SURVEY.md 8d: voter k=13 with
+    the documented proxy A=256, L=8; state-transition k=15 with A=4, L=1, P=3), on the batched entry points: all the
+    columns of one phase go through one launch set.  Per proof: MSMs of n = A + 2L + P + L + 1 + 3 + ~2,
+    iNTT n the same count, extended NTTs A + 1 + 3L + P, one extended iNTT."""
+    from zksnap_circuits_halo2_amd.fields import R_MOD, omega_for
+
+    res = {}
+    for name, k, A, L, P in (("voter_k13", 13, 256, 8, 64), ("state_transition_k15", 15, 4, 1, 3)):
+        n, ek = 1 << k, k + 2
+        n_msm = A + 2 * L + P + L + 1 + 3 + 2
+        n_ext = A + 1 + 3 * L + P
+        t0, dd = F.fr_encode([4242 + k])[0], F.fr_encode([0x9E3779B97F4A7C15])[0]
+        g = torch.empty(n * 8, dtype=torch.int64, device=dev)
+        _lib.check(lib.zkhip_g1_gen_walk_device(t0.ctypes.data, dd.ctypes.data, n, g.data_ptr(), stream))
+        h = C.c_uint64(0)
+        _lib.check(lib.zkhip_prepare_bases_device(g.data_ptr(), n, C.byref(h)))
+        cols = torch.from_numpy(synth_scalars(n_msm * n, 77 + k).view(np.int64)).to(dev)
+        extc = torch.from_numpy(synth_scalars(n_ext << ek, 78 + k).view(np.int64)).to(dev)
+        outs = torch.zeros(n_msm * 12, dtype=torch.int64, device=dev)
+        om_i = F.fr_encode([pow(omega_for(k), -1, R_MOD)])[0]
+        div = F.fr_encode([pow(n, -1, R_MOD)])[0]
+        om_e = F.fr_encode([omega_for(ek)])[0]
+        om_ei = F.fr_encode([pow(omega_for(ek), -1, R_MOD)])[0]
+        div_e = F.fr_encode([pow(1 << ek, -1, R_MOD)])[0]
+
+        def batched():
+            _lib.check(lib.zkhip_ifft_scaled_batch_device(cols.data_ptr(), om_i.ctypes.data, k, div.ctypes.data, n_msm, n, stream))
+            _lib.check(lib.zkhip_msm_g1_prepared_batch_device(h, 0, cols.data_ptr(), n, n_msm, n, outs.data_ptr(), stream))
+            _lib.check(lib.zkhip_ntt_fr_batch_device(extc.data_ptr(), om_e.ctypes.data, ek, n_ext, 1 << ek, stream))
+            _lib.check(lib.zkhip_ifft_scaled_device(extc.data_ptr(), om_ei.ctypes.data, ek, div_e.ctypes.data, stream))
+
+        def one_by_one():
+            for b in range(n_msm):
+                _lib.check(lib.zkhip_ifft_scaled_device(cols.data_ptr() + b * n * 32, om_i.ctypes.data, k, div.ctypes.data, stream))
+                _lib.check(lib.zkhip_msm_g1_prepared_device(h, 0, cols.data_ptr() + b * n * 32, n, outs.data_ptr() + b * 96, stream))
+            for b in range(n_ext):
+                _lib.check(lib.zkhip_ntt_fr_device(extc.data_ptr() + (b << ek) * 32, om_e.ctypes.data, ek, stream))
+            _lib.check(lib.zkhip_ifft_scaled_device(extc.data_ptr(), om_ei.ctypes.data, ek, div_e.ctypes.data, stream))
+
+        tb, to = timed(batched, 3), timed(one_by_one, 1)
+        res[name] = {"workload": f"k={k}: {n_msm} MSM 2^{k} + {n_msm} iNTT 2^{k} + {n_ext} NTT 2^{ek} + 1 iNTT 2^{ek}, device-resident",
+                     "batched_ms": round(tb, 3), "proofs_per_s_msm_ntt_portion": round(1e3 / tb, 1), "one_call_per_column_ms": round(to, 3)}
+        lib.zkhip_release_bases(h)
+        del g, cols, extc, outs
+    return res
 
 
 def cpu_baseline(log_n, d_scalars, d_bases, d_out, n) -> dict:

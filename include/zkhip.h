@@ -42,6 +42,10 @@ int zkhip_device_name(char *buf, size_t len);
  * (n == 0 gives the identity).  out_xyz: Jacobian, canonical Montgomery limbs, any valid representative. */
 int zkhip_msm_g1(const uint64_t *scalars, const uint64_t *bases, size_t n, uint64_t out_xyz[12]);
 
+/* Multi-column commit: `batch` scalar vectors (contiguous, n elements each) against the same bases, e.g. every advice column of
+ * a circuit; out_xyz: batch Jacobian points.  With registered bases this is one launch set (see the _device variant). */
+int zkhip_msm_g1_batch(const uint64_t *scalars, const uint64_t *bases, size_t n, size_t batch, uint64_t *out_xyz);
+
 /* Residency for `ParamsKZG::{g, g_lagrange}` (static per params object): upload once and build the prepared table
  * (2^(c w) * P_i for every window w: W * 64 bytes per point of HBM, one-time ~25 ms per 2^20 points); zkhip_msm_g1
  * recognises `bases` pointers inside a registered range (any sub-range), skips the upload and runs the prepared
@@ -52,6 +56,9 @@ int zkhip_unregister_bases(const uint64_t *bases);
 /* ---- NTT: replaces `best_fft(a: &mut [Fr], omega: Fr, log_n: u32)` --------------------------------- */
 /* In place, natural order in and out: a[i] <- sum_j a[j] * omega^(i j).  log_n <= 28. */
 int zkhip_ntt_fr(uint64_t *a, const uint64_t omega[4], uint32_t log_n);
+
+/* `batch` contiguous polynomials, each transformed in place, one launch set */
+int zkhip_ntt_fr_batch(uint64_t *a, const uint64_t omega[4], uint32_t log_n, uint32_t batch);
 
 /* ---- EvaluationDomain pieces ([DEP] halo2_proofs/src/poly/domain.rs), host buffers ----------------- */
 /* `EvaluationDomain::ifft`: best_fft with omega_inv, then every element times `divisor`. */

@@ -247,6 +247,16 @@ class ParamsKZG {
     if (poly.size() > n_) throw std::invalid_argument("commit: polynomial longer than the SRS");
     return best_multiexp(poly.data(), poly.size(), g_.data(), poly.size());
   }
+  // multi-column commit (not in the reference API: its provers commit column by column): K polynomials of equal length,
+  // stored back to back, in one launch set
+  std::vector<G1> commit_many(const std::vector<Fr>& polys, size_t len, bool lagrange = false) const {
+    if (len == 0 || len > n_ || polys.size() % len != 0) throw std::invalid_argument("commit_many: bad shape");
+    const std::vector<G1Affine>& b = lagrange ? g_lagrange_ : g_;
+    if (b.empty()) throw std::invalid_argument("commit_many: no such basis");
+    std::vector<G1> out(polys.size() / len);
+    check(zkhip_msm_g1_batch(polys.data()->l, b.data()->x, len, out.size(), out.data()->x), "commit_many");
+    return out;
+  }
   G1 commit_lagrange(const std::vector<Fr>& poly) const {
     if (g_lagrange_.empty()) throw std::invalid_argument("commit_lagrange: no Lagrange basis");
     if (poly.size() > n_) throw std::invalid_argument("commit_lagrange: polynomial longer than the SRS");

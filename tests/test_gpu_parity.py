@@ -244,6 +244,35 @@ def test_msm_prepared_batch_vs_reference_algorithm(lib, cref, n, batch, pad):
         _lib.check(lib.zkhip_release_bases(h))
 
 
+def test_commit_many_and_host_batch_ntt(lib, cref):
+    """host-buffer batch entry points: ParamsKZG.commit_many (registered SRS) and zkhip_ntt_fr_batch."""
+    k, n, K = 11, 1 << 11, 6
+    bases, t0, d = cref.gen_bases(1700, n)
+    params = Z.ParamsKZG(k, bases)
+    try:
+        polys = np.stack([cref.gen_scalars(1701 + i, n, i % 2) for i in range(K)])
+        got = params.commit_many(polys)
+        for i in range(K):
+            assert np.array_equal(aff(cref, got[i]), structured_expect(cref, polys[i], t0, d)), i
+        short = params.commit_many(np.ascontiguousarray(polys[:, :1000]))      # prefix of the registered SRS
+        for i in range(K):
+            assert np.array_equal(aff(cref, short[i]), aff(cref, cref.best_multiexp(np.ascontiguousarray(polys[i, :1000]), bases[:1000], 4)))
+    finally:
+        params.close()
+    # unregistered bases: falls back to one general-path MSM per vector
+    out = np.zeros((2, 12), dtype=np.uint64)
+    two = np.ascontiguousarray(polys[:2])
+    _lib.check(lib.zkhip_msm_g1_batch(two.ctypes.data, bases.ctypes.data, n, 2, out.ctypes.data))
+    assert np.array_equal(aff(cref, out[1]), structured_expect(cref, polys[1], t0, d))
+    a = np.ascontiguousarray(polys.copy())
+    om = F.fr_encode([O.omega_for(k)])[0]
+    _lib.check(lib.zkhip_ntt_fr_batch(a.ctypes.data, om.ctypes.data, k, K))
+    for i in range(K):
+        ref = polys[i].copy()
+        cref.best_fft(ref, om, k, 4)
+        assert np.array_equal(a[i], ref), i
+
+
 def test_gen_walk_matches_oracle(lib, cref):
     import torch
 

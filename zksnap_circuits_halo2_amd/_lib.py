@@ -15,6 +15,8 @@ _SIGS = {
     "zkhip_last_error": (C.c_char_p, []),
     "zkhip_device_name": (C.c_int, [C.c_char_p, C.c_size_t]),
     "zkhip_msm_g1": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "zkhip_msm_g1_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
+    "zkhip_ntt_fr_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]),
     "zkhip_register_bases": (C.c_int, [C.c_void_p, C.c_size_t]),
     "zkhip_unregister_bases": (C.c_int, [C.c_void_p]),
     "zkhip_ntt_fr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),

@@ -199,6 +199,36 @@ int zkhip_msm_g1(const uint64_t* scalars, const uint64_t* bases, size_t n, uint6
   return ZKHIP_OK;
 }
 
+// `batch` scalar vectors (contiguous, n elements each) against the same bases; out: batch Jacobian points.
+// Registered bases: one batched launch set; otherwise one general-path MSM per vector.
+int zkhip_msm_g1_batch(const uint64_t* scalars, const uint64_t* bases, size_t n, size_t batch, uint64_t* out_xyz) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (!out_xyz || (n && batch && (!scalars || !bases))) { set_error("msm_batch: null pointer"); return ZKHIP_EINVAL; }
+  if (batch == 0) return ZKHIP_OK;
+  size_t off = 0;
+  const prepared_bases* pb = n ? find_registered(bases, n, &off) : nullptr;
+  if (!pb || pb->c > 16) {
+    for (size_t k = 0; k < batch; k++)
+      if ((rc = zkhip_msm_g1(scalars + k * n * 4, bases, n, out_xyz + k * 12)) != ZKHIP_OK) return rc;
+    return ZKHIP_OK;
+  }
+  hipStream_t s = g_ctx.stream;
+  if ((rc = g_ctx.scalars.reserve(n * batch * 32)) != ZKHIP_OK) return rc;
+  if ((rc = g_ctx.small.reserve(4096 + batch * 96)) != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(g_ctx.scalars.p, scalars, n * batch * 32, hipMemcpyHostToDevice, s));
+  // reuse the handle-based entry point through a temporary handle for the registered table
+  const uint64_t tmp_handle = g_ctx.next_handle++;
+  g_ctx.handles[tmp_handle] = const_cast<prepared_bases*>(pb);
+  rc = zkhip_msm_g1_prepared_batch_device(tmp_handle, off, g_ctx.scalars.p, n, batch, n, g_ctx.small.p, s);
+  g_ctx.handles.erase(tmp_handle);
+  if (rc != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(out_xyz, g_ctx.small.p, batch * 96, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return ZKHIP_OK;
+}
+
 int zkhip_register_bases(const uint64_t* bases, size_t n) {
   guard_t g(g_mu);
   int rc = ensure_init();
@@ -390,6 +420,23 @@ static int host_transform(const uint64_t* in, size_t in_len, uint64_t* out, size
                      (const uint32_t*)omega, in_scale, in_period, out_scale, out_period, s);
   if (rc != ZKHIP_OK) return rc;
   HIPCHK(hipMemcpyAsync(out, g_ctx.poly.p, out_len * 32, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return ZKHIP_OK;
+}
+
+// `batch` contiguous polynomials of 2^log_n elements, transformed in place in one launch set
+int zkhip_ntt_fr_batch(uint64_t* a, const uint64_t omega[4], uint32_t log_n, uint32_t batch) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (!a || !omega || log_n > 28) { set_error("ntt_batch: bad argument"); return ZKHIP_EINVAL; }
+  if (batch == 0) return ZKHIP_OK;
+  const size_t N = (size_t)1 << log_n, total = N * batch;
+  hipStream_t s = g_ctx.stream;
+  if ((rc = g_ctx.poly.reserve(total * 32)) != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(g_ctx.poly.p, a, total * 32, hipMemcpyHostToDevice, s));
+  if ((rc = zkhip_ntt_fr_batch_device(g_ctx.poly.p, omega, log_n, batch, N, s)) != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(a, g_ctx.poly.p, total * 32, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   return ZKHIP_OK;
 }

@@ -32,6 +32,16 @@ class ParamsKZG:
         assert poly.shape[0] <= self.n
         return best_multiexp(poly, self.g_lagrange[: poly.shape[0]])
 
+    def commit_many(self, polys: np.ndarray, lagrange: bool = False) -> np.ndarray:
+        """Commit to K polynomials of equal length at once ((K, len, 4) uint64) -> (K, 12) uint64: one launch set."""
+        polys = np.ascontiguousarray(polys, dtype=np.uint64)
+        assert polys.ndim == 3 and polys.shape[2] == 4 and polys.shape[1] <= self.n
+        bases = self.g_lagrange if lagrange else self.g
+        assert bases is not None
+        out = np.zeros((polys.shape[0], 12), dtype=np.uint64)
+        _lib.check(_lib.load().zkhip_msm_g1_batch(polys.ctypes.data, bases.ctypes.data, polys.shape[1], polys.shape[0], out.ctypes.data))
+        return out
+
     def close(self) -> None:
         lib = _lib.load()
         lib.zkhip_unregister_bases(self.g.ctypes.data)
