@@ -71,6 +71,13 @@ def load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc, gfx950).  There is no CPU fallback.")
+    # Load order matters: libtorch_hip.so asks for "libamdhip64.so" (no version), so if libzkhip.so came first and bound
+    # /opt/rocm's libamdhip64.so.7, torch would later load its own bundled copy -> two HIP runtimes in one process, and the
+    # second one finds no GPU.  With torch first, our libamdhip64.so.7 request resolves to the copy torch already loaded.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)  # AttributeError = header/library mismatch
