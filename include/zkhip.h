@@ -88,6 +88,51 @@ int zkhip_fr_kate_division_device(const void *d_a, size_t n, const uint64_t b[4]
 int zkhip_fr_batch_invert_device(void *d_a, size_t n, void *stream);
 int zkhip_fr_prefix_product_device(const void *d_v, size_t n, void *d_out, void *stream);
 
+/* ---- row programs: the quotient numerator and every other pointwise pass ---------- */
+/* [DEP] halo2_proofs/src/plonk/evaluation.rs evaluates h(X)'s numerator row by row over the extended coset with a small
+ * straight-line program per row (`GraphEvaluator`: `Calculation::{Add,Sub,Mul,Square,Double,Negate,Horner,Store}` over
+ * `ValueSource::{Constant,Intermediate,Fixed,Advice,Instance,Challenge,Beta,Gamma,Theta,Y,PreviousValue}` with rotations
+ * `(row + rot * rot_scale) mod rows`), followed by hand-written permutation / lookup terms of the same shape; reached from
+ * create_proof, /root/reference/aggregator/src/wrapper.rs:129.  `zkhip_fr_eval_rows` runs such a program for every row in one
+ * fused pass: each thread owns a row, the program is decoded once per wavefront.  The same entry point expresses the
+ * multiopen linear combinations, `divide_by_vanishing_poly`, and the numerators / denominators of the grand products.
+ *
+ * Operands (zkhip_vm_operand):
+ *   ZKHIP_SRC_CONST   constants[index]                 (Constant / Challenge / Beta / Gamma / Theta / Y of the reference)
+ *   ZKHIP_SRC_REG     register `index` < ZKHIP_VM_REGS (Intermediate; registers start at 0 for every row)
+ *   ZKHIP_SRC_COLUMN  columns[index][(row + rotations[rot] * rot_scale) mod rows]      (Fixed / Advice / Instance)
+ *   ZKHIP_SRC_PREV    out[row] as it was before the call (PreviousValue); 0 unless `accumulate`
+ *   ZKHIP_SRC_ROWPOW  omega^row  (the reference's running `beta_term *= extended_omega`; needs `omega`)
+ * Instructions: dst = MOV a | a + b | a - b | a * b | -a | 2a | a^2 | a * b + c.   out[row] = register `result_reg`.
+ * rows = 2^log_rows; all field elements are canonical Montgomery Fr words, in and out.  The register count is fixed so that the
+ * register file stays in VGPRs: a host compiling a `GraphEvaluator` reuses registers (linear scan over last uses). */
+#define ZKHIP_VM_REGS 12
+enum { ZKHIP_SRC_CONST = 0, ZKHIP_SRC_REG = 1, ZKHIP_SRC_COLUMN = 2, ZKHIP_SRC_PREV = 3, ZKHIP_SRC_ROWPOW = 4 };
+enum { ZKHIP_OP_MOV = 0, ZKHIP_OP_ADD = 1, ZKHIP_OP_SUB = 2, ZKHIP_OP_MUL = 3, ZKHIP_OP_NEG = 4, ZKHIP_OP_DBL = 5, ZKHIP_OP_SQR = 6,
+       ZKHIP_OP_MAD = 7 };
+typedef struct zkhip_vm_operand { uint8_t kind; uint8_t rot; uint16_t index; } zkhip_vm_operand;
+typedef struct zkhip_vm_insn { uint8_t op; uint8_t dst; uint16_t reserved; zkhip_vm_operand a, b, c; } zkhip_vm_insn;   /* 16 bytes */
+typedef struct zkhip_vm_program {
+  const zkhip_vm_insn *insns; uint32_t n_insns;
+  const uint64_t *constants;  uint32_t n_constants;   /* n_constants x 4 words, host memory */
+  const int32_t *rotations;   uint32_t n_rotations;   /* rotation slots, in rows of the base domain */
+  int32_t rot_scale;                                  /* 1 on the base domain, 2^(extended_k - k) on the extended one */
+  uint32_t result_reg;
+  const uint64_t *omega;                              /* 4 words or NULL when ZKHIP_SRC_ROWPOW is not used */
+} zkhip_vm_program;
+/* columns: n_columns host pointers to 2^log_rows elements each; out: 2^log_rows elements (read first when accumulate != 0) */
+int zkhip_fr_eval_rows(const zkhip_vm_program *prog, const uint64_t *const *columns, uint32_t n_columns, uint32_t log_rows,
+                       int accumulate, uint64_t *out);
+/* same with device-resident columns / output (`d_columns` itself is a host array of device pointers; out may alias a column
+ * only if that column is read at rotation 0 exclusively) */
+int zkhip_fr_eval_rows_device(const zkhip_vm_program *prog, const void *const *d_columns, uint32_t n_columns, uint32_t log_rows,
+                              int accumulate, void *d_out, void *stream);
+/* grand product of the permutation / lookup arguments [DEP plonk/permutation/prover.rs, plonk/lookup/prover.rs]:
+ * z[0] = 1, z[i+1] = z[i] * num[i] / den[i] for i < n - 1  (zero denominators count as zero, like BatchInvert).
+ * num is preserved, den is overwritten (inverted in place), z may alias num. */
+int zkhip_fr_grand_product(const uint64_t *num, const uint64_t *den, size_t n, uint64_t *z);
+int zkhip_fr_grand_product_device(const void *d_num, void *d_den, size_t n, void *d_z, void *stream);
+
 /* ---- device-resident variants (pointers are HIP device pointers; stream is a hipStream_t or NULL) --- */
 /* Used by the pipeline / bench so that polynomials and scalars stay in HBM between calls. */
 int zkhip_msm_g1_device(const void *d_scalars, const void *d_bases, size_t n, void *d_out_xyz, void *stream);

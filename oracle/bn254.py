@@ -405,6 +405,128 @@ def prefix_product(v: Sequence[int]) -> List[int]:
     return out
 
 
+def grand_product(num: Sequence[int], den: Sequence[int]) -> List[int]:
+    """z[0] = 1, z[i+1] = z[i] * num[i] / den[i]  ([DEP] plonk/permutation/prover.rs, plonk/lookup/prover.rs); zero
+    denominators count as zero (BatchInvert)."""
+    inv = batch_invert(den)
+    return prefix_product([a * b % R_MOD for a, b in zip(num, inv)])
+
+
+# ----------------------------------------------------------------------------------------------
+# SURVEY.md section 8(f) row 1: the quotient numerator ([DEP] halo2-axiom plonk/evaluation.rs, reached from
+# /root/reference/aggregator/src/wrapper.rs:129).  Two independent restatements:
+#   * row_program_run  -- interpreter of the row-program ABI (include/zkhip.h), row by row, big ints;
+#   * evaluate_h_direct -- the constraint formulas of `Evaluator::evaluate_h` written out directly (custom gates,
+#     permutation argument, lookup argument, Horner in y), without going through a program.
+# ----------------------------------------------------------------------------------------------
+FR_DELTA = pow(FR_GENERATOR, 1 << FR_S, R_MOD)      # `Fr::DELTA` [DEP ff::PrimeField]: generator of the t-order subgroup
+
+
+def row_program_run(insns, constants, rotations, rot_scale, result_reg, columns, log_rows, omega=None, prev=None, n_regs=12,
+                    only_rows=None):
+    """insns: (op, dst, a, b, c) with operands (kind, index, rot_slot); kinds 0 const, 1 reg, 2 column, 3 prev, 4 omega^row;
+    ops 0 mov, 1 add, 2 sub, 3 mul, 4 neg, 5 dbl, 6 sqr, 7 mad (a*b + c)."""
+    rows = 1 << log_rows
+    out = []
+    for row in (range(rows) if only_rows is None else only_rows):
+        regs = [0] * n_regs
+        xp = pow(omega, row, R_MOD) if omega is not None else None
+
+        def val(o):
+            kind, index, rot = o
+            if kind == 0: return constants[index]
+            if kind == 1: return regs[index]
+            if kind == 2: return columns[index][(row + rotations[rot] * rot_scale) % rows]
+            if kind == 3: return prev[row] if prev is not None else 0
+            if kind == 4: return xp
+            raise ValueError(kind)
+
+        for op, dst, a, b, c in insns:
+            if op == 0: v = val(a)
+            elif op == 1: v = val(a) + val(b)
+            elif op == 2: v = val(a) - val(b)
+            elif op == 3: v = val(a) * val(b)
+            elif op == 4: v = -val(a)
+            elif op == 5: v = 2 * val(a)
+            elif op == 6: v = val(a) ** 2
+            elif op == 7: v = val(a) * val(b) + val(c)
+            else: raise ValueError(op)
+            regs[dst] = v % R_MOD
+        out.append(regs[result_reg])
+    return out
+
+
+def eval_expression(e, fixed, advice, instance, challenges, row, rows, rot_scale):
+    """`plonk::Expression::evaluate` at one row of the extended coset; e has fields kind / a / b."""
+    rec = lambda x: eval_expression(x, fixed, advice, instance, challenges, row, rows, rot_scale)
+    k = e.kind
+    if k == "constant": return e.a % R_MOD
+    if k == "fixed": return fixed[e.a][(row + e.b * rot_scale) % rows]
+    if k == "advice": return advice[e.a][(row + e.b * rot_scale) % rows]
+    if k == "instance": return instance[e.a][(row + e.b * rot_scale) % rows]
+    if k == "challenge": return challenges[e.a]
+    if k == "neg": return -rec(e.a) % R_MOD
+    if k == "sum": return (rec(e.a) + rec(e.b)) % R_MOD
+    if k == "product": return rec(e.a) * rec(e.b) % R_MOD
+    if k == "scaled": return rec(e.a) * e.b % R_MOD
+    raise ValueError(k)
+
+
+def evaluate_h_direct(cs, k, extended_k, fixed, advice, instance, l0, l_last, l_active, sigma, perm_products, lookups,
+                      beta, gamma, theta, y, challenges=(), zeta=FR_ZETA):
+    """`values` of evaluate_h before divide_by_vanishing_poly.  All column arguments are lists of ints over the extended coset;
+    lookups: per lookup (product, permuted_input, permuted_table)."""
+    rows = 1 << extended_k
+    rot_scale = 1 << (extended_k - k)
+    omega_ext = omega_for(extended_k)
+    last_rotation = -(cs.blinding_factors + 1)
+    chunk_len = cs.degree - 2
+    pick = {"fixed": fixed, "advice": advice, "instance": instance}
+    out = []
+    for idx in range(rows):
+        r_next = (idx + rot_scale) % rows
+        r_prev = (idx - rot_scale) % rows
+        r_last = (idx + last_rotation * rot_scale) % rows
+        value = 0
+        for polys in cs.gates:
+            for poly in polys:
+                value = (value * y + eval_expression(poly, fixed, advice, instance, challenges, idx, rows, rot_scale)) % R_MOD
+        if cs.permutation_columns:
+            sets = perm_products
+            first, last = sets[0], sets[-1]
+            value = (value * y + (1 - first[idx]) * l0[idx]) % R_MOD
+            value = (value * y + (last[idx] * last[idx] - last[idx]) * l_last[idx]) % R_MOD
+            for si in range(1, len(sets)):
+                value = (value * y + (sets[si][idx] - sets[si - 1][r_last]) * l0[idx]) % R_MOD
+            current_delta = beta * zeta % R_MOD * pow(omega_ext, idx, R_MOD) % R_MOD
+            for si, zs in enumerate(sets):
+                chunk = cs.permutation_columns[si * chunk_len:(si + 1) * chunk_len]
+                left = zs[r_next]
+                for j, (kind, ci) in enumerate(chunk):
+                    left = left * (pick[kind][ci][idx] + beta * sigma[si * chunk_len + j][idx] + gamma) % R_MOD
+                right = zs[idx]
+                for (kind, ci) in chunk:
+                    right = right * (pick[kind][ci][idx] + current_delta + gamma) % R_MOD
+                    current_delta = current_delta * FR_DELTA % R_MOD
+                value = (value * y + (left - right) * l_active[idx]) % R_MOD
+        for lk, (prod, pin, ptab) in zip(cs.lookups, lookups):
+            cin = 0
+            for e in lk.input_expressions:
+                cin = (cin * theta + eval_expression(e, fixed, advice, instance, challenges, idx, rows, rot_scale)) % R_MOD
+            ctab = 0
+            for e in lk.table_expressions:
+                ctab = (ctab * theta + eval_expression(e, fixed, advice, instance, challenges, idx, rows, rot_scale)) % R_MOD
+            table_value = (cin + beta) * (ctab + gamma) % R_MOD
+            a_minus_s = (pin[idx] - ptab[idx]) % R_MOD
+            value = (value * y + (1 - prod[idx]) * l0[idx]) % R_MOD
+            value = (value * y + (prod[idx] * prod[idx] - prod[idx]) * l_last[idx]) % R_MOD
+            value = (value * y + (prod[r_next] * (pin[idx] + beta) * (ptab[idx] + gamma) - prod[idx] * table_value) * l_active[idx]) % R_MOD
+            value = (value * y + a_minus_s * l0[idx]) % R_MOD
+            value = (value * y + a_minus_s * (pin[idx] - pin[r_prev]) * l_active[idx]) % R_MOD
+        out.append(value)
+    return out
+
+
 # ----------------------------------------------------------------------------------------------
 # Deterministic input generators shared by tests / bench / C oracle (SURVEY.md section 8d)
 # ----------------------------------------------------------------------------------------------

@@ -1,0 +1,230 @@
+"""GPU (-m gpu): SURVEY.md section 8(f) rows 1-3 -- row programs (`zkhip_fr_eval_rows`: the quotient numerator of
+[DEP] plonk/evaluation.rs, multiopen linear combinations) and the grand products, bit-exact against the oracle's big-int
+restatements (oracle/bn254.py: `row_program_run`, `evaluate_h_direct`, `grand_product`)."""
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+
+from oracle import bn254 as O
+from zksnap_circuits_halo2_amd import _lib, evaluation as E, fields as F
+
+pytestmark = pytest.mark.gpu
+R = O.R_MOD
+
+
+def enc(col):
+    return F.fr_encode(col)
+
+
+def run_host(prog, cols, log_rows, prev=None):
+    out = None
+    if prev is not None:
+        out = enc(prev)
+    res = prog.run([enc(c) for c in cols], log_rows, out=out, accumulate=prev is not None)
+    return F.fr_decode(res)
+
+
+def oracle_run(prog, cols, log_rows, prev=None, only_rows=None):
+    return O.row_program_run(prog.insns, prog.constants, prog.rotations, prog.rot_scale, prog.result_reg, cols, log_rows,
+                             omega=prog.omega, prev=prev, only_rows=only_rows)
+
+
+def random_program(rng, n_cols, n_insns, rot_scale, omega, use_prev):
+    """straight-line program over every opcode / operand kind; registers are read only after they were written"""
+    p = E.RowProgram(rot_scale=rot_scale, omega=omega)
+    written = []
+    edge = [0, 1, R - 1, R - 2, (R - 1) // 2, 2, 1 << 253]
+
+    def operand():
+        kinds = ["const", "col"] + (["reg"] if written else []) + (["prev"] if use_prev else []) + (["rowpow"] if omega else [])
+        k = rng.choice(kinds)
+        if k == "const": return p.constant(rng.choice(edge) if rng.random() < 0.5 else rng.randrange(R))
+        if k == "col": return p.column(rng.randrange(n_cols), rng.choice([0, 0, 1, -1, 2, 3, -3, 7]))
+        if k == "reg": return E.RowProgram.reg(rng.choice(written))
+        if k == "prev": return E.RowProgram.PREV
+        return E.RowProgram.ROWPOW
+
+    for _ in range(n_insns):
+        op = rng.randrange(8)
+        dst = rng.randrange(_lib.VM_REGS)
+        p.emit(op, dst, operand(), operand(), operand())
+        if dst not in written:
+            written.append(dst)
+    p.result_reg = written[-1]
+    return p
+
+
+@pytest.mark.parametrize("log_rows,seed", [(0, 1), (1, 2), (5, 3), (8, 4), (8, 5), (9, 6), (13, 7)])
+def test_row_program_random_vs_interpreter(lib, log_rows, seed):
+    rng = random.Random(seed)
+    rows = 1 << log_rows
+    n_cols = 5
+    cols = [[rng.randrange(R) for _ in range(rows)] for _ in range(n_cols)]
+    # edge values: 0 and r-1 runs stress the conditional subtractions
+    for i in range(min(rows, 16)):
+        cols[0][i] = [0, R - 1, 1, R - 2][i % 4]
+        cols[1][i] = [R - 1, R - 1, 0, 1][i % 4]
+    omega = O.omega_for(log_rows) if log_rows >= 1 and seed % 2 == 0 else (O.omega_for(max(log_rows, 1)) if seed == 7 else None)
+    use_prev = seed % 3 == 0
+    prev = [rng.randrange(R) for _ in range(rows)] if use_prev else None
+    n_insns = 200 if log_rows < 13 else 60
+    prog = random_program(rng, n_cols, n_insns, rot_scale=rng.choice([1, 2, 4]), omega=omega, use_prev=use_prev)
+    only = None if log_rows <= 9 else sorted(rng.sample(range(rows), 200) + [0, 1, rows - 1, 4095, 4096, 4097])
+    got = run_host(prog, cols, log_rows, prev)
+    exp = oracle_run(prog, cols, log_rows, prev, only)
+    if only is None:
+        assert got == exp
+    else:
+        assert [got[i] for i in only] == exp
+
+
+def test_row_program_long_add_sub_chains_at_the_bounds(lib):
+    """chains of add / sub / dbl / neg on 0, 1, r-1: every intermediate must stay a correct residue (values < 2r inside)"""
+    p = E.RowProgram()
+    a, b = p.column(0), p.column(1)
+    p.emit(E.OP_ADD, 0, a, b)
+    for i in range(40):
+        p.emit(E.OP_DBL, 1, E.RowProgram.reg(0))
+        p.emit(E.OP_SUB, 2, E.RowProgram.reg(1), b)
+        p.emit(E.OP_NEG, 3, E.RowProgram.reg(2))
+        p.emit(E.OP_ADD, 0, E.RowProgram.reg(3), E.RowProgram.reg(1))
+        p.emit(E.OP_SUB, 0, E.RowProgram.reg(0), p.constant(R - 1))
+        p.emit(E.OP_MAD, 0, E.RowProgram.reg(0), p.constant(R - 1), E.RowProgram.reg(2))
+    p.result_reg = 0
+    vals = [0, 1, R - 1, R - 2, 2, (R + 1) // 2, (R - 1) // 2, 12345]
+    cols = [[vals[i % 8] for i in range(64)], [vals[(i // 8) % 8] for i in range(64)]]
+    assert run_host(p, cols, 6) == oracle_run(p, cols, 6)
+
+
+def halo2_lib_like_cs(n_gate_cols=3):
+    """a constraint system of the shape halo2-lib's BaseCircuitBuilder configures (the wrapper / state-transition circuits,
+    /root/reference/aggregator/src/wrapper.rs:792-797): per advice column one vertical gate q (a + b c - d) over rotations 0..3,
+    a range-check lookup, a two-expression lookup (exercises theta), a permutation over advice + fixed + instance columns."""
+    A = n_gate_cols
+    gates = [[E.Fixed(i) * (E.Advice(i, 0) + E.Advice(i, 1) * E.Advice(i, 2) - E.Advice(i, 3))] for i in range(A)]
+    lookups = [E.Lookup([E.Advice(A)], [E.Fixed(A)]),
+               E.Lookup([E.Advice(0) * E.Fixed(A + 1), E.Advice(1, -1) + E.Constant(5)], [E.Fixed(A), E.Fixed(A + 1) * 3])]
+    perm = [("advice", i) for i in range(A)] + [("fixed", A + 1), ("instance", 0)]
+    return E.ConstraintSystem(num_fixed=A + 2, num_advice=A + 1, num_instance=1, gates=gates, lookups=lookups,
+                              permutation_columns=perm, blinding_factors=5, degree=4)
+
+
+@pytest.mark.parametrize("k,extended_k,gate_cols", [(3, 5, 1), (5, 7, 3), (6, 8, 4)])
+def test_evaluate_h_matches_reference_formulas(lib, k, extended_k, gate_cols):
+    rng = random.Random(100 + k)
+    cs = halo2_lib_like_cs(gate_cols)
+    qc = E.quotient_columns(cs)
+    rows = 1 << extended_k
+    cols = [[rng.randrange(R) for _ in range(rows)] for _ in range(qc.total)]
+    beta, gamma, theta, y = (rng.randrange(R) for _ in range(4))
+    prog = E.evaluate_h_program(cs, k, extended_k, beta, gamma, theta, y)
+    got = run_host(prog, cols, extended_k)
+    sets = cs.num_permutation_sets
+    exp = O.evaluate_h_direct(
+        cs, k, extended_k, cols[qc.fixed:qc.fixed + cs.num_fixed], cols[qc.advice:qc.advice + cs.num_advice],
+        cols[qc.instance:qc.instance + cs.num_instance], cols[qc.l0], cols[qc.l_last], cols[qc.l_active_row],
+        cols[qc.sigma:qc.sigma + len(cs.permutation_columns)], cols[qc.perm_product:qc.perm_product + sets],
+        [tuple(cols[qc.lookup + 3 * i + j] for j in range(3)) for i in range(len(cs.lookups))], beta, gamma, theta, y)
+    assert got == exp
+
+
+def test_evaluate_h_device_resident_large_spot_check(lib):
+    """k = 14 / extended 16 on device-resident columns; 150 rows (incl. the wrap-around rows) against the interpreter"""
+    import torch
+
+    k, ek = 14, 16
+    rows = 1 << ek
+    cs = halo2_lib_like_cs(3)
+    qc = E.quotient_columns(cs)
+    g = np.random.default_rng(5)
+    host_cols = []
+    for _ in range(qc.total):
+        a = g.integers(0, 1 << 64, size=(rows, 4), dtype=np.uint64)
+        a[:, 3] = g.integers(0, 0x30644E72E131A029, size=rows, dtype=np.uint64)     # canonical: top limb below the modulus'
+        host_cols.append(a)
+    d_cols = [torch.from_numpy(a.view(np.int64)).cuda() for a in host_cols]
+    d_out = torch.zeros(rows * 4, dtype=torch.int64, device="cuda")
+    rng = random.Random(9)
+    beta, gamma, theta, y = (rng.randrange(R) for _ in range(4))
+    prog = E.evaluate_h_program(cs, k, ek, beta, gamma, theta, y)
+    prog.run_device([t.data_ptr() for t in d_cols], ek, d_out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy().view(np.uint64).reshape(rows, 4)
+    only = sorted(set(rng.sample(range(rows), 140) + [0, 1, 2, 3, rows - 1, rows - 2, rows - 24, 4095, 4096, 8191]))
+    # the interpreter needs column values at rotated rows only: decode the rows it touches
+    need = set()
+    for r in only:
+        for rot in prog.rotations:
+            need.add((r + rot * prog.rot_scale) % rows)
+    need = sorted(need)
+    sparse = [dict(zip(need, F.fr_decode(a[need]))) for a in host_cols]
+    exp = O.row_program_run(prog.insns, prog.constants, prog.rotations, prog.rot_scale, prog.result_reg, sparse, ek,
+                            omega=prog.omega, only_rows=only)
+    assert F.fr_decode(got[only]) == exp
+
+
+def test_linear_combination_and_accumulate(lib):
+    rng = random.Random(31)
+    log_rows, n = 10, 7
+    rows = 1 << log_rows
+    cols = [[rng.randrange(R) for _ in range(rows)] for _ in range(n)]
+    coeffs = [rng.randrange(R) for _ in range(n)]
+    prog = E.linear_combination_program(coeffs)
+    exp = [sum(c * col[i] for c, col in zip(coeffs, cols)) % R for i in range(rows)]
+    assert run_host(prog, cols, log_rows) == exp
+    # accumulate: out = out * x + column (the multiopen Horner over polynomials)
+    x = rng.randrange(R)
+    p = E.RowProgram()
+    p.emit(E.OP_MAD, 0, E.RowProgram.PREV, p.constant(x), p.column(0))
+    prev = [rng.randrange(R) for _ in range(rows)]
+    assert run_host(p, cols[:1], log_rows, prev) == [(a * x + b) % R for a, b in zip(prev, cols[0])]
+
+
+@pytest.mark.parametrize("n", [1, 2, 33, 1000, 4097, 1 << 16])
+def test_grand_product_vs_reference_algorithm(lib, cref, n):
+    num = cref.gen_scalars(900 + n, n, 0)
+    den = cref.gen_scalars(901 + n, n, 0)
+    if n > 40:
+        den[17] = 0            # a zero denominator counts as zero (BatchInvert), so every later z is zero
+    z = np.zeros_like(num)
+    _lib.check(lib.zkhip_fr_grand_product(num.ctypes.data, den.ctypes.data, n, z.ctypes.data))
+    inv = den.copy()
+    cref.batch_invert(inv)
+    ratio = cref.field_op(1, 0, num, inv)
+    assert np.array_equal(z, cref.prefix_product(ratio))
+    if n <= 1000:
+        assert F.fr_decode(z) == O.grand_product(F.fr_decode(num), F.fr_decode(den))
+
+
+def test_row_program_rejects_malformed_programs(lib):
+    col = enc([1, 2, 3, 4])
+    out = np.zeros((4, 4), dtype=np.uint64)
+    ptrs = (C.c_void_p * 1)(col.ctypes.data)
+
+    def rc_of(p, n_cols=1):
+        prog, keep = p._marshal()
+        return lib.zkhip_fr_eval_rows(C.byref(prog), ptrs, n_cols, 2, 0, out.ctypes.data)
+
+    good = E.RowProgram()
+    good.emit(E.OP_MOV, 0, good.column(0))
+    assert rc_of(good) == 0 and F.fr_decode(out) == [1, 2, 3, 4]
+    bad = E.RowProgram(); bad.emit(E.OP_MOV, _lib.VM_REGS, bad.column(0))
+    assert rc_of(bad) == -1 and b"register" in lib.zkhip_last_error()
+    bad = E.RowProgram(); bad.emit(9, 0, bad.column(0))
+    assert rc_of(bad) == -1
+    bad = E.RowProgram(); bad.emit(E.OP_MOV, 0, bad.column(3))
+    assert rc_of(bad) == -1
+    bad = E.RowProgram(); bad.emit(E.OP_MOV, 0, E.RowProgram.ROWPOW)          # no omega given
+    assert rc_of(bad) == -1
+    bad = E.RowProgram(); bad.emit(E.OP_MOV, 0, (E.SRC_CONST, 5, 0))
+    assert rc_of(bad) == -1
+    bad = E.RowProgram(); bad.constants.append(R); bad.emit(E.OP_MOV, 0, (E.SRC_CONST, 0, 0))
+    prog, keep = bad._marshal()
+    raw = np.array([O.limbs4(R)], dtype=np.uint64)                              # a non-canonical constant
+    prog.constants = raw.ctypes.data
+    assert lib.zkhip_fr_eval_rows(C.byref(prog), ptrs, 1, 2, 0, out.ctypes.data) == -1
+    empty = E.RowProgram()
+    prog, keep = empty._marshal()
+    assert lib.zkhip_fr_eval_rows(C.byref(prog), ptrs, 1, 2, 0, out.ctypes.data) == -1

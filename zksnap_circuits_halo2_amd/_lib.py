@@ -32,6 +32,10 @@ _SIGS = {
     "zkhip_fr_kate_division_device": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "zkhip_fr_batch_invert_device": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "zkhip_fr_prefix_product_device": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "zkhip_fr_eval_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]),
+    "zkhip_fr_eval_rows_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]),
+    "zkhip_fr_grand_product": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "zkhip_fr_grand_product_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "zkhip_msm_g1_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "zkhip_prepare_bases_device": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]),
     "zkhip_prepare_bases_device_c": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint64)]),
@@ -54,6 +58,24 @@ _SIGS = {
     "zkhip_test_g1_op": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
 }
 
+
+
+class VmOperand(C.Structure):      # zkhip_vm_operand
+    _fields_ = [("kind", C.c_uint8), ("rot", C.c_uint8), ("index", C.c_uint16)]
+
+
+class VmInsn(C.Structure):         # zkhip_vm_insn (16 bytes)
+    _fields_ = [("op", C.c_uint8), ("dst", C.c_uint8), ("reserved", C.c_uint16), ("a", VmOperand), ("b", VmOperand), ("c", VmOperand)]
+
+
+class VmProgram(C.Structure):      # zkhip_vm_program
+    _fields_ = [("insns", C.POINTER(VmInsn)), ("n_insns", C.c_uint32),
+                ("constants", C.c_void_p), ("n_constants", C.c_uint32),
+                ("rotations", C.POINTER(C.c_int32)), ("n_rotations", C.c_uint32),
+                ("rot_scale", C.c_int32), ("result_reg", C.c_uint32), ("omega", C.c_void_p)]
+
+
+VM_REGS = 12
 _lib = None
 
 

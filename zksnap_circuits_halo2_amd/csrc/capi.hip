@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <vector>
 #include <mutex>
 #include "zkhip_internal.hpp"
 
@@ -70,7 +71,7 @@ struct context {
   bool ready = false;
   int device = 0;
   hipStream_t stream = nullptr;
-  dev_buf ws, scalars, bases, poly, poly2, small, ntt_tmp;
+  dev_buf ws, scalars, bases, poly, poly2, small, ntt_tmp, vm;
   std::map<const void*, prepared_bases*> registered;   // host ptr -> prepared table (slice 0 of the table = the bases themselves)
   std::map<uint64_t, prepared_bases*> handles;          // zkhip_prepare_bases_device handles
   uint64_t next_handle = 1;
@@ -130,7 +131,7 @@ void zkhip_shutdown(void) {
   g_ctx.registered.clear();
   for (auto& kv : g_ctx.handles) release_prepared(kv.second);
   g_ctx.handles.clear();
-  g_ctx.ws.release(); g_ctx.scalars.release(); g_ctx.bases.release(); g_ctx.poly.release(); g_ctx.poly2.release(); g_ctx.small.release(); g_ctx.ntt_tmp.release();
+  g_ctx.ws.release(); g_ctx.scalars.release(); g_ctx.bases.release(); g_ctx.poly.release(); g_ctx.poly2.release(); g_ctx.small.release(); g_ctx.ntt_tmp.release(); g_ctx.vm.release();
   (void)hipStreamDestroy(g_ctx.stream);
   g_ctx.stream = nullptr;
   g_ctx.ready = false;
@@ -598,6 +599,72 @@ int zkhip_fr_prefix_product(const uint64_t* v, size_t n, uint64_t* out) {
   if (n && (!v || !out)) { set_error("prefix_product: null pointer"); return ZKHIP_EINVAL; }
   if (n == 0) return ZKHIP_OK;
   return host_vec_op(3, v, n, nullptr, out, n);
+}
+
+// ---- section 8(f): row programs and grand products -------------------------------------------------------------
+int zkhip_fr_eval_rows_device(const zkhip_vm_program* prog, const void* const* d_columns, uint32_t n_columns, uint32_t log_rows,
+                              int accumulate, void* d_out, void* stream) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if ((rc = row_vm_validate(prog, n_columns, log_rows, accumulate)) != ZKHIP_OK) return rc;
+  if (!d_out || (n_columns && !d_columns)) { set_error("eval_rows: null pointer"); return ZKHIP_EINVAL; }
+  if ((rc = g_ctx.vm.reserve(row_vm_workspace_bytes(prog, n_columns, log_rows))) != ZKHIP_OK) return rc;
+  return row_vm_device(prog, d_columns, n_columns, log_rows, accumulate, (uint32_t*)d_out, g_ctx.vm.p, g_ctx.vm.cap,
+                       stream ? (hipStream_t)stream : g_ctx.stream);
+}
+
+int zkhip_fr_eval_rows(const zkhip_vm_program* prog, const uint64_t* const* columns, uint32_t n_columns, uint32_t log_rows,
+                       int accumulate, uint64_t* out) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if ((rc = row_vm_validate(prog, n_columns, log_rows, accumulate)) != ZKHIP_OK) return rc;
+  if (!out || (n_columns && !columns)) { set_error("eval_rows: null pointer"); return ZKHIP_EINVAL; }
+  const size_t rows = (size_t)1 << log_rows, bytes = rows * 32;
+  hipStream_t s = g_ctx.stream;
+  if ((rc = g_ctx.poly.reserve((size_t)(n_columns ? n_columns : 1) * bytes)) != ZKHIP_OK) return rc;
+  if ((rc = g_ctx.poly2.reserve(bytes)) != ZKHIP_OK) return rc;
+  std::vector<const void*> d_cols(n_columns);
+  for (uint32_t i = 0; i < n_columns; i++) {
+    if (!columns[i]) { set_error("eval_rows: column %u is null", i); return ZKHIP_EINVAL; }
+    d_cols[i] = (char*)g_ctx.poly.p + (size_t)i * bytes;
+    HIPCHK(hipMemcpyAsync((void*)d_cols[i], columns[i], bytes, hipMemcpyHostToDevice, s));
+  }
+  if (accumulate) HIPCHK(hipMemcpyAsync(g_ctx.poly2.p, out, bytes, hipMemcpyHostToDevice, s));
+  if ((rc = zkhip_fr_eval_rows_device(prog, d_cols.data(), n_columns, log_rows, accumulate, g_ctx.poly2.p, s)) != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(out, g_ctx.poly2.p, bytes, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return ZKHIP_OK;
+}
+
+int zkhip_fr_grand_product_device(const void* d_num, void* d_den, size_t n, void* d_z, void* stream) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (n && (!d_num || !d_den || !d_z)) { set_error("grand_product: null pointer"); return ZKHIP_EINVAL; }
+  if (n == 0) return ZKHIP_OK;
+  hipStream_t s = stream ? (hipStream_t)stream : g_ctx.stream;
+  if ((rc = zkhip_fr_batch_invert_device(d_den, n, s)) != ZKHIP_OK) return rc;
+  if ((rc = fr_pointwise_mul_device((const uint32_t*)d_num, (const uint32_t*)d_den, n, (uint32_t*)d_den, s)) != ZKHIP_OK) return rc;
+  return zkhip_fr_prefix_product_device(d_den, n, d_z, s);
+}
+
+int zkhip_fr_grand_product(const uint64_t* num, const uint64_t* den, size_t n, uint64_t* z) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (n && (!num || !den || !z)) { set_error("grand_product: null pointer"); return ZKHIP_EINVAL; }
+  if (n == 0) return ZKHIP_OK;
+  hipStream_t s = g_ctx.stream;
+  if ((rc = g_ctx.poly.reserve(n * 32)) != ZKHIP_OK) return rc;
+  if ((rc = g_ctx.poly2.reserve(n * 32)) != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(g_ctx.poly.p, num, n * 32, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(g_ctx.poly2.p, den, n * 32, hipMemcpyHostToDevice, s));
+  if ((rc = zkhip_fr_grand_product_device(g_ctx.poly.p, g_ctx.poly2.p, n, g_ctx.poly.p, s)) != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(z, g_ctx.poly.p, n * 32, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return ZKHIP_OK;
 }
 
 int zkhip_profile_enable(int on) {

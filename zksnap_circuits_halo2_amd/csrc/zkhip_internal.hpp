@@ -47,6 +47,13 @@ int fr_kate_division_device(const uint32_t* d_a, size_t n, const uint32_t b_host
 int fr_prefix_product_device(const uint32_t* d_v, size_t n, uint32_t* d_out, void* ws, size_t ws_bytes, hipStream_t stream);
 int fr_batch_invert_device(uint32_t* d_a, size_t n, void* ws, size_t ws_bytes, hipStream_t stream);
 
+// rowvm.hip
+int row_vm_validate(const zkhip_vm_program* p, uint32_t n_columns, uint32_t log_rows, int accumulate);
+size_t row_vm_workspace_bytes(const zkhip_vm_program* p, uint32_t n_columns, uint32_t log_rows);
+int row_vm_device(const zkhip_vm_program* p, const void* const* d_columns, uint32_t n_columns, uint32_t log_rows, int accumulate,
+                  uint32_t* d_out, void* ws, size_t ws_bytes, hipStream_t stream);
+int fr_pointwise_mul_device(const uint32_t* d_a, const uint32_t* d_b, size_t n, uint32_t* d_out, hipStream_t stream);
+
 // selftest.hip
 int test_field_op(int field, int op, const uint32_t* d_a, const uint32_t* d_b, uint32_t* d_out, size_t n, hipStream_t stream);
 int test_g1_op(int op, const uint32_t* d_a, const uint32_t* d_b, uint32_t* d_out, size_t n, hipStream_t stream);

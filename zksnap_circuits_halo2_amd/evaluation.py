@@ -1,0 +1,380 @@
+"""`halo2_proofs::plonk::evaluation` mirror [DEP halo2-axiom plonk/evaluation.rs], reached from create_proof
+(/root/reference/aggregator/src/wrapper.rs:129): the quotient numerator h(X)·(X^n − 1) is evaluated row by row over the
+extended coset.  The reference compiles every gate / lookup `Expression` into a `GraphEvaluator` (a list of
+`Calculation`s over `ValueSource`s, hash-consed) and interprets it per row on the CPU, then adds the permutation and lookup
+terms with hand-written loops.  Here the same graph -- including the permutation and lookup terms -- is compiled once into a
+row program for `zkhip_fr_eval_rows` (include/zkhip.h) and run as one fused GPU pass, one thread per row.
+
+Host logic only: graph construction, register allocation, argument marshalling.  All field arithmetic on columns happens in
+libzkhip.so; there is no CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import _lib
+from . import fields as F
+
+# operand kinds / opcodes of include/zkhip.h
+SRC_CONST, SRC_REG, SRC_COLUMN, SRC_PREV, SRC_ROWPOW = 0, 1, 2, 3, 4
+OP_MOV, OP_ADD, OP_SUB, OP_MUL, OP_NEG, OP_DBL, OP_SQR, OP_MAD = range(8)
+_N_OPERANDS = {OP_MOV: 1, OP_ADD: 2, OP_SUB: 2, OP_MUL: 2, OP_NEG: 1, OP_DBL: 1, OP_SQR: 1, OP_MAD: 3}
+
+
+# ---------------------------------------------------------------------------------------------------
+# Expression: the reference's `plonk::Expression<F>` as a tiny AST
+# ---------------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class Expr:
+    kind: str                      # constant | fixed | advice | instance | challenge | neg | sum | product | scaled
+    a: object = None
+    b: object = None
+
+    def __add__(self, o): return Expr("sum", self, o)
+    def __sub__(self, o): return Expr("sum", self, Expr("neg", o))
+    def __mul__(self, o): return Expr("product", self, o) if isinstance(o, Expr) else Expr("scaled", self, int(o))
+    def __neg__(self): return Expr("neg", self)
+
+
+def Constant(v: int) -> Expr: return Expr("constant", int(v) % F.R_MOD)
+def Fixed(col: int, rot: int = 0) -> Expr: return Expr("fixed", col, rot)
+def Advice(col: int, rot: int = 0) -> Expr: return Expr("advice", col, rot)
+def Instance(col: int, rot: int = 0) -> Expr: return Expr("instance", col, rot)
+def Challenge(i: int) -> Expr: return Expr("challenge", i)
+
+
+@dataclass
+class Lookup:                      # `lookup::Argument`
+    input_expressions: List[Expr]
+    table_expressions: List[Expr]
+
+
+@dataclass
+class ConstraintSystem:            # the parts of `plonk::ConstraintSystem` evaluate_h reads
+    num_fixed: int
+    num_advice: int
+    num_instance: int = 0
+    gates: List[List[Expr]] = field(default_factory=list)                  # per gate: its polynomials
+    lookups: List[Lookup] = field(default_factory=list)
+    permutation_columns: List[Tuple[str, int]] = field(default_factory=list)   # ("advice" | "fixed" | "instance", index)
+    blinding_factors: int = 5
+    degree: int = 4                                                         # cs.degree(); chunk_len = degree - 2
+
+    @property
+    def chunk_len(self) -> int: return self.degree - 2
+    @property
+    def num_permutation_sets(self) -> int:
+        return (len(self.permutation_columns) + self.chunk_len - 1) // self.chunk_len if self.permutation_columns else 0
+
+
+# ---------------------------------------------------------------------------------------------------
+# Graph: hash-consed calculations (the reference's GraphEvaluator::add_calculation / add_constant / add_rotation)
+# ---------------------------------------------------------------------------------------------------
+Node = Tuple  # ("const", value) | ("col", column, rot) | ("prev",) | ("rowpow",) | ("op", opcode, a_id, b_id, c_id)
+
+
+class Graph:
+    def __init__(self):
+        self.nodes: List[Node] = []
+        self._index: Dict[Node, int] = {}
+
+    def _add(self, node: Node) -> int:
+        i = self._index.get(node)
+        if i is None:
+            i = len(self.nodes)
+            self.nodes.append(node)
+            self._index[node] = i
+        return i
+
+    def const(self, v: int) -> int: return self._add(("const", int(v) % F.R_MOD))
+    def col(self, column: int, rot: int = 0) -> int: return self._add(("col", int(column), int(rot)))
+    def prev(self) -> int: return self._add(("prev",))
+    def rowpow(self) -> int: return self._add(("rowpow",))
+
+    def op(self, opcode: int, a: int, b: int = -1, c: int = -1) -> int:
+        if opcode in (OP_ADD, OP_MUL) and b < a:      # commutative: canonical operand order (as the reference does)
+            a, b = b, a
+        return self._add(("op", opcode, a, b, c))
+
+    def add(self, a, b): return self.op(OP_ADD, a, b)
+    def sub(self, a, b): return self.op(OP_SUB, a, b)
+    def mul(self, a, b): return self.op(OP_SQR, a) if a == b else self.op(OP_MUL, a, b)
+    def neg(self, a): return self.op(OP_NEG, a)
+    def dbl(self, a): return self.op(OP_DBL, a)
+    def mad(self, a, b, c): return self._add(("op", OP_MAD, a, b, c))        # a * b + c
+
+    def horner(self, start: int, parts: Sequence[int], factor: int) -> int:
+        """`Calculation::Horner(start, parts, factor)`: value = start; value = value * factor + part for each part."""
+        v = start
+        for p in parts:
+            v = self.mad(v, factor, p)
+        return v
+
+
+# ---------------------------------------------------------------------------------------------------
+# RowProgram: the marshalled form zkhip_fr_eval_rows takes
+# ---------------------------------------------------------------------------------------------------
+class RowProgram:
+    def __init__(self, rot_scale: int = 1, omega: Optional[int] = None):
+        self.insns: List[Tuple[int, int, Tuple[int, int, int], Tuple[int, int, int], Tuple[int, int, int]]] = []
+        self.constants: List[int] = []
+        self._const_index: Dict[int, int] = {}
+        self.rotations: List[int] = []
+        self._rot_index: Dict[int, int] = {}
+        self.rot_scale = rot_scale
+        self.omega = omega
+        self.result_reg = 0
+        self.n_columns = 0
+
+    # operands are (kind, index, rot_slot)
+    def constant(self, v: int):
+        v = int(v) % F.R_MOD
+        if v not in self._const_index:
+            self._const_index[v] = len(self.constants)
+            self.constants.append(v)
+        return (SRC_CONST, self._const_index[v], 0)
+
+    def column(self, column: int, rot: int = 0):
+        if rot not in self._rot_index:
+            self._rot_index[rot] = len(self.rotations)
+            self.rotations.append(rot)
+        self.n_columns = max(self.n_columns, column + 1)
+        return (SRC_COLUMN, column, self._rot_index[rot])
+
+    @staticmethod
+    def reg(i: int): return (SRC_REG, i, 0)
+    PREV = (SRC_PREV, 0, 0)
+    ROWPOW = (SRC_ROWPOW, 0, 0)
+
+    def emit(self, op: int, dst: int, a, b=None, c=None):
+        z = (SRC_CONST, 0, 0)
+        self.insns.append((op, dst, a, b or z, c or z))
+
+    # ---- marshalling -------------------------------------------------------------------------------
+    def _marshal(self):
+        n = len(self.insns)
+        arr = (_lib.VmInsn * n)()
+        for i, (op, dst, a, b, c) in enumerate(self.insns):
+            arr[i].op, arr[i].dst = op, dst
+            for name, o in (("a", a), ("b", b), ("c", c)):
+                f = getattr(arr[i], name)
+                f.kind, f.index, f.rot = o[0], o[1], o[2]
+        consts = F.fr_encode(self.constants) if self.constants else np.zeros((1, 4), dtype=np.uint64)
+        rots = (C.c_int32 * max(len(self.rotations), 1))(*self.rotations)
+        omega = F.fr_encode([self.omega])[0] if self.omega is not None else None
+        prog = _lib.VmProgram()
+        prog.insns, prog.n_insns = arr, n
+        prog.constants, prog.n_constants = consts.ctypes.data, len(self.constants)
+        prog.rotations, prog.n_rotations = rots, len(self.rotations)
+        prog.rot_scale, prog.result_reg = self.rot_scale, self.result_reg
+        prog.omega = omega.ctypes.data if omega is not None else None
+        keep = (arr, consts, rots, omega)      # keep the buffers alive for the duration of the call
+        return prog, keep
+
+    def run(self, columns: Sequence[np.ndarray], log_rows: int, out: Optional[np.ndarray] = None, accumulate: bool = False) -> np.ndarray:
+        """Host columns ((2^log_rows, 4) uint64 each) -> (2^log_rows, 4) uint64."""
+        rows = 1 << log_rows
+        cols = [np.ascontiguousarray(c, dtype=np.uint64).reshape(rows, 4) for c in columns]
+        assert len(cols) >= self.n_columns, "program reads more columns than were passed"
+        if out is None:
+            assert not accumulate
+            out = np.zeros((rows, 4), dtype=np.uint64)
+        assert out.dtype == np.uint64 and out.flags.c_contiguous and out.size == 4 * rows
+        ptrs = (C.c_void_p * max(len(cols), 1))(*[c.ctypes.data for c in cols])
+        prog, keep = self._marshal()
+        _lib.check(_lib.load().zkhip_fr_eval_rows(C.byref(prog), ptrs, len(cols), log_rows, int(accumulate), out.ctypes.data))
+        del keep
+        return out
+
+    def run_device(self, d_columns: Sequence[int], log_rows: int, d_out: int, accumulate: bool = False, stream: int = 0) -> None:
+        """Device-resident columns: `d_columns` are device addresses (e.g. torch `tensor.data_ptr()`)."""
+        assert len(d_columns) >= self.n_columns, "program reads more columns than were passed"
+        ptrs = (C.c_void_p * max(len(d_columns), 1))(*d_columns)
+        prog, keep = self._marshal()
+        _lib.check(_lib.load().zkhip_fr_eval_rows_device(C.byref(prog), ptrs, len(d_columns), log_rows, int(accumulate), d_out, stream))
+        del keep
+
+
+def compile_graph(g: Graph, result: int, rot_scale: int = 1, omega: Optional[int] = None) -> RowProgram:
+    """Lower the calculations `result` depends on to a RowProgram: creation order is a valid schedule (operands precede their
+    users), leaves become instruction operands, and registers are reused after an intermediate's last use."""
+    needed = set()
+    stack = [result]
+    while stack:
+        i = stack.pop()
+        if i in needed:
+            continue
+        needed.add(i)
+        n = g.nodes[i]
+        if n[0] == "op":
+            stack.extend(x for x in n[2:5] if x >= 0)
+    order = [i for i in sorted(needed) if g.nodes[i][0] == "op"]
+    last_use: Dict[int, int] = {}
+    for pos, i in enumerate(order):
+        for x in g.nodes[i][2:5]:
+            if x >= 0:
+                last_use[x] = pos
+    last_use[result] = len(order)
+    prog = RowProgram(rot_scale=rot_scale, omega=omega)
+    free = list(range(_lib.VM_REGS - 1, -1, -1))
+    reg_of: Dict[int, int] = {}
+
+    def operand(x: int):
+        n = g.nodes[x]
+        if n[0] == "const": return prog.constant(n[1])
+        if n[0] == "col": return prog.column(n[1], n[2])
+        if n[0] == "prev": return RowProgram.PREV
+        if n[0] == "rowpow":
+            assert omega is not None, "graph uses omega^row but no omega was given"
+            return RowProgram.ROWPOW
+        return RowProgram.reg(reg_of[x])
+
+    for pos, i in enumerate(order):
+        _, opcode, a, b, c = g.nodes[i]
+        ops = [operand(x) for x in (a, b, c)[: _N_OPERANDS[opcode]]]
+        # operands whose last use is this instruction release their register before the destination is chosen
+        for x in {a, b, c}:
+            if x >= 0 and g.nodes[x][0] == "op" and last_use[x] == pos:
+                free.append(reg_of.pop(x))
+        if not free:
+            raise ValueError(f"row program needs more than {_lib.VM_REGS} live registers")
+        reg_of[i] = free.pop()
+        prog.emit(opcode, reg_of[i], *ops)
+    if g.nodes[result][0] != "op":       # the result is a leaf: materialise it
+        prog.emit(OP_MOV, 0, operand(result))
+        prog.result_reg = 0
+    else:
+        prog.result_reg = reg_of[result]
+    return prog
+
+
+# ---------------------------------------------------------------------------------------------------
+# evaluate_h: column layout + graph of the whole quotient numerator
+# ---------------------------------------------------------------------------------------------------
+@dataclass
+class QuotientColumns:
+    """Column order `evaluate_h_program` expects (all are evaluations over the extended coset, 2^extended_k rows each)."""
+    fixed: int
+    advice: int
+    instance: int
+    l0: int
+    l_last: int
+    l_active_row: int
+    sigma: int            # first of the permutation cosets (pk.permutation.cosets), one per permutation column
+    perm_product: int     # first of the permutation product cosets, one per set
+    lookup: int           # first lookup triple: product, permuted_input, permuted_table per lookup
+    total: int
+
+
+def quotient_columns(cs: ConstraintSystem) -> QuotientColumns:
+    o = 0
+    fixed = o; o += cs.num_fixed
+    advice = o; o += cs.num_advice
+    instance = o; o += cs.num_instance
+    l0 = o; l_last = o + 1; l_active = o + 2; o += 3
+    sigma = o; o += len(cs.permutation_columns)
+    perm = o; o += cs.num_permutation_sets
+    lookup = o; o += 3 * len(cs.lookups)
+    return QuotientColumns(fixed, advice, instance, l0, l_last, l_active, sigma, perm, lookup, o)
+
+
+def _add_expression(g: Graph, cs: ConstraintSystem, qc: QuotientColumns, e: Expr, challenges: Sequence[int]) -> int:
+    k = e.kind
+    if k == "constant": return g.const(e.a)
+    if k == "fixed": return g.col(qc.fixed + e.a, e.b)
+    if k == "advice": return g.col(qc.advice + e.a, e.b)
+    if k == "instance": return g.col(qc.instance + e.a, e.b)
+    if k == "challenge": return g.const(challenges[e.a])
+    if k == "neg": return g.neg(_add_expression(g, cs, qc, e.a, challenges))
+    if k == "sum":
+        if e.b.kind == "neg":      # the reference folds a + (-b) into Sub
+            return g.sub(_add_expression(g, cs, qc, e.a, challenges), _add_expression(g, cs, qc, e.b.a, challenges))
+        return g.add(_add_expression(g, cs, qc, e.a, challenges), _add_expression(g, cs, qc, e.b, challenges))
+    if k == "product": return g.mul(_add_expression(g, cs, qc, e.a, challenges), _add_expression(g, cs, qc, e.b, challenges))
+    if k == "scaled": return g.mul(_add_expression(g, cs, qc, e.a, challenges), g.const(e.b))
+    raise ValueError(k)
+
+
+DELTA = pow(7, 1 << F.S, F.R_MOD)     # `Fr::DELTA` = g^(2^S), generator of the odd-order subgroup cosets
+
+
+def evaluate_h_program(cs: ConstraintSystem, k: int, extended_k: int, beta: int, gamma: int, theta: int, y: int,
+                       challenges: Sequence[int] = (), zeta: int = F.ZETA) -> RowProgram:
+    """The program whose output column is `evaluate_h`'s `values` (before `divide_by_vanishing_poly`).
+    Terms and their order follow [DEP] plonk/evaluation.rs `Evaluator::evaluate_h`: custom gates, permutation, lookups."""
+    g = Graph()
+    qc = quotient_columns(cs)
+    Y, BETA, GAMMA, THETA, ONE = g.const(y), g.const(beta), g.const(gamma), g.const(theta), g.const(1)
+    value = g.const(0)
+    last_rotation = -(cs.blinding_factors + 1)
+
+    def fold(term: int):
+        nonlocal value
+        value = g.mad(value, Y, term)
+
+    # custom gates: Horner(PreviousValue = 0, all gate polynomials in order, y)
+    for polys in cs.gates:
+        for poly in polys:
+            fold(_add_expression(g, cs, qc, poly, challenges))
+
+    l0, l_last, l_active = g.col(qc.l0), g.col(qc.l_last), g.col(qc.l_active_row)
+
+    # permutation argument
+    if cs.permutation_columns:
+        sets = cs.num_permutation_sets
+        z = lambda s, rot=0: g.col(qc.perm_product + s, rot)
+        fold(g.mul(g.sub(ONE, z(0)), l0))                                   # l_0 (1 - z_0)
+        zl = z(sets - 1)
+        fold(g.mul(g.sub(g.mul(zl, zl), zl), l_last))                       # l_last (z_l^2 - z_l)
+        for s in range(1, sets):
+            fold(g.mul(g.sub(z(s), z(s - 1, last_rotation)), l0))           # l_0 (z_i - z_{i-1}(w^last X))
+        # current_delta = beta * zeta * delta^j * extended_omega^row
+        x_term = g.mul(g.rowpow(), g.const(beta * zeta % F.R_MOD))
+        delta_pow = 1
+        col_of = {"fixed": qc.fixed, "advice": qc.advice, "instance": qc.instance}
+        for s in range(sets):
+            chunk = cs.permutation_columns[s * cs.chunk_len:(s + 1) * cs.chunk_len]
+            left = z(s, 1)
+            for j, (kind, idx) in enumerate(chunk):
+                v = g.col(col_of[kind] + idx)
+                sig = g.col(qc.sigma + s * cs.chunk_len + j)
+                left = g.mul(left, g.add(g.mad(sig, BETA, v), GAMMA))       # v + beta sigma + gamma
+            right = z(s)
+            for (kind, idx) in chunk:
+                v = g.col(col_of[kind] + idx)
+                cur = x_term if delta_pow == 1 else g.mul(x_term, g.const(delta_pow))
+                right = g.mul(right, g.add(g.add(v, cur), GAMMA))           # v + delta^j beta X + gamma
+                delta_pow = delta_pow * DELTA % F.R_MOD
+            fold(g.mul(g.sub(left, right), l_active))
+
+    # lookup arguments
+    for li, lk in enumerate(cs.lookups):
+        prod = lambda rot=0: g.col(qc.lookup + 3 * li, rot)
+        pin = lambda rot=0: g.col(qc.lookup + 3 * li + 1, rot)
+        ptab = g.col(qc.lookup + 3 * li + 2)
+        zero = g.const(0)
+        cin = g.horner(zero, [_add_expression(g, cs, qc, e, challenges) for e in lk.input_expressions], THETA)
+        ctab = g.horner(zero, [_add_expression(g, cs, qc, e, challenges) for e in lk.table_expressions], THETA)
+        table_value = g.mul(g.add(cin, BETA), g.add(ctab, GAMMA))
+        a_minus_s = g.sub(pin(), ptab)
+        fold(g.mul(g.sub(ONE, prod()), l0))
+        fold(g.mul(g.sub(g.mul(prod(), prod()), prod()), l_last))
+        lhs = g.mul(g.mul(prod(1), g.add(pin(), BETA)), g.add(ptab, GAMMA))
+        fold(g.mul(g.sub(lhs, g.mul(prod(), table_value)), l_active))
+        fold(g.mul(a_minus_s, l0))
+        fold(g.mul(g.mul(a_minus_s, g.sub(pin(), pin(-1))), l_active))
+
+    omega_ext = F.omega_for(extended_k)
+    return compile_graph(g, value, rot_scale=1 << (extended_k - k), omega=omega_ext)
+
+
+def linear_combination_program(coeffs: Sequence[int]) -> RowProgram:
+    """out[row] = sum_k coeffs[k] * column_k[row]  (multiopen: the per-point polynomial combinations)."""
+    g = Graph()
+    acc = g.mul(g.col(0), g.const(coeffs[0]))
+    for kk in range(1, len(coeffs)):
+        acc = g.mad(g.col(kk), g.const(coeffs[kk]), acc)
+    return compile_graph(g, acc)
