@@ -104,9 +104,10 @@ int zkhip_fr_prefix_product_device(const void *d_v, size_t n, void *d_out, void 
  *   ZKHIP_SRC_PREV    out[row] as it was before the call (PreviousValue); 0 unless `accumulate`
  *   ZKHIP_SRC_ROWPOW  omega^row  (the reference's running `beta_term *= extended_omega`; needs `omega`)
  * Instructions: dst = MOV a | a + b | a - b | a * b | -a | 2a | a^2 | a * b + c.   out[row] = register `result_reg`.
- * rows = 2^log_rows; all field elements are canonical Montgomery Fr words, in and out.  The register count is fixed so that the
- * register file stays in VGPRs: a host compiling a `GraphEvaluator` reuses registers (linear scan over last uses). */
-#define ZKHIP_VM_REGS 12
+ * rows = 2^log_rows; all field elements are canonical Montgomery Fr words, in and out.  The register file stays in VGPRs, and the
+ * library runs the kernel variant sized for the highest register a program names (6 / 8 / 12 / 16: fewer registers = more waves in
+ * flight), so a host compiling a `GraphEvaluator` should reuse registers (linear scan over last uses) and number them from 0. */
+#define ZKHIP_VM_REGS 16
 enum { ZKHIP_SRC_CONST = 0, ZKHIP_SRC_REG = 1, ZKHIP_SRC_COLUMN = 2, ZKHIP_SRC_PREV = 3, ZKHIP_SRC_ROWPOW = 4 };
 enum { ZKHIP_OP_MOV = 0, ZKHIP_OP_ADD = 1, ZKHIP_OP_SUB = 2, ZKHIP_OP_MUL = 3, ZKHIP_OP_NEG = 4, ZKHIP_OP_DBL = 5, ZKHIP_OP_SQR = 6,
        ZKHIP_OP_MAD = 7 };

@@ -422,7 +422,7 @@ def grand_product(num: Sequence[int], den: Sequence[int]) -> List[int]:
 FR_DELTA = pow(FR_GENERATOR, 1 << FR_S, R_MOD)      # `Fr::DELTA` [DEP ff::PrimeField]: generator of the t-order subgroup
 
 
-def row_program_run(insns, constants, rotations, rot_scale, result_reg, columns, log_rows, omega=None, prev=None, n_regs=12,
+def row_program_run(insns, constants, rotations, rot_scale, result_reg, columns, log_rows, omega=None, prev=None, n_regs=16,
                     only_rows=None):
     """insns: (op, dst, a, b, c) with operands (kind, index, rot_slot); kinds 0 const, 1 reg, 2 column, 3 prev, 4 omega^row;
     ops 0 mov, 1 add, 2 sub, 3 mul, 4 neg, 5 dbl, 6 sqr, 7 mad (a*b + c)."""

@@ -75,7 +75,7 @@ class VmProgram(C.Structure):      # zkhip_vm_program
                 ("rot_scale", C.c_int32), ("result_reg", C.c_uint32), ("omega", C.c_void_p)]
 
 
-VM_REGS = 12
+VM_REGS = 16
 _lib = None
 
 

@@ -23,7 +23,7 @@
 
 namespace zkhip {
 
-constexpr int VM_REGS = ZKHIP_VM_REGS;
+constexpr int VM_MAX_REGS = ZKHIP_VM_REGS;   // kernel variants exist for 6 / 8 / 12 / 16 registers (occupancy 4 / 3 / 2 / 2 waves per SIMD)
 constexpr uint32_t POW_LO_BITS = 12;   // omega^row = hi[row >> 12] * lo[row & 4095]
 
 struct vm_launch {
@@ -88,24 +88,26 @@ __device__ __forceinline__ fe vm_times32(const fe& a) {   // a < 2r < 2^255: rep
   return fe_unpack<5>(w);
 }
 
-#define VM_REG_CASES(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11)
-static_assert(VM_REGS == 12, "VM_REG_CASES lists the registers");
+#define VM_REG_CASES(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+static_assert(VM_MAX_REGS == 16, "VM_REG_CASES lists the registers");
 
-// Register selection is spelled out with distinct inline-asm markers per case: without them LLVM sinks the twelve
+// Register selection is spelled out with distinct inline-asm markers per case: without them LLVM sinks the
 // `r[k] = v` stores into one store through a phi of addresses, which keeps the whole file in scratch memory.
-__device__ __forceinline__ fe vm_reg_get(const fe (&r)[VM_REGS], uint32_t i) {
+template <int R>
+__device__ __forceinline__ fe vm_reg_get(const fe (&r)[R], uint32_t i) {
   fe v = r[0];
   switch (i) {
-#define X(k) case k: asm volatile("; vm get r" #k); v = r[k]; break;
+#define X(k) case k: if constexpr (k < R) { asm volatile("; vm get r" #k); v = r[k]; } break;
     VM_REG_CASES(X)
 #undef X
     default: break;
   }
   return v;
 }
-__device__ __forceinline__ void vm_reg_set(fe (&r)[VM_REGS], uint32_t i, const fe& v) {
+template <int R>
+__device__ __forceinline__ void vm_reg_set(fe (&r)[R], uint32_t i, const fe& v) {
   switch (i) {
-#define X(k) case k: r[k] = v; asm volatile("; vm set r" #k ::: "memory"); break;
+#define X(k) case k: if constexpr (k < R) { r[k] = v; asm volatile("; vm set r" #k ::: "memory"); } break;
     VM_REG_CASES(X)
 #undef X
     default: break;
@@ -113,8 +115,8 @@ __device__ __forceinline__ void vm_reg_set(fe (&r)[VM_REGS], uint32_t i, const f
 }
 
 // operand fetch; TIMES32: the value scaled by 2^5 (second factor of a product)
-template <bool TIMES32>
-__device__ __forceinline__ fe vm_fetch(const vm_launch& L, uint32_t opnd, uint64_t row, const fe (&r)[VM_REGS], const fe& prev, const fe& xpow) {
+template <bool TIMES32, int R>
+__device__ __forceinline__ fe vm_fetch(const vm_launch& L, uint32_t opnd, uint64_t row, const fe (&r)[R], const fe& prev, const fe& xpow) {
   const uint32_t kind = opnd & 0xff, rot = (opnd >> 8) & 0xff, index = opnd >> 16;
   if (kind == ZKHIP_SRC_COLUMN || kind == ZKHIP_SRC_CONST) {
     uint32_t w[8];
@@ -130,12 +132,13 @@ __device__ __forceinline__ fe vm_fetch(const vm_launch& L, uint32_t opnd, uint64
   return TIMES32 ? vm_times32(v) : v;
 }
 
+template <int R>
 __global__ void __launch_bounds__(256) k_row_vm(const vm_launch L) {
   const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= L.rows) return;
-  fe r[VM_REGS];
+  fe r[R];
 #pragma unroll
-  for (int i = 0; i < VM_REGS; i++) r[i] = fe_zero();
+  for (int i = 0; i < R; i++) r[i] = fe_zero();
   fe prev = fe_zero(), xpow = fe_zero();
   if (L.accumulate) prev = load_ext(L.out, row);
   if (L.pow_lo) {
@@ -150,16 +153,16 @@ __global__ void __launch_bounds__(256) k_row_vm(const vm_launch L) {
     const uint32_t head = __builtin_amdgcn_readfirstlane(q.x), oa = __builtin_amdgcn_readfirstlane(q.y),
                    ob = __builtin_amdgcn_readfirstlane(q.z), oc = __builtin_amdgcn_readfirstlane(q.w);
     const uint32_t op = head & 0xff, dst = (head >> 8) & 0xff;
-    const fe a = vm_fetch<false>(L, oa, row, r, prev, xpow);
+    const fe a = vm_fetch<false, R>(L, oa, row, r, prev, xpow);
     fe t;
     if (op == ZKHIP_OP_MUL || op == ZKHIP_OP_SQR || op == ZKHIP_OP_MAD) {
-      const fe b32 = op == ZKHIP_OP_SQR ? vm_times32(a) : vm_fetch<true>(L, ob, row, r, prev, xpow);
+      const fe b32 = op == ZKHIP_OP_SQR ? vm_times32(a) : vm_fetch<true, R>(L, ob, row, r, prev, xpow);
       t = fe_mul<Fr>(a, b32);
-      if (op == ZKHIP_OP_MAD) t = vm_add(t, vm_fetch<false>(L, oc, row, r, prev, xpow));
+      if (op == ZKHIP_OP_MAD) t = vm_add(t, vm_fetch<false, R>(L, oc, row, r, prev, xpow));
     } else if (op == ZKHIP_OP_ADD) {
-      t = vm_add(a, vm_fetch<false>(L, ob, row, r, prev, xpow));
+      t = vm_add(a, vm_fetch<false, R>(L, ob, row, r, prev, xpow));
     } else if (op == ZKHIP_OP_SUB) {
-      t = vm_sub(a, vm_fetch<false>(L, ob, row, r, prev, xpow));
+      t = vm_sub(a, vm_fetch<false, R>(L, ob, row, r, prev, xpow));
     } else if (op == ZKHIP_OP_NEG) {
       t = vm_sub(fe_zero(), a);
     } else if (op == ZKHIP_OP_DBL) {
@@ -221,7 +224,7 @@ int row_vm_validate(const zkhip_vm_program* p, uint32_t n_columns, uint32_t log_
   if (log_rows > 28) { set_error("eval_rows: log_rows %u > 28", log_rows); return ZKHIP_EINVAL; }
   if (p->n_insns == 0 || !p->insns) { set_error("eval_rows: empty program"); return ZKHIP_EINVAL; }
   if (p->n_insns > (1u << 20)) { set_error("eval_rows: program too long (%u instructions)", p->n_insns); return ZKHIP_EINVAL; }
-  if (p->result_reg >= (uint32_t)VM_REGS) { set_error("eval_rows: result register %u out of range", p->result_reg); return ZKHIP_EINVAL; }
+  if (p->result_reg >= (uint32_t)VM_MAX_REGS) { set_error("eval_rows: result register %u out of range", p->result_reg); return ZKHIP_EINVAL; }
   if ((p->n_constants && !p->constants) || (p->n_rotations && !p->rotations)) { set_error("eval_rows: null table"); return ZKHIP_EINVAL; }
   if (p->n_constants > 65536 || n_columns > 65536 || p->n_rotations > 256) { set_error("eval_rows: table too large"); return ZKHIP_EINVAL; }
   for (uint32_t i = 0; i < p->n_constants; i++)
@@ -230,14 +233,14 @@ int row_vm_validate(const zkhip_vm_program* p, uint32_t n_columns, uint32_t log_
   for (uint32_t pc = 0; pc < p->n_insns; pc++) {
     const zkhip_vm_insn& in = p->insns[pc];
     if (in.op > ZKHIP_OP_MAD) { set_error("eval_rows: instruction %u: unknown op %u", pc, in.op); return ZKHIP_EINVAL; }
-    if (in.dst >= VM_REGS) { set_error("eval_rows: instruction %u: destination register %u out of range", pc, in.dst); return ZKHIP_EINVAL; }
+    if (in.dst >= VM_MAX_REGS) { set_error("eval_rows: instruction %u: destination register %u out of range", pc, in.dst); return ZKHIP_EINVAL; }
     const int n_opnd = (in.op == ZKHIP_OP_MAD) ? 3 : ((in.op == ZKHIP_OP_ADD || in.op == ZKHIP_OP_SUB || in.op == ZKHIP_OP_MUL) ? 2 : 1);
     const zkhip_vm_operand* o[3] = {&in.a, &in.b, &in.c};
     for (int k = 0; k < n_opnd; k++) {
       bool ok = true;
       switch (o[k]->kind) {
         case ZKHIP_SRC_CONST: ok = o[k]->index < p->n_constants; break;
-        case ZKHIP_SRC_REG: ok = o[k]->index < (uint32_t)VM_REGS; break;
+        case ZKHIP_SRC_REG: ok = o[k]->index < (uint32_t)VM_MAX_REGS; break;
         case ZKHIP_SRC_COLUMN: ok = o[k]->index < n_columns && o[k]->rot < p->n_rotations; break;
         case ZKHIP_SRC_PREV: break;
         case ZKHIP_SRC_ROWPOW: ok = p->omega != nullptr; break;
@@ -304,7 +307,19 @@ int row_vm_device(const zkhip_vm_program* p, const void* const* d_columns, uint3
     L.pow_lo = (const uint32_t*)(d + o_lo);
     L.pow_hi = (const uint32_t*)(d + o_hi);
   }
-  hipLaunchKernelGGL(k_row_vm, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, L);
+  // smallest register-file variant that holds every register the program names
+  uint32_t top = p->result_reg;
+  for (uint32_t pc = 0; pc < p->n_insns; pc++) {
+    const zkhip_vm_insn& in = p->insns[pc];
+    if (in.dst > top) top = in.dst;
+    const zkhip_vm_operand* o[3] = {&in.a, &in.b, &in.c};
+    for (int k = 0; k < 3; k++) if (o[k]->kind == ZKHIP_SRC_REG && o[k]->index < (uint32_t)VM_MAX_REGS && o[k]->index > top) top = o[k]->index;
+  }
+  const dim3 grid((unsigned)((rows + 255) / 256));
+  if (top < 6) hipLaunchKernelGGL(k_row_vm<6>, grid, dim3(256), 0, stream, L);
+  else if (top < 8) hipLaunchKernelGGL(k_row_vm<8>, grid, dim3(256), 0, stream, L);
+  else if (top < 12) hipLaunchKernelGGL(k_row_vm<12>, grid, dim3(256), 0, stream, L);
+  else hipLaunchKernelGGL(k_row_vm<16>, grid, dim3(256), 0, stream, L);
   HIPCHK(hipGetLastError());
   return ZKHIP_OK;
 }
