@@ -259,10 +259,94 @@ def extras(lib, _lib, F, torch, dev, stream) -> dict:
     bufs.clear()
     torch.cuda.empty_cache()
     out["small_circuit_replays"] = small_replays(lib, _lib, F, torch, dev, stream, timed)
+    out["prover_phases_k22"] = prover_phases(lib, _lib, F, torch, dev, stream, timed)
     out["wrapper_replay"] = {"workload": "k=22: 18 MSM 2^22 + 13 iNTT 2^22 + 13 NTT 2^24 + 1 iNTT 2^24, device-resident",
                              "ms": round(ms, 2), "proofs_per_s_msm_ntt_portion": round(1e3 / ms, 3),
-                             "note": "MSM+NTT portion only; the Rust host (witness, evaluate_h, transcript) cannot run here"}
+                             "note": "MSM+NTT portion only; the Rust host (witness, transcript) cannot run here"}
+    tot = ms + out["prover_phases_k22"]["total_ms"]
+    out["wrapper_replay"]["with_prover_phases_ms"] = round(tot, 2)          # + quotient, grand products, multiopen (8(f) rows 1-3)
+    out["wrapper_replay"]["proofs_per_s_device_portion"] = round(1e3 / tot, 3)
     return out
+
+
+def prover_phases(lib, _lib, F, torch, dev, stream, timed) -> dict:
+    """SURVEY.md 8(f) rows 1-3 on the wrapper shape (halo2-lib BaseConfig k = 22, advice [4], lookup [1,0,0], fixed 1:
+    /root/reference/aggregator/benches/wrapper_circuit.rs:61-68; degree 4 -> extended k = 24, 7 permutation columns in 4 sets):
+    the fused quotient-numerator pass, the grand products of the permutation / lookup arguments, and the multiopen
+    evaluations -- the parts of create_proof besides MSM / NTT that run on device-resident columns."""
+    import random
+
+    from zksnap_circuits_halo2_amd import evaluation as E
+
+    k, ek = 22, 24
+    n, rows = 1 << k, 1 << ek
+    gates = [[E.Fixed(i) * (E.Advice(i, 0) + E.Advice(i, 1) * E.Advice(i, 2) - E.Advice(i, 3))] for i in range(4)]
+    cs = E.ConstraintSystem(num_fixed=6, num_advice=5, num_instance=1, gates=gates, lookups=[E.Lookup([E.Advice(4)], [E.Fixed(5)])],
+                            permutation_columns=[("advice", i) for i in range(5)] + [("fixed", 4), ("instance", 0)],
+                            blinding_factors=5, degree=4)
+    qc = E.quotient_columns(cs)
+    rng = random.Random(22)
+    beta, gamma, theta, y, x = (rng.randrange(F.R_MOD) for _ in range(5))
+    cols = []
+    for _ in range(qc.total):
+        t = torch.randint(0, 1 << 62, (rows, 4), dtype=torch.int64, device=dev)
+        t[:, 3] &= (1 << 61) - 1                      # canonical Fr words
+        cols.append(t)
+    outb = torch.zeros(rows * 4, dtype=torch.int64, device=dev)
+    polys = [c.data_ptr() + q * n * 32 for c in cols for q in range(4)]      # 116 distinct 2^22-element polynomials
+    res = {}
+    # quotient: evaluate_h + divide_by_vanishing_poly
+    prog = E.evaluate_h_program(cs, k, ek, beta, gamma, theta, y)
+    tinv = torch.from_numpy(F.fr_encode([rng.randrange(1, F.R_MOD) for _ in range(4)]).view(np.int64)).to(dev)
+    ptrs = [c.data_ptr() for c in cols]
+
+    def quotient():
+        prog.run_device(ptrs, ek, outb.data_ptr(), stream=stream)
+        _lib.check(lib.zkhip_mul_periodic_device(outb.data_ptr(), rows, tinv.data_ptr(), 4, stream))
+
+    ms_q = timed(quotient, 3)
+    reads = len({(o[1], o[2]) for ins in prog.insns for o in ins[2:5] if o[0] == E.SRC_COLUMN})
+    res["quotient_numerator_2^24_rows"] = {"ms": round(ms_q, 3), "program_insns": len(prog.insns), "columns": qc.total,
+                                           "column_reads_per_row": reads, "Mrows_per_s": round(rows / ms_q / 1e3, 1),
+                                           "hbm_frac_algorithmic": round((qc.total + 1) * 32.0 * rows / (ms_q * 1e-3) / 8e12, 4)}
+    # grand products: 4 permutation sets (2 + 2 + 2 + 1 columns) + 1 lookup
+    num_b, den_b = outb.data_ptr(), outb.data_ptr() + n * 32
+    perm_progs = []
+    for s_i, width in enumerate((2, 2, 2, 1)):
+        perm_progs.append((E.permutation_numerator_program(width, 2 * s_i, beta, gamma, k), E.permutation_denominator_program(width, beta, gamma), width))
+    lk_num, lk_den = E.lookup_product_programs(1, 1, beta, gamma, theta)
+
+    def products():
+        for pn, pd, w in perm_progs:
+            pn.run_device(polys[:w], k, num_b, stream=stream)
+            pd.run_device(polys[:2 * w], k, den_b, stream=stream)
+            _lib.check(lib.zkhip_fr_grand_product_device(num_b, den_b, n, num_b, stream))
+        lk_num.run_device(polys[4:6], k, num_b, stream=stream)
+        lk_den.run_device(polys[6:8], k, den_b, stream=stream)
+        _lib.check(lib.zkhip_fr_grand_product_device(num_b, den_b, n, num_b, stream))
+
+    ms_p = timed(products, 3)
+    res["grand_products_4_perm_sets_1_lookup_2^22"] = {"ms": round(ms_p, 3)}
+    # multiopen: 40 evaluations, a 40-polynomial linear combination, 4 divisions by (X - x)
+    xw = F.fr_encode([x])[0]
+    lin = E.linear_combination_program([rng.randrange(F.R_MOD) for _ in range(40)])
+    ev = torch.zeros(4, dtype=torch.int64, device=dev)
+
+    def multiopen():
+        for i in range(40):
+            _lib.check(lib.zkhip_fr_eval_polynomial_device(polys[i], n, xw.ctypes.data, ev.data_ptr(), stream))
+        lin.run_device(polys[:40], k, num_b, stream=stream)
+        for i in range(4):
+            _lib.check(lib.zkhip_fr_kate_division_device(polys[i], n, xw.ctypes.data, den_b, stream))
+
+    ms_m = timed(multiopen, 3)
+    res["multiopen_40_evals_1_lincomb_4_divisions_2^22"] = {"ms": round(ms_m, 3)}
+    res["total_ms"] = round(ms_q + ms_p + ms_m, 3)
+    res["note"] = ("device-side share of create_proof besides MSM/NTT; not included: witness generation, the lookup argument's "
+                   "permute_expression_pair sort, transcript hashing (host side in the reference)")
+    del cols, outb
+    torch.cuda.empty_cache()
+    return res
 
 
 def small_replays(lib, _lib, F, torch, dev, stream, timed) -> dict:

@@ -230,3 +230,37 @@ def test_row_program_rejects_malformed_programs(lib):
     empty = E.RowProgram()
     prog, keep = empty._marshal()
     assert lib.zkhip_fr_eval_rows(C.byref(prog), ptrs, 1, 2, 0, out.ctypes.data) == -1
+
+
+def test_grand_product_inputs_of_permutation_and_lookup_arguments(lib):
+    """numerator / denominator programs + zkhip_fr_grand_product == the permutation / lookup product columns written out
+    directly ([DEP] plonk/permutation/prover.rs, plonk/lookup/prover.rs)"""
+    rng = random.Random(77)
+    k = 8
+    n = 1 << k
+    beta, gamma, theta = (rng.randrange(R) for _ in range(3))
+    omega = O.omega_for(k)
+    # permutation: a chunk of 2 columns starting at permutation column 3
+    vals = [[rng.randrange(R) for _ in range(n)] for _ in range(2)]
+    sig = [[rng.randrange(R) for _ in range(n)] for _ in range(2)]
+    num = run_host(E.permutation_numerator_program(2, 3, beta, gamma, k), vals, k)
+    den = run_host(E.permutation_denominator_program(2, beta, gamma), vals + sig, k)
+    exp_num, exp_den = [], []
+    for i in range(n):
+        a = b = 1
+        for j in range(2):
+            a = a * (vals[j][i] + pow(O.FR_DELTA, 3 + j, R) * beta % R * pow(omega, i, R) + gamma) % R
+            b = b * (vals[j][i] + beta * sig[j][i] + gamma) % R
+        exp_num.append(a); exp_den.append(b)
+    assert num == exp_num and den == exp_den
+    z = np.zeros((n, 4), dtype=np.uint64)
+    N, D = enc(num), enc(den)
+    _lib.check(lib.zkhip_fr_grand_product(N.ctypes.data, D.ctypes.data, n, z.ctypes.data))
+    assert F.fr_decode(z) == O.grand_product(exp_num, exp_den)
+    # lookup: two input / table expressions compressed with theta
+    ins = [[rng.randrange(R) for _ in range(n)] for _ in range(2)]
+    tabs = [[rng.randrange(R) for _ in range(n)] for _ in range(2)]
+    perm = [[rng.randrange(R) for _ in range(n)] for _ in range(2)]
+    pn, pd = E.lookup_product_programs(2, 2, beta, gamma, theta)
+    assert run_host(pn, ins + tabs, k) == [((ins[0][i] * theta + ins[1][i] + beta) * (tabs[0][i] * theta + tabs[1][i] + gamma)) % R for i in range(n)]
+    assert run_host(pd, perm, k) == [(perm[0][i] + beta) * (perm[1][i] + gamma) % R for i in range(n)]

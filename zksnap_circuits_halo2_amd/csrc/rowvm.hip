@@ -274,6 +274,14 @@ int row_vm_device(const zkhip_vm_program* p, const void* const* d_columns, uint3
   std::vector<unsigned char> blob(o_lo, 0);
   static_assert(sizeof(zkhip_vm_insn) == 16, "instruction layout");
   std::memcpy(blob.data() + o_prog, p->insns, (size_t)p->n_insns * 16);
+  // a product's second factor is fetched scaled by 2^5: free for a column / constant (the other unpacking shift), a repack for a
+  // register -- so put the memory operand second where the host did not
+  for (uint32_t pc = 0; pc < p->n_insns; pc++) {
+    zkhip_vm_insn* in = (zkhip_vm_insn*)(blob.data() + o_prog) + pc;
+    const bool a_mem = in->a.kind == ZKHIP_SRC_COLUMN || in->a.kind == ZKHIP_SRC_CONST;
+    const bool b_mem = in->b.kind == ZKHIP_SRC_COLUMN || in->b.kind == ZKHIP_SRC_CONST;
+    if ((in->op == ZKHIP_OP_MUL || in->op == ZKHIP_OP_MAD) && a_mem && !b_mem) { const zkhip_vm_operand t = in->a; in->a = in->b; in->b = t; }
+  }
   if (p->n_constants) std::memcpy(blob.data() + o_const, p->constants, (size_t)p->n_constants * 32);
   for (uint32_t i = 0; i < p->n_rotations; i++) {
     const int64_t off = ((int64_t)p->rotations[i] * (int64_t)p->rot_scale) % (int64_t)rows;

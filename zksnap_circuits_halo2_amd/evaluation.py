@@ -104,7 +104,10 @@ class Graph:
     def mul(self, a, b): return self.op(OP_SQR, a) if a == b else self.op(OP_MUL, a, b)
     def neg(self, a): return self.op(OP_NEG, a)
     def dbl(self, a): return self.op(OP_DBL, a)
-    def mad(self, a, b, c): return self._add(("op", OP_MAD, a, b, c))        # a * b + c
+    def mad(self, a, b, c):                                                   # a * b + c
+        if self.nodes[a] == ("const", 0) or self.nodes[b] == ("const", 0):
+            return c                                                          # 0 * b + c (the first Horner step of the reference)
+        return self._add(("op", OP_MAD, a, b, c))
 
     def horner(self, start: int, parts: Sequence[int], factor: int) -> int:
         """`Calculation::Horner(start, parts, factor)`: value = start; value = value * factor + part for each part."""
@@ -378,3 +381,43 @@ def linear_combination_program(coeffs: Sequence[int]) -> RowProgram:
     for kk in range(1, len(coeffs)):
         acc = g.mad(g.col(kk), g.const(coeffs[kk]), acc)
     return compile_graph(g, acc)
+
+
+# ---------------------------------------------------------------------------------------------------
+# grand-product inputs ([DEP] plonk/permutation/prover.rs `Argument::commit`, plonk/lookup/prover.rs `commit_product`):
+# numerator / denominator columns over the base domain (Lagrange basis, 2^k rows), fed to zkhip_fr_grand_product
+# ---------------------------------------------------------------------------------------------------
+def permutation_denominator_program(n_cols: int, beta: int, gamma: int) -> RowProgram:
+    """columns [0, n) = the chunk's values, [n, 2n) = its permutation columns sigma_j:  prod_j (v_j + beta sigma_j + gamma)"""
+    g = Graph()
+    B, G = g.const(beta), g.const(gamma)
+    acc = None
+    for j in range(n_cols):
+        t = g.add(g.mad(g.col(n_cols + j), B, g.col(j)), G)
+        acc = t if acc is None else g.mul(acc, t)
+    return compile_graph(g, acc)
+
+
+def permutation_numerator_program(n_cols: int, first_col: int, beta: int, gamma: int, k: int) -> RowProgram:
+    """columns [0, n) = the chunk's values; the chunk starts at permutation column `first_col`:
+    prod_j (v_j + delta^(first_col + j) beta omega^row + gamma)"""
+    g = Graph()
+    G = g.const(gamma)
+    acc = None
+    for j in range(n_cols):
+        t = g.add(g.mad(g.rowpow(), g.const(pow(DELTA, first_col + j, F.R_MOD) * beta % F.R_MOD), g.col(j)), G)
+        acc = t if acc is None else g.mul(acc, t)
+    return compile_graph(g, acc, omega=F.omega_for(k))
+
+
+def lookup_product_programs(n_inputs: int, n_tables: int, beta: int, gamma: int, theta: int) -> Tuple[RowProgram, RowProgram]:
+    """numerator over columns [inputs..., tables...]: (theta-compressed inputs + beta)(theta-compressed tables + gamma);
+    denominator over columns [permuted_input, permuted_table]: (a' + beta)(s' + gamma)"""
+    g = Graph()
+    T = g.const(theta)
+    cin = g.horner(g.const(0), [g.col(i) for i in range(n_inputs)], T)
+    ctab = g.horner(g.const(0), [g.col(n_inputs + i) for i in range(n_tables)], T)
+    num = compile_graph(g, g.mul(g.add(cin, g.const(beta)), g.add(ctab, g.const(gamma))))
+    g2 = Graph()
+    den = compile_graph(g2, g2.mul(g2.add(g2.col(0), g2.const(beta)), g2.add(g2.col(1), g2.const(gamma))))
+    return num, den
