@@ -70,6 +70,7 @@ def main() -> None:
         dist.init_process_group("nccl", device_id=dev)
 
     from zksnap_circuits_halo2_amd import _lib, fields as F
+    from zksnap_circuits_halo2_amd.multi_gpu import gather_fold_device
 
     lib = _lib.load()
     devs = (C.c_int * 1)(local_rank)
@@ -97,11 +98,8 @@ def main() -> None:
 
     def step():
         _lib.check(lib.zkhip_msm_g1_prepared_device(handle, 0, d_scalars.data_ptr(), n, d_out.data_ptr(), stream))
-        if world > 1:
-            dist.all_gather_into_tensor(d_gather, d_out)
-            # every rank folds the gathered partials (slots are 16 x int64; compact to 12 first)
-            parts = d_gather.view(world, 16)[:, :12].contiguous()
-            _lib.check(lib.zkhip_g1_sum_device(parts.data_ptr(), world, d_final.data_ptr(), stream))
+        if world > 1:   # every rank gathers the 128-byte slots and folds the partials
+            gather_fold_device(d_out, d_gather, d_final, stream)
 
     for _ in range(args.warmup):
         step()

@@ -600,3 +600,63 @@ def test_cpp_host_mirror(cref, tmp_path):
     assert np.array_equal(take(1, 4)[0], cref.eval_polynomial(poly, enc1(dom.omega)))
     assert np.array_equal(take(n - 1, 4), cref.kate_division(poly, enc1(dom.omega)))
     assert pos == raw.size
+
+
+def _gather_fold_worker(rank, world, port, n, q):
+    """one of `world` processes sharing the single GPU of the test box; gloo stands in for RCCL"""
+    import ctypes as C
+
+    import torch
+    import torch.distributed as dist
+
+    from oracle import cpu_ref as Cr
+    from zksnap_circuits_halo2_amd import _lib as L
+    from zksnap_circuits_halo2_amd.multi_gpu import gather_fold_device, shard_range
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    lib = L.load()
+    bases, t0, d = Cr.gen_bases(4321, n)
+    sc = Cr.gen_scalars(8765, n, 0)
+    lo, hi = shard_range(n, rank, world)
+    d_b = torch.from_numpy(np.ascontiguousarray(bases[lo:hi]).view(np.int64)).cuda()
+    d_s = torch.from_numpy(np.ascontiguousarray(sc[lo:hi]).view(np.int64)).cuda()
+    d_out = torch.zeros(16, dtype=torch.int64, device="cuda")
+    d_gather = torch.zeros(16 * world, dtype=torch.int64, device="cuda")
+    d_final = torch.zeros(16, dtype=torch.int64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    h = C.c_uint64(0)
+    L.check(lib.zkhip_prepare_bases_device(d_b.data_ptr(), hi - lo, C.byref(h)))
+    for _ in range(2):      # twice: the buffers are reused step after step in bench.py
+        L.check(lib.zkhip_msm_g1_prepared_device(h, 0, d_s.data_ptr(), hi - lo, d_out.data_ptr(), stream))
+        gather_fold_device(d_out, d_gather, d_final, stream)
+    torch.cuda.synchronize()
+    exp = Cr.jac_to_affine(Cr.scalar_mul(Cr.expected_scalar(sc, t0, d), Cr.generator()))
+    got = Cr.jac_to_affine(np.ascontiguousarray(d_final.cpu().numpy().view(np.uint64)[:12]))
+    q.put((rank, bool(np.array_equal(got, exp))))
+    lib.zkhip_release_bases(h)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_exchange_path_two_ranks_on_one_gpu():
+    """the N > 1 step of bench.py (prepared MSM on the rank's shard -> gather 128-byte slots -> fold) with two processes on this
+    box's single GPU and gloo in place of RCCL"""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world, n = 2, 5001
+    procs = [ctx.Process(target=_gather_fold_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
