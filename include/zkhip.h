@@ -177,7 +177,8 @@ int zkhip_profile_read(double *ms, char (*names)[64], int max);
 /* ---- parity hooks for the field / curve layer (rows a1/a2 of SURVEY.md section 8) ------------------ */
 /* field: 0 = Fq, 1 = Fr.  op: 0 mul, 1 add, 2 sub, 3 square (b ignored).  Elementwise on n elements. */
 int zkhip_test_field_op(int field, int op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
-/* op: 0 = affine a[i] + affine b[i], 1 = 2 * a[i], 2 = a[i] + (-b[i]).  out: n Jacobian points. */
+/* op: 0 = affine a[i] + affine b[i], 1 = 2 * a[i], 2 = a[i] + (-b[i]); with the quad-cooperative formulas of the reduction tail:
+ * 3 = 2 a[i] + 2 b[i], 4 = 4 a[i].  out: n Jacobian points. */
 int zkhip_test_g1_op(int op, const uint64_t *a, const uint64_t *b, uint64_t *out_xyz, size_t n);
 
 #ifdef __cplusplus

@@ -69,6 +69,32 @@ def test_curve_ops_vs_oracle(lib, cref):
         assert F.g1_decode_jacobian(out[5]) is None or op == 1
 
 
+def test_quad_cooperative_curve_ops_vs_oracle(lib, cref):
+    """the 4-lane formulas of the reduction tail (csrc/ec_quad.hpp): 2a + 2b (general add of two non-affine points) and 4a,
+    incl. identities on either side, equal points (the doubling branch) and opposite points"""
+    n = 1501                                          # ragged: the last workgroup is partly empty
+    A, _, _ = cref.gen_bases(15, n)
+    B, _, _ = cref.gen_bases(16, n)
+    A[3] = 0; B[4] = 0; A[5] = 0; B[5] = 0
+    B[6] = A[6]
+    B[7] = A[7]; B[7, 4:8] = F.g1_encode([O.neg(O.affine_from_limbs([int(x) for x in A[7]]))])[0, 4:8]
+    one = np.array(O.limbs4(O.to_mont(1, O.Q_MOD)), dtype=np.uint64)
+    tojac = lambda r: np.concatenate([r, one]) if r.any() else np.zeros(12, dtype=np.uint64)
+    dbl = lambda j: cref.jac_add(j, j)
+    for op in (3, 4):
+        out = np.zeros((n, 12), dtype=np.uint64)
+        _lib.check(lib.zkhip_test_g1_op(op, A.ctypes.data, B.ctypes.data, out.ctypes.data, n))
+        for i in list(range(0, 40)) + list(range(40, n, 13)) + [n - 1]:
+            ja, jb = tojac(A[i]), tojac(B[i])
+            exp = cref.jac_add(dbl(ja), dbl(jb)) if op == 3 else dbl(dbl(ja))
+            assert np.array_equal(cref.jac_to_affine(out[i]), cref.jac_to_affine(exp)), (op, i)
+        pts = [O.affine_from_limbs([int(x) for x in r]) for r in A[:8]], [O.affine_from_limbs([int(x) for x in r]) for r in B[:8]]
+        for i in range(8):
+            P, Q = pts[0][i], pts[1][i]
+            exp = O.add(O.add(P, P), O.add(Q, Q)) if op == 3 else O.add(O.add(P, P), O.add(P, P))
+            assert F.g1_decode_jacobian(out[i]) == exp, (op, i)
+
+
 # ---------------------------------------------------------------- row a3: best_multiexp
 def test_msm_golden_vectors(cref):
     data = json.load(open(os.path.join(GOLD, "msm_g1.json")))

@@ -722,7 +722,7 @@ int zkhip_test_g1_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
-  if (op < 0 || op > 2 || (n && (!a || !b || !out_xyz))) { set_error("test_g1_op: bad argument"); return ZKHIP_EINVAL; }
+  if (op < 0 || op > 4 || (n && (!a || !b || !out_xyz))) { set_error("test_g1_op: bad argument"); return ZKHIP_EINVAL; }
   if (n == 0) return ZKHIP_OK;
   hipStream_t s = g_ctx.stream;
   dev_buf tmp;

@@ -26,7 +26,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
-#include "ec.hpp"
+#include "ec_quad.hpp"
 #include "zkhip_internal.hpp"
 
 namespace zkhip {
@@ -567,6 +567,28 @@ __global__ void __launch_bounds__(128) k_combine_seq(const uint32_t* __restrict_
   if (live && q == 0) store_xyzz(buckets, k, acc);
 }
 
+// the same with a quad per lane of the above (small MSMs: the bucket count is far below the chip's lane count and the step is
+// the latency of its additions)
+template <int COMBINE_LANES>
+__global__ void __launch_bounds__(128) k_combine_seq_quad(const uint32_t* __restrict__ task_off, uint32_t nbuckets,
+                                                          const uint32_t* __restrict__ partials, uint32_t* __restrict__ buckets,
+                                                          uint32_t seq_parts) {
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t q = gid & 3, lane = (gid >> 2) % COMBINE_LANES, k = (gid >> 2) / COMBINE_LANES;
+  const bool live = k < nbuckets;                  // whole groups of 4 * COMBINE_LANES lanes are live or dead together
+  xyzz acc = xyzz_identity();
+  if (live) {
+    const uint32_t t = task_off[k], m = task_off[k + 1] - t;
+    const uint32_t stride = 1u << (2 * tree_levels_for(m, seq_parts));
+    const uint32_t left = (m + stride - 1) / stride;
+#pragma unroll 1
+    for (uint32_t j = lane; j < left; j += COMBINE_LANES) acc = xyzz_add_quad(acc, load_xyzz(partials, t + j * stride), q);
+  }
+#pragma unroll 1
+  for (int mask = 1; mask < COMBINE_LANES; mask <<= 1) acc = xyzz_add_quad(acc, xyzz_shfl_xor(acc, 4 * mask), q);
+  if (live && lane == 0 && q == 0) store_xyzz(buckets, k, acc);
+}
+
 // ------------------------------------------------------------------------------------------------
 // 8. pyramid reduction.  Per window, state at the start of step s (1-based):
 //      X   : N elements            (N = B >> (s-1))
@@ -597,6 +619,30 @@ __global__ void __launch_bounds__(128) k_pyramid_step(const uint32_t* __restrict
   store_xyzz(wo, tid, xyzz_add(load_xyzz(wi, ia), load_xyzz(wi, ib)));
 }
 
+// the same step with the 4 lanes of a quad per addition (ec_quad.hpp): every pyramid level is far smaller than the chip, so the
+// step time is the latency of one addition -- 4 stages of one multiplication instead of 14 dependent ones
+__global__ void __launch_bounds__(128) k_pyramid_step_quad(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                           uint32_t N, int s, uint32_t in_stride, uint32_t out_stride) {
+  const uint32_t per_win = N / 2 + (uint32_t)s * (N / 4);
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t tid = gid >> 2, q = gid & 3;
+  if (tid >= per_win) return;                          // whole quads leave together
+  const int win = blockIdx.y;
+  const uint32_t* wi = in + (size_t)win * in_stride * 36;
+  uint32_t* wo = out + (size_t)win * out_stride * 36;
+  uint32_t ia, ib;
+  if (tid < N / 2) {
+    ia = 2 * tid; ib = 2 * tid + 1;
+  } else {
+    uint32_t r = tid - N / 2;
+    uint32_t l = r / (N / 4), u = r % (N / 4);
+    if ((int)l == s - 1) { ia = 4 * u + 1; ib = 4 * u + 3; }
+    else { ia = N + l * (N / 2) + 2 * u; ib = ia + 1; }
+  }
+  const xyzz r = xyzz_add_quad(load_xyzz(wi, ia), load_xyzz(wi, ib), q);
+  if (q == 0) store_xyzz(wo, tid, r);
+}
+
 // 9a. per-window weighted sum.  Input state after the last pyramid step: X has 2 elements, Z^0..Z^(nz-1) one each.
 //     window sum = X0 + X1 + sum_l 2^l Z^l + 2^nz X1.  One 32-lane group per window: lane l < nz computes 2^l Z^l by l
 //     doublings, lane nz computes 2^nz X1, lane nz + 1 holds X0 + X1; a 4-step shuffle tree adds the terms.
@@ -620,15 +666,43 @@ __global__ void __launch_bounds__(64) k_window_horner(const uint32_t* __restrict
   if (win < W && lane == 0) store_xyzz(winsum, win, acc);
 }
 
-// 9b. fold windows: result = sum_w 2^(c w) winsum[w]; writes the Jacobian result (24 words)
+// The same with one quad per term: a 128-thread workgroup per window, term t = threadIdx / 4 (t < 32), doubling chains and the
+// 5-step addition tree on the quad formulas; the two wavefronts meet through LDS for the last addition.
+__global__ void __launch_bounds__(128) k_window_horner_quad(const uint32_t* __restrict__ in, uint32_t in_stride, int nz,
+                                                            uint32_t* __restrict__ winsum) {
+  __shared__ __attribute__((aligned(16))) uint32_t xch[36];
+  const int win = blockIdx.x, term = threadIdx.x >> 2;
+  const uint32_t q = threadIdx.x & 3;
+  const uint32_t* wi = in + (size_t)win * in_stride * 36;
+  xyzz acc = xyzz_identity();
+  int dbl = 0;
+  if (term < nz) { acc = load_xyzz(wi, 2 + term); dbl = term; }
+  else if (term == nz) { acc = load_xyzz(wi, 1); dbl = nz; }
+  else if (term == nz + 1) acc = xyzz_add_quad(load_xyzz(wi, 0), load_xyzz(wi, 1), q);
+#pragma unroll 1
+  for (int i = 0; i < dbl; i++) acc = xyzz_dbl_quad(acc, q);
+#pragma unroll 1
+  for (int mask = 4; mask < 64; mask <<= 1) acc = xyzz_add_quad(acc, xyzz_shfl_xor(acc, mask), q);   // quads 4 lanes apart
+  if (threadIdx.x == 64) store_xyzz(xch, 0, acc);       // sum of terms 16..31
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    acc = xyzz_add_quad(acc, load_xyzz(xch, 0), q);
+    if (q == 0) store_xyzz(winsum, win, acc);
+  }
+}
+
+// 9b. fold windows: result = sum_w 2^(c w) winsum[w]; writes the Jacobian result (24 words).  One quad: c (W - 1) dependent
+// doublings are the whole cost (the general path only; prepared bases need no fold).
 __global__ void __launch_bounds__(64) k_fold(const uint32_t* __restrict__ winsum, int W, int c, uint32_t* __restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (threadIdx.x >= 4 || blockIdx.x != 0) return;
+  const uint32_t q = threadIdx.x;
   xyzz acc = load_xyzz(winsum, W - 1);
   for (int w = W - 2; w >= 0; w--) {
-    for (int i = 0; i < c; i++) acc = xyzz_dbl(acc);
-    acc = xyzz_add(acc, load_xyzz(winsum, w));
+#pragma unroll 1
+    for (int i = 0; i < c; i++) acc = xyzz_dbl_quad(acc, q);
+    acc = xyzz_add_quad(acc, load_xyzz(winsum, w), q);
   }
-  store_jacobian(acc, out);
+  if (q == 0) store_jacobian(acc, out);
 }
 
 // batched prepared MSM: every bucket set's weighted sum is a final result
@@ -637,16 +711,18 @@ __global__ void __launch_bounds__(64) k_store_results(const uint32_t* __restrict
   if (k < K) store_jacobian(load_xyzz(winsum, k), out + (size_t)k * 24);
 }
 
-// sum of `m` Jacobian points (multi-GPU partial fold): out = sum in[i].  One wave: lane l sums points l, l + 64, ...,
-// then a 6-step shuffle tree (8 GPUs: depth 3 additions instead of 8 sequential ones).
+// sum of `m` Jacobian points (multi-GPU partial fold): out = sum in[i].  One wave of 16 quads on the quad formulas, then a
+// 4-step shuffle tree (8 GPUs: depth 3 additions instead of 8 sequential ones).
 __global__ void __launch_bounds__(64) k_sum_jacobian(const uint32_t* __restrict__ in, int m, uint32_t* __restrict__ out) {
   if (blockIdx.x != 0) return;
+  const uint32_t q = threadIdx.x & 3;
+  const int grp = threadIdx.x >> 2;                 // 16 quads: quad g sums points g, g + 16, ...
   xyzz acc = xyzz_identity();
-  for (int i = threadIdx.x; i < m; i += 64) acc = xyzz_add(acc, load_jacobian(in + (size_t)i * 24));
+  for (int i = grp; i < m; i += 16) acc = xyzz_add_quad(acc, load_jacobian(in + (size_t)i * 24), q);
 #pragma unroll 1
-  for (int mask = 1; mask < 64; mask <<= 1) {
-    if (mask >= m && mask > 1) break;          // lanes >= m hold the identity: higher steps add nothing
-    acc = xyzz_add(acc, xyzz_shfl_xor(acc, mask));
+  for (int mask = 4; mask < 64; mask <<= 1) {
+    if ((mask >> 2) >= m && mask > 4) break;        // quads >= m hold the identity: higher steps add nothing
+    acc = xyzz_add_quad(acc, xyzz_shfl_xor(acc, mask), q);
   }
   if (threadIdx.x == 0) store_jacobian(acc, out);
 }
@@ -850,14 +926,26 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   {
     uint32_t blocks = (uint32_t)((max_tasks + 127) / 128);
     if (blocks > 2048) blocks = 2048;
-    for (int level = 0; level < COMBINE_LEVELS; level++)
+    // a bucket holds at most max_tasks partials: levels beyond ceil(log4(max_tasks / seq_parts)) can never be needed
+    int levels = 0;
+    while (levels < COMBINE_LEVELS && (((uint64_t)max_tasks + ((uint64_t)1 << (2 * levels)) - 1) >> (2 * levels)) > seq_parts) levels++;
+    for (int level = 0; level < levels; level++)
       hipLaunchKernelGGL(k_combine_tree, dim3(blocks), dim3(128), 0, stream, tasks, counters + 1, task_off, counters + 2, partials, level, seq_parts);
   }
   {
-    if (combine_lanes == 1) hipLaunchKernelGGL(k_combine_seq<1>, dim3((NB + 127) / 128), dim3(128), 0, stream, task_off, NB, partials, pyrA, seq_parts);
-    else if (combine_lanes == 2) hipLaunchKernelGGL(k_combine_seq<2>, dim3((unsigned)(((size_t)NB * 2 + 127) / 128)), dim3(128), 0, stream, task_off, NB, partials, pyrA, seq_parts);
-    else if (combine_lanes == 4) hipLaunchKernelGGL(k_combine_seq<4>, dim3((unsigned)(((size_t)NB * 4 + 127) / 128)), dim3(128), 0, stream, task_off, NB, partials, pyrA, seq_parts);
-    else hipLaunchKernelGGL(k_combine_seq<8>, dim3((unsigned)(((size_t)NB * 8 + 127) / 128)), dim3(128), 0, stream, task_off, NB, partials, pyrA, seq_parts);
+    const size_t lanes_total = (size_t)NB * combine_lanes;
+    const bool quad = lanes_total * 4 <= 131072;        // far below the chip's lane count: the additions' latency is the step time
+    const unsigned blocks = (unsigned)((lanes_total * (quad ? 4 : 1) + 127) / 128);
+#define ZK_LAUNCH_COMBINE(L)                                                                                                                        \
+    do {                                                                                                                                              \
+      if (quad) hipLaunchKernelGGL(k_combine_seq_quad<L>, dim3(blocks), dim3(128), 0, stream, task_off, NB, partials, pyrA, seq_parts);             \
+      else hipLaunchKernelGGL(k_combine_seq<L>, dim3(blocks), dim3(128), 0, stream, task_off, NB, partials, pyrA, seq_parts);                       \
+    } while (0)
+    if (combine_lanes == 1) ZK_LAUNCH_COMBINE(1);
+    else if (combine_lanes == 2) ZK_LAUNCH_COMBINE(2);
+    else if (combine_lanes == 4) ZK_LAUNCH_COMBINE(4);
+    else ZK_LAUNCH_COMBINE(8);
+#undef ZK_LAUNCH_COMBINE
   }
   prof_mark(stream, "combine");
   // 8. pyramid: buckets were written with window stride B (dense).  Steps 1 .. c-2 leave X with 2 elements.
@@ -871,7 +959,9 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
     while (N > 2) {
       uint32_t per_win = N / 2 + (uint32_t)s * (N / 4);
       uint32_t out_stride = per_win;
-      hipLaunchKernelGGL(k_pyramid_step, dim3((per_win + 127) / 128, WB), dim3(128), 0, stream, cur, nxt, N, s, in_stride, out_stride);
+      // below ~1/4 of the chip's lanes an addition's latency is the step time: four lanes per addition
+      if ((size_t)per_win * WB <= 65536) hipLaunchKernelGGL(k_pyramid_step_quad, dim3((4 * per_win + 127) / 128, WB), dim3(128), 0, stream, cur, nxt, N, s, in_stride, out_stride);
+      else hipLaunchKernelGGL(k_pyramid_step, dim3((per_win + 127) / 128, WB), dim3(128), 0, stream, cur, nxt, N, s, in_stride, out_stride);
       uint32_t* t = cur; cur = nxt; nxt = t;
       in_stride = out_stride;
       N >>= 1;
@@ -886,7 +976,8 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
     set_error("msm: internal: B == 1");
     return ZKHIP_EINVAL;
   }
-  hipLaunchKernelGGL(k_window_horner, dim3((WB * 32 + 63) / 64), dim3(64), 0, stream, cur, in_stride, nz, winsum, WB);
+  if (WB <= 2048) hipLaunchKernelGGL(k_window_horner_quad, dim3(WB), dim3(128), 0, stream, cur, in_stride, nz, winsum);
+  else hipLaunchKernelGGL(k_window_horner, dim3((WB * 32 + 63) / 64), dim3(64), 0, stream, cur, in_stride, nz, winsum, WB);
   prof_mark(stream, "horner");
   if (prepared) hipLaunchKernelGGL(k_store_results, dim3((K + 63) / 64), dim3(64), 0, stream, winsum, K, d_out);   // one result per bucket set
   else hipLaunchKernelGGL(k_fold, dim3(1), dim3(64), 0, stream, winsum, WB, c, d_out);

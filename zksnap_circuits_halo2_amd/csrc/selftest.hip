@@ -2,7 +2,7 @@
 // they expose the device arithmetic of fp29.hpp / ec.hpp in the external memory format so tests can diff it
 // against the oracle.  Not used by the MSM / NTT paths themselves.
 #include <hip/hip_runtime.h>
-#include "ec.hpp"
+#include "ec_quad.hpp"
 #include "zkhip_internal.hpp"
 
 namespace zkhip {
@@ -44,6 +44,22 @@ __global__ void __launch_bounds__(128) k_g1_op(int op, const uint32_t* a, const 
   store_jacobian(acc, out + i * 24);
 }
 
+// quad-cooperative formulas (ec_quad.hpp), 4 lanes per element: op 3 = 2a + 2b, op 4 = 4a
+__global__ void __launch_bounds__(128) k_g1_op_quad(int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = gid >> 2;
+  const uint32_t q = (uint32_t)gid & 3;
+  if (i >= n) return;                                   // whole quads leave together
+  affine_words pa = load_affine(a, i), pb = load_affine(b, i);
+  xyzz A = xyzz_identity(), B = xyzz_identity();
+  if (!affine_is_identity(pa)) xyzz_madd(A, fe_from_ext_lazy(pa.x), fe_from_ext_lazy(pa.y));
+  if (!affine_is_identity(pb)) xyzz_madd(B, fe_from_ext_lazy(pb.x), fe_from_ext_lazy(pb.y));
+  xyzz r;
+  if (op == 3) r = xyzz_add_quad(xyzz_dbl_quad(A, q), xyzz_dbl_quad(B, q), q);
+  else r = xyzz_dbl_quad(xyzz_dbl_quad(A, q), q);
+  if (q == 0) store_jacobian(r, out + i * 24);
+}
+
 int test_field_op(int field, int op, const uint32_t* d_a, const uint32_t* d_b, uint32_t* d_out, size_t n, hipStream_t stream) {
   if (n == 0) return ZKHIP_OK;
   dim3 grid((unsigned)((n + 255) / 256)), block(256);
@@ -54,7 +70,8 @@ int test_field_op(int field, int op, const uint32_t* d_a, const uint32_t* d_b, u
 
 int test_g1_op(int op, const uint32_t* d_a, const uint32_t* d_b, uint32_t* d_out, size_t n, hipStream_t stream) {
   if (n == 0) return ZKHIP_OK;
-  hipLaunchKernelGGL(k_g1_op, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, stream, op, d_a, d_b, d_out, n);
+  if (op >= 3) hipLaunchKernelGGL(k_g1_op_quad, dim3((unsigned)((4 * n + 127) / 128)), dim3(128), 0, stream, op, d_a, d_b, d_out, n);
+  else hipLaunchKernelGGL(k_g1_op, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, stream, op, d_a, d_b, d_out, n);
   return hipGetLastError() == hipSuccess ? ZKHIP_OK : ZKHIP_EHIP;
 }
 
