@@ -411,9 +411,16 @@ def cpu_baseline(log_n, d_scalars, d_bases, d_out, n) -> dict:
     if m == n:
         got = d_out.cpu().numpy().view(np.uint64)[:12]
         agree = bool(np.array_equal(Cr.jac_to_affine(np.ascontiguousarray(got)), Cr.jac_to_affine(ref)))
+    # one host thread ("plus a T=1 run"), on a 2^17-point prefix of the same inputs
+    m1 = min(m, 1 << 17)
+    t = time.perf_counter()
+    Cr.best_multiexp(np.ascontiguousarray(sc[:m1]), np.ascontiguousarray(bs[:m1]), 1)
+    dt1 = time.perf_counter() - t
     return {"value": round(m / dt / 1e6, 4), "unit": "Mpoints/s", "cores": threads, "kind": "port",
             "sample": f"one 2^{log_s}-point MSM, same inputs as the GPU run, {threads} threads, {dt:.2f} s wall",
-            "gpu_result_matches": agree}
+            "gpu_result_matches": agree,
+            "single_thread": {"value": round(m1 / dt1 / 1e6, 5), "unit": "Mpoints/s", "cores": 1,
+                              "sample": f"one 2^{m1.bit_length() - 1}-point MSM, {dt1:.2f} s wall"}}
 
 
 if __name__ == "__main__":

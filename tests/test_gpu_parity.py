@@ -686,3 +686,41 @@ def test_bench_exchange_path_two_ranks_on_one_gpu():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_device_buffer_pipeline_without_torch(lib, cref):
+    """a host that does not link HIP: zkhip_alloc / upload / download around the `_device` entry points (stream = NULL), chained
+    iNTT -> commit -> extended coset NTT -> back, compared with the host-buffer entry points"""
+    import ctypes as C
+
+    k, ek = 10, 12
+    n = 1 << k
+    a = cref.gen_scalars(4242, n, 0)
+    bases, t0, d = cref.gen_bases(4243, n)
+    d_a, d_b, d_out = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    _lib.check(lib.zkhip_alloc(n * 32, C.byref(d_a)))
+    _lib.check(lib.zkhip_alloc(n * 64, C.byref(d_b)))
+    _lib.check(lib.zkhip_alloc(96, C.byref(d_out)))
+    try:
+        _lib.check(lib.zkhip_upload(d_a, a.ctypes.data, n * 32))
+        _lib.check(lib.zkhip_upload(d_b, bases.ctypes.data, n * 64))
+        om_i = F.fr_encode([pow(F.omega_for(k), -1, F.R_MOD)])[0]
+        div = F.fr_encode([pow(n, -1, F.R_MOD)])[0]
+        _lib.check(lib.zkhip_ifft_scaled_device(d_a, om_i.ctypes.data, k, div.ctypes.data, None))        # lagrange_to_coeff
+        _lib.check(lib.zkhip_msm_g1_device(d_a, d_b, n, d_out, None))                                     # commit
+        coeffs = np.zeros((n, 4), dtype=np.uint64)
+        out = np.zeros(12, dtype=np.uint64)
+        _lib.check(lib.zkhip_download(coeffs.ctypes.data, d_a, n * 32))
+        _lib.check(lib.zkhip_download(out.ctypes.data, d_out, 96))
+        _lib.check(lib.zkhip_sync())
+        ref = a.copy()
+        _lib.check(lib.zkhip_ifft_scaled(ref.ctypes.data, om_i.ctypes.data, k, div.ctypes.data))
+        assert np.array_equal(coeffs, ref)
+        assert np.array_equal(aff(cref, out), aff(cref, Z.best_multiexp(ref, bases)))
+    finally:
+        for p in (d_a, d_b, d_out):
+            _lib.check(lib.zkhip_free(p))
+    assert lib.zkhip_free(None) == 0
+    z = C.c_void_p(1)
+    assert lib.zkhip_alloc(0, C.byref(z)) == 0 and not z.value
+    assert lib.zkhip_alloc(1 << 50, C.byref(z)) == -4 and not z.value            # ZKHIP_ENOMEM, no abort

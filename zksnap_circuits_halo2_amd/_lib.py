@@ -36,6 +36,11 @@ _SIGS = {
     "zkhip_fr_eval_rows_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]),
     "zkhip_fr_grand_product": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "zkhip_fr_grand_product_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "zkhip_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "zkhip_free": (C.c_int, [C.c_void_p]),
+    "zkhip_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "zkhip_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "zkhip_sync": (C.c_int, []),
     "zkhip_msm_g1_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "zkhip_prepare_bases_device": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]),
     "zkhip_prepare_bases_device_c": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint64)]),

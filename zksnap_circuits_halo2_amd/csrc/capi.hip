@@ -601,6 +601,58 @@ int zkhip_fr_prefix_product(const uint64_t* v, size_t n, uint64_t* out) {
   return host_vec_op(3, v, n, nullptr, out, n);
 }
 
+// ---- device buffers for hosts that do not link HIP -------------------------------------------------------------
+int zkhip_alloc(size_t bytes, void** d_ptr) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (!d_ptr) { set_error("alloc: null pointer"); return ZKHIP_EINVAL; }
+  *d_ptr = nullptr;
+  if (bytes == 0) return ZKHIP_OK;
+  if (hipMalloc(d_ptr, bytes) != hipSuccess) { (void)hipGetLastError(); *d_ptr = nullptr; set_error("hipMalloc(%zu) failed", bytes); return ZKHIP_ENOMEM; }
+  return ZKHIP_OK;
+}
+
+int zkhip_free(void* d_ptr) {
+  guard_t g(g_mu);
+  if (!d_ptr) return ZKHIP_OK;
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  HIPCHK(hipStreamSynchronize(g_ctx.stream));   // kernels queued on the library stream may still read it
+  HIPCHK(hipFree(d_ptr));
+  return ZKHIP_OK;
+}
+
+int zkhip_upload(void* d_dst, const void* src, size_t bytes) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (bytes && (!d_dst || !src)) { set_error("upload: null pointer"); return ZKHIP_EINVAL; }
+  if (bytes == 0) return ZKHIP_OK;
+  HIPCHK(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, g_ctx.stream));
+  HIPCHK(hipStreamSynchronize(g_ctx.stream));
+  return ZKHIP_OK;
+}
+
+int zkhip_download(void* dst, const void* d_src, size_t bytes) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (bytes && (!dst || !d_src)) { set_error("download: null pointer"); return ZKHIP_EINVAL; }
+  if (bytes == 0) return ZKHIP_OK;
+  HIPCHK(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, g_ctx.stream));
+  HIPCHK(hipStreamSynchronize(g_ctx.stream));
+  return ZKHIP_OK;
+}
+
+int zkhip_sync(void) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  HIPCHK(hipStreamSynchronize(g_ctx.stream));
+  return ZKHIP_OK;
+}
+
 // ---- section 8(f): row programs and grand products -------------------------------------------------------------
 int zkhip_fr_eval_rows_device(const zkhip_vm_program* prog, const void* const* d_columns, uint32_t n_columns, uint32_t log_rows,
                               int accumulate, void* d_out, void* stream) {
