@@ -134,6 +134,15 @@ int zkhip_fr_eval_rows_device(const zkhip_vm_program *prog, const void *const *d
 int zkhip_fr_grand_product(const uint64_t *num, const uint64_t *den, size_t n, uint64_t *z);
 int zkhip_fr_grand_product_device(const void *d_num, void *d_den, size_t n, void *d_z, void *stream);
 
+/* `permute_expression_pair` of the lookup argument [DEP plonk/lookup/prover.rs]: the first `usable_rows` rows of `input` sorted by
+ * canonical value into permuted_input; permuted_table holds, at the first row of every run of equal input values, that value, and at
+ * the other rows the table values not consumed this way, ascending, handed out from the last such row backwards (the reference's
+ * BTreeMap iteration + Vec::pop).  Rows >= usable_rows of the outputs (the blinding rows) are not written.  ZKHIP_EINVAL when an
+ * input value does not occur in the table (the reference's Error::ConstraintSystemFailure).  Outputs must not alias the inputs. */
+int zkhip_lookup_permute(const uint64_t *input, const uint64_t *table, size_t usable_rows, uint64_t *permuted_input, uint64_t *permuted_table);
+int zkhip_lookup_permute_device(const void *d_input, const void *d_table, size_t usable_rows, void *d_permuted_input, void *d_permuted_table,
+                                void *stream);
+
 /* ---- device buffers for a host that does not link HIP itself (handles instead of host slices) ---- */
 /* The `_device` entry points below take HIP device pointers so that polynomials stay in HBM from iNTT through commit, extended
  * NTT, quotient and back (PCIe is 8x slower than the NTT kernel: DESIGN.md section 5).  A Rust / C host obtains such pointers

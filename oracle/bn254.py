@@ -412,6 +412,32 @@ def grand_product(num: Sequence[int], den: Sequence[int]) -> List[int]:
     return prefix_product([a * b % R_MOD for a, b in zip(num, inv)])
 
 
+def permute_expression_pair(input_expression: Sequence[int], table_expression: Sequence[int], usable_rows: int):
+    """[DEP] halo2_proofs/src/plonk/lookup/prover.rs `permute_expression_pair`, statement by statement: sort the input, give the
+    first row of every run its own value from the table's multiset (a BTreeMap value -> count; missing value = error), then
+    iterate the map in ascending order and pop repeated rows from the end of the list for the leftovers.  Returns the usable
+    rows only (the reference appends blinding_factors + 1 random rows)."""
+    permuted_input = sorted(x % R_MOD for x in input_expression[:usable_rows])
+    leftover = {}
+    for v in table_expression[:usable_rows]:
+        leftover[v % R_MOD] = leftover.get(v % R_MOD, 0) + 1
+    permuted_table = [0] * usable_rows
+    repeated_input_rows = []
+    for row, v in enumerate(permuted_input):
+        if row == 0 or v != permuted_input[row - 1]:
+            permuted_table[row] = v
+            if leftover.get(v, 0) == 0:
+                raise ValueError("ConstraintSystemFailure: lookup input value not in table")
+            leftover[v] -= 1
+        else:
+            repeated_input_rows.append(row)
+    for coeff in sorted(leftover):                 # BTreeMap iteration order
+        for _ in range(leftover[coeff]):
+            permuted_table[repeated_input_rows.pop()] = coeff
+    assert not repeated_input_rows
+    return permuted_input, permuted_table
+
+
 # ----------------------------------------------------------------------------------------------
 # SURVEY.md section 8(f) row 1: the quotient numerator ([DEP] halo2-axiom plonk/evaluation.rs, reached from
 # /root/reference/aggregator/src/wrapper.rs:129).  Two independent restatements:

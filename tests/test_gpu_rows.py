@@ -264,3 +264,41 @@ def test_grand_product_inputs_of_permutation_and_lookup_arguments(lib):
     pn, pd = E.lookup_product_programs(2, 2, beta, gamma, theta)
     assert run_host(pn, ins + tabs, k) == [((ins[0][i] * theta + ins[1][i] + beta) * (tabs[0][i] * theta + tabs[1][i] + gamma)) % R for i in range(n)]
     assert run_host(pd, perm, k) == [(perm[0][i] + beta) * (perm[1][i] + gamma) % R for i in range(n)]
+
+
+@pytest.mark.parametrize("n,bits,seed", [(1, 3, 1), (2, 1, 2), (64, 3, 3), (1000, 6, 4), (5000, 10, 5), (1 << 14, 12, 6), (3000, 250, 7)])
+def test_lookup_permute_expression_pair_vs_reference_algorithm(lib, n, bits, seed):
+    """range-check shaped lookups (inputs below 2^bits, table = the range, padded) and full-width values; the usable rows exclude
+    the blinding rows as in the reference"""
+    rng = random.Random(seed)
+    usable = max(1, n - 6) if n > 8 else n
+    if bits < 200:
+        table = [i % (1 << bits) for i in range(n)]
+        if n < (1 << bits):                                         # small table: inputs must come from what the table holds
+            inputs = [rng.choice(table[:usable]) for _ in range(n)]
+        else:
+            inputs = [rng.randrange(1 << bits) for _ in range(n)]
+    else:
+        table = [rng.randrange(R) for _ in range(n)]
+        inputs = [rng.choice(table[:usable]) for _ in range(n)]
+    head = table[:usable]
+    rng.shuffle(head)
+    table[:usable] = head
+    exp_in, exp_tab = O.permute_expression_pair(inputs, table, usable)
+    got_in, got_tab = E.permute_expression_pair(enc(inputs), enc(table), usable)
+    assert F.fr_decode(got_in) == exp_in
+    assert F.fr_decode(got_tab) == exp_tab
+    # the defining property of the permuted pair
+    for i in range(usable):
+        assert exp_tab[i] == exp_in[i] or (i > 0 and exp_in[i] == exp_in[i - 1])
+
+
+def test_lookup_permute_reports_missing_table_value(lib):
+    inputs, table = [1, 2, 3, 9], [1, 2, 3, 4]
+    with pytest.raises(_lib.ZkhipError, match="missing from the table"):
+        E.permute_expression_pair(enc(inputs), enc(table), 4)
+    with pytest.raises(ValueError):
+        O.permute_expression_pair(inputs, table, 4)
+    # all inputs equal: one first row, the rest take the leftovers in descending row order
+    got_in, got_tab = E.permute_expression_pair(enc([5] * 6), enc([5, 1, 2, 3, 4, 0]), 6)
+    assert F.fr_decode(got_in) == [5] * 6 and F.fr_decode(got_tab) == [5, 4, 3, 2, 1, 0]

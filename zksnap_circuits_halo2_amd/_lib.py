@@ -36,6 +36,8 @@ _SIGS = {
     "zkhip_fr_eval_rows_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]),
     "zkhip_fr_grand_product": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "zkhip_fr_grand_product_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "zkhip_lookup_permute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "zkhip_lookup_permute_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "zkhip_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "zkhip_free": (C.c_int, [C.c_void_p]),
     "zkhip_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -601,6 +601,40 @@ int zkhip_fr_prefix_product(const uint64_t* v, size_t n, uint64_t* out) {
   return host_vec_op(3, v, n, nullptr, out, n);
 }
 
+// ---- lookup argument: permute_expression_pair ----------------------------------------------------------------------
+int zkhip_lookup_permute_device(const void* d_input, const void* d_table, size_t usable_rows, void* d_permuted_input, void* d_permuted_table,
+                                void* stream) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (usable_rows && (!d_input || !d_table || !d_permuted_input || !d_permuted_table)) { set_error("lookup_permute: null pointer"); return ZKHIP_EINVAL; }
+  if (usable_rows == 0) return ZKHIP_OK;
+  if ((rc = g_ctx.vm.reserve(lookup_permute_workspace_bytes(usable_rows))) != ZKHIP_OK) return rc;
+  return lookup_permute_device((const uint32_t*)d_input, (const uint32_t*)d_table, usable_rows, (uint32_t*)d_permuted_input,
+                               (uint32_t*)d_permuted_table, g_ctx.vm.p, g_ctx.vm.cap, stream ? (hipStream_t)stream : g_ctx.stream);
+}
+
+int zkhip_lookup_permute(const uint64_t* input, const uint64_t* table, size_t usable_rows, uint64_t* permuted_input, uint64_t* permuted_table) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (usable_rows && (!input || !table || !permuted_input || !permuted_table)) { set_error("lookup_permute: null pointer"); return ZKHIP_EINVAL; }
+  if (usable_rows == 0) return ZKHIP_OK;
+  const size_t bytes = usable_rows * 32;
+  hipStream_t s = g_ctx.stream;
+  if ((rc = g_ctx.poly.reserve(2 * bytes)) != ZKHIP_OK) return rc;
+  if ((rc = g_ctx.poly2.reserve(2 * bytes)) != ZKHIP_OK) return rc;
+  char* in = (char*)g_ctx.poly.p;
+  char* out = (char*)g_ctx.poly2.p;
+  HIPCHK(hipMemcpyAsync(in, input, bytes, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(in + bytes, table, bytes, hipMemcpyHostToDevice, s));
+  if ((rc = zkhip_lookup_permute_device(in, in + bytes, usable_rows, out, out + bytes, s)) != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(permuted_input, out, bytes, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(permuted_table, out + bytes, bytes, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return ZKHIP_OK;
+}
+
 // ---- device buffers for hosts that do not link HIP -------------------------------------------------------------
 int zkhip_alloc(size_t bytes, void** d_ptr) {
   guard_t g(g_mu);

@@ -54,6 +54,11 @@ int row_vm_device(const zkhip_vm_program* p, const void* const* d_columns, uint3
                   uint32_t* d_out, void* ws, size_t ws_bytes, hipStream_t stream);
 int fr_pointwise_mul_device(const uint32_t* d_a, const uint32_t* d_b, size_t n, uint32_t* d_out, hipStream_t stream);
 
+// lookup.hip
+size_t lookup_permute_workspace_bytes(size_t usable_rows);
+int lookup_permute_device(const uint32_t* d_input, const uint32_t* d_table, size_t usable_rows, uint32_t* d_out_input, uint32_t* d_out_table,
+                          void* ws, size_t ws_bytes, hipStream_t stream);
+
 // selftest.hip
 int test_field_op(int field, int op, const uint32_t* d_a, const uint32_t* d_b, uint32_t* d_out, size_t n, hipStream_t stream);
 int test_g1_op(int op, const uint32_t* d_a, const uint32_t* d_b, uint32_t* d_out, size_t n, hipStream_t stream);

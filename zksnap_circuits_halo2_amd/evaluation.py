@@ -421,3 +421,16 @@ def lookup_product_programs(n_inputs: int, n_tables: int, beta: int, gamma: int,
     g2 = Graph()
     den = compile_graph(g2, g2.mul(g2.add(g2.col(0), g2.const(beta)), g2.add(g2.col(1), g2.const(gamma))))
     return num, den
+
+
+def permute_expression_pair(input_expression: np.ndarray, table_expression: np.ndarray, usable_rows: int):
+    """`lookup::prover::permute_expression_pair` [DEP plonk/lookup/prover.rs] on the usable rows: ((n,4) uint64, (n,4) uint64) ->
+    (permuted_input, permuted_table), each (usable_rows, 4) uint64.  Raises ZkhipError when an input value is not in the table
+    (the reference's Error::ConstraintSystemFailure).  The caller appends the blinding rows."""
+    a = np.ascontiguousarray(input_expression, dtype=np.uint64).reshape(-1, 4)
+    s = np.ascontiguousarray(table_expression, dtype=np.uint64).reshape(-1, 4)
+    assert a.shape[0] >= usable_rows and s.shape[0] >= usable_rows
+    pa = np.zeros((usable_rows, 4), dtype=np.uint64)
+    ps = np.zeros((usable_rows, 4), dtype=np.uint64)
+    _lib.check(_lib.load().zkhip_lookup_permute(a.ctypes.data, s.ctypes.data, usable_rows, pa.ctypes.data, ps.ctypes.data))
+    return pa, ps
