@@ -7,6 +7,8 @@
 //     halo2_proofs::poly::EvaluationDomain::{new, lagrange_to_coeff, coeff_to_extended, extended_to_coeff,
 //                                           divide_by_vanishing_poly, extended_len, get_omega, ...}
 //     halo2_proofs::poly::kzg::commitment::ParamsKZG::{commit, commit_lagrange, get_g, k, n}
+//     ff::BatchInvert, the grand products, plonk::lookup::prover::permute_expression_pair, and row programs (plonk::evaluation)
+//     over device-resident columns (DeviceVec, RowProgram)
 // Types are the Rust memory layouts (Montgomery limbs), so buffers can be shared with a Rust host unchanged.
 // The reference's functions are infallible (`assert!` / `unwrap()`): here a failing call throws std::runtime_error with
 // zkhip_last_error(), and length mismatches throw std::invalid_argument (the `assert_eq!` of best_multiexp / best_fft).
@@ -18,6 +20,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 #include "zkhip.h"
 
@@ -154,6 +157,87 @@ inline std::vector<Fr> kate_division(const std::vector<Fr>& a, const Fr& b) {
   if (a.size() > 1) check(zkhip_fr_kate_division(a.data()->l, a.size(), b.l, q.data()->l), "kate_division");
   return q;
 }
+
+// ---- the prover's other Fr-vector steps ---------------------------
+// ff::BatchInvert: in place, zeros stay zero
+inline void batch_invert(std::vector<Fr>& a) {
+  if (!a.empty()) check(zkhip_fr_batch_invert(a.data()->l, a.size()), "batch_invert");
+}
+// the z column of the permutation / lookup arguments: z[0] = 1, z[i+1] = z[i] * num[i] / den[i]
+inline std::vector<Fr> grand_product(const std::vector<Fr>& num, const std::vector<Fr>& den) {
+  if (num.size() != den.size()) throw std::invalid_argument("grand_product: num.len() != den.len()");
+  std::vector<Fr> z(num.size());
+  if (!num.empty()) check(zkhip_fr_grand_product(num.data()->l, den.data()->l, num.size(), z.data()->l), "grand_product");
+  return z;
+}
+// plonk::lookup::prover::permute_expression_pair on the usable rows; throws (like the reference's ConstraintSystemFailure) when an
+// input value is missing from the table
+inline std::pair<std::vector<Fr>, std::vector<Fr>> permute_expression_pair(const std::vector<Fr>& input, const std::vector<Fr>& table,
+                                                                            size_t usable_rows) {
+  if (input.size() < usable_rows || table.size() < usable_rows) throw std::invalid_argument("permute_expression_pair: usable_rows > len");
+  std::vector<Fr> pi(usable_rows), pt(usable_rows);
+  if (usable_rows) check(zkhip_lookup_permute(input.data()->l, table.data()->l, usable_rows, pi.data()->l, pt.data()->l), "permute_expression_pair");
+  return {std::move(pi), std::move(pt)};
+}
+
+// A polynomial / column that lives in HBM between calls (zkhip_alloc / upload / download): what a host passes to the `_device`
+// entry points so that iNTT -> commit -> extended NTT -> quotient never cross PCIe.
+class DeviceVec {
+ public:
+  explicit DeviceVec(size_t len) : len_(len) { check(zkhip_alloc(len * sizeof(Fr), &p_), "DeviceVec"); }
+  explicit DeviceVec(const std::vector<Fr>& host) : DeviceVec(host.size()) {
+    if (len_) check(zkhip_upload(p_, host.data(), len_ * sizeof(Fr)), "DeviceVec upload");
+  }
+  DeviceVec(const DeviceVec&) = delete;
+  DeviceVec& operator=(const DeviceVec&) = delete;
+  DeviceVec(DeviceVec&& o) noexcept : p_(o.p_), len_(o.len_) { o.p_ = nullptr; o.len_ = 0; }
+  ~DeviceVec() { (void)zkhip_free(p_); }
+  void* data() const { return p_; }
+  size_t size() const { return len_; }
+  std::vector<Fr> to_host() const {
+    std::vector<Fr> h(len_);
+    if (len_) check(zkhip_download(h.data(), p_, len_ * sizeof(Fr)), "DeviceVec download");
+    return h;
+  }
+
+ private:
+  void* p_ = nullptr;
+  size_t len_ = 0;
+};
+
+// A row program (plonk::evaluation::GraphEvaluator lowered to include/zkhip.h's instruction set) over device-resident columns.
+struct RowProgram {
+  std::vector<zkhip_vm_insn> insns;
+  std::vector<Fr> constants;
+  std::vector<int32_t> rotations;
+  int32_t rot_scale = 1;
+  uint32_t result_reg = 0;
+  bool uses_omega = false;
+  Fr omega{};
+
+  static zkhip_vm_operand constant(uint16_t i) { return zkhip_vm_operand{ZKHIP_SRC_CONST, 0, i}; }
+  static zkhip_vm_operand reg(uint16_t i) { return zkhip_vm_operand{ZKHIP_SRC_REG, 0, i}; }
+  static zkhip_vm_operand column(uint16_t col, uint8_t rot_slot) { return zkhip_vm_operand{ZKHIP_SRC_COLUMN, rot_slot, col}; }
+  void emit(uint8_t op, uint8_t dst, zkhip_vm_operand a, zkhip_vm_operand b = {}, zkhip_vm_operand c = {}) {
+    insns.push_back(zkhip_vm_insn{op, dst, 0, a, b, c});
+  }
+  // out[row] = program(row) for 2^log_rows rows; `accumulate`: ZKHIP_SRC_PREV reads out[row]
+  void run(const std::vector<const DeviceVec*>& columns, uint32_t log_rows, DeviceVec& out, bool accumulate = false) const {
+    std::vector<const void*> ptrs;
+    for (const DeviceVec* c : columns) {
+      if (c->size() < ((size_t)1 << log_rows)) throw std::invalid_argument("RowProgram: column shorter than 2^log_rows");
+      ptrs.push_back(c->data());
+    }
+    if (out.size() < ((size_t)1 << log_rows)) throw std::invalid_argument("RowProgram: output shorter than 2^log_rows");
+    zkhip_vm_program p{};
+    p.insns = insns.data(); p.n_insns = (uint32_t)insns.size();
+    p.constants = constants.empty() ? nullptr : constants.data()->l; p.n_constants = (uint32_t)constants.size();
+    p.rotations = rotations.data(); p.n_rotations = (uint32_t)rotations.size();
+    p.rot_scale = rot_scale; p.result_reg = result_reg;
+    p.omega = uses_omega ? omega.l : nullptr;
+    check(zkhip_fr_eval_rows_device(&p, ptrs.data(), (uint32_t)ptrs.size(), log_rows, accumulate ? 1 : 0, out.data(), nullptr), "RowProgram::run");
+  }
+};
 
 // ---- halo2_proofs::poly::EvaluationDomain -----------------------------------------------------------------------
 class EvaluationDomain {

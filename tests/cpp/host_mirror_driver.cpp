@@ -3,7 +3,8 @@
 //   usage: host_mirror_driver <in.bin> <out.bin>
 //   in : u32 j, u32 k, then 2^k Fr (polynomial), 2^k G1Affine (SRS g)
 //   out: omega, extended_omega (Fr each), commit (G1), best_fft(poly, omega), lagrange_to_coeff(poly), coeff_to_extended(poly),
-//        divide_by_vanishing_poly(ext), extended_to_coeff(ext), eval_polynomial(poly, omega), kate_division(poly, omega)
+//        divide_by_vanishing_poly(ext), extended_to_coeff(ext), eval_polynomial(poly, omega), kate_division(poly, omega),
+//        grand_product, permute_expression_pair (2 vectors of 2^k - 6), a row program's output column
 #include <cstdio>
 #include <vector>
 #include "zkhip.hpp"
@@ -44,6 +45,30 @@ int main(int argc, char** argv) {
     Fr e = eval_polynomial(poly, domain.get_omega());
     fwrite(&e, sizeof(Fr), 1, out);
     put(out, kate_division(poly, domain.get_omega()));
+    // 8(f): grand product of (poly / shifted poly), lookup permutation of a range-shaped pair, and a row program on device columns:
+    // out[row] = poly[row] * poly[row + 1] + 7 * poly[row]
+    std::vector<Fr> den(poly.begin() + 1, poly.end());
+    den.push_back(poly[0]);
+    put(out, grand_product(poly, den));
+    std::vector<Fr> lin(n), ltab(n);
+    for (size_t i = 0; i < n; i++) {
+      lin[i] = detail::from_u64((poly[i].l[0] >> 7) % 37);
+      ltab[i] = detail::from_u64(i % 37);
+    }
+    auto perm = permute_expression_pair(lin, ltab, n - 6);
+    put(out, perm.first);
+    put(out, perm.second);
+    {
+      DeviceVec col(poly), res(n);
+      RowProgram rp;
+      rp.constants.push_back(detail::from_u64(7));
+      rp.rotations = {0, 1};
+      rp.emit(ZKHIP_OP_MUL, 0, RowProgram::column(0, 0), RowProgram::constant(0));
+      rp.emit(ZKHIP_OP_MAD, 1, RowProgram::column(0, 0), RowProgram::column(0, 1), RowProgram::reg(0));
+      rp.result_reg = 1;
+      rp.run({&col}, k, res);
+      put(out, res.to_host());
+    }
     fclose(out);
     // error behaviour: the reference's assert_eq!(coeffs.len(), bases.len())
     bool threw = false;

@@ -625,6 +625,14 @@ def test_cpp_host_mirror(cref, tmp_path):
     assert np.array_equal(back[:n], poly) and not back[n:].any()
     assert np.array_equal(take(1, 4)[0], cref.eval_polynomial(poly, enc1(dom.omega)))
     assert np.array_equal(take(n - 1, 4), cref.kate_division(poly, enc1(dom.omega)))
+    # section 8(f) pieces of the mirror
+    pv = F.fr_decode(poly)
+    assert F.fr_decode(take(n, 4)) == O.grand_product(pv, pv[1:] + pv[:1])
+    lin = [(int(poly[i, 0]) >> 7) % 37 for i in range(n)]
+    exp_in, exp_tab = O.permute_expression_pair(lin, [i % 37 for i in range(n)], n - 6)
+    assert F.fr_decode(take(n - 6, 4)) == exp_in
+    assert F.fr_decode(take(n - 6, 4)) == exp_tab
+    assert F.fr_decode(take(n, 4)) == [(pv[i] * pv[(i + 1) % n] + 7 * pv[i]) % O.R_MOD for i in range(n)]
     assert pos == raw.size
 
 
