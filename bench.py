@@ -343,11 +343,11 @@ def prover_phases(lib, _lib, F, torch, dev, stream, timed) -> dict:
     # multiopen: 40 evaluations, a 40-polynomial linear combination, 4 divisions by (X - x)
     xw = F.fr_encode([x])[0]
     lin = E.linear_combination_program([rng.randrange(F.R_MOD) for _ in range(40)])
-    ev = torch.zeros(4, dtype=torch.int64, device=dev)
+    ev = torch.zeros(40 * 4, dtype=torch.int64, device=dev)
+    ev_ptrs = (C.c_void_p * 40)(*polys[:40])
 
     def multiopen():
-        for i in range(40):
-            _lib.check(lib.zkhip_fr_eval_polynomial_device(polys[i], n, xw.ctypes.data, ev.data_ptr(), stream))
+        _lib.check(lib.zkhip_fr_eval_polynomial_batch_device(ev_ptrs, 40, n, xw.ctypes.data, ev.data_ptr(), stream))
         lin.run_device(polys[:40], k, num_b, stream=stream)
         for i in range(4):
             _lib.check(lib.zkhip_fr_kate_division_device(polys[i], n, xw.ctypes.data, den_b, stream))

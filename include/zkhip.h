@@ -85,6 +85,9 @@ int zkhip_fr_batch_invert(uint64_t *a, size_t n);
 int zkhip_fr_prefix_product(const uint64_t *v, size_t n, uint64_t *out);
 int zkhip_fr_eval_polynomial_device(const void *d_poly, size_t n, const uint64_t point[4], void *d_out, void *stream);
 int zkhip_fr_kate_division_device(const void *d_a, size_t n, const uint64_t b[4], void *d_q, void *stream);
+/* multiopen: `count` device-resident polynomials of n coefficients each (d_polys: host array of device pointers), all evaluated at
+ * `point`; d_out receives count results (32 bytes each).  One launch per recursion level for the whole batch. */
+int zkhip_fr_eval_polynomial_batch_device(const void *const *d_polys, size_t count, size_t n, const uint64_t point[4], void *d_out, void *stream);
 int zkhip_fr_batch_invert_device(void *d_a, size_t n, void *stream);
 int zkhip_fr_prefix_product_device(const void *d_v, size_t n, void *d_out, void *stream);
 

@@ -302,3 +302,25 @@ def test_lookup_permute_reports_missing_table_value(lib):
     # all inputs equal: one first row, the rest take the leftovers in descending row order
     got_in, got_tab = E.permute_expression_pair(enc([5] * 6), enc([5, 1, 2, 3, 4, 0]), 6)
     assert F.fr_decode(got_in) == [5] * 6 and F.fr_decode(got_tab) == [5, 4, 3, 2, 1, 0]
+
+
+@pytest.mark.parametrize("n,count", [(1, 3), (31, 2), (32, 1), (33, 5), (1025, 7), (70001, 3), (1 << 16, 40)])
+def test_eval_polynomial_batch_vs_single(lib, cref, n, count):
+    """multiopen: many polynomials at one point, one launch per recursion level; each result equals the single-polynomial path
+    and (small cases) the oracle"""
+    import torch
+
+    polys = [cref.gen_scalars(5000 + n + i, n, i % 2) for i in range(count)]
+    x = cref.gen_scalars(77 + n, 1, 0)[0]
+    d = [torch.from_numpy(p.view(np.int64)).cuda() for p in polys]
+    out = torch.zeros(count * 4, dtype=torch.int64, device="cuda")
+    ptrs = (C.c_void_p * count)(*[t.data_ptr() for t in d])
+    _lib.check(lib.zkhip_fr_eval_polynomial_batch_device(ptrs, count, n, x.ctypes.data, out.data_ptr(), None))
+    _lib.check(lib.zkhip_sync())
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(np.uint64).reshape(count, 4)
+    for i in range(count):
+        assert np.array_equal(got[i], cref.eval_polynomial(polys[i], x)), i
+    if n <= 1025:
+        xv = F.fr_decode(x)[0]
+        assert F.fr_decode(got[0]) == [O.eval_polynomial(F.fr_decode(polys[0]), xv)]

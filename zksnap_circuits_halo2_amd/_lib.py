@@ -29,6 +29,7 @@ _SIGS = {
     "zkhip_fr_batch_invert": (C.c_int, [C.c_void_p, C.c_size_t]),
     "zkhip_fr_prefix_product": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "zkhip_fr_eval_polynomial_device": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "zkhip_fr_eval_polynomial_batch_device": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "zkhip_fr_kate_division_device": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "zkhip_fr_batch_invert_device": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "zkhip_fr_prefix_product_device": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),

@@ -526,6 +526,18 @@ int zkhip_fr_eval_polynomial_device(const void* d_poly, size_t n, const uint64_t
                                    stream ? (hipStream_t)stream : g_ctx.stream);
 }
 
+int zkhip_fr_eval_polynomial_batch_device(const void* const* d_polys, size_t count, size_t n, const uint64_t point[4], void* d_out, void* stream) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (count && (!d_polys || !point || !d_out)) { set_error("eval_polynomial_batch: null pointer"); return ZKHIP_EINVAL; }
+  for (size_t i = 0; i < count && n; i++)
+    if (!d_polys[i]) { set_error("eval_polynomial_batch: polynomial %zu is null", i); return ZKHIP_EINVAL; }
+  if ((rc = g_ctx.ws.reserve(poly_batch_workspace_bytes(n, count))) != ZKHIP_OK) return rc;
+  return fr_eval_polynomial_batch_device(d_polys, count, n, (const uint32_t*)point, (uint32_t*)d_out, g_ctx.ws.p, g_ctx.ws.cap,
+                                         stream ? (hipStream_t)stream : g_ctx.stream);
+}
+
 int zkhip_fr_kate_division_device(const void* d_a, size_t n, const uint64_t b[4], void* d_q, void* stream) {
   guard_t g(g_mu);
   int rc = ensure_init();

@@ -66,6 +66,23 @@ __global__ void k_pow_const(const fe_arg* __restrict__ b_dev, uint32_t e, uint32
   for (int i = 0; i < 8; i++) out_ext[i] = w[i];
 }
 
+// batched form of pass A for many polynomials of one length evaluated at one point (multiopen: every advice / fixed / permutation
+// polynomial at x): blockIdx.y = polynomial; level 0 reads through a pointer table, deeper levels a dense [count][n] array.
+// The last level (n <= CH) is the evaluation itself.
+__global__ void __launch_bounds__(256) k_horner_agg_batch(const uint32_t* const* __restrict__ ptrs, const uint32_t* __restrict__ base, size_t n,
+                                                          const fe_arg* __restrict__ b_dev, uint32_t* __restrict__ agg, size_t m) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t lo = t * POLY_CH;
+  if (lo >= n) return;
+  const size_t hi = lo + POLY_CH < n ? lo + POLY_CH : n;
+  const uint32_t* a = ptrs ? ptrs[blockIdx.y] : base + (size_t)blockIdx.y * n * 8;
+  const fe_arg b_ext = *b_dev;
+  const fe b = fr_const_internal(b_ext);
+  fe q = fe_zero();
+  for (size_t i = hi; i-- > lo;) q = fe_norm(fe_add(load_ext(a, i), fe_mul<Fr>(b, q)));
+  store_canon(agg + (size_t)blockIdx.y * m * 8, t, q);
+}
+
 // ---- prefix product --------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_prod_agg(const uint32_t* __restrict__ v, size_t n, uint32_t* __restrict__ agg) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -210,6 +227,48 @@ int fr_eval_polynomial_device(const uint32_t* d_a, size_t n, const uint32_t x_ho
   int rc = stage_const(x_host, (char*)ws, ws_bytes, stream, &b);
   if (rc != ZKHIP_OK) return rc;
   return horner_scan(d_a, n, b, nullptr, 0, d_result, (char*)ws, stream);
+}
+
+// `count` polynomials of n coefficients each, all evaluated at x: d_results[p] = sum_i poly_p[i] x^i.  One launch per recursion
+// level for the whole batch (ceil(log_32 n) levels) instead of one recursion per polynomial.
+size_t poly_batch_workspace_bytes(size_t n, size_t count) {
+  size_t total = 8192 + ((count * 8 + 255) / 256) * 256, m = n;
+  while (m > 1) { m = chunks_of(m); total += ((count * m * 32 + 255) / 256) * 256 + 256; }
+  return total;
+}
+
+int fr_eval_polynomial_batch_device(const void* const* d_polys_host, size_t count, size_t n, const uint32_t x_host[8], uint32_t* d_results,
+                                    void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (count == 0) return ZKHIP_OK;
+  if (n == 0) { HIPCHK(hipMemsetAsync(d_results, 0, count * 32, stream)); return ZKHIP_OK; }
+  if (count > 65535) { set_error("eval_polynomial_batch: more than 65535 polynomials"); return ZKHIP_EINVAL; }
+  if (ws_bytes < poly_batch_workspace_bytes(n, count)) { set_error("eval_polynomial_batch: workspace too small"); return ZKHIP_EINVAL; }
+  char* p = (char*)ws;
+  const uint32_t** d_ptrs = (const uint32_t**)p;
+  p += ((count * 8 + 255) / 256) * 256;
+  fe_arg* b = (fe_arg*)p;
+  p += 256;
+  HIPCHK(hipMemcpyAsync(d_ptrs, d_polys_host, count * 8, hipMemcpyHostToDevice, stream));
+  HIPCHK(hipMemcpyAsync(b, x_host, 32, hipMemcpyHostToDevice, stream));
+  HIPCHK(hipStreamSynchronize(stream));                     // both sources are caller memory
+  const uint32_t* cur = nullptr;                            // level 0 reads through d_ptrs
+  size_t cur_n = n;
+  while (true) {
+    const size_t m = chunks_of(cur_n);
+    uint32_t* agg = m == 1 ? d_results : (uint32_t*)p;      // the last level's single aggregate per polynomial is the evaluation
+    hipLaunchKernelGGL(k_horner_agg_batch, dim3((unsigned)((m + 255) / 256), (unsigned)count), dim3(256), 0, stream,
+                       cur ? (const uint32_t* const*)nullptr : (const uint32_t* const*)d_ptrs, cur, cur_n, (const fe_arg*)b, agg, m);
+    if (m == 1) break;
+    p += ((count * m * 32 + 255) / 256) * 256;
+    fe_arg* bpow = (fe_arg*)p;
+    p += 256;
+    hipLaunchKernelGGL(k_pow_const, dim3(1), dim3(64), 0, stream, (const fe_arg*)b, POLY_CH, (uint32_t*)bpow);
+    b = bpow;
+    cur = agg;
+    cur_n = m;
+  }
+  HIPCHK(hipGetLastError());
+  return ZKHIP_OK;
 }
 
 // kate_division: q[i] = a[i+1] + b q[i+1], i < n-1  (quotient of a(X) by (X - b), remainder dropped)
