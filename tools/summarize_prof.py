@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 output directories into the summaries committed under profiles/.
+  summarize_prof.py stats <dir> <out.csv>            copy the --stats kernel table (largest first)
+  summarize_prof.py pmc <fetch_dir> <write_dir> <out.txt> <out.json>   per-kernel averages of FETCH_SIZE / WRITE_SIZE (KiB per dispatch)
+FETCH_SIZE gets the gfx950 x2 correction the MI355X guide prescribes for wide coalesced streams; both figures are listed."""
+import csv, glob, json, os, re, sqlite3, sys
+from collections import defaultdict
+
+def find(d, suffix):
+    hits = glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True)
+    if not hits: raise SystemExit(f"no *{suffix} under {d}")
+    return hits[0]
+
+def short(name):
+    m = re.match(r"(?:void )?(zkhip::\w+(?:<[^>]*>)?)", name)
+    return m.group(1) if m else name[:60]
+
+def counters(d, counter):
+    """per kernel: (dispatches, average counter value); reads rocprofv3's rocpd database (default output) or its csv output"""
+    acc = defaultdict(list)
+    dbs = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
+    if dbs:
+        for name, value in sqlite3.connect(dbs[0]).execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
+            acc[short(name)].append(float(value))
+    else:
+        with open(find(d, "counter_collection.csv")) as f:
+            for r in csv.DictReader(f):
+                if r["Counter_Name"] == counter: acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    return {k: (len(v), sum(v) / len(v)) for k, v in acc.items()}
+
+def kernel_stats(d):
+    dbs = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
+    if not dbs: return list(csv.reader(open(find(d, "kernel_stats.csv"))))
+    per = defaultdict(list)
+    for name, dur in sqlite3.connect(dbs[0]).execute("select name, duration from kernels"): per[name].append(int(dur))
+    total = sum(sum(v) for v in per.values())
+    rows = [["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"]]
+    for name, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+        rows.append([name, len(v), sum(v), round(sum(v) / len(v), 1), round(100.0 * sum(v) / total, 2), min(v), max(v)])
+    return rows
+
+if sys.argv[1] == "stats":
+    rows = kernel_stats(sys.argv[2])
+    with open(sys.argv[3], "w", newline="") as f: csv.writer(f, quoting=csv.QUOTE_NONNUMERIC).writerows(rows)
+else:
+    fetch, write = counters(sys.argv[2], "FETCH_SIZE"), counters(sys.argv[3], "WRITE_SIZE")
+    lines = ["rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), same command as the bench line:",
+             "python3 bench.py --steps 3 --warmup 1 --no-extras --no-cpu-baseline.  Counter unit: KiB per dispatch (average over the kernel's",
+             "dispatches).  gfx950 (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts half the bytes of a wide coalesced stream; x2 = corrected.", "", "FETCH_SIZE"]
+    for k, (n, v) in sorted(fetch.items(), key=lambda kv: -kv[1][1])[:16]:
+        lines.append(f"  {k:44s} dispatches={n:4d}  avg = {v:12.1f} KiB = {v*1024/1e6:9.1f} MB   x2 = {2*v*1024/1e6:9.1f} MB")
+    lines += ["", "WRITE_SIZE"]
+    for k, (n, v) in sorted(write.items(), key=lambda kv: -kv[1][1])[:16]:
+        lines.append(f"  {k:44s} dispatches={n:4d}  avg = {v:12.1f} KiB = {v*1024/1e6:9.1f} MB")
+    open(sys.argv[4], "w").write("\n".join(lines) + "\n")
+    def entry(k):
+        fr = fetch.get(k, (0, 0.0))[1] * 1024; wr = write.get(k, (0, 0.0))[1] * 1024
+        return {"fetch_bytes_raw": round(fr), "fetch_bytes_corrected": round(2 * fr), "write_bytes": round(wr), "hbm_bytes_per_launch": round(2 * fr + wr)}
+    out = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, --kernel-trace), python3 bench.py --steps 3 --warmup 1 --no-extras --no-cpu-baseline",
+           "workload": "prepared MSM 2^20 (bench headline configuration)",
+           "correction": "FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported; counters are KiB",
+           "k_accumulate": entry("zkhip::k_accumulate"), "k_sort_pass_scatter": entry("zkhip::k_sort_pass<true>")}
+    json.dump(out, open(sys.argv[5], "w"), indent=1)
