@@ -1,0 +1,147 @@
+"""GPU (-m gpu): the §8(f) pieces composed the way create_proof composes them ([DEP] halo2-axiom plonk/prover.rs, reached from
+/root/reference/aggregator/src/wrapper.rs:129), on a small satisfied circuit of the halo2-lib shape: vertical gate
+q (a + b c - d), a range lookup, copy constraints over advice and fixed columns.
+
+Parity at this boundary is unpinned by the reference (no fixtures), and evaluate_h is restated from the published algorithm; this
+test therefore pins the restatement to the *mathematics* instead: for a satisfying witness the quotient numerator built by the
+row program must be divisible by X^n - 1, i.e. after divide_by_vanishing_poly and the inverse extended transform every
+coefficient of degree >= 3n vanishes -- and it must stop vanishing as soon as one gate output, one copy, or one grand product is
+broken.  Along the way: both grand products close (z(omega^u) = 1) and the permuted lookup pair satisfies its defining property."""
+import random
+
+import numpy as np
+import pytest
+
+import zksnap_circuits_halo2_amd as Z
+from oracle import bn254 as O
+from zksnap_circuits_halo2_amd import _lib, evaluation as E, fields as F
+
+pytestmark = pytest.mark.gpu
+R = O.R_MOD
+K, BLIND = 6, 5
+N = 1 << K
+U = N - (BLIND + 1)                       # usable rows
+PERM_COLUMNS = [("advice", 0), ("advice", 1), ("fixed", 1)]
+
+
+def enc(v):
+    return F.fr_encode(v)
+
+
+def toy_circuit(rng, break_gate=False, break_copy=False):
+    """fixed [q0, fconst, table], advice [a0 (gate column), a1 (lookup input)]; returns the Lagrange columns and sigma"""
+    q0 = [1 if (i % 4 == 0 and i + 3 < U) else 0 for i in range(N)]
+    table = [i % 16 for i in range(N)]
+    fconst = [rng.randrange(R) for _ in range(N)]
+    a0 = [rng.randrange(R) for _ in range(N)]
+    a1 = [rng.randrange(16) if i < U else rng.randrange(R) for i in range(N)]
+    # copy constraints between free cells (gate inputs, lookup inputs, fixed constants): cycles of (column, row)
+    cycles = [[(0, 1), (2, 2)], [(1, 10), (1, 20)], [(0, 13), (1, 30)], [(0, 17), (0, 21), (2, 5)]]
+    cols = [a0, a1, fconst]
+    for cyc in cycles:
+        lookup_rows = [r for c, r in cyc if c == 1]
+        v = a1[lookup_rows[0]] if lookup_rows else cols[cyc[0][0]][cyc[0][1]]     # a cycle through a lookup cell carries a table value
+        for c, r in cyc:
+            cols[c][r] = v
+    if break_copy:
+        a0[21] = (a0[21] + 1) % R                           # before the gate outputs: only the copy is broken
+    for i in range(N):
+        if q0[i]:
+            a0[i + 3] = (a0[i] + a0[i + 1] * a0[i + 2]) % R
+    if break_gate:
+        a0[7] = (a0[7] + 1) % R
+    # sigma: identity, then each cycle maps a cell to the next one
+    sigma = {(c, r): (c, r) for c in range(3) for r in range(N)}
+    for cyc in cycles:
+        for idx, cell in enumerate(cyc):
+            sigma[cell] = cyc[(idx + 1) % len(cyc)]
+    omega = O.omega_for(K)
+    sig_cols = [[pow(O.FR_DELTA, sigma[(c, r)][0], R) * pow(omega, sigma[(c, r)][1], R) % R for r in range(N)] for c in range(3)]
+    return dict(fixed=[q0, fconst, table], advice=[a0, a1], sigma=sig_cols)
+
+
+def quotient_top_coefficients(circ, rng, tamper_z=False):
+    cs = E.ConstraintSystem(num_fixed=3, num_advice=2, num_instance=0,
+                            gates=[[E.Fixed(0) * (E.Advice(0, 0) + E.Advice(0, 1) * E.Advice(0, 2) - E.Advice(0, 3))]],
+                            lookups=[E.Lookup([E.Advice(1)], [E.Fixed(2)])], permutation_columns=PERM_COLUMNS,
+                            blinding_factors=BLIND, degree=4)
+    dom = Z.EvaluationDomain(4, K)
+    ek = dom.extended_k
+    beta, gamma, theta, y = (rng.randrange(R) for _ in range(4))
+    lagr = {"fixed": circ["fixed"], "advice": circ["advice"]}
+    values = [lagr[kind][idx] for kind, idx in PERM_COLUMNS]
+    blind = lambda col: col[:U + 1] + [rng.randrange(R) for _ in range(N - U - 1)]
+
+    # permutation argument: one z per chunk of chunk_len columns, chained through z_k[0] = z_{k-1}[u]
+    z_sets, last_z = [], 1
+    for s in range(cs.num_permutation_sets):
+        lo, hi = s * cs.chunk_len, min((s + 1) * cs.chunk_len, len(values))
+        w = hi - lo
+        num = E.permutation_numerator_program(w, lo, beta, gamma, K).run([enc(c) for c in values[lo:hi]], K)
+        den = E.permutation_denominator_program(w, beta, gamma).run([enc(c) for c in values[lo:hi]] + [enc(c) for c in circ["sigma"][lo:hi]], K)
+        z = np.zeros((N, 4), dtype=np.uint64)
+        _lib.check(_lib.load().zkhip_fr_grand_product(num.ctypes.data, den.ctypes.data, N, z.ctypes.data))
+        z = [v * last_z % R for v in F.fr_decode(z)]
+        last_z = z[U]
+        z_sets.append(blind(z))
+    perm_closes = last_z == 1
+
+    # lookup argument
+    A, S = circ["advice"][1], circ["fixed"][2]
+    pa, ps = E.permute_expression_pair(enc(A), enc(S), U)
+    pa = F.fr_decode(pa) + [rng.randrange(R) for _ in range(N - U)]
+    ps = F.fr_decode(ps) + [rng.randrange(R) for _ in range(N - U)]
+    for i in range(U):
+        assert ps[i] == pa[i] or (i > 0 and pa[i] == pa[i - 1])
+    pn, pd = E.lookup_product_programs(1, 1, beta, gamma, theta)
+    num, den = pn.run([enc(A), enc(S)], K), pd.run([enc(pa), enc(ps)], K)
+    zl = np.zeros((N, 4), dtype=np.uint64)
+    _lib.check(_lib.load().zkhip_fr_grand_product(num.ctypes.data, den.ctypes.data, N, zl.ctypes.data))
+    zl = F.fr_decode(zl)
+    lookup_closes = zl[U] == 1
+    zl = blind(zl)
+    if tamper_z:
+        z_sets[0][9] = (z_sets[0][9] + 1) % R
+
+    l0 = [1 if i == 0 else 0 for i in range(N)]
+    l_last = [1 if i == U else 0 for i in range(N)]
+    l_active = [1 if i < U else 0 for i in range(N)]
+    qc = E.quotient_columns(cs)
+    lagrange_cols = circ["fixed"] + circ["advice"] + [l0, l_last, l_active] + circ["sigma"] + z_sets + [zl, pa, ps]
+    assert len(lagrange_cols) == qc.total
+    ext_cols = [dom.coeff_to_extended(dom.lagrange_to_coeff(enc(c))) for c in lagrange_cols]
+
+    prog = E.evaluate_h_program(cs, K, ek, beta, gamma, theta, y)
+    numerator = prog.run(ext_cols, ek)
+    h_ext = dom.divide_by_vanishing_poly(numerator)
+    coeffs = np.zeros((dom.extended_len(), 4), dtype=np.uint64)
+    buf = h_ext.copy()
+    _lib.check(_lib.load().zkhip_extended_to_coeff(buf.ctypes.data, ek, dom.extended_omega_inv.ctypes.data, dom.extended_ifft_divisor.ctypes.data,
+                                                   dom.g_coset.ctypes.data, coeffs.ctypes.data, dom.extended_len()))
+    c = F.fr_decode(coeffs)
+    return c[:3 * N], c[3 * N:], perm_closes, lookup_closes
+
+
+def test_satisfied_circuit_gives_a_polynomial_quotient(lib):
+    rng = random.Random(2024)
+    low, top, perm_closes, lookup_closes = quotient_top_coefficients(toy_circuit(rng), rng)
+    assert perm_closes and lookup_closes
+    assert any(low) and not any(top)                      # h has degree < 3n: the numerator is a multiple of X^n - 1
+
+
+@pytest.mark.parametrize("what", ["gate", "copy", "z"])
+def test_broken_witness_is_not_divisible(lib, what):
+    rng = random.Random(7)
+    circ = toy_circuit(rng, break_gate=what == "gate", break_copy=what == "copy")
+    low, top, perm_closes, lookup_closes = quotient_top_coefficients(circ, rng, tamper_z=what == "z")
+    assert any(top)
+    assert perm_closes == (what != "copy")                # a broken copy also leaves the permutation product open
+    assert lookup_closes
+
+
+def test_lookup_input_outside_the_table_is_reported(lib):
+    rng = random.Random(9)
+    circ = toy_circuit(rng)
+    circ["advice"][1][3] = 99                              # not a table value
+    with pytest.raises(_lib.ZkhipError):
+        quotient_top_coefficients(circ, rng)
