@@ -287,7 +287,7 @@ int zkhip_unregister_bases(const uint64_t* bases) {
   guard_t g(g_mu);
   auto it = g_ctx.registered.find(bases);
   if (it == g_ctx.registered.end()) { set_error("unregister_bases: pointer not registered"); return ZKHIP_EINVAL; }
-  (void)hipStreamSynchronize(g_ctx.stream);
+  (void)hipDeviceSynchronize();             // the table may still be in use on a caller's stream
   release_prepared(it->second);
   g_ctx.registered.erase(it);
   return ZKHIP_OK;
