@@ -177,6 +177,13 @@ int zkhip_msm_g1_device_c(const void *d_scalars, const void *d_bases, size_t n, 
 int zkhip_ntt_fr_device(void *d_a, const uint64_t omega[4], uint32_t log_n, void *stream);
 int zkhip_ifft_scaled_device(void *d_a, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4], void *stream);
 int zkhip_mul_periodic_device(void *d_a, size_t n, const void *d_table, uint32_t period, void *stream);
+/* coset transforms on device-resident polynomials, `batch` of them per launch set (polynomial b at base + b * stride elements;
+ * d_out must not overlap d_a).  coeff_to_extended reads 2^k coefficients and writes 2^ext_k evaluations per polynomial;
+ * extended_to_coeff reads 2^ext_k evaluations and writes out_len coefficients per polynomial. */
+int zkhip_coeff_to_extended_device(const void *d_a, size_t a_stride, uint32_t k, void *d_out, size_t out_stride, uint32_t ext_k, uint32_t batch,
+                                   const uint64_t ext_omega[4], const uint64_t zeta[4], void *stream);
+int zkhip_extended_to_coeff_device(const void *d_a, size_t a_stride, uint32_t ext_k, const uint64_t ext_omega_inv[4], const uint64_t ext_divisor[4],
+                                   const uint64_t zeta[4], void *d_out, size_t out_stride, size_t out_len, uint32_t batch, void *stream);
 /* `batch` polynomials of 2^log_n elements, polynomial b at d_a + b * stride elements (stride >= 2^log_n), one launch set:
  * many small transforms (voter / state-transition columns at k = 13..17) run at large-transform throughput */
 int zkhip_ntt_fr_batch_device(void *d_a, const uint64_t omega[4], uint32_t log_n, uint32_t batch, size_t stride, void *stream);

@@ -732,3 +732,37 @@ def test_device_buffer_pipeline_without_torch(lib, cref):
     z = C.c_void_p(1)
     assert lib.zkhip_alloc(0, C.byref(z)) == 0 and not z.value
     assert lib.zkhip_alloc(1 << 50, C.byref(z)) == -4 and not z.value            # ZKHIP_ENOMEM, no abort
+
+
+@pytest.mark.parametrize("k,batch", [(3, 1), (10, 3), (13, 2)])
+def test_coset_transforms_device_batch_vs_host_entry_points(lib, cref, k, batch):
+    """zkhip_coeff_to_extended_device / zkhip_extended_to_coeff_device (batched, strided, device-resident) against the host-buffer
+    entry points and the reference algorithm"""
+    import torch
+
+    dom = Z.EvaluationDomain(4, k)
+    n, en, ek = dom.n, dom.extended_len(), dom.extended_k
+    a_stride, e_stride, o_stride = n + 8, en + 16, 3 * n + 4
+    polys = [cref.gen_scalars(9100 + k + b, n, b % 2) for b in range(batch)]
+    d_a = torch.zeros(batch * a_stride * 4, dtype=torch.int64, device="cuda")
+    for b, p in enumerate(polys):
+        d_a[b * a_stride * 4:(b * a_stride + n) * 4] = torch.from_numpy(p.view(np.int64).reshape(-1)).cuda()
+    d_e = torch.zeros(batch * e_stride * 4, dtype=torch.int64, device="cuda")
+    d_o = torch.zeros(batch * o_stride * 4, dtype=torch.int64, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.zkhip_coeff_to_extended_device(d_a.data_ptr(), a_stride, k, d_e.data_ptr(), e_stride, ek, batch,
+                                                  dom.extended_omega.ctypes.data, dom.g_coset.ctypes.data, s))
+    _lib.check(lib.zkhip_extended_to_coeff_device(d_e.data_ptr(), e_stride, ek, dom.extended_omega_inv.ctypes.data, dom.extended_ifft_divisor.ctypes.data,
+                                                  dom.g_coset.ctypes.data, d_o.data_ptr(), o_stride, 3 * n, batch, s))
+    torch.cuda.synchronize()
+    ext = d_e.cpu().numpy().view(np.uint64).reshape(batch, e_stride, 4)
+    back = d_o.cpu().numpy().view(np.uint64).reshape(batch, o_stride, 4)
+    enc1 = lambda v: F.fr_encode([v])[0]
+    od = O.EvaluationDomain(4, k)
+    for b, p in enumerate(polys):
+        assert np.array_equal(ext[b, :en], dom.coeff_to_extended(p)), b
+        ref = np.zeros((en, 4), dtype=np.uint64); ref[:n] = p
+        cref.distribute_powers_zeta(ref[:n], enc1(od.g_coset), enc1(od.g_coset_inv)); cref.best_fft(ref, enc1(od.extended_omega), ek, 4)
+        assert np.array_equal(ext[b, :en], ref), b
+        assert not ext[b, en:].any() and not back[b, 3 * n:].any()            # the padding between polynomials is untouched
+        assert np.array_equal(back[b, :n], p) and not back[b, n:3 * n].any(), b

@@ -56,6 +56,8 @@ _SIGS = {
     "zkhip_ifft_scaled_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_size_t, C.c_void_p]),
     "zkhip_ifft_scaled_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "zkhip_mul_periodic_device": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "zkhip_coeff_to_extended_device": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "zkhip_extended_to_coeff_device": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint32, C.c_void_p]),
     "zkhip_g1_sum_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "zkhip_g1_sum": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "zkhip_msm_window_bits": (C.c_int, [C.c_size_t]),

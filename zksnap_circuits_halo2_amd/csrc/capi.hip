@@ -9,6 +9,7 @@
 #include <vector>
 #include <mutex>
 #include "zkhip_internal.hpp"
+#include "../../include/zkhip.hpp"   // host-side 4 x 64 Montgomery arithmetic for domain constants (zkhip::halo2::detail)
 
 namespace zkhip {
 
@@ -455,32 +456,29 @@ int zkhip_ifft_scaled(uint64_t* a, const uint64_t omega_inv[4], uint32_t log_n, 
   return host_transform(a, N, a, N, log_n, omega_inv, nullptr, 0, (const uint32_t*)divisor, 1);
 }
 
-// c[0] = base, c[1] = base * z, c[2] = base * z^2 computed on the device through the periodic-multiply kernel
-static int zeta_powers(const uint64_t* base, const uint64_t* z1, const uint64_t* z2, uint32_t out[24]) {
-  // out = {base, base*z1, base*z2}: uses mul hook on 2 elements
-  uint64_t a[8], b[8], r[8];
-  memcpy(a, base, 32); memcpy(a + 4, base, 32);
-  memcpy(b, z1, 32); memcpy(b + 4, z2, 32);
-  int rc = zkhip_test_field_op(1, 0, a, b, r, 2);
-  if (rc != ZKHIP_OK) return rc;
-  memcpy(out, base, 32); memcpy(out + 8, r, 64);
-  return ZKHIP_OK;
+// scale triples of the coset transforms, computed on the host (4 x 64 Montgomery, include/zkhip.hpp):
+//   into the coset:   {1, zeta, zeta^2}                      (distribute_powers_zeta(.., true): [g_coset, g_coset_inv])
+//   out of the coset: divisor * {1, zeta^2, zeta}            (distribute_powers_zeta(.., false) + the ifft divisor)
+static void coset_scales(const uint64_t zeta[4], const uint64_t* divisor, uint32_t out[24]) {
+  namespace hd = zkhip::halo2::detail;
+  zkhip::halo2::Fr z, zz, c0;
+  memcpy(z.l, zeta, 32);
+  zz = hd::mul(z, z);
+  if (!divisor) {
+    c0 = hd::one();
+    memcpy(out, c0.l, 32); memcpy(out + 8, z.l, 32); memcpy(out + 16, zz.l, 32);
+  } else {
+    memcpy(c0.l, divisor, 32);
+    const zkhip::halo2::Fr c1 = hd::mul(c0, zz), c2 = hd::mul(c0, z);
+    memcpy(out, c0.l, 32); memcpy(out + 8, c1.l, 32); memcpy(out + 16, c2.l, 32);
+  }
 }
 
 int zkhip_coeff_to_extended(const uint64_t* a, uint32_t k, uint64_t* out, uint32_t ext_k, const uint64_t ext_omega[4], const uint64_t zeta[4]) {
   guard_t g(g_mu);
   if (!a || !out || !ext_omega || !zeta || k > ext_k || ext_k > 28) { set_error("coeff_to_extended: bad argument"); return ZKHIP_EINVAL; }
-  // in-scale {1, zeta, zeta^2}: zeta^2 via one device multiply; "1" in Montgomery form = zeta^3, obtained the same way
-  uint64_t zz[8], z3[4];
-  uint64_t za[8], zb[8];
-  memcpy(za, zeta, 32); memcpy(za + 4, zeta, 32);
-  memcpy(zb, zeta, 32); memcpy(zb + 4, zeta, 32);
-  int rc = zkhip_test_field_op(1, 0, za, zb, zz, 1);          // zz[0..4) = zeta^2
-  if (rc != ZKHIP_OK) return rc;
-  rc = zkhip_test_field_op(1, 0, zz, zeta, z3, 1);            // zeta^3 (= 1 for a cube root of unity)
-  if (rc != ZKHIP_OK) return rc;
   uint32_t sc[24];
-  memcpy(sc, z3, 32); memcpy(sc + 8, zeta, 32); memcpy(sc + 16, zz, 32);
+  coset_scales(zeta, nullptr, sc);
   return host_transform(a, (size_t)1 << k, out, (size_t)1 << ext_k, ext_k, ext_omega, sc, 3, nullptr, 0);
 }
 
@@ -488,14 +486,38 @@ int zkhip_extended_to_coeff(uint64_t* a, uint32_t ext_k, const uint64_t ext_omeg
                             const uint64_t zeta[4], uint64_t* out, size_t out_len) {
   guard_t g(g_mu);
   if (!a || !out || !ext_omega_inv || !ext_divisor || !zeta || ext_k > 28) { set_error("extended_to_coeff: bad argument"); return ZKHIP_EINVAL; }
-  // out-scale divisor * {1, zeta^2, zeta}   (distribute_powers_zeta(.., false) uses [g_coset_inv, g_coset] = [zeta^2, zeta])
-  uint64_t zz[4];
-  int rc = zkhip_test_field_op(1, 0, zeta, zeta, zz, 1);
-  if (rc != ZKHIP_OK) return rc;
   uint32_t sc[24];
-  rc = zeta_powers(ext_divisor, zz, zeta, sc);
-  if (rc != ZKHIP_OK) return rc;
+  coset_scales(zeta, ext_divisor, sc);
   return host_transform(a, (size_t)1 << ext_k, out, out_len, ext_k, ext_omega_inv, nullptr, 0, sc, 3);
+}
+
+// device-resident forms, `batch` polynomials per launch set (polynomial b at base + b * stride elements)
+int zkhip_coeff_to_extended_device(const void* d_a, size_t a_stride, uint32_t k, void* d_out, size_t out_stride, uint32_t ext_k, uint32_t batch,
+                                   const uint64_t ext_omega[4], const uint64_t zeta[4], void* stream) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (!d_a || !d_out || !ext_omega || !zeta || k > ext_k || ext_k > 28 || a_stride < ((size_t)1 << k) || out_stride < ((size_t)1 << ext_k) ||
+      a_stride >= ((size_t)1 << 32) || out_stride >= ((size_t)1 << 32)) { set_error("coeff_to_extended: bad argument"); return ZKHIP_EINVAL; }
+  if (batch == 0) return ZKHIP_OK;
+  uint32_t sc[24];
+  coset_scales(zeta, nullptr, sc);
+  return run_transform((const uint32_t*)d_a, 1u << k, (uint32_t)a_stride, (uint32_t*)d_out, 1u << ext_k, (uint32_t)out_stride, batch, ext_k,
+                       (const uint32_t*)ext_omega, sc, 3, nullptr, 0, stream ? (hipStream_t)stream : g_ctx.stream);
+}
+
+int zkhip_extended_to_coeff_device(const void* d_a, size_t a_stride, uint32_t ext_k, const uint64_t ext_omega_inv[4], const uint64_t ext_divisor[4],
+                                   const uint64_t zeta[4], void* d_out, size_t out_stride, size_t out_len, uint32_t batch, void* stream) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (!d_a || !d_out || !ext_omega_inv || !ext_divisor || !zeta || ext_k > 28 || out_len > ((size_t)1 << ext_k) || a_stride < ((size_t)1 << ext_k) ||
+      out_stride < out_len || a_stride >= ((size_t)1 << 32) || out_stride >= ((size_t)1 << 32)) { set_error("extended_to_coeff: bad argument"); return ZKHIP_EINVAL; }
+  if (batch == 0 || out_len == 0) return ZKHIP_OK;
+  uint32_t sc[24];
+  coset_scales(zeta, ext_divisor, sc);
+  return run_transform((const uint32_t*)d_a, 1u << ext_k, (uint32_t)a_stride, (uint32_t*)d_out, (uint32_t)out_len, (uint32_t)out_stride, batch, ext_k,
+                       (const uint32_t*)ext_omega_inv, nullptr, 0, sc, 3, stream ? (hipStream_t)stream : g_ctx.stream);
 }
 
 int zkhip_mul_periodic(uint64_t* a, size_t n, const uint64_t* table, uint32_t period) {
