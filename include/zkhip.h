@@ -149,16 +149,17 @@ int zkhip_lookup_permute_device(const void *d_input, const void *d_table, size_t
 /* ---- device buffers for a host that does not link HIP itself (handles instead of host slices) ---- */
 /* The `_device` entry points below take HIP device pointers so that polynomials stay in HBM from iNTT through commit, extended
  * NTT, quotient and back (PCIe is 8x slower than the NTT kernel: DESIGN.md section 5).  A Rust / C host obtains such pointers
- * here.  Copies are ordered with respect to the library's kernels on its internal stream (the one used when `stream` is NULL);
+ * here.  Copies run on HIP's default stream (the one the `_device` entry points use when `stream` is NULL) and block:
  * zkhip_download returns when the data is in `dst`, zkhip_upload when `src` may be reused. */
 int zkhip_alloc(size_t bytes, void **d_ptr);
 int zkhip_free(void *d_ptr);
 int zkhip_upload(void *d_dst, const void *src, size_t bytes);
 int zkhip_download(void *dst, const void *d_src, size_t bytes);
-/* wait for everything queued on the library's internal stream */
+/* wait for everything this process has queued on the device */
 int zkhip_sync(void);
 
-/* ---- device-resident variants (pointers are HIP device pointers; stream is a hipStream_t or NULL) --- */
+/* ---- device-resident variants (pointers are HIP device pointers; stream is a hipStream_t; NULL = HIP's default stream 0, ordered
+ * with the caller's other default-stream work -- e.g. what torch.cuda.current_stream().cuda_stream is when no stream was set) --- */
 /* Used by the pipeline / bench so that polynomials and scalars stay in HBM between calls. */
 int zkhip_msm_g1_device(const void *d_scalars, const void *d_bases, size_t n, void *d_out_xyz, void *stream);
 /* prepared (fixed-base) path for device-resident bases: the handle owns the table until released */

@@ -97,6 +97,11 @@ static const prepared_bases* find_registered(const uint64_t* bases, size_t n, si
   return nullptr;
 }
 
+// `stream` argument of the `_device` entry points: NULL is HIP's default (legacy) stream -- stream 0, which is what a caller
+// holding "the default stream" (e.g. torch.cuda.current_stream().cuda_stream == 0) passes, and which is ordered with that caller's
+// other default-stream work.  (The host-buffer entry points use the library's own non-blocking stream and synchronise it.)
+static inline hipStream_t caller_stream(void* stream) { return (hipStream_t)stream; }
+
 }  // namespace zkhip
 
 using namespace zkhip;
@@ -161,7 +166,7 @@ int zkhip_msm_g1_device_c(const void* d_scalars, const void* d_bases, size_t n, 
   const int c = window_bits > 0 ? window_bits : msm_pick_window(n ? n : 1);
   const size_t need = n ? msm_workspace_bytes(n, c) : 0;
   if ((rc = g_ctx.ws.reserve(need)) != ZKHIP_OK) return rc;
-  hipStream_t s = stream ? (hipStream_t)stream : g_ctx.stream;
+  hipStream_t s = caller_stream(stream);
   return msm_g1_device((const uint32_t*)d_scalars, (const uint32_t*)d_bases, n, (uint32_t*)d_out_xyz, g_ctx.ws.p, g_ctx.ws.cap, c, s);
 }
 
@@ -255,6 +260,7 @@ int zkhip_prepare_bases_device_c(const void* d_bases, size_t n, int window_bits,
   if (rc != ZKHIP_OK) return rc;
   if (!d_bases || !handle || n == 0) { set_error("prepare_bases: bad argument"); return ZKHIP_EINVAL; }
   prepared_bases* pb = nullptr;
+  HIPCHK(hipDeviceSynchronize());           // d_bases may still be being written on the caller's stream; one-time call
   if ((rc = prepare_bases_device((const uint32_t*)d_bases, n, g_ctx.stream, &pb, window_bits)) != ZKHIP_OK) return rc;
   *handle = g_ctx.next_handle++;
   g_ctx.handles[*handle] = pb;
@@ -281,7 +287,7 @@ int zkhip_msm_g1_prepared_device(uint64_t handle, size_t offset, const void* d_s
   const prepared_bases* pb = it->second;
   if ((rc = g_ctx.ws.reserve(n ? msm_workspace_bytes(n, pb->c, true) : 0)) != ZKHIP_OK) return rc;
   return msm_g1_device((const uint32_t*)d_scalars, nullptr, n, (uint32_t*)d_out_xyz, g_ctx.ws.p, g_ctx.ws.cap, 0,
-                       stream ? (hipStream_t)stream : g_ctx.stream, pb, offset);
+                       caller_stream(stream), pb, offset);
 }
 
 int zkhip_unregister_bases(const uint64_t* bases) {
@@ -303,8 +309,8 @@ int zkhip_msm_g1_prepared_batch_device(uint64_t handle, size_t offset, const voi
   if (it == g_ctx.handles.end()) { set_error("msm_prepared_batch: unknown handle"); return ZKHIP_EINVAL; }
   if (!d_out_xyz || (n && batch && !d_scalars) || (batch > 1 && scalar_stride < n)) { set_error("msm_prepared_batch: bad argument"); return ZKHIP_EINVAL; }
   const prepared_bases* pb = it->second;
-  hipStream_t s = stream ? (hipStream_t)stream : g_ctx.stream;
-  // tables built for wide windows (n >= 2^21) do not batch: those MSMs are throughput-bound one at a time
+  hipStream_t s = caller_stream(stream);
+  // tables built for wide windows (n >= 2^20) do not batch: those MSMs are throughput-bound one at a time
   size_t group = (pb->c > 16 || batch <= 1) ? 1 : batch;
   while (group > 1 && ((size_t)((256 + pb->c - 1) / pb->c) * n * group >= (1ull << 31) || (group << (pb->c - 1)) > (1ull << 22))) group = (group + 1) / 2;   // <= 4 Mi buckets per launch set
   for (size_t k0 = 0; k0 < batch; k0 += group) {
@@ -322,7 +328,7 @@ int zkhip_g1_sum_device(const void* d_points_xyz, int m, void* d_out_xyz, void* 
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
   if (m < 0 || !d_out_xyz || (m && !d_points_xyz)) { set_error("g1_sum: bad argument"); return ZKHIP_EINVAL; }
-  return sum_jacobian_device((const uint32_t*)d_points_xyz, m, (uint32_t*)d_out_xyz, stream ? (hipStream_t)stream : g_ctx.stream);
+  return sum_jacobian_device((const uint32_t*)d_points_xyz, m, (uint32_t*)d_out_xyz, caller_stream(stream));
 }
 
 int zkhip_g1_sum(const uint64_t* points_xyz, int m, uint64_t out_xyz[12]) {
@@ -364,7 +370,7 @@ int zkhip_ntt_fr_batch_device(void* d_a, const uint64_t omega[4], uint32_t log_n
   if (!d_a || !omega || log_n > 28 || stride < ((size_t)1 << log_n) || stride >= ((size_t)1 << 32)) { set_error("ntt_batch: bad argument"); return ZKHIP_EINVAL; }
   const uint32_t N = 1u << log_n;
   return run_transform((const uint32_t*)d_a, N, (uint32_t)stride, (uint32_t*)d_a, N, (uint32_t)stride, batch, log_n, (const uint32_t*)omega, nullptr, 0,
-                       nullptr, 0, stream ? (hipStream_t)stream : g_ctx.stream);
+                       nullptr, 0, caller_stream(stream));
 }
 
 int zkhip_ifft_scaled_batch_device(void* d_a, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4], uint32_t batch, size_t stride,
@@ -375,7 +381,7 @@ int zkhip_ifft_scaled_batch_device(void* d_a, const uint64_t omega_inv[4], uint3
   if (!d_a || !omega_inv || !divisor || log_n > 28 || stride < ((size_t)1 << log_n) || stride >= ((size_t)1 << 32)) { set_error("ifft_batch: bad argument"); return ZKHIP_EINVAL; }
   const uint32_t N = 1u << log_n;
   return run_transform((const uint32_t*)d_a, N, (uint32_t)stride, (uint32_t*)d_a, N, (uint32_t)stride, batch, log_n, (const uint32_t*)omega_inv, nullptr, 0,
-                       (const uint32_t*)divisor, 1, stream ? (hipStream_t)stream : g_ctx.stream);
+                       (const uint32_t*)divisor, 1, caller_stream(stream));
 }
 
 int zkhip_ntt_fr_device(void* d_a, const uint64_t omega[4], uint32_t log_n, void* stream) {
@@ -385,7 +391,7 @@ int zkhip_ntt_fr_device(void* d_a, const uint64_t omega[4], uint32_t log_n, void
   if (!d_a || !omega) { set_error("ntt: null pointer"); return ZKHIP_EINVAL; }
   if (log_n > 28) { set_error("ntt: log_n = %u > 28", log_n); return ZKHIP_EINVAL; }
   const uint32_t N = 1u << log_n;
-  return run_transform((const uint32_t*)d_a, N, N, (uint32_t*)d_a, N, N, 1, log_n, (const uint32_t*)omega, nullptr, 0, nullptr, 0, stream ? (hipStream_t)stream : g_ctx.stream);
+  return run_transform((const uint32_t*)d_a, N, N, (uint32_t*)d_a, N, N, 1, log_n, (const uint32_t*)omega, nullptr, 0, nullptr, 0, caller_stream(stream));
 }
 
 int zkhip_ifft_scaled_device(void* d_a, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4], void* stream) {
@@ -396,7 +402,7 @@ int zkhip_ifft_scaled_device(void* d_a, const uint64_t omega_inv[4], uint32_t lo
   if (log_n > 28) { set_error("ifft: log_n = %u > 28", log_n); return ZKHIP_EINVAL; }
   const uint32_t N = 1u << log_n;
   return run_transform((const uint32_t*)d_a, N, N, (uint32_t*)d_a, N, N, 1, log_n, (const uint32_t*)omega_inv, nullptr, 0, (const uint32_t*)divisor, 1,
-                       stream ? (hipStream_t)stream : g_ctx.stream);
+                       caller_stream(stream));
 }
 
 int zkhip_mul_periodic_device(void* d_a, size_t n, const void* d_table, uint32_t period, void* stream) {
@@ -404,7 +410,7 @@ int zkhip_mul_periodic_device(void* d_a, size_t n, const void* d_table, uint32_t
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
   if ((n && !d_a) || !d_table) { set_error("mul_periodic: null pointer"); return ZKHIP_EINVAL; }
-  return fr_mul_periodic_device((uint32_t*)d_a, n, (const uint32_t*)d_table, period, stream ? (hipStream_t)stream : g_ctx.stream);
+  return fr_mul_periodic_device((uint32_t*)d_a, n, (const uint32_t*)d_table, period, caller_stream(stream));
 }
 
 static int host_transform(const uint64_t* in, size_t in_len, uint64_t* out, size_t out_len, uint32_t log_n, const uint64_t* omega,
@@ -503,7 +509,7 @@ int zkhip_coeff_to_extended_device(const void* d_a, size_t a_stride, uint32_t k,
   uint32_t sc[24];
   coset_scales(zeta, nullptr, sc);
   return run_transform((const uint32_t*)d_a, 1u << k, (uint32_t)a_stride, (uint32_t*)d_out, 1u << ext_k, (uint32_t)out_stride, batch, ext_k,
-                       (const uint32_t*)ext_omega, sc, 3, nullptr, 0, stream ? (hipStream_t)stream : g_ctx.stream);
+                       (const uint32_t*)ext_omega, sc, 3, nullptr, 0, caller_stream(stream));
 }
 
 int zkhip_extended_to_coeff_device(const void* d_a, size_t a_stride, uint32_t ext_k, const uint64_t ext_omega_inv[4], const uint64_t ext_divisor[4],
@@ -517,7 +523,7 @@ int zkhip_extended_to_coeff_device(const void* d_a, size_t a_stride, uint32_t ex
   uint32_t sc[24];
   coset_scales(zeta, ext_divisor, sc);
   return run_transform((const uint32_t*)d_a, 1u << ext_k, (uint32_t)a_stride, (uint32_t*)d_out, (uint32_t)out_len, (uint32_t)out_stride, batch, ext_k,
-                       (const uint32_t*)ext_omega_inv, nullptr, 0, sc, 3, stream ? (hipStream_t)stream : g_ctx.stream);
+                       (const uint32_t*)ext_omega_inv, nullptr, 0, sc, 3, caller_stream(stream));
 }
 
 int zkhip_mul_periodic(uint64_t* a, size_t n, const uint64_t* table, uint32_t period) {
@@ -545,7 +551,7 @@ int zkhip_fr_eval_polynomial_device(const void* d_poly, size_t n, const uint64_t
   if (!point || !d_out || (n && !d_poly)) { set_error("eval_polynomial: null pointer"); return ZKHIP_EINVAL; }
   if ((rc = g_ctx.ws.reserve(poly_workspace_bytes(n))) != ZKHIP_OK) return rc;
   return fr_eval_polynomial_device((const uint32_t*)d_poly, n, (const uint32_t*)point, (uint32_t*)d_out, g_ctx.ws.p, g_ctx.ws.cap,
-                                   stream ? (hipStream_t)stream : g_ctx.stream);
+                                   caller_stream(stream));
 }
 
 int zkhip_fr_eval_polynomial_batch_device(const void* const* d_polys, size_t count, size_t n, const uint64_t point[4], void* d_out, void* stream) {
@@ -557,7 +563,7 @@ int zkhip_fr_eval_polynomial_batch_device(const void* const* d_polys, size_t cou
     if (!d_polys[i]) { set_error("eval_polynomial_batch: polynomial %zu is null", i); return ZKHIP_EINVAL; }
   if ((rc = g_ctx.ws.reserve(poly_batch_workspace_bytes(n, count))) != ZKHIP_OK) return rc;
   return fr_eval_polynomial_batch_device(d_polys, count, n, (const uint32_t*)point, (uint32_t*)d_out, g_ctx.ws.p, g_ctx.ws.cap,
-                                         stream ? (hipStream_t)stream : g_ctx.stream);
+                                         caller_stream(stream));
 }
 
 int zkhip_fr_kate_division_device(const void* d_a, size_t n, const uint64_t b[4], void* d_q, void* stream) {
@@ -567,7 +573,7 @@ int zkhip_fr_kate_division_device(const void* d_a, size_t n, const uint64_t b[4]
   if (!b || (n > 1 && (!d_a || !d_q))) { set_error("kate_division: null pointer"); return ZKHIP_EINVAL; }
   if ((rc = g_ctx.ws.reserve(poly_workspace_bytes(n))) != ZKHIP_OK) return rc;
   return fr_kate_division_device((const uint32_t*)d_a, n, (const uint32_t*)b, (uint32_t*)d_q, g_ctx.ws.p, g_ctx.ws.cap,
-                                 stream ? (hipStream_t)stream : g_ctx.stream);
+                                 caller_stream(stream));
 }
 
 int zkhip_fr_batch_invert_device(void* d_a, size_t n, void* stream) {
@@ -576,7 +582,7 @@ int zkhip_fr_batch_invert_device(void* d_a, size_t n, void* stream) {
   if (rc != ZKHIP_OK) return rc;
   if (n && !d_a) { set_error("batch_invert: null pointer"); return ZKHIP_EINVAL; }
   if ((rc = g_ctx.ws.reserve(poly_workspace_bytes(n))) != ZKHIP_OK) return rc;
-  return fr_batch_invert_device((uint32_t*)d_a, n, g_ctx.ws.p, g_ctx.ws.cap, stream ? (hipStream_t)stream : g_ctx.stream);
+  return fr_batch_invert_device((uint32_t*)d_a, n, g_ctx.ws.p, g_ctx.ws.cap, caller_stream(stream));
 }
 
 int zkhip_fr_prefix_product_device(const void* d_v, size_t n, void* d_out, void* stream) {
@@ -585,7 +591,7 @@ int zkhip_fr_prefix_product_device(const void* d_v, size_t n, void* d_out, void*
   if (rc != ZKHIP_OK) return rc;
   if (n && (!d_v || !d_out)) { set_error("prefix_product: null pointer"); return ZKHIP_EINVAL; }
   if ((rc = g_ctx.ws.reserve(poly_workspace_bytes(n))) != ZKHIP_OK) return rc;
-  return fr_prefix_product_device((const uint32_t*)d_v, n, (uint32_t*)d_out, g_ctx.ws.p, g_ctx.ws.cap, stream ? (hipStream_t)stream : g_ctx.stream);
+  return fr_prefix_product_device((const uint32_t*)d_v, n, (uint32_t*)d_out, g_ctx.ws.p, g_ctx.ws.cap, caller_stream(stream));
 }
 
 // host-buffer wrappers: upload to the poly scratch, run, download
@@ -645,7 +651,7 @@ int zkhip_lookup_permute_device(const void* d_input, const void* d_table, size_t
   if (usable_rows == 0) return ZKHIP_OK;
   if ((rc = g_ctx.vm.reserve(lookup_permute_workspace_bytes(usable_rows))) != ZKHIP_OK) return rc;
   return lookup_permute_device((const uint32_t*)d_input, (const uint32_t*)d_table, usable_rows, (uint32_t*)d_permuted_input,
-                               (uint32_t*)d_permuted_table, g_ctx.vm.p, g_ctx.vm.cap, stream ? (hipStream_t)stream : g_ctx.stream);
+                               (uint32_t*)d_permuted_table, g_ctx.vm.p, g_ctx.vm.cap, caller_stream(stream));
 }
 
 int zkhip_lookup_permute(const uint64_t* input, const uint64_t* table, size_t usable_rows, uint64_t* permuted_input, uint64_t* permuted_table) {
@@ -686,7 +692,7 @@ int zkhip_free(void* d_ptr) {
   if (!d_ptr) return ZKHIP_OK;
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
-  HIPCHK(hipStreamSynchronize(g_ctx.stream));   // kernels queued on the library stream may still read it
+  HIPCHK(hipDeviceSynchronize());               // kernels queued on any stream may still use it
   HIPCHK(hipFree(d_ptr));
   return ZKHIP_OK;
 }
@@ -697,8 +703,7 @@ int zkhip_upload(void* d_dst, const void* src, size_t bytes) {
   if (rc != ZKHIP_OK) return rc;
   if (bytes && (!d_dst || !src)) { set_error("upload: null pointer"); return ZKHIP_EINVAL; }
   if (bytes == 0) return ZKHIP_OK;
-  HIPCHK(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, g_ctx.stream));
-  HIPCHK(hipStreamSynchronize(g_ctx.stream));
+  HIPCHK(hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));      // default stream, blocking
   return ZKHIP_OK;
 }
 
@@ -708,8 +713,7 @@ int zkhip_download(void* dst, const void* d_src, size_t bytes) {
   if (rc != ZKHIP_OK) return rc;
   if (bytes && (!dst || !d_src)) { set_error("download: null pointer"); return ZKHIP_EINVAL; }
   if (bytes == 0) return ZKHIP_OK;
-  HIPCHK(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, g_ctx.stream));
-  HIPCHK(hipStreamSynchronize(g_ctx.stream));
+  HIPCHK(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
   return ZKHIP_OK;
 }
 
@@ -717,7 +721,7 @@ int zkhip_sync(void) {
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
-  HIPCHK(hipStreamSynchronize(g_ctx.stream));
+  HIPCHK(hipDeviceSynchronize());
   return ZKHIP_OK;
 }
 
@@ -731,7 +735,7 @@ int zkhip_fr_eval_rows_device(const zkhip_vm_program* prog, const void* const* d
   if (!d_out || (n_columns && !d_columns)) { set_error("eval_rows: null pointer"); return ZKHIP_EINVAL; }
   if ((rc = g_ctx.vm.reserve(row_vm_workspace_bytes(prog, n_columns, log_rows))) != ZKHIP_OK) return rc;
   return row_vm_device(prog, d_columns, n_columns, log_rows, accumulate, (uint32_t*)d_out, g_ctx.vm.p, g_ctx.vm.cap,
-                       stream ? (hipStream_t)stream : g_ctx.stream);
+                       caller_stream(stream));
 }
 
 int zkhip_fr_eval_rows(const zkhip_vm_program* prog, const uint64_t* const* columns, uint32_t n_columns, uint32_t log_rows,
@@ -764,7 +768,7 @@ int zkhip_fr_grand_product_device(const void* d_num, void* d_den, size_t n, void
   if (rc != ZKHIP_OK) return rc;
   if (n && (!d_num || !d_den || !d_z)) { set_error("grand_product: null pointer"); return ZKHIP_EINVAL; }
   if (n == 0) return ZKHIP_OK;
-  hipStream_t s = stream ? (hipStream_t)stream : g_ctx.stream;
+  hipStream_t s = caller_stream(stream);
   if ((rc = zkhip_fr_batch_invert_device(d_den, n, s)) != ZKHIP_OK) return rc;
   if ((rc = fr_pointwise_mul_device((const uint32_t*)d_num, (const uint32_t*)d_den, n, (uint32_t*)d_den, s)) != ZKHIP_OK) return rc;
   return zkhip_fr_prefix_product_device(d_den, n, d_z, s);
@@ -814,7 +818,7 @@ int zkhip_g1_gen_walk_device(const uint64_t t0[4], const uint64_t d[4], size_t n
   if (!t0 || !d || (n && !d_out)) { set_error("gen_walk: null pointer"); return ZKHIP_EINVAL; }
   if ((rc = g_ctx.ws.reserve(g1_gen_walk_workspace(n))) != ZKHIP_OK) return rc;
   return g1_gen_walk_device((const uint32_t*)t0, (const uint32_t*)d, n, (uint32_t*)d_out, g_ctx.ws.p, g_ctx.ws.cap,
-                            stream ? (hipStream_t)stream : g_ctx.stream);
+                            caller_stream(stream));
 }
 
 // ---- parity hooks ----------------------------------------------------------------------------------

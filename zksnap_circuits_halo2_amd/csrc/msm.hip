@@ -753,7 +753,7 @@ int msm_pick_window_prepared(size_t n) {
   for (int c = 2; c <= MAX_WINDOW_PREPARED; c++) {
     double W = (256 + c - 1) / c;
     double cost = W * 10.0 * (double)n + 28.0 * (double)(1u << (c - 1)) + (c > 16 ? W * 1.0 * (double)n : 0.0);
-    if (c > 16 && n < ((size_t)1 << 21)) continue;   // measured: c = 20 ties at 2^20 (2.07 vs 2.05 ms), wins from 2^21 (3.57 vs 3.71 ms)
+    if (c > 16 && n < ((size_t)1 << 20)) continue;   // measured with the quad-cooperative tail: c = 20 loses at 2^19 (1.47 vs 1.34 ms), wins from 2^20 (1.84 vs 1.94 ms)
     if (cost < best_cost) { best_cost = cost; best = c; }
   }
   if (const char* e = getenv("ZKHIP_MAX_WINDOW")) { int m = atoi(e); if (m >= 2 && best > m) best = m; }   // A/B knob
