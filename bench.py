@@ -55,6 +55,7 @@ def main() -> None:
     ap.add_argument("--log-n", type=int, default=20, help="log2 points per GPU (BASELINE configs[1] = 20)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the NTT / wrapper-replay extras")
+    ap.add_argument("--no-general-path", action="store_true", help="skip the unregistered-bases MSM (rocprofv3 runs: keeps per-kernel averages to the headline path)")
     args = ap.parse_args()
 
     import torch
@@ -153,13 +154,16 @@ def main() -> None:
             _lib.check(lib.zkhip_msm_g1_prepared_device(handle, 0, d_scalars.data_ptr(), n, d_out.data_ptr(), stream))
             for name, ms in profile_read(lib):
                 acc[name] = acc.get(name, 0.0) + ms / reps
+            if args.no_general_path:
+                continue
             _lib.check(lib.zkhip_msm_g1_device(d_scalars.data_ptr(), d_bases.data_ptr(), n, d_out.data_ptr(), stream))
             for name, ms in profile_read(lib):
                 gen[name] = gen.get(name, 0.0) + ms / reps
         lib.zkhip_profile_enable(0)
         # arbitrary (unregistered) bases: per-window bucket sets + window fold
-        result["general_path"] = {"ms": round(sum(gen.values()), 4), "Mpoints_per_s": round(n / sum(gen.values()) / 1e3, 2),
-                                  "phases_ms": {k: round(v, 4) for k, v in gen.items()}}
+        if gen:
+            result["general_path"] = {"ms": round(sum(gen.values()), 4), "Mpoints_per_s": round(n / sum(gen.values()) / 1e3, 2),
+                                      "phases_ms": {k: round(v, 4) for k, v in gen.items()}}
         _lib.check(lib.zkhip_msm_g1_prepared_device(handle, 0, d_scalars.data_ptr(), n, d_out.data_ptr(), stream))
         torch.cuda.synchronize()
         t_acc = acc.get("accumulate", float("nan"))
@@ -177,9 +181,11 @@ def main() -> None:
                               "whole_msm_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / 8000.0, 5),
                               "note": "256-bit modular-integer work: ALU-bound, not HBM-bound (DESIGN.md)"}
         # issue-rate view of the same kernel: 8M + 2S mixed addition = 8*162 + 2*126 v_mad_u64_u32 (ISA count),
-        # W*n additions per launch; peak = the v_mad_u64_u32-only issue rate measured by tools/isa_rate.hip at 4 waves/SIMD
-        imads = (8 * 162 + 2 * 126) * 16.0 * n
-        result["valu_roofline"] = {"kernel": "k_accumulate", "unit": "T v_mad_u64_u32 lane-ops/s", "achieved": round(imads / (t_acc * 1e-3) / 1e12, 2),
+        # W*n additions per launch (W = ceil(256 / c) windows of the prepared table); peak = the v_mad_u64_u32-only issue rate measured by tools/isa_rate.hip at 4 waves/SIMD
+        c_bits = lib.zkhip_prepared_window_bits(handle)
+        windows = (256 + c_bits - 1) // c_bits
+        imads = (8 * 162 + 2 * 126) * float(windows) * n
+        result["valu_roofline"] = {"kernel": "k_accumulate", "window_bits": c_bits, "windows": windows, "unit": "T v_mad_u64_u32 lane-ops/s", "achieved": round(imads / (t_acc * 1e-3) / 1e12, 2),
                                    "peak": 27.95, "frac": round(imads / (t_acc * 1e-3) / 1e12 / 27.95, 3),
                                    "note": "the other ~1/3 of the kernel's instructions (carry splits, masks, adds) share the same issue slots"}
         result["phases_ms"] = {k: round(v, 4) for k, v in acc.items()}

@@ -167,6 +167,8 @@ int zkhip_prepare_bases_device(const void *d_bases, size_t n, uint64_t *handle);
 /* same with an explicit window size (2..20; 0 = automatic) -- experiments and tests of the wide-window path */
 int zkhip_prepare_bases_device_c(const void *d_bases, size_t n, int window_bits, uint64_t *handle);
 int zkhip_release_bases(uint64_t handle);
+/* window size (bits) the handle's table was built for; <= 0 for an unknown handle */
+int zkhip_prepared_window_bits(uint64_t handle);
 int zkhip_msm_g1_prepared_device(uint64_t handle, size_t offset, const void *d_scalars, size_t n, void *d_out_xyz, void *stream);
 /* `batch` scalar vectors (vector k at d_scalars + k * scalar_stride elements) against the same prepared bases in one launch
  * set -- e.g. all advice columns of a circuit: small MSMs (k = 13..17) then run at large-MSM throughput.  d_out_xyz: batch

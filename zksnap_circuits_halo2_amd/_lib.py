@@ -48,6 +48,7 @@ _SIGS = {
     "zkhip_prepare_bases_device": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]),
     "zkhip_prepare_bases_device_c": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint64)]),
     "zkhip_release_bases": (C.c_int, [C.c_uint64]),
+    "zkhip_prepared_window_bits": (C.c_int, [C.c_uint64]),
     "zkhip_msm_g1_prepared_device": (C.c_int, [C.c_uint64, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "zkhip_msm_g1_prepared_batch_device": (C.c_int, [C.c_uint64, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]),
     "zkhip_msm_g1_device_c": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),

@@ -277,6 +277,13 @@ int zkhip_release_bases(uint64_t handle) {
   return ZKHIP_OK;
 }
 
+int zkhip_prepared_window_bits(uint64_t handle) {
+  guard_t g(g_mu);
+  auto it = g_ctx.handles.find(handle);
+  if (it == g_ctx.handles.end()) { set_error("prepared_window_bits: unknown handle"); return ZKHIP_EINVAL; }
+  return it->second->c;
+}
+
 int zkhip_msm_g1_prepared_device(uint64_t handle, size_t offset, const void* d_scalars, size_t n, void* d_out_xyz, void* stream) {
   guard_t g(g_mu);
   int rc = ensure_init();
