@@ -766,3 +766,39 @@ def test_coset_transforms_device_batch_vs_host_entry_points(lib, cref, k, batch)
         assert np.array_equal(ext[b, :en], ref), b
         assert not ext[b, en:].any() and not back[b, 3 * n:].any()            # the padding between polynomials is untouched
         assert np.array_equal(back[b, :n], p) and not back[b, n:3 * n].any(), b
+
+
+@pytest.mark.parametrize("pattern", ["all_equal", "two_values", "ragged_zero_tail"])
+def test_msm_wide_window_path_under_skew(lib, cref, pattern):
+    """the configuration bench.py times (prepared bases, n >= 2^20: c = 20, two-level sort) with scalar vectors that put every entry
+    of a window into one or two buckets, and with a ragged length whose tail is all zero"""
+    import ctypes as C
+
+    import torch
+
+    n = (1 << 20) + (37 if pattern == "ragged_zero_tail" else 0)
+    T0, D = 0x5A4B534E41500777, 0x9E3779B97F4A7C15F39CC0605CEDC835
+    t0m, dm = F.fr_encode([T0])[0], F.fr_encode([D])[0]
+    bases = torch.empty(n * 8, dtype=torch.int64, device="cuda")
+    _lib.check(lib.zkhip_g1_gen_walk_device(t0m.ctypes.data, dm.ctypes.data, n, bases.data_ptr(), None))
+    h = C.c_uint64(0)
+    _lib.check(lib.zkhip_prepare_bases_device(bases.data_ptr(), n, C.byref(h)))
+    assert lib.zkhip_prepared_window_bits(h) == 20
+    try:
+        if pattern == "all_equal":
+            sc = np.tile(cref.gen_scalars(1, 1, 0), (n, 1))
+        elif pattern == "two_values":
+            two = cref.gen_scalars(2, 2, 0)
+            sc = two[np.arange(n) % 2]
+        else:
+            sc = cref.gen_scalars(3, n, 1)
+            sc[n // 2:] = 0
+        sc = np.ascontiguousarray(sc)
+        dsc = torch.from_numpy(sc.view(np.int64)).cuda()
+        out = torch.zeros(12, dtype=torch.int64, device="cuda")
+        _lib.check(lib.zkhip_msm_g1_prepared_device(h, 0, dsc.data_ptr(), n, out.data_ptr(), None))
+        torch.cuda.synchronize()
+        exp = cref.jac_to_affine(cref.scalar_mul(cref.expected_scalar(sc, T0, D), cref.generator()))
+        assert np.array_equal(aff(cref, out.cpu().numpy().view(np.uint64)), exp)
+    finally:
+        _lib.check(lib.zkhip_release_bases(h))
