@@ -7,13 +7,15 @@
 //   * hands the map's leftover entries, in ascending order, to the remaining rows taken from the *end* (Vec::pop).
 // Restated for a GPU as sorts, a binary search and two scans:
 //   keys      canonical integers of A and S (one Montgomery multiply each)
-//   sort      both key arrays (rocPRIM merge sort with a 256-bit comparison; plain library sort, not a hot kernel)
+//   sort      both key arrays (rocPRIM: radix sort of the low limbs when every key fits 64 bits -- range checks --, else a merge sort
+//             with a 256-bit comparison; plain library sorts, not hot kernels)
 //   mark      first-of-run rows of A'; each looks up its value in the sorted table (lower bound) and marks that instance used
 //   scan      rank of every repeated row among the repeated rows; rank of every unused table instance among the unused ones
 //   assign    S'[first row] = A'[row];  S'[repeated row of rank r] = unused instance of rank R - 1 - r   (R = number of repeated rows)
 // Rows >= usable_rows (the blinding rows) are left to the caller.
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_merge_sort.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <cstdint>
 #include "fp29.hpp"
@@ -39,8 +41,10 @@ __device__ __forceinline__ bool key_eq(const key256& a, const key256& b) {
   return a.w[0] == b.w[0] && a.w[1] == b.w[1] && a.w[2] == b.w[2] && a.w[3] == b.w[3];
 }
 
-// Montgomery words x*2^256 -> the integer x (one multiply by 2^5 in the radix-2^261 domain)
-__global__ void __launch_bounds__(256) k_lookup_keys(const uint32_t* __restrict__ in, size_t n, key256* __restrict__ keys) {
+// Montgomery words x*2^256 -> the integer x (one multiply by 2^5 in the radix-2^261 domain).  *wide is set when a key does not fit 64
+// bits: range-check lookups (the common case: values below 2^lookup_bits) then sort 8-byte keys with a radix sort instead.
+__global__ void __launch_bounds__(256) k_lookup_keys(const uint32_t* __restrict__ in, size_t n, key256* __restrict__ keys, uint64_t* __restrict__ low,
+                                                     uint32_t* __restrict__ wide) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   fe c;
@@ -51,6 +55,16 @@ __global__ void __launch_bounds__(256) k_lookup_keys(const uint32_t* __restrict_
   key256 out;
 #pragma unroll
   for (int k = 0; k < 4; k++) out.w[k] = (uint64_t)w[2 * k] | ((uint64_t)w[2 * k + 1] << 32);
+  keys[i] = out;
+  low[i] = out.w[0];
+  if (out.w[1] | out.w[2] | out.w[3]) atomicOr(wide, 1u);
+}
+
+__global__ void __launch_bounds__(256) k_lookup_widen(const uint64_t* __restrict__ low, size_t n, key256* __restrict__ keys) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  key256 out;
+  out.w[0] = low[i]; out.w[1] = 0; out.w[2] = 0; out.w[3] = 0;
   keys[i] = out;
 }
 
@@ -119,6 +133,11 @@ static size_t sort_temp_bytes(size_t u) {
   (void)rocprim::merge_sort(nullptr, bytes, (key256*)nullptr, (key256*)nullptr, u, key256_less{});
   return bytes;
 }
+static size_t radix_temp_bytes(size_t u) {
+  size_t bytes = 0;
+  (void)rocprim::radix_sort_keys(nullptr, bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, u);
+  return bytes;
+}
 static size_t scan_temp_bytes(size_t u) {
   size_t bytes = 0;
   (void)rocprim::exclusive_scan(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, u, rocprim::plus<uint32_t>{});
@@ -126,7 +145,9 @@ static size_t scan_temp_bytes(size_t u) {
 }
 
 size_t lookup_permute_workspace_bytes(size_t u) {
-  return 5 * al256(u * sizeof(key256)) + 4 * al256((u + 1) * sizeof(uint32_t)) + al256(sort_temp_bytes(u)) + al256(scan_temp_bytes(u + 1)) + 512;
+  const size_t st = sort_temp_bytes(u), rt = radix_temp_bytes(u);
+  return 5 * al256(u * sizeof(key256)) + 4 * al256(u * sizeof(uint64_t)) + 4 * al256((u + 1) * sizeof(uint32_t)) + al256(st > rt ? st : rt) +
+         al256(scan_temp_bytes(u + 1)) + 512;
 }
 
 // d_input / d_table: n elements each; the first `u` rows are permuted into d_out_input / d_out_table (which may not alias the inputs)
@@ -146,17 +167,31 @@ int lookup_permute_device(const uint32_t* d_input, const uint32_t* d_table, size
   uint32_t* unused = (uint32_t*)carve((u + 1) * 4);
   uint32_t* repeated_rank = (uint32_t*)carve((u + 1) * 4);
   uint32_t* unused_rank = (uint32_t*)carve((u + 1) * 4);
-  size_t sort_bytes = sort_temp_bytes(u), scan_bytes = scan_temp_bytes(u + 1);
-  void* sort_tmp = carve(sort_bytes);
+  uint64_t* la = (uint64_t*)carve(u * sizeof(uint64_t));
+  uint64_t* ls = (uint64_t*)carve(u * sizeof(uint64_t));
+  uint64_t* la_sorted = (uint64_t*)carve(u * sizeof(uint64_t));
+  uint64_t* ls_sorted = (uint64_t*)carve(u * sizeof(uint64_t));
+  size_t sort_bytes = sort_temp_bytes(u), radix_bytes = radix_temp_bytes(u), scan_bytes = scan_temp_bytes(u + 1);
+  void* sort_tmp = carve(sort_bytes > radix_bytes ? sort_bytes : radix_bytes);
   void* scan_tmp = carve(scan_bytes);
-  uint32_t* flags = (uint32_t*)carve(512);         // [0] error
+  uint32_t* flags = (uint32_t*)carve(512);         // [0] error, [1] some key wider than 64 bits
   const uint32_t n = (uint32_t)u;
   const dim3 grid((unsigned)((u + 255) / 256)), grid1((unsigned)((u + 256) / 256)), block(256);
   HIPCHK(hipMemsetAsync(flags, 0, 512, stream));
-  hipLaunchKernelGGL(k_lookup_keys, grid, block, 0, stream, d_input, u, ka);
-  hipLaunchKernelGGL(k_lookup_keys, grid, block, 0, stream, d_table, u, ks);
-  HIPCHK(rocprim::merge_sort(sort_tmp, sort_bytes, ka, sa, u, key256_less{}, stream));
-  HIPCHK(rocprim::merge_sort(sort_tmp, sort_bytes, ks, st, u, key256_less{}, stream));
+  hipLaunchKernelGGL(k_lookup_keys, grid, block, 0, stream, d_input, u, ka, la, flags + 1);
+  hipLaunchKernelGGL(k_lookup_keys, grid, block, 0, stream, d_table, u, ks, ls, flags + 1);
+  uint32_t wide = 1;
+  HIPCHK(hipMemcpyAsync(&wide, flags + 1, 4, hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipStreamSynchronize(stream));
+  if (wide) {                                      // full-width values (theta-compressed multi-column lookups): 256-bit comparison sort
+    HIPCHK(rocprim::merge_sort(sort_tmp, sort_bytes, ka, sa, u, key256_less{}, stream));
+    HIPCHK(rocprim::merge_sort(sort_tmp, sort_bytes, ks, st, u, key256_less{}, stream));
+  } else {                                         // every key fits 64 bits: radix sort of the low limbs
+    HIPCHK(rocprim::radix_sort_keys(sort_tmp, radix_bytes, la, la_sorted, u, 0, 64, stream));
+    HIPCHK(rocprim::radix_sort_keys(sort_tmp, radix_bytes, ls, ls_sorted, u, 0, 64, stream));
+    hipLaunchKernelGGL(k_lookup_widen, grid, block, 0, stream, (const uint64_t*)la_sorted, u, sa);
+    hipLaunchKernelGGL(k_lookup_widen, grid, block, 0, stream, (const uint64_t*)ls_sorted, u, st);
+  }
   hipLaunchKernelGGL(k_fill_u32, grid1, block, 0, stream, unused, n + 1, 1u);
   HIPCHK(hipMemsetAsync(repeated + u, 0, 4, stream));
   hipLaunchKernelGGL(k_lookup_mark, grid, block, 0, stream, (const key256*)sa, (const key256*)st, n, repeated, unused, flags);
