@@ -730,11 +730,20 @@ __global__ void __launch_bounds__(64) k_sum_jacobian(const uint32_t* __restrict_
 // ------------------------------------------------------------------------------------------------
 // host orchestration
 // ------------------------------------------------------------------------------------------------
+// A scalar has 254 bits, so the top window holds 254 - (W - 1) c of them.  With 1..5 bits there every point lands in one of at most 16
+// buckets of that window: a few enormous buckets whose partial sums are combined as long chains (measured, general path at 2^18:
+// c = 14 -> 2 top bits 2.29 ms, c = 13 -> 7 bits 1.59 ms, c = 15 -> carries only 1.58 ms).  Such window sizes are never chosen.
+static bool msm_top_window_is_degenerate(int c) {
+  const int W = (256 + c - 1) / c, top_bits = 254 - (W - 1) * c;
+  return top_bits > 0 && top_bits < 6;
+}
+
 int msm_pick_window(size_t n) {
   // cost model in field multiplications: W * (10 n + 2 * 14 * 2^(c-1)), W = ceil(256 / c); c <= 16 (int16 digits, 128 KiB LDS)
-  int best = 2;
+  int best = 16;
   double best_cost = 1e300;
   for (int c = 2; c <= 16; c++) {
+    if (msm_top_window_is_degenerate(c)) continue;
     double W = (256 + c - 1) / c;
     double cost = W * (10.0 * (double)n + 28.0 * (double)(1u << (c - 1)));
     if (cost < best_cost) { best_cost = cost; best = c; }
@@ -753,6 +762,7 @@ int msm_pick_window_prepared(size_t n) {
   for (int c = 2; c <= MAX_WINDOW_PREPARED; c++) {
     double W = (256 + c - 1) / c;
     double cost = W * 10.0 * (double)n + 28.0 * (double)(1u << (c - 1)) + (c > 16 ? W * 1.0 * (double)n : 0.0);
+    if (msm_top_window_is_degenerate(c)) continue;
     if (c > 16 && n < ((size_t)1 << 20)) continue;   // measured with the quad-cooperative tail: c = 20 loses at 2^19 (1.47 vs 1.34 ms), wins from 2^20 (1.84 vs 1.94 ms)
     if (cost < best_cost) { best_cost = cost; best = c; }
   }
