@@ -65,7 +65,79 @@ def main():
               "divide_by_vanishing_poly": [hx(O.fr_to_limbs(x)) for x in dom.divide_by_vanishing_poly(ext)],
               "extended_to_coeff": [hx(O.fr_to_limbs(x)) for x in dom.extended_to_coeff(ext)]}
     json.dump({"ntt": ntt, "domain": domain}, open(os.path.join(HERE, "ntt_fr.json"), "w"), indent=0)
-    print("wrote msm_g1.json, ntt_fr.json")
+    json.dump(prover_steps(g), open(os.path.join(HERE, "prover_steps.json"), "w"), indent=0)
+    print("wrote msm_g1.json, ntt_fr.json, prover_steps.json")
+
+
+class E:   # the three fields oracle.eval_expression reads of a plonk::Expression node
+    def __init__(self, kind, a=None, b=None): self.kind, self.a, self.b = kind, a, b
+
+
+class Obj:
+    def __init__(self, **kw): self.__dict__.update(kw)
+
+
+def halo2_lib_like_cs(gate_cols, blinding):
+    """the constraint-system shape of tests/test_gpu_rows.py::halo2_lib_like_cs, as plain oracle-side objects"""
+    A = gate_cols
+    adv, fix = (lambda c, r=0: E("advice", c, r)), (lambda c, r=0: E("fixed", c, r))
+    sub = lambda x, y: E("sum", x, E("neg", y))
+    gates = [[E("product", fix(i), sub(E("sum", adv(i, 0), E("product", adv(i, 1), adv(i, 2))), adv(i, 3)))] for i in range(A)]
+    lookups = [Obj(input_expressions=[adv(A)], table_expressions=[fix(A)]),
+               Obj(input_expressions=[E("product", adv(0), fix(A + 1)), E("sum", adv(1, -1), E("constant", 5))],
+                   table_expressions=[fix(A), E("scaled", fix(A + 1), 3)])]
+    perm = [("advice", i) for i in range(A)] + [("fixed", A + 1), ("instance", 0)]
+    return Obj(num_fixed=A + 2, num_advice=A + 1, num_instance=1, gates=gates, lookups=lookups, permutation_columns=perm,
+               blinding_factors=blinding, degree=4)
+
+
+def prover_steps(g):
+    fr = lambda v: hx(O.fr_to_limbs(v))
+    # 1. a row program in the ABI's own terms (include/zkhip.h): every opcode and operand kind, rotations with wrap-around, PREV
+    log_rows, rot_scale = 4, 2
+    rows = 1 << log_rows
+    cols = [[g.fr() for _ in range(rows)] for _ in range(3)]
+    cols[0][0], cols[0][1], cols[1][0] = 0, O.R_MOD - 1, O.R_MOD - 1
+    prev = [g.fr() for _ in range(rows)]
+    consts, rots, omega = [g.fr(), 1, O.R_MOD - 1, 0], [0, 1, -1, 3], O.omega_for(log_rows)
+    C_, R_, COL, PREV, POW = (lambda i: (0, i, 0)), (lambda i: (1, i, 0)), (lambda c, r: (2, c, r)), (3, 0, 0), (4, 0, 0)
+    z = (0, 0, 0)
+    insns = [(0, 0, COL(0, 0), z, z), (1, 1, R_(0), COL(1, 1), z), (2, 2, R_(1), COL(2, 2), z), (3, 3, R_(2), R_(1), z),
+             (4, 4, R_(3), z, z), (5, 5, R_(4), z, z), (6, 6, R_(5), z, z), (7, 7, R_(6), C_(0), PREV),
+             (3, 8, POW, COL(0, 3), z), (7, 0, R_(8), R_(7), C_(2)), (2, 9, C_(3), R_(0), z), (1, 15, R_(9), POW, z)]
+    row_program = {"log_rows": log_rows, "rot_scale": rot_scale, "rotations": rots, "constants": [fr(c) for c in consts], "omega": fr(omega),
+                   "result_reg": 15, "insns": [[op, dst] + list(a) + list(b) + list(c) for op, dst, a, b, c in insns],
+                   "columns": [[fr(x) for x in c] for c in cols], "prev": [fr(x) for x in prev],
+                   "expected": [fr(x) for x in O.row_program_run(insns, consts, rots, rot_scale, 15, cols, log_rows, omega=omega, prev=prev)]}
+    # 2. evaluate_h on the halo2-lib shape, from the direct restatement of the formulas
+    k, ek, gate_cols, blinding = 3, 5, 2, 2
+    cs = halo2_lib_like_cs(gate_cols, blinding)
+    n_perm, sets = len(cs.permutation_columns), (len(cs.permutation_columns) + 1) // 2
+    total = cs.num_fixed + cs.num_advice + cs.num_instance + 3 + n_perm + sets + 3 * len(cs.lookups)
+    c = [[g.fr() for _ in range(1 << ek)] for _ in range(total)]
+    beta, gamma, theta, y = g.fr(), g.fr(), g.fr(), g.fr()
+    o = 0
+    fixed = c[o:o + cs.num_fixed]; o += cs.num_fixed
+    advice = c[o:o + cs.num_advice]; o += cs.num_advice
+    inst = c[o:o + 1]; o += 1
+    l0, l_last, l_active = c[o], c[o + 1], c[o + 2]; o += 3
+    sigma = c[o:o + n_perm]; o += n_perm
+    zs = c[o:o + sets]; o += sets
+    lk = [tuple(c[o + 3 * i + j] for j in range(3)) for i in range(len(cs.lookups))]
+    exp = O.evaluate_h_direct(cs, k, ek, fixed, advice, inst, l0, l_last, l_active, sigma, zs, lk, beta, gamma, theta, y)
+    evaluate_h = {"k": k, "extended_k": ek, "gate_cols": gate_cols, "blinding_factors": blinding, "beta": fr(beta), "gamma": fr(gamma),
+                  "theta": fr(theta), "y": fr(y), "columns": [[fr(x) for x in col] for col in c], "expected": [fr(x) for x in exp]}
+    # 3. lookup permutation and grand product
+    usable = 26
+    table = [i % 8 for i in range(32)]
+    inputs = [table[g.next() % usable] for _ in range(32)]
+    pi, pt = O.permute_expression_pair(inputs, table, usable)
+    num, den = [g.fr() for _ in range(32)], [g.fr() for _ in range(32)]
+    den[9] = 0
+    return {"row_program": row_program, "evaluate_h": evaluate_h,
+            "lookup_permute": {"usable_rows": usable, "input": [fr(x) for x in inputs], "table": [fr(x) for x in table],
+                               "permuted_input": [fr(x) for x in pi], "permuted_table": [fr(x) for x in pt]},
+            "grand_product": {"num": [fr(x) for x in num], "den": [fr(x) for x in den], "z": [fr(x) for x in O.grand_product(num, den)]}}
 
 
 if __name__ == "__main__":

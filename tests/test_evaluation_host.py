@@ -82,3 +82,34 @@ def test_leaf_result_and_marshalling_layout():
     assert C.sizeof(_lib.VmInsn) == 16 and p.n_insns == 1 and p.n_rotations == 1 and p.n_constants == 0
     raw = bytes(C.string_at(C.addressof(p.insns[0]), 16))
     assert raw == bytes([E.OP_MOV, 0, 0, 0, E.SRC_COLUMN, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0])   # op dst rsvd | kind rot index(LE) x3
+
+
+def _unhex(s):
+    return sum(int(s[16 * i:16 * i + 16], 16) << (64 * i) for i in range(4)) * pow(1 << 256, -1, R) % R
+
+
+def test_golden_prover_steps_against_oracle_and_compiler():
+    """tests/golden/prover_steps.json (generated from the oracle alone): the oracle reproduces it, and the host compiler's program
+    for the same constraint system, interpreted by the oracle, gives the fixture's evaluate_h column"""
+    import json
+    import os
+
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "prover_steps.json")))
+    rp = gold["row_program"]
+    insns = [(r[0], r[1], tuple(r[2:5]), tuple(r[5:8]), tuple(r[8:11])) for r in rp["insns"]]
+    cols = [[_unhex(x) for x in c] for c in rp["columns"]]
+    got = O.row_program_run(insns, [_unhex(x) for x in rp["constants"]], rp["rotations"], rp["rot_scale"], rp["result_reg"], cols,
+                            rp["log_rows"], omega=_unhex(rp["omega"]), prev=[_unhex(x) for x in rp["prev"]])
+    assert got == [_unhex(x) for x in rp["expected"]]
+    eh = gold["evaluate_h"]
+    cs = make_cs(eh["gate_cols"])
+    cs.blinding_factors = eh["blinding_factors"]
+    prog = E.evaluate_h_program(cs, eh["k"], eh["extended_k"], *(_unhex(eh[c]) for c in ("beta", "gamma", "theta", "y")))
+    cols = [[_unhex(x) for x in c] for c in eh["columns"]]
+    got = O.row_program_run(prog.insns, prog.constants, prog.rotations, prog.rot_scale, prog.result_reg, cols, eh["extended_k"], omega=prog.omega)
+    assert got == [_unhex(x) for x in eh["expected"]]
+    lp = gold["lookup_permute"]
+    pi, pt = O.permute_expression_pair([_unhex(x) for x in lp["input"]], [_unhex(x) for x in lp["table"]], lp["usable_rows"])
+    assert pi == [_unhex(x) for x in lp["permuted_input"]] and pt == [_unhex(x) for x in lp["permuted_table"]]
+    gp = gold["grand_product"]
+    assert O.grand_product([_unhex(x) for x in gp["num"]], [_unhex(x) for x in gp["den"]]) == [_unhex(x) for x in gp["z"]]

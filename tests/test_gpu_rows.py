@@ -324,3 +324,35 @@ def test_eval_polynomial_batch_vs_single(lib, cref, n, count):
     if n <= 1025:
         xv = F.fr_decode(x)[0]
         assert F.fr_decode(got[0]) == [O.eval_polynomial(F.fr_decode(polys[0]), xv)]
+
+
+def test_golden_prover_steps(lib):
+    """the committed fixtures of the 8(f) steps (tests/golden/prover_steps.json, generated from the oracle) through the C ABI"""
+    import json
+    import os
+
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "prover_steps.json")))
+    words = lambda hs: np.array([[int(h[16 * i:16 * i + 16], 16) for i in range(4)] for h in hs], dtype=np.uint64)
+    val = lambda h: F.fr_decode(words([h]))[0]
+    rp = gold["row_program"]
+    p = E.RowProgram(rot_scale=rp["rot_scale"], omega=val(rp["omega"]))
+    p.constants = [val(h) for h in rp["constants"]]
+    p.rotations = list(rp["rotations"])
+    p.insns = [(r[0], r[1], tuple(r[2:5]), tuple(r[5:8]), tuple(r[8:11])) for r in rp["insns"]]
+    p.result_reg, p.n_columns = rp["result_reg"], len(rp["columns"])
+    out = words(rp["prev"]).copy()
+    p.run([words(c) for c in rp["columns"]], rp["log_rows"], out=out, accumulate=True)
+    assert np.array_equal(out, words(rp["expected"]))
+    eh = gold["evaluate_h"]
+    cs = halo2_lib_like_cs(eh["gate_cols"])
+    cs.blinding_factors = eh["blinding_factors"]
+    prog = E.evaluate_h_program(cs, eh["k"], eh["extended_k"], *(val(eh[c]) for c in ("beta", "gamma", "theta", "y")))
+    assert np.array_equal(prog.run([words(c) for c in eh["columns"]], eh["extended_k"]), words(eh["expected"]))
+    lp = gold["lookup_permute"]
+    pi, pt = E.permute_expression_pair(words(lp["input"]), words(lp["table"]), lp["usable_rows"])
+    assert np.array_equal(pi, words(lp["permuted_input"])) and np.array_equal(pt, words(lp["permuted_table"]))
+    gp = gold["grand_product"]
+    num, den = words(gp["num"]), words(gp["den"])
+    z = np.zeros_like(num)
+    _lib.check(lib.zkhip_fr_grand_product(num.ctypes.data, den.ctypes.data, num.shape[0], z.ctypes.data))
+    assert np.array_equal(z, words(gp["z"]))
