@@ -202,6 +202,10 @@ int zkhip_msm_window_bits(size_t n);
  * discrete logs are known, so MSM(a, out) = [sum a_i (t0 + i d)] G can be checked with one scalar multiplication.
  * t0, d: Fr in the usual Montgomery memory format. */
 int zkhip_g1_gen_walk_device(const uint64_t t0[4], const uint64_t d[4], size_t n, void *d_out, void *stream);
+/* `ParamsKZG::setup` [DEP poly/kzg/commitment.rs] building block: d_out[i] = scalars[i] * G as
+ * G1Affine for the BN254 generator G = (1, 2), i < n -- g = [s^i] G and g_lagrange = [L_i(s)] G are two such calls on scalar vectors
+ * the Fr primitives above produce on the device.  The first call builds a 32 MiB table of generator multiples. */
+int zkhip_g1_fixed_base_mul_device(const void *d_scalars, size_t n, void *d_out, void *stream);
 /* Per-phase timing with HIP events on the stream the kernels run on.  enable(1), run one call, then
  * zkhip_profile_read synchronises and returns the number of phases of the last profiled call, writing up to
  * `max` durations (milliseconds) and names (63 chars + NUL each). */

@@ -802,3 +802,42 @@ def test_msm_wide_window_path_under_skew(lib, cref, pattern):
         assert np.array_equal(aff(cref, out.cpu().numpy().view(np.uint64)), exp)
     finally:
         _lib.check(lib.zkhip_release_bases(h))
+
+
+def test_params_kzg_setup_small_vs_oracle(lib):
+    """ParamsKZG::setup with a known trapdoor: g[i] = [s^i] G and g_lagrange[i] = [L_i(s)] G against the big-int oracle"""
+    k, s = 4, 0x1234567890ABCDEF1234567890ABCDEF
+    n = 1 << k
+    params = Z.ParamsKZG.setup(k, s)
+    try:
+        srs = O.structured_srs(s, n)
+        assert [O.affine_from_limbs([int(x) for x in row]) for row in params.g] == srs
+        w = O.omega_for(k)
+        mult = (pow(s, n, O.R_MOD) - 1) * pow(n, -1, O.R_MOD) % O.R_MOD
+        for i in range(n):
+            li = mult * pow(w, i, O.R_MOD) % O.R_MOD * pow((s - pow(w, i, O.R_MOD)) % O.R_MOD, -1, O.R_MOD) % O.R_MOD
+            assert O.affine_from_limbs([int(x) for x in params.g_lagrange[i]]) == O.scalar_mul(li, O.G1_GEN), i
+    finally:
+        params.close()
+
+
+@pytest.mark.parametrize("k", [10, 15])
+def test_kzg_commitments_agree_across_bases(lib, cref, k):
+    """a structured SRS ties the MSM, the NTT and the setup together: for evaluations e of a polynomial p over the domain,
+    commit_lagrange(e) = commit(lagrange_to_coeff(e)) = [p(s)] G"""
+    from zksnap_circuits_halo2_amd import arithmetic as A
+
+    s = 0x0123456789ABCDEF_FEDCBA9876543210_0F1E2D3C4B5A6978 % O.R_MOD
+    n = 1 << k
+    params = Z.ParamsKZG.setup(k, s)
+    try:
+        dom = Z.EvaluationDomain(4, k)
+        evals = cref.gen_scalars(31337 + k, n, 0)
+        coeffs = dom.lagrange_to_coeff(evals)
+        c1 = aff(cref, params.commit_lagrange(evals))
+        c2 = aff(cref, params.commit(coeffs))
+        p_at_s = F.fr_decode(A.eval_polynomial(coeffs, F.fr_encode([s])[0]))[0]
+        exp = cref.jac_to_affine(cref.scalar_mul(p_at_s, cref.generator()))
+        assert np.array_equal(c1, c2) and np.array_equal(c1, exp)
+    finally:
+        params.close()

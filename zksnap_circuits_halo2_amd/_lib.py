@@ -62,6 +62,7 @@ _SIGS = {
     "zkhip_g1_sum_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "zkhip_g1_sum": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "zkhip_msm_window_bits": (C.c_int, [C.c_size_t]),
+    "zkhip_g1_fixed_base_mul_device": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "zkhip_g1_gen_walk_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "zkhip_profile_enable": (C.c_int, [C.c_int]),
     "zkhip_profile_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),

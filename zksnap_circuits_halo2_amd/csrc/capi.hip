@@ -72,7 +72,8 @@ struct context {
   bool ready = false;
   int device = 0;
   hipStream_t stream = nullptr;
-  dev_buf ws, scalars, bases, poly, poly2, small, ntt_tmp, vm;
+  dev_buf ws, scalars, bases, poly, poly2, small, ntt_tmp, vm, fixed_table;
+  bool fixed_table_ready = false;   // multiples of the generator for zkhip_g1_fixed_base_mul_device
   std::map<const void*, prepared_bases*> registered;   // host ptr -> prepared table (slice 0 of the table = the bases themselves)
   std::map<uint64_t, prepared_bases*> handles;          // zkhip_prepare_bases_device handles
   uint64_t next_handle = 1;
@@ -137,7 +138,7 @@ void zkhip_shutdown(void) {
   g_ctx.registered.clear();
   for (auto& kv : g_ctx.handles) release_prepared(kv.second);
   g_ctx.handles.clear();
-  g_ctx.ws.release(); g_ctx.scalars.release(); g_ctx.bases.release(); g_ctx.poly.release(); g_ctx.poly2.release(); g_ctx.small.release(); g_ctx.ntt_tmp.release(); g_ctx.vm.release();
+  g_ctx.ws.release(); g_ctx.scalars.release(); g_ctx.bases.release(); g_ctx.poly.release(); g_ctx.poly2.release(); g_ctx.small.release(); g_ctx.ntt_tmp.release(); g_ctx.vm.release(); g_ctx.fixed_table.release(); g_ctx.fixed_table_ready = false;
   (void)hipStreamDestroy(g_ctx.stream);
   g_ctx.stream = nullptr;
   g_ctx.ready = false;
@@ -816,6 +817,22 @@ int zkhip_profile_read(double* ms, char (*names)[64], int max) {
     if (names) snprintf(names[i], 64, "%s", g_prof_names[i]);
   }
   return g_prof_n;
+}
+
+int zkhip_g1_fixed_base_mul_device(const void* d_scalars, size_t n, void* d_out, void* stream) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (n && (!d_scalars || !d_out)) { set_error("fixed_base_mul: null pointer"); return ZKHIP_EINVAL; }
+  if (n == 0) return ZKHIP_OK;
+  hipStream_t s = caller_stream(stream);
+  if ((rc = g_ctx.ws.reserve(g1_fixed_base_workspace(n))) != ZKHIP_OK) return rc;
+  if (!g_ctx.fixed_table_ready) {              // one-time: 16 windows x 2^15 multiples of the generator (32 MiB)
+    if ((rc = g_ctx.fixed_table.reserve(g1_fixed_base_table_bytes())) != ZKHIP_OK) return rc;
+    if ((rc = g1_fixed_base_table_build((uint32_t*)g_ctx.fixed_table.p, g_ctx.ws.p, g_ctx.ws.cap, s)) != ZKHIP_OK) return rc;
+    g_ctx.fixed_table_ready = true;
+  }
+  return g1_fixed_base_mul_device((const uint32_t*)d_scalars, n, (const uint32_t*)g_ctx.fixed_table.p, (uint32_t*)d_out, g_ctx.ws.p, g_ctx.ws.cap, s);
 }
 
 int zkhip_g1_gen_walk_device(const uint64_t t0[4], const uint64_t d[4], size_t n, void* d_out, void* stream) {

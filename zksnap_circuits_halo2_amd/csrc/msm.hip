@@ -1087,6 +1087,27 @@ __global__ void __launch_bounds__(64) k_gen_walk(const uint32_t* __restrict__ t0
   }
 }
 
+// Montgomery words of 2^e (e < 256), i.e. 2^e * 2^256 mod r, by e modular doublings of R = 2^256 mod r on the host
+static void fr_pow2_montgomery(int e, uint32_t out[8]) {
+  static const uint64_t RMOD[4] = {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+  uint64_t v[4] = {0xac96341c4ffffffbull, 0x36fc76959f60cd29ull, 0x666ea36f7879462eull, 0x0e0a77c19a07df2full};   // R mod r
+  for (int k = 0; k < e; k++) {
+    uint64_t carry = 0;                                 // v < r < 2^254: the doubled value fits 256 bits
+    for (int i = 0; i < 4; i++) { const uint64_t nc = v[i] >> 63; v[i] = (v[i] << 1) | carry; carry = nc; }
+    bool ge = true;
+    for (int i = 3; i >= 0; i--) { if (v[i] != RMOD[i]) { ge = v[i] > RMOD[i]; break; } }
+    if (ge) {
+      unsigned __int128 borrow = 0;
+      for (int i = 0; i < 4; i++) {
+        const unsigned __int128 d = (unsigned __int128)v[i] - RMOD[i] - borrow;
+        v[i] = (uint64_t)d;
+        borrow = (d >> 64) ? 1 : 0;
+      }
+    }
+  }
+  for (int i = 0; i < 4; i++) { out[2 * i] = (uint32_t)v[i]; out[2 * i + 1] = (uint32_t)(v[i] >> 32); }
+}
+
 size_t g1_gen_walk_workspace(size_t n) { return align_up(n * 144, 256) + align_up(n * 36, 256) + 256; }
 
 int g1_gen_walk_device(const uint32_t t0_ext[8], const uint32_t d_ext[8], size_t n, uint32_t* d_out, void* ws, size_t ws_bytes, hipStream_t stream) {
@@ -1107,6 +1128,103 @@ int g1_gen_walk_device(const uint32_t t0_ext[8], const uint32_t d_ext[8], size_t
   return ZKHIP_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// fixed-base multiplication by the generator: out[i] = k_i G as affine points -- what `ParamsKZG::setup` [DEP halo2-axiom
+// poly/kzg/commitment.rs] does n times for g = [s^i] G and n times for g_lagrange = [L_i(s)] G (reached from
+// /root/reference/voter/benches/voter_circuit.rs:60, aggregator/benches/state_transition_circuit.rs:64).
+// Table T[w][d - 1] = d 2^(16 w) G for d = 1 .. 2^15, w < 16 (32 MiB, built once with the generator walk above); a scalar is 16 signed
+// 16-bit digits -> at most 16 mixed additions.  A thread owns FIXED_CHUNK consecutive scalars and normalises its results with one
+// inversion, like k_gen_walk.
+// ------------------------------------------------------------------------------------------------
+constexpr int FIXED_C = 16, FIXED_W = 16, FIXED_CHUNK = 32;
+constexpr uint32_t FIXED_B = 1u << (FIXED_C - 1);
+
+__global__ void __launch_bounds__(64) k_fixed_base_mul(const uint32_t* __restrict__ scalars, uint32_t n, const uint32_t* __restrict__ table,
+                                                       uint32_t* __restrict__ out, uint32_t* __restrict__ tmp_pts, uint32_t* __restrict__ tmp_pref) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lo = j * FIXED_CHUNK;
+  if (lo >= n) return;
+  const uint32_t cnt = min((uint32_t)FIXED_CHUNK, n - lo);
+  fe c32;
+#pragma unroll
+  for (int k = 0; k < NL; k++) c32.l[k] = FrParams::FROM_EXT_CANON[k];
+  fe pref = fe_one<Fq>();
+  for (uint32_t i = 0; i < cnt; i++) {
+    uint32_t w[8];
+    load_words(scalars + (size_t)(lo + i) * 8, w);
+    fe_pack(fe_canon_lt2p<FrParams>(fe_mul<FrParams>(c32, fe_unpack<0>(w))), w);      // the scalar as a plain integer
+    xyzz acc = xyzz_identity();
+    uint32_t carry = 0;
+#pragma unroll 1
+    for (int win = 0; win < FIXED_W; win++) {
+      const uint32_t v = ((w[win >> 1] >> ((win & 1) * 16)) & 0xffffu) + carry;
+      int32_t d;
+      if (v >= FIXED_B) { d = (int32_t)v - (int32_t)(1u << FIXED_C); carry = 1; } else { d = (int32_t)v; carry = 0; }
+      if (d == 0) continue;
+      const affine_words pt = load_affine(table, (size_t)win * FIXED_B + (uint32_t)(d < 0 ? -d : d) - 1);
+      fe y2 = fe_from_ext_lazy(pt.y);
+      if (d < 0) y2 = fe_neg_red(y2, Fq::P64_S1);
+      xyzz_madd(acc, fe_from_ext_lazy(pt.x), y2);
+    }
+    // carry out of the top window is impossible: scalars are below r < 2^254, so the top digit is below 2^14
+    store_xyzz(tmp_pts, lo + i, acc);
+    store_fe9_generic(tmp_pref, lo + i, pref);
+    if (!xyzz_is_identity(acc)) pref = fe_mul<Fq>(pref, fe_mul<Fq>(acc.ZZ, acc.ZZZ));
+  }
+  fe inv = fq_inverse(pref);
+  for (uint32_t ii = cnt; ii-- > 0;) {
+    const xyzz Q = load_xyzz(tmp_pts, lo + ii);
+    uint32_t* o = out + (size_t)(lo + ii) * 16;
+    if (xyzz_is_identity(Q)) {
+#pragma unroll
+      for (int t = 0; t < 16; t++) o[t] = 0;
+      continue;
+    }
+    const fe pre = load_fe9_generic(tmp_pref, lo + ii);
+    const fe winv = fe_mul<Fq>(inv, pre);                           // 1 / (ZZ * ZZZ)
+    inv = fe_mul<Fq>(inv, fe_mul<Fq>(Q.ZZ, Q.ZZZ));
+    const fe x = fe_mul<Fq>(fe_mul<Fq>(winv, Q.ZZZ), Q.X);          // X / ZZ
+    const fe y = fe_mul<Fq>(fe_mul<Fq>(winv, Q.ZZ), Q.Y);           // Y / ZZZ
+    uint32_t wx[8], wy[8];
+    fe_to_ext<Fq>(x, wx);
+    fe_to_ext<Fq>(y, wy);
+#pragma unroll
+    for (int t = 0; t < 8; t++) { o[t] = wx[t]; o[8 + t] = wy[t]; }
+  }
+}
+
+size_t g1_fixed_base_table_bytes() { return (size_t)FIXED_W * FIXED_B * 64; }
+size_t g1_fixed_base_workspace(size_t n) {
+  const size_t a = g1_gen_walk_workspace(FIXED_B), b = align_up(n * 144, 256) + align_up(n * 36, 256);
+  return (a > b ? a : b) + 256;
+}
+
+// d_table: g1_fixed_base_table_bytes() of device memory, filled here (window w = the walk 2^(16 w), 2 * 2^(16 w), ...)
+int g1_fixed_base_table_build(uint32_t* d_table, void* ws, size_t ws_bytes, hipStream_t stream) {
+  for (int w = 0; w < FIXED_W; w++) {
+    // step = 2^(16 w) as a Montgomery Fr element: host big-integer shift of R = 2^256 mod r is avoided by building the constant
+    // from its plain words with one device multiply inside k_gen_walk -- it takes Montgomery words, so pass 2^(16 w) * R mod r
+    uint32_t step[8];
+    fr_pow2_montgomery(16 * w, step);
+    int rc = g1_gen_walk_device(step, step, FIXED_B, d_table + (size_t)w * FIXED_B * 16, ws, ws_bytes, stream);
+    if (rc != ZKHIP_OK) return rc;
+  }
+  return ZKHIP_OK;
+}
+
+int g1_fixed_base_mul_device(const uint32_t* d_scalars, size_t n, const uint32_t* d_table, uint32_t* d_out, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (n == 0) return ZKHIP_OK;
+  if (n >= (1ull << 31)) { set_error("fixed_base_mul: n too large"); return ZKHIP_EINVAL; }
+  if (ws_bytes < g1_fixed_base_workspace(n)) { set_error("fixed_base_mul: workspace too small"); return ZKHIP_EINVAL; }
+  char* p = (char*)ws;
+  uint32_t* tmp_pts = (uint32_t*)p; p += align_up(n * 144, 256);
+  uint32_t* tmp_pref = (uint32_t*)p;
+  const uint32_t threads = (uint32_t)((n + FIXED_CHUNK - 1) / FIXED_CHUNK);
+  hipLaunchKernelGGL(k_fixed_base_mul, dim3((threads + 63) / 64), dim3(64), 0, stream, d_scalars, (uint32_t)n, d_table, d_out, tmp_pts, tmp_pref);
+  HIPCHK(hipGetLastError());
+  return ZKHIP_OK;
+}
 
 // ------------------------------------------------------------------------------------------------
 // prepared bases: table[w * n + i] = 2^(c w) * P_i (affine, external format), w < W.  One thread per point walks the

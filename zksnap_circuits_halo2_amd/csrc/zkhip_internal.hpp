@@ -16,6 +16,10 @@ void prof_mark(hipStream_t stream, const char* name);
 // msm.hip
 int g1_gen_walk_device(const uint32_t t0_ext[8], const uint32_t d_ext[8], size_t n, uint32_t* d_out, void* ws, size_t ws_bytes, hipStream_t stream);
 size_t g1_gen_walk_workspace(size_t n);
+size_t g1_fixed_base_table_bytes();
+size_t g1_fixed_base_workspace(size_t n);
+int g1_fixed_base_table_build(uint32_t* d_table, void* ws, size_t ws_bytes, hipStream_t stream);
+int g1_fixed_base_mul_device(const uint32_t* d_scalars, size_t n, const uint32_t* d_table, uint32_t* d_out, void* ws, size_t ws_bytes, hipStream_t stream);
 int msm_pick_window(size_t n);
 size_t msm_workspace_bytes(size_t n, int c, bool prepared = false, size_t batch = 1);
 struct prepared_bases {   // table[w * n + i] = 2^(c w) * P_i, affine external format

@@ -18,6 +18,52 @@ class ParamsKZG:
         if self.g_lagrange is not None:
             _lib.check(lib.zkhip_register_bases(self.g_lagrange.ctypes.data, self.n))
 
+    @classmethod
+    def setup(cls, k: int, s: int) -> "ParamsKZG":
+        """`ParamsKZG::setup(k, rng)` [DEP poly/kzg/commitment.rs] with the trapdoor `s` given instead of drawn (what the reference's
+        benches and `gen_srs` test parameters amount to: /root/reference/voter/benches/voter_circuit.rs:60): g[i] = [s^i] G and
+        g_lagrange[i] = [(s^n - 1)/n * w^i / (s - w^i)] G, both computed on the GPU -- the scalar vectors with the Fr primitives
+        (prefix product, row programs, batch inversion), the points with the fixed-base multiplication."""
+        import ctypes as C
+
+        from . import evaluation as E
+        from .fields import R_MOD, fr_encode, omega_for
+
+        n = 1 << k
+        s %= R_MOD
+        omega = omega_for(k)
+        assert pow(s, n, R_MOD) != 1, "the trapdoor lies in the evaluation domain"
+        lib = _lib.load()
+        d_sc, d_tmp, d_pts = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        for ptr, size in ((d_sc, n * 32), (d_tmp, n * 32), (d_pts, n * 64)):
+            _lib.check(lib.zkhip_alloc(size, C.byref(ptr)))
+        try:
+            def points() -> np.ndarray:
+                _lib.check(lib.zkhip_g1_fixed_base_mul_device(d_sc, n, d_pts, None))
+                out = np.zeros((n, 8), dtype=np.uint64)
+                _lib.check(lib.zkhip_download(out.ctypes.data, d_pts, n * 64))
+                return out
+
+            # s^i: exclusive prefix product of the constant vector (s, s, ...)
+            const = np.ascontiguousarray(np.tile(fr_encode([s]), (n, 1)))
+            _lib.check(lib.zkhip_upload(d_sc, const.ctypes.data, n * 32))
+            _lib.check(lib.zkhip_fr_prefix_product_device(d_sc, n, d_sc, None))
+            g = points()
+            # Lagrange scalars: (s - w^i) -> inverse -> times w^i * (s^n - 1) / n
+            den = E.RowProgram(omega=omega)
+            den.emit(E.OP_SUB, 0, den.constant(s), E.RowProgram.ROWPOW)
+            den.run_device([], k, d_tmp.value)
+            _lib.check(lib.zkhip_fr_batch_invert_device(d_tmp, n, None))
+            num = E.RowProgram(omega=omega)
+            num.emit(E.OP_MUL, 0, E.RowProgram.ROWPOW, num.column(0))
+            num.emit(E.OP_MUL, 0, E.RowProgram.reg(0), num.constant((pow(s, n, R_MOD) - 1) * pow(n, -1, R_MOD) % R_MOD))
+            num.run_device([d_tmp.value], k, d_sc.value)
+            g_lagrange = points()
+        finally:
+            for ptr in (d_sc, d_tmp, d_pts):
+                lib.zkhip_free(ptr)
+        return cls(k, g, g_lagrange)
+
     def get_g(self) -> np.ndarray:
         return self.g
 
