@@ -841,3 +841,37 @@ def test_kzg_commitments_agree_across_bases(lib, cref, k):
         assert np.array_equal(c1, c2) and np.array_equal(c1, exp)
     finally:
         params.close()
+
+
+def test_c_abi_rejects_bad_arguments_without_aborting(lib):
+    """every entry point returns ZKHIP_EINVAL (-1) with a message on null / inconsistent arguments (the reference's functions are
+    infallible, the C ABI never aborts: SURVEY.md section 8(b))"""
+    import ctypes as C
+
+    buf = np.zeros((64, 4), dtype=np.uint64)
+    pts = np.zeros((64, 8), dtype=np.uint64)
+    out = np.zeros(12, dtype=np.uint64)
+    om = F.fr_encode([F.omega_for(4)])[0]
+    p, q, o, w = buf.ctypes.data, pts.ctypes.data, out.ctypes.data, om.ctypes.data
+    bad = [
+        lib.zkhip_msm_g1(None, q, 4, o), lib.zkhip_msm_g1(p, None, 4, o), lib.zkhip_msm_g1(p, q, 4, None),
+        lib.zkhip_ntt_fr(None, w, 4), lib.zkhip_ntt_fr(p, None, 4), lib.zkhip_ntt_fr(p, w, 29),
+        lib.zkhip_ifft_scaled(p, w, 4, None), lib.zkhip_mul_periodic(p, 16, None, 4), lib.zkhip_mul_periodic(p, 16, p, 0),
+        lib.zkhip_coeff_to_extended(p, 5, p, 4, w, w), lib.zkhip_extended_to_coeff(p, 29, w, w, w, p, 4),
+        lib.zkhip_coeff_to_extended_device(p, 8, 4, p, 64, 6, 1, w, w, None),          # stride shorter than the polynomial
+        lib.zkhip_extended_to_coeff_device(p, 64, 6, w, w, w, p, 8, 16, 1, None),      # out_stride < out_len
+        lib.zkhip_fr_eval_polynomial(None, 4, w, o), lib.zkhip_fr_kate_division(p, 4, None, p), lib.zkhip_fr_batch_invert(None, 4),
+        lib.zkhip_fr_prefix_product(p, 4, None), lib.zkhip_fr_grand_product(p, None, 4, p), lib.zkhip_lookup_permute(p, p, 4, None, p),
+        lib.zkhip_fr_eval_polynomial_batch_device(None, 2, 4, w, p, None), lib.zkhip_fr_eval_rows(None, None, 0, 2, 0, p),
+        lib.zkhip_register_bases(None, 4), lib.zkhip_unregister_bases(q), lib.zkhip_release_bases(123456),
+        lib.zkhip_msm_g1_prepared_device(123456, 0, p, 4, o, None), lib.zkhip_prepare_bases_device(None, 4, C.byref(C.c_uint64())),
+        lib.zkhip_g1_fixed_base_mul_device(None, 4, q, None), lib.zkhip_g1_sum(None, 2, o), lib.zkhip_upload(None, p, 8), lib.zkhip_download(p, None, 8),
+        lib.zkhip_alloc(8, None), lib.zkhip_test_field_op(2, 0, p, p, p, 4), lib.zkhip_test_g1_op(9, q, q, o, 1),
+    ]
+    assert bad == [-1] * len(bad), bad
+    assert lib.zkhip_last_error()                                          # a message is available
+    assert lib.zkhip_prepared_window_bits(123456) == -1
+    # and the library is still usable afterwards
+    a = F.fr_encode(list(range(16)))
+    _lib.check(lib.zkhip_ntt_fr(a.ctypes.data, w, 4))
+    assert F.fr_decode(a) == O.best_fft(list(range(16)), F.omega_for(4), 4)
