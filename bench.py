@@ -292,6 +292,18 @@ def extras(lib, _lib, F, torch, dev, stream) -> dict:
                              "note": "MSM+NTT portion only; the Rust host (witness, transcript) cannot run here"}
     out["wrapper_replay"]["host_buffers_ms"] = round(ms_host, 1)              # PCIe-inclusive: never `value`
     out["wrapper_replay"]["proofs_per_s_host_buffers"] = round(1e3 / ms_host, 3)
+    # a transcript-less create_proof of a *satisfied* halo2-lib-shaped circuit (4 gate columns, lookup, copy constraints), device-resident,
+    # with the prover's invariants checked (tools/prove_flow.py): quotient is a polynomial, grand products close, commitments agree
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import prove_flow
+
+        flow = prove_flow.run(22, 4, seed=22, verbose=False)
+        out["prover_flow_k22"] = {"prove_ms": round(flow["prove_ms"], 2), "columns": flow["columns"], "msms": flow["msms"], "checks": flow["checks"],
+                                  "timings_ms": {kk: round(v, 2) for kk, v in flow["timings_ms"].items()},
+                                  "note": "no transcript (seeded challenges); every column, fixed ones included, is transformed"}
+    except Exception as exc:   # an extra: never fail the bench line
+        out["prover_flow_k22"] = {"error": repr(exc)}
     tot = ms + out["prover_phases_k22"]["total_ms"]
     out["wrapper_replay"]["with_prover_phases_ms"] = round(tot, 2)          # + quotient, grand products, multiopen (8(f) rows 1-3)
     out["wrapper_replay"]["proofs_per_s_device_portion"] = round(1e3 / tot, 3)

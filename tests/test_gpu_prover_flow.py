@@ -145,3 +145,18 @@ def test_lookup_input_outside_the_table_is_reported(lib):
     circ["advice"][1][3] = 99                              # not a table value
     with pytest.raises(_lib.ZkhipError):
         quotient_top_coefficients(circ, rng)
+
+
+@pytest.mark.parametrize("k,gate_cols", [(7, 1), (10, 3)])
+def test_device_resident_prover_flow(lib, k, gate_cols):
+    """tools/prove_flow.py: the same composition on device-resident columns with the batched entry points and a structured SRS
+    (setup, advice commitments in the Lagrange basis, permutation / lookup arguments, batched iNTT / coset NTT, fused quotient, h
+    commitments, batched evaluations); the prover's invariants must hold, and must break with the witness"""
+    from tools import prove_flow
+
+    res = prove_flow.run(k, gate_cols, seed=5 + k, verbose=False)
+    assert all(res["checks"].values()), res["checks"]
+    bad = prove_flow.run(k, gate_cols, seed=5 + k, corrupt="gate", verbose=False)["checks"]
+    assert not bad["quotient_is_a_polynomial"] and bad["permutation_product_closes"] and bad["commit_lagrange_equals_commit_coeff"]
+    bad = prove_flow.run(k, gate_cols, seed=5 + k, corrupt="copy", verbose=False)["checks"]
+    assert not bad["quotient_is_a_polynomial"] and not bad["permutation_product_closes"]

@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""A transcript-less `create_proof` for a *satisfied* circuit of the halo2-lib shape, device-resident from witness columns to
+quotient commitments -- the steps of [DEP] halo2-axiom plonk/prover.rs in the order the reference's prover runs them
+(/root/reference/aggregator/src/wrapper.rs:129), composed from this repo's entry points only:
+
+  SRS (ParamsKZG.setup, known trapdoor) -> advice commitments (Lagrange basis) -> permutation and lookup arguments (row programs,
+  permute_expression_pair, grand products) -> Lagrange -> coefficients (batched iNTT) -> commitments -> extended coset (batched NTT)
+  -> fused quotient program -> / (X^n - 1) -> inverse extended transform -> h commitments -> evaluations at x.
+
+Circuit: `gate_cols` advice columns with the vertical gate q (a + b c - d) on rows 0, 4, 8, ..., one range-lookup column against a
+2^bits-entry table, copy constraints across advice / fixed columns, 5 blinding rows.  Checks (the prover's own invariants): both
+grand products close, the quotient is a polynomial (coefficients of degree >= 3n vanish), commit_lagrange(column) = commit(coefficients).
+There is no transcript: challenges are seeded.  Usage: prove_flow.py [k] [gate_cols]   (default 16 4)."""
+import ctypes as C
+import os
+import random
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import numpy as np
+import torch
+
+import zksnap_circuits_halo2_amd as Z
+from zksnap_circuits_halo2_amd import _lib, evaluation as E, fields as F
+
+R = F.R_MOD
+BLIND = 5
+
+
+def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True):
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    n, u = 1 << k, (1 << k) - (BLIND + 1)
+    lookup_bits = min(lookup_bits, k - 1)            # every table value must occur among the usable rows
+    rng = random.Random(seed)
+    torch.manual_seed(seed)
+    beta, gamma, theta, y, x, s = (rng.randrange(1, R) for _ in range(6))
+    dom = Z.EvaluationDomain(4, k)
+    ek, en = dom.extended_k, dom.extended_len()
+    G = gate_cols
+    t = {}
+    clock = [time.perf_counter()]
+
+    def lap(name):
+        torch.cuda.synchronize()
+        now = time.perf_counter()
+        t[name] = t.get(name, 0.0) + (now - clock[0]) * 1e3
+        clock[0] = now
+
+    def words(vals):                     # python ints -> device tensor of Montgomery words
+        return torch.from_numpy(F.fr_encode(vals).view(np.int64)).to(dev)
+
+    ONE = words([1])[0]
+
+    def rand_fr(m):                      # uniformly random canonical word patterns = random field elements
+        a = torch.randint(-(1 << 63), (1 << 63) - 1, (m, 4), dtype=torch.int64, device=dev)
+        a[:, 3] = torch.randint(0, 1 << 61, (m,), dtype=torch.int64, device=dev)
+        return a
+
+    def run_prog(prog, cols, log_rows, out=None):
+        if out is None:
+            out = torch.empty(((1 << log_rows), 4), dtype=torch.int64, device=dev)
+        prog.run_device([c.data_ptr() for c in cols], log_rows, out.data_ptr())
+        return out
+
+    to_mont = E.RowProgram()             # raw integer words are the Montgomery form of a / R: multiply by R
+    to_mont.emit(E.OP_MUL, 0, to_mont.column(0), to_mont.constant(pow(2, 256, R)))
+
+    def small_ints(v):                   # int64 tensor of small non-negative integers -> Montgomery words
+        a = torch.zeros((v.shape[0], 4), dtype=torch.int64, device=dev)
+        a[:, 0] = v
+        return run_prog(to_mont, [a], k)
+
+    rows = torch.arange(n, dtype=torch.int64, device=dev)
+    clock[0] = time.perf_counter()
+    # ---- SRS -------------------------------------------------------------------------------------------------------------
+    params = Z.ParamsKZG.setup(k, s)
+    d_g = torch.from_numpy(params.g.view(np.int64)).to(dev)
+    d_gl = torch.from_numpy(params.g_lagrange.view(np.int64)).to(dev)
+    params.close()
+    h_g, h_gl = C.c_uint64(0), C.c_uint64(0)
+    _lib.check(lib.zkhip_prepare_bases_device(d_g.data_ptr(), n, C.byref(h_g)))
+    _lib.check(lib.zkhip_prepare_bases_device(d_gl.data_ptr(), n, C.byref(h_gl)))
+    lap("setup_srs")
+
+    def commit(handle, col):
+        out = torch.zeros(12, dtype=torch.int64, device=dev)
+        _lib.check(lib.zkhip_msm_g1_prepared_device(handle, 0, col.data_ptr(), n, out.data_ptr(), None))
+        return out
+
+    def affine(jac):
+        return F.g1_decode_jacobian(jac.cpu().numpy().view(np.uint64))
+
+    try:
+        # ---- fixed and advice columns (Lagrange basis) ---------------------------------------------------------------------
+        gate_rows = (rows % 4 == 0) & (rows + 3 < u)
+        sel = torch.where(gate_rows[:, None], ONE[None, :], torch.zeros_like(ONE)[None, :]).contiguous()
+        sel3 = torch.roll(sel, 3, 0).contiguous()                                  # 1 on the gates' output rows
+        fixed = [sel.clone() for _ in range(G)] + [rand_fr(n), small_ints(rows % (1 << lookup_bits))]        # q_0.., fconst, table
+        fconst, table = fixed[G], fixed[G + 1]
+        advice = [rand_fr(n) for _ in range(G)]
+        lk = small_ints(torch.randint(0, 1 << lookup_bits, (n,), dtype=torch.int64, device=dev))
+        lk[u:] = rand_fr(n - u)
+        advice.append(lk)
+        perm_cols = [("advice", i) for i in range(G + 1)] + [("fixed", G)]         # every advice column and the constants column
+        pcol = lambda c: advice[c] if c <= G else fconst
+        cycles = [[(0, 1), (G + 1, 2)], [(G, 10), (G, 20)], [(0, 13), (G, 30)], [(0, 17), (0, 21), (G + 1, 5)]]
+        for cyc in cycles:                # equal values along every cycle (a cycle through the lookup column carries a table value)
+            src = next(((c, r) for c, r in cyc if c == G), cyc[0])
+            v = pcol(src[0])[src[1]].clone()
+            for c, r in cyc:
+                pcol(c)[r] = v
+        gate = E.RowProgram()             # out = a + sel3 * ((a[-3] + a[-2] a[-1]) - a): the gate outputs, everything else unchanged
+        gate.emit(E.OP_MUL, 0, gate.column(0, -2), gate.column(0, -1))
+        gate.emit(E.OP_ADD, 0, E.RowProgram.reg(0), gate.column(0, -3))
+        gate.emit(E.OP_SUB, 0, E.RowProgram.reg(0), gate.column(0, 0))
+        gate.emit(E.OP_MAD, 0, E.RowProgram.reg(0), gate.column(1, 0), gate.column(0, 0))
+        for i in range(G):
+            advice[i] = run_prog(gate, [advice[i], sel3], k)
+        if corrupt == "gate":
+            advice[0][7] = advice[0][8].clone()
+        if corrupt == "copy":
+            advice[0][21] = advice[0][22].clone()
+        lap("witness_columns")
+        adv_commit = [commit(h_gl, a) for a in advice]                             # advice is committed in the Lagrange basis
+        lap("commit_advice")
+
+        # ---- permutation argument --------------------------------------------------------------------------------------------
+        omega = F.omega_for(k)
+        sigma = []
+        for j in range(len(perm_cols)):
+            p = E.RowProgram(omega=omega)
+            p.emit(E.OP_MUL, 0, E.RowProgram.ROWPOW, p.constant(pow(E.DELTA, j, R)))
+            sigma.append(run_prog(p, [], k))
+        for cyc in cycles:
+            for idx, (c, r) in enumerate(cyc):
+                c2, r2 = cyc[(idx + 1) % len(cyc)]
+                sigma[c][r] = words([pow(E.DELTA, c2, R) * pow(omega, r2, R) % R])[0]
+        cs = E.ConstraintSystem(
+            num_fixed=G + 2, num_advice=G + 1, num_instance=0,
+            gates=[[E.Fixed(i) * (E.Advice(i, 0) + E.Advice(i, 1) * E.Advice(i, 2) - E.Advice(i, 3))] for i in range(G)],
+            lookups=[E.Lookup([E.Advice(G)], [E.Fixed(G + 1)])], permutation_columns=perm_cols, blinding_factors=BLIND, degree=4)
+        z_sets, last_z = [], 1
+        for si in range(cs.num_permutation_sets):
+            lo, hi = si * cs.chunk_len, min((si + 1) * cs.chunk_len, len(perm_cols))
+            vals = [pcol(c) for c in range(lo, hi)]
+            num = run_prog(E.permutation_numerator_program(hi - lo, lo, beta, gamma, k), vals, k)
+            den = run_prog(E.permutation_denominator_program(hi - lo, beta, gamma), vals + sigma[lo:hi], k)
+            _lib.check(lib.zkhip_fr_grand_product_device(num.data_ptr(), den.data_ptr(), n, num.data_ptr(), None))
+            if last_z != 1:                                                        # chain: z_k[0] = z_{k-1}[u]
+                sc = E.RowProgram()
+                sc.emit(E.OP_MUL, 0, sc.column(0), sc.constant(last_z))
+                num = run_prog(sc, [num], k)
+            last_z = F.fr_decode(num[u].cpu().numpy().view(np.uint64))[0]
+            num[u + 1:] = rand_fr(n - u - 1)                                       # blinding rows
+            z_sets.append(num)
+        perm_closes = last_z == 1
+        lap("permutation_products")
+
+        # ---- lookup argument ---------------------------------------------------------------------------------------------------
+        pa, ps = rand_fr(n), rand_fr(n)                                             # rows >= u stay random (blinding)
+        _lib.check(lib.zkhip_lookup_permute_device(lk.data_ptr(), table.data_ptr(), u, pa.data_ptr(), ps.data_ptr(), None))
+        pn, pd = E.lookup_product_programs(1, 1, beta, gamma, theta)
+        zl = run_prog(pn, [lk, table], k)
+        den = run_prog(pd, [pa, ps], k)
+        _lib.check(lib.zkhip_fr_grand_product_device(zl.data_ptr(), den.data_ptr(), n, zl.data_ptr(), None))
+        lookup_closes = F.fr_decode(zl[u].cpu().numpy().view(np.uint64))[0] == 1
+        zl[u + 1:] = rand_fr(n - u - 1)
+        lap("lookup_permute_and_product")
+
+        # ---- Lagrange -> coefficients, commitments, extended coset ---------------------------------------------------------------
+        l0 = torch.zeros((n, 4), dtype=torch.int64, device=dev); l0[0] = ONE
+        l_last = torch.zeros((n, 4), dtype=torch.int64, device=dev); l_last[u] = ONE
+        l_active = torch.where((rows < u)[:, None], ONE[None, :], torch.zeros_like(ONE)[None, :]).contiguous()
+        lagrange = fixed + advice + [l0, l_last, l_active] + sigma + z_sets + [zl, pa, ps]
+        qc = E.quotient_columns(cs)
+        assert len(lagrange) == qc.total
+        ncol = len(lagrange)
+        coeff = torch.stack(lagrange).contiguous()                                  # [ncol][n][4]
+        _lib.check(lib.zkhip_ifft_scaled_batch_device(coeff.data_ptr(), dom.omega_inv.ctypes.data, k, dom.ifft_divisor.ctypes.data, ncol, n, None))
+        lap("lagrange_to_coeff")
+        first_prover_poly = qc.sigma + len(perm_cols)                               # z sets, lookup product, permuted pair
+        prod_commit = [commit(h_g, coeff[i]) for i in range(first_prover_poly, ncol)]
+        a0_coeff_commit = commit(h_g, coeff[qc.advice])
+        lap("commit_products")
+        ext = torch.empty((ncol, en, 4), dtype=torch.int64, device=dev)
+        _lib.check(lib.zkhip_coeff_to_extended_device(coeff.data_ptr(), n, k, ext.data_ptr(), en, ek, ncol, dom.extended_omega.ctypes.data,
+                                                      dom.g_coset.ctypes.data, None))
+        lap("coeff_to_extended")
+
+        # ---- quotient ---------------------------------------------------------------------------------------------------------------
+        prog = E.evaluate_h_program(cs, k, ek, beta, gamma, theta, y)
+        h_ext = run_prog(prog, [ext[i] for i in range(ncol)], ek)
+        tinv = torch.from_numpy(dom.t_evaluations.view(np.int64)).to(dev)
+        _lib.check(lib.zkhip_mul_periodic_device(h_ext.data_ptr(), en, tinv.data_ptr(), tinv.shape[0], None))
+        lap("evaluate_h")
+        h_coeff = torch.empty((en, 4), dtype=torch.int64, device=dev)
+        _lib.check(lib.zkhip_extended_to_coeff_device(h_ext.data_ptr(), en, ek, dom.extended_omega_inv.ctypes.data, dom.extended_ifft_divisor.ctypes.data,
+                                                      dom.g_coset.ctypes.data, h_coeff.data_ptr(), en, en, 1, None))
+        lap("extended_to_coeff")
+        h_commit = [commit(h_g, h_coeff[i * n:(i + 1) * n]) for i in range(3)]
+        lap("commit_h")
+
+        # ---- evaluations at x ----------------------------------------------------------------------------------------------------------
+        evals = torch.zeros((ncol + 3, 4), dtype=torch.int64, device=dev)
+        ptrs = (C.c_void_p * (ncol + 3))(*([coeff[i].data_ptr() for i in range(ncol)] + [h_coeff[i * n:].data_ptr() for i in range(3)]))
+        _lib.check(lib.zkhip_fr_eval_polynomial_batch_device(ptrs, ncol + 3, n, F.fr_encode([x])[0].ctypes.data, evals.data_ptr(), None))
+        lap("evaluations")
+
+        top_is_zero = not bool(h_coeff[3 * n:].any().item())
+        low_nonzero = bool(h_coeff[:3 * n].any().item())
+        commit_agrees = affine(adv_commit[0]) == affine(a0_coeff_commit)
+        checks = {"permutation_product_closes": perm_closes, "lookup_product_closes": lookup_closes, "quotient_is_a_polynomial": top_is_zero and low_nonzero,
+                  "commit_lagrange_equals_commit_coeff": commit_agrees}
+        n_msm = len(adv_commit) + len(prod_commit) + 1 + len(h_commit)
+        prove_ms = sum(v for kk, v in t.items() if kk not in ("setup_srs", "witness_columns"))
+        if verbose:
+            print(f"k={k} gate_cols={G}: {ncol} columns, {n_msm} MSMs of 2^{k}, {ncol} iNTT 2^{k}, {ncol} NTT 2^{ek}, 1 iNTT 2^{ek}")
+            for name, ms in t.items():
+                print(f"  {name:28s} {ms:9.3f} ms")
+            print(f"  {'prover steps (no setup/witness)':28s} {prove_ms:9.3f} ms")
+            print("  checks:", checks)
+        return {"timings_ms": t, "prove_ms": prove_ms, "checks": checks, "columns": ncol, "msms": n_msm}
+    finally:
+        torch.cuda.synchronize()
+        lib.zkhip_release_bases(h_g)
+        lib.zkhip_release_bases(h_gl)
+
+
+if __name__ == "__main__":
+    kk = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    gg = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    res = run(kk, gg)
+    sys.exit(0 if all(res["checks"].values()) else 1)
