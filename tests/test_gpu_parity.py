@@ -875,3 +875,26 @@ def test_c_abi_rejects_bad_arguments_without_aborting(lib):
     a = F.fr_encode(list(range(16)))
     _lib.check(lib.zkhip_ntt_fr(a.ctypes.data, w, 4))
     assert F.fr_decode(a) == O.best_fft(list(range(16)), F.omega_for(4), 4)
+
+
+def test_ntt_batch_larger_than_the_scratch_cap_runs_in_sub_batches(lib):
+    """5 polynomials of 2^24 (2.7 GB) exceed the 2 GiB scratch cap: the batch is transformed in sub-batches of 4 + 1; each polynomial must
+    equal its single-call transform, and the inverse batch must restore the input"""
+    import torch
+
+    L, B = 24, 5
+    n = 1 << L
+    x = torch.randint(0, 1 << 62, (B, n, 4), dtype=torch.int64, device="cuda")
+    x[:, :, 3] &= (1 << 61) - 1
+    orig = x.clone()
+    om = F.fr_encode([F.omega_for(L)])[0]
+    omi = F.fr_encode([pow(F.omega_for(L), -1, F.R_MOD)])[0]
+    div = F.fr_encode([pow(n, -1, F.R_MOD)])[0]
+    single = orig[4].clone()
+    _lib.check(lib.zkhip_ntt_fr_device(single.data_ptr(), om.ctypes.data, L, None))
+    _lib.check(lib.zkhip_ntt_fr_batch_device(x.data_ptr(), om.ctypes.data, L, B, n, None))
+    torch.cuda.synchronize()
+    assert torch.equal(x[4], single)
+    _lib.check(lib.zkhip_ifft_scaled_batch_device(x.data_ptr(), omi.ctypes.data, L, div.ctypes.data, B, n, None))
+    torch.cuda.synchronize()
+    assert torch.equal(x, orig)

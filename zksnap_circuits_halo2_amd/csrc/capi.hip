@@ -1,6 +1,7 @@
 // C ABI of libzkhip.so (include/zkhip.h): context, device buffers, registered-base residency, and the host-buffer
 // wrappers around the device paths in msm.hip / ntt.hip.  No CPU arithmetic lives here.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -360,7 +361,12 @@ static int run_transform(const uint32_t* d_in, uint32_t in_len, uint32_t in_stri
                          const uint32_t* out_scale, uint32_t out_period, hipStream_t s) {
   if (L > 28) { set_error("ntt: log_n = %u > 28", L); return ZKHIP_EINVAL; }
   const int np = ntt_passes(L);
-  const size_t one = (size_t)batch << L;   // elements
+  // the passes ping-pong through one or two scratch copies of the batch: cap the scratch at ~2 GiB per copy by transforming a large
+  // batch in sub-batches (same kernels, same throughput; 26 polynomials of 2^24 would otherwise need 28 GB of scratch)
+  uint32_t sub = batch;
+  const size_t cap = (size_t)1 << 31;
+  if (batch > 1 && (((size_t)batch << L) * 32) > cap) sub = (uint32_t)std::max<size_t>(1, cap / (((size_t)1 << L) * 32));
+  const size_t one = (size_t)sub << L;     // elements per scratch copy
   uint32_t *t0 = nullptr, *t1 = nullptr;
   if (np >= 2) {
     int rc = g_ctx.ntt_tmp.reserve(one * 32 * (np >= 3 ? 2 : 1));
@@ -368,7 +374,13 @@ static int run_transform(const uint32_t* d_in, uint32_t in_len, uint32_t in_stri
     t0 = (uint32_t*)g_ctx.ntt_tmp.p;
     if (np >= 3) t1 = t0 + one * 8;
   }
-  return ntt_transform(d_in, in_len, in_stride, d_out, out_len, out_stride, batch, L, omega, in_scale, in_period, out_scale, out_period, t0, t1, s);
+  for (uint32_t b0 = 0; b0 < batch; b0 += sub) {
+    const uint32_t nb = batch - b0 < sub ? batch - b0 : sub;
+    int rc = ntt_transform(d_in + (size_t)b0 * in_stride * 8, in_len, in_stride, d_out + (size_t)b0 * out_stride * 8, out_len, out_stride, nb, L, omega,
+                           in_scale, in_period, out_scale, out_period, t0, t1, s);
+    if (rc != ZKHIP_OK) return rc;
+  }
+  return ZKHIP_OK;
 }
 
 int zkhip_ntt_fr_batch_device(void* d_a, const uint64_t omega[4], uint32_t log_n, uint32_t batch, size_t stride, void* stream) {
