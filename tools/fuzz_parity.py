@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Randomised differential run of the C ABI against the oracles (test infrastructure: imports oracle/).  `fuzz_parity.py SECONDS [SEED]`:
+random sizes, window overrides, scalar distributions and programs until the time is up; stops at the first mismatch with a repro line."""
+import ctypes as C, os, random, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import numpy as np, torch
+from oracle import bn254 as O, cpu_ref as Cr
+from zksnap_circuits_halo2_amd import _lib, arithmetic as A, evaluation as E, fields as F
+
+Cr.load()
+lib = _lib.load()
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+rng = random.Random(seed0)
+R = O.R_MOD
+T0, D = 0x5A4B534E41500999, 0x9E3779B97F4A7C15F39CC0605CEDC835
+t0m, dm = F.fr_encode([T0])[0], F.fr_encode([D])[0]
+counts = {}
+
+def aff(x): return Cr.jac_to_affine(np.ascontiguousarray(x))
+
+def scalars(n, seed):
+    kind = rng.randrange(4)
+    if kind < 2: return Cr.gen_scalars(seed, n, kind)
+    if kind == 2:                                      # few distinct values: heavy buckets
+        vals = Cr.gen_scalars(seed, rng.randint(1, 4), 0)
+        return np.ascontiguousarray(vals[np.random.default_rng(seed).integers(0, vals.shape[0], n)])
+    s = Cr.gen_scalars(seed, n, 0); s[rng.randrange(n):] = 0; return s      # zero tail
+
+def fuzz_msm(seed):
+    n = rng.choice([rng.randint(1, 300), rng.randint(300, 20000), rng.randint(20000, 300000)])
+    bases = torch.empty(n * 8, dtype=torch.int64, device="cuda")
+    _lib.check(lib.zkhip_g1_gen_walk_device(t0m.ctypes.data, dm.ctypes.data, n, bases.data_ptr(), None))
+    sc = scalars(n, seed)
+    dsc = torch.from_numpy(sc.view(np.int64)).cuda()
+    exp = aff(Cr.scalar_mul(Cr.expected_scalar(sc, T0, D), Cr.generator()))
+    out = torch.zeros(12, dtype=torch.int64, device="cuda")
+    c = rng.choice([0, 0, rng.randint(2, 16)])
+    _lib.check(lib.zkhip_msm_g1_device_c(dsc.data_ptr(), bases.data_ptr(), n, out.data_ptr(), c, None))
+    torch.cuda.synchronize()
+    assert np.array_equal(aff(out.cpu().numpy().view(np.uint64)), exp), f"general msm n={n} c={c}"
+    cp = rng.choice([0, 0, rng.randint(2, 20)])
+    h = C.c_uint64(0)
+    _lib.check(lib.zkhip_prepare_bases_device_c(bases.data_ptr(), n, cp, C.byref(h)))
+    try:
+        off = rng.randrange(0, max(1, n // 3)); m = rng.randint(1, n - off)
+        _lib.check(lib.zkhip_msm_g1_prepared_device(h, 0, dsc.data_ptr(), n, out.data_ptr(), None))
+        torch.cuda.synchronize()
+        assert np.array_equal(aff(out.cpu().numpy().view(np.uint64)), exp), f"prepared msm n={n} c={cp}"
+        _lib.check(lib.zkhip_msm_g1_prepared_device(h, off, dsc.data_ptr() + off * 32, m, out.data_ptr(), None))
+        torch.cuda.synchronize()
+        sub = np.ascontiguousarray(sc[off:off + m])
+        e2 = aff(Cr.scalar_mul(Cr.expected_scalar(sub, (T0 + off * D) % R, D), Cr.generator()))
+        assert np.array_equal(aff(out.cpu().numpy().view(np.uint64)), e2), f"prepared sub-range n={n} c={cp} off={off} m={m}"
+    finally:
+        lib.zkhip_release_bases(h)
+
+def fuzz_ntt(seed):
+    L = rng.randint(0, 17)
+    a = Cr.gen_scalars(seed, 1 << L, rng.randrange(2))
+    om = F.fr_encode([F.omega_for(L)])[0]
+    ref = a.copy(); Cr.best_fft(ref, om, L, 4)
+    got = a.copy(); A.best_fft(got, om, L)
+    assert np.array_equal(got, ref), f"ntt L={L}"
+
+def fuzz_poly(seed):
+    n = rng.choice([rng.randint(1, 70), rng.randint(70, 5000), rng.randint(5000, 200000)])
+    a = Cr.gen_scalars(seed, n, rng.randrange(2)); x = Cr.gen_scalars(seed + 1, 1, 0)[0]
+    assert np.array_equal(A.eval_polynomial(a, x), Cr.eval_polynomial(a, x)), f"eval n={n}"
+    assert np.array_equal(A.kate_division(a, x), Cr.kate_division(a, x)), f"kate n={n}"
+    assert np.array_equal(A.prefix_product(a), Cr.prefix_product(a)), f"prefix n={n}"
+    b, r = a.copy(), a.copy(); A.batch_invert(b); Cr.batch_invert(r)
+    assert np.array_equal(b, r), f"invert n={n}"
+
+def fuzz_rows(seed):
+    log_rows = rng.randint(0, 8); rows = 1 << log_rows; n_cols = rng.randint(1, 4)
+    cols = [[rng.randrange(R) if rng.random() < 0.9 else rng.choice([0, 1, R - 1]) for _ in range(rows)] for _ in range(n_cols)]
+    omega = O.omega_for(log_rows) if rng.random() < 0.5 else None
+    prev = [rng.randrange(R) for _ in range(rows)] if rng.random() < 0.5 else None
+    p = E.RowProgram(rot_scale=rng.choice([1, 2, 4]), omega=omega)
+    written = []
+    def operand():
+        kinds = ["const", "col"] + (["reg"] if written else []) + (["prev"] if prev is not None else []) + (["rowpow"] if omega else [])
+        k = rng.choice(kinds)
+        if k == "const": return p.constant(rng.choice([0, 1, R - 1, rng.randrange(R)]))
+        if k == "col": return p.column(rng.randrange(n_cols), rng.choice([0, 1, -1, 2, -5]))
+        if k == "reg": return E.RowProgram.reg(rng.choice(written))
+        return E.RowProgram.PREV if k == "prev" else E.RowProgram.ROWPOW
+    n_regs = rng.choice([6, 8, 12, 16])
+    for _ in range(rng.randint(1, 120)):
+        dst = rng.randrange(n_regs); p.emit(rng.randrange(8), dst, operand(), operand(), operand())
+        if dst not in written: written.append(dst)
+    p.result_reg = rng.choice(written)
+    out = F.fr_encode(prev) if prev is not None else None
+    got = F.fr_decode(p.run([F.fr_encode(c) for c in cols] + [F.fr_encode(cols[0])] * (p.n_columns - n_cols), log_rows, out=out, accumulate=prev is not None))
+    exp = O.row_program_run(p.insns, p.constants, p.rotations, p.rot_scale, p.result_reg, cols + [cols[0]] * 8, log_rows, omega=omega, prev=prev)
+    assert got == exp, f"row program rows={rows}"
+
+def fuzz_lookup(seed):
+    n = rng.randint(1, 3000); bits = rng.choice([1, 3, 8, 250])
+    table = [rng.randrange(1 << bits) % R for _ in range(n)]
+    usable = rng.randint(1, n)
+    inputs = [rng.choice(table[:usable]) for _ in range(n)]
+    gi, gt = E.permute_expression_pair(F.fr_encode(inputs), F.fr_encode(table), usable)
+    ei, et = O.permute_expression_pair(inputs, table, usable)
+    assert F.fr_decode(gi) == ei and F.fr_decode(gt) == et, f"lookup n={n} usable={usable} bits={bits}"
+
+fns = [fuzz_msm, fuzz_ntt, fuzz_poly, fuzz_rows, fuzz_lookup]
+t_end = time.time() + budget
+it = 0
+while time.time() < t_end:
+    f = fns[it % len(fns)]
+    seed = rng.randrange(1 << 30)
+    state = rng.getstate()
+    try:
+        f(seed)
+    except AssertionError as e:
+        print(f"MISMATCH in {f.__name__}: {e}  (run seed {seed0}, iteration {it}, case seed {seed})", flush=True)
+        sys.exit(1)
+    counts[f.__name__] = counts.get(f.__name__, 0) + 1
+    it += 1
+    if it % 50 == 0: print(f"{it} cases ok {counts}", flush=True)
+print(f"done: {it} cases, no mismatch {counts}")
