@@ -105,7 +105,60 @@ def fuzz_lookup(seed):
     ei, et = O.permute_expression_pair(inputs, table, usable)
     assert F.fr_decode(gi) == ei and F.fr_decode(gt) == et, f"lookup n={n} usable={usable} bits={bits}"
 
-fns = [fuzz_msm, fuzz_ntt, fuzz_poly, fuzz_rows, fuzz_lookup]
+def fuzz_batched(seed):
+    """the batched / strided device entry points against their single-call forms"""
+    import zksnap_circuits_halo2_amd as Z
+    k = rng.randint(1, 12); n = 1 << k; B = rng.randint(1, 5); pad = rng.choice([0, 8, 40])
+    dom = Z.EvaluationDomain(4, k)
+    polys = [Cr.gen_scalars(seed + b, n, rng.randrange(2)) for b in range(B)]
+    stride = n + pad
+    x = torch.zeros((B, stride, 4), dtype=torch.int64, device="cuda")
+    for b in range(B): x[b, :n] = torch.from_numpy(polys[b].view(np.int64)).cuda()
+    om = F.fr_encode([F.omega_for(k)])[0]
+    _lib.check(lib.zkhip_ntt_fr_batch_device(x.data_ptr(), om.ctypes.data, k, B, stride, None))
+    torch.cuda.synchronize()
+    for b in range(B):
+        ref = polys[b].copy(); Cr.best_fft(ref, om, k, 4)
+        assert np.array_equal(x[b, :n].cpu().numpy().view(np.uint64), ref), f"ntt batch k={k} B={B} pad={pad}"
+    assert not x[:, n:].any().item(), "ntt batch wrote into the padding"
+    # coset round trip, device, strided
+    en, ek = dom.extended_len(), dom.extended_k
+    c = torch.zeros((B, stride, 4), dtype=torch.int64, device="cuda")
+    for b in range(B): c[b, :n] = torch.from_numpy(polys[b].view(np.int64)).cuda()
+    e = torch.zeros((B, en + pad, 4), dtype=torch.int64, device="cuda")
+    _lib.check(lib.zkhip_coeff_to_extended_device(c.data_ptr(), stride, k, e.data_ptr(), en + pad, ek, B, dom.extended_omega.ctypes.data, dom.g_coset.ctypes.data, None))
+    torch.cuda.synchronize()
+    assert np.array_equal(e[B - 1, :en].cpu().numpy().view(np.uint64), dom.coeff_to_extended(polys[B - 1])), f"coeff_to_extended batch k={k}"
+    o = torch.zeros((B, 3 * n + pad, 4), dtype=torch.int64, device="cuda")
+    _lib.check(lib.zkhip_extended_to_coeff_device(e.data_ptr(), en + pad, ek, dom.extended_omega_inv.ctypes.data, dom.extended_ifft_divisor.ctypes.data,
+                                                  dom.g_coset.ctypes.data, o.data_ptr(), 3 * n + pad, 3 * n, B, None))
+    torch.cuda.synchronize()
+    for b in range(B):
+        back = o[b].cpu().numpy().view(np.uint64)
+        assert np.array_equal(back[:n], polys[b]) and not back[n:].any(), f"extended_to_coeff batch k={k} b={b}"
+    # batched evaluation and batched prepared MSM
+    pt = Cr.gen_scalars(seed + 99, 1, 0)[0]
+    ev = torch.zeros((B, 4), dtype=torch.int64, device="cuda")
+    ptrs = (C.c_void_p * B)(*[c[b].data_ptr() for b in range(B)])
+    _lib.check(lib.zkhip_fr_eval_polynomial_batch_device(ptrs, B, n, pt.ctypes.data, ev.data_ptr(), None))
+    torch.cuda.synchronize()
+    for b in range(B):
+        assert np.array_equal(ev[b].cpu().numpy().view(np.uint64), Cr.eval_polynomial(polys[b], pt)), f"eval batch k={k} b={b}"
+    bases = torch.empty(n * 8, dtype=torch.int64, device="cuda")
+    _lib.check(lib.zkhip_g1_gen_walk_device(t0m.ctypes.data, dm.ctypes.data, n, bases.data_ptr(), None))
+    h = C.c_uint64(0)
+    _lib.check(lib.zkhip_prepare_bases_device_c(bases.data_ptr(), n, rng.choice([0, rng.randint(2, 16)]), C.byref(h)))
+    try:
+        outs = torch.zeros((B, 12), dtype=torch.int64, device="cuda")
+        _lib.check(lib.zkhip_msm_g1_prepared_batch_device(h, 0, c.data_ptr(), n, B, stride, outs.data_ptr(), None))
+        torch.cuda.synchronize()
+        for b in range(B):
+            exp = aff(Cr.scalar_mul(Cr.expected_scalar(polys[b], T0, D), Cr.generator()))
+            assert np.array_equal(aff(outs[b].cpu().numpy().view(np.uint64)), exp), f"msm batch k={k} b={b}"
+    finally:
+        lib.zkhip_release_bases(h)
+
+fns = [fuzz_msm, fuzz_ntt, fuzz_poly, fuzz_rows, fuzz_lookup, fuzz_batched]
 t_end = time.time() + budget
 it = 0
 while time.time() < t_end:
