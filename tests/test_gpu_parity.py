@@ -898,3 +898,31 @@ def test_ntt_batch_larger_than_the_scratch_cap_runs_in_sub_batches(lib):
     _lib.check(lib.zkhip_ifft_scaled_batch_device(x.data_ptr(), omi.ctypes.data, L, div.ctypes.data, B, n, None))
     torch.cuda.synchronize()
     assert torch.equal(x, orig)
+
+
+@pytest.mark.parametrize("log_n", [25, 26, 28])
+def test_ntt_above_the_direct_twiddle_table_limit(lib, log_n):
+    """2^25 .. 2^28 (the ABI's maximum): pass twiddles come from two sqrt-size tables instead of one direct table.  Device-resident:
+    NTT(delta_j)[i] = omega^(i j) at sampled i, and iNTT(NTT(a)) = a on random data."""
+    import torch
+
+    n = 1 << log_n
+    w = O.omega_for(log_n)
+    om, omi = F.fr_encode([w])[0], F.fr_encode([pow(w, -1, O.R_MOD)])[0]
+    div = F.fr_encode([pow(n, -1, O.R_MOD)])[0]
+    j = 0x2F3A5 % n
+    d = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+    d[j] = torch.from_numpy(F.fr_encode([1]).view(np.int64))[0].cuda()
+    _lib.check(lib.zkhip_ntt_fr_device(d.data_ptr(), om.ctypes.data, log_n, None))
+    torch.cuda.synchronize()
+    idx = [0, 1, 2, 4097, 65537, n // 2 + 3, n - 1]
+    got = F.fr_decode(d[idx].cpu().numpy().view(np.uint64))
+    assert got == [pow(w, i * j, O.R_MOD) for i in idx]
+    del d
+    a = torch.randint(-(1 << 63), (1 << 63) - 1, (n, 4), dtype=torch.int64, device="cuda")
+    a[:, 3] = torch.randint(0, 1 << 61, (n,), dtype=torch.int64, device="cuda")
+    orig = a.clone()
+    _lib.check(lib.zkhip_ntt_fr_device(a.data_ptr(), om.ctypes.data, log_n, None))
+    _lib.check(lib.zkhip_ifft_scaled_device(a.data_ptr(), omi.ctypes.data, log_n, div.ctypes.data, None))
+    torch.cuda.synchronize()
+    assert torch.equal(a, orig)
