@@ -91,3 +91,25 @@ def test_shard_ranges_partition_exactly():
             assert all(r[i][1] == r[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in r]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_header_is_plain_c99_and_links(tmp_path):
+    """include/zkhip.h is what a cgo / Rust-bindgen / JNI binding would consume: it must compile as strict C99, and a C program must
+    link against libzkhip.so with it (no C++ in the interface)"""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "abi.c"
+    src.write_text('#include "zkhip.h"\n'
+                   "int main(void) {\n"
+                   "  zkhip_vm_insn insn; zkhip_vm_program prog; (void)insn; (void)prog;\n"
+                   "  /* no GPU here: the call must fail cleanly with ZKHIP_ENODEV and leave a message */\n"
+                   "  unsigned long long a[4] = {0, 0, 0, 0}, w[4] = {1, 0, 0, 0};\n"
+                   "  int rc = zkhip_ntt_fr((uint64_t *)a, (const uint64_t *)w, 0);\n"
+                   "  return (rc == ZKHIP_ENODEV || rc == ZKHIP_OK) && zkhip_last_error() != 0 ? 0 : 1;\n"
+                   "}\n")
+    exe = tmp_path / "abi"
+    lib_dir = os.path.join(root, "zksnap_circuits_halo2_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+                           "-L", lib_dir, "-lzkhip", "-Wl,-rpath," + lib_dir])
+    assert subprocess.call([str(exe)]) == 0
