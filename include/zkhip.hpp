@@ -317,11 +317,51 @@ class ParamsKZG {
     if (!g_lagrange_.empty()) check(zkhip_register_bases(g_lagrange_.data()->x, g_lagrange_.size()), "ParamsKZG::register g_lagrange");
   }
   ~ParamsKZG() {
-    zkhip_unregister_bases(g_.data()->x);
+    if (!g_.empty()) zkhip_unregister_bases(g_.data()->x);
     if (!g_lagrange_.empty()) zkhip_unregister_bases(g_lagrange_.data()->x);
   }
   ParamsKZG(const ParamsKZG&) = delete;
   ParamsKZG& operator=(const ParamsKZG&) = delete;
+
+  // `ParamsKZG::setup(k, rng)` with the trapdoor given (tests / benches, as the reference's benches do with a seeded rng):
+  // g[i] = [s^i] G, g_lagrange[i] = [(s^n - 1)/n * w^i / (s - w^i)] G.  The scalar vectors are O(n) host multiplications plus one
+  // batch inversion on the device; the 2n fixed-base multiplications run on the device.
+  static ParamsKZG setup(uint32_t k, const Fr& s) {
+    const uint64_t n = (uint64_t)1 << k;
+    Fr omega = fr_root_of_unity();
+    for (uint32_t i = k; i < 28; i++) omega = detail::mul(omega, omega);
+    std::vector<Fr> pw(n), den(n);
+    Fr cur = detail::one(), wi = detail::one();
+    for (uint64_t i = 0; i < n; i++) {
+      pw[i] = cur;
+      den[i] = detail::sub_fr(s, wi);
+      cur = detail::mul(cur, s);
+      wi = detail::mul(wi, omega);
+    }
+    const Fr s_n = cur;                                             // s^n
+    if (std::memcmp(s_n.l, detail::one().l, 32) == 0) throw std::invalid_argument("ParamsKZG::setup: trapdoor lies in the domain");
+    batch_invert(den);
+    const Fr mult = detail::mul(detail::sub_fr(s_n, detail::one()), detail::invert(detail::from_u64(n)));
+    wi = detail::one();
+    for (uint64_t i = 0; i < n; i++) {
+      den[i] = detail::mul(detail::mul(den[i], wi), mult);          // L_i(s)
+      wi = detail::mul(wi, omega);
+    }
+    auto points = [n](const std::vector<Fr>& scalars) {
+      DeviceVec d_sc(scalars);
+      void* d_pts = nullptr;
+      check(zkhip_alloc(n * sizeof(G1Affine), &d_pts), "setup alloc");
+      std::vector<G1Affine> out(n);
+      int rc = zkhip_g1_fixed_base_mul_device(d_sc.data(), n, d_pts, nullptr);
+      if (rc == ZKHIP_OK) rc = zkhip_download(out.data(), d_pts, n * sizeof(G1Affine));
+      (void)zkhip_free(d_pts);
+      check(rc, "ParamsKZG::setup");
+      return out;
+    };
+    std::vector<G1Affine> g = points(pw), gl = points(den);
+    return ParamsKZG(k, std::move(g), std::move(gl));
+  }
+  ParamsKZG(ParamsKZG&& o) noexcept : k_(o.k_), n_(o.n_), g_(std::move(o.g_)), g_lagrange_(std::move(o.g_lagrange_)) {}   // the registered arrays keep their addresses
 
   uint32_t k() const { return k_; }
   uint64_t n() const { return n_; }

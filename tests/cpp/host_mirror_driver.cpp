@@ -4,7 +4,8 @@
 //   in : u32 j, u32 k, then 2^k Fr (polynomial), 2^k G1Affine (SRS g)
 //   out: omega, extended_omega (Fr each), commit (G1), best_fft(poly, omega), lagrange_to_coeff(poly), coeff_to_extended(poly),
 //        divide_by_vanishing_poly(ext), extended_to_coeff(ext), eval_polynomial(poly, omega), kate_division(poly, omega),
-//        grand_product, permute_expression_pair (2 vectors of 2^k - 6), a row program's output column
+//        grand_product, permute_expression_pair (2 vectors of 2^k - 6), a row program's output column,
+//        setup(k, s): g[0..4), commit(poly), commit_lagrange(poly)
 #include <cstdio>
 #include <vector>
 #include "zkhip.hpp"
@@ -68,6 +69,14 @@ int main(int argc, char** argv) {
       rp.result_reg = 1;
       rp.run({&col}, k, res);
       put(out, res.to_host());
+    }
+    // ParamsKZG::setup with a known trapdoor: first SRS points, and the same polynomial committed in both bases
+    {
+      ParamsKZG ps = ParamsKZG::setup(k, detail::from_u64(0x1234567ULL));
+      fwrite(ps.get_g().data(), sizeof(G1Affine), 4, out);
+      G1 c1 = ps.commit(poly), c2 = ps.commit_lagrange(poly);
+      fwrite(&c1, sizeof(G1), 1, out);
+      fwrite(&c2, sizeof(G1), 1, out);
     }
     fclose(out);
     // error behaviour: the reference's assert_eq!(coeffs.len(), bases.len())

@@ -633,6 +633,13 @@ def test_cpp_host_mirror(cref, tmp_path):
     assert F.fr_decode(take(n - 6, 4)) == exp_in
     assert F.fr_decode(take(n - 6, 4)) == exp_tab
     assert F.fr_decode(take(n, 4)) == [(pv[i] * pv[(i + 1) % n] + 7 * pv[i]) % O.R_MOD for i in range(n)]
+    # ParamsKZG::setup(k, s): g[i] = [s^i] G; commit(p) = [p(s)] G; commit_lagrange(e) = [interpolant of e at s] G
+    s_trap = 0x1234567
+    g4 = take(4, 8)
+    assert [O.affine_from_limbs([int(x) for x in row]) for row in g4] == O.structured_srs(s_trap, 4)
+    c1, c2 = take(1, 12)[0], take(1, 12)[0]
+    assert F.g1_decode_jacobian(c1) == O.scalar_mul(O.eval_polynomial(pv, s_trap), O.G1_GEN)
+    assert F.g1_decode_jacobian(c2) == O.scalar_mul(O.eval_polynomial(dom.lagrange_to_coeff(pv), s_trap), O.G1_GEN)
     assert pos == raw.size
 
 
