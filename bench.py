@@ -298,7 +298,9 @@ def extras(lib, _lib, F, torch, dev, stream) -> dict:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import prove_flow
 
-        flow = prove_flow.run(22, 4, seed=22, verbose=False)
+        flows = [prove_flow.run(22, 4, seed=22 + r, verbose=False) for r in range(2)]     # the first run pays one-time allocations
+        assert all(all(f["checks"].values()) for f in flows), [f["checks"] for f in flows]
+        flow = min(flows, key=lambda f: f["prove_ms"])
         out["prover_flow_k22"] = {"prove_ms": round(flow["prove_ms"], 2), "columns": flow["columns"], "msms": flow["msms"], "checks": flow["checks"],
                                   "timings_ms": {kk: round(v, 2) for kk, v in flow["timings_ms"].items()},
                                   "note": "no transcript (seeded challenges); every column, fixed ones included, is transformed"}

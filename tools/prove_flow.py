@@ -178,6 +178,7 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True):
         assert len(lagrange) == qc.total
         ncol = len(lagrange)
         coeff = torch.stack(lagrange).contiguous()                                  # [ncol][n][4]
+        lap("stack_columns")
         _lib.check(lib.zkhip_ifft_scaled_batch_device(coeff.data_ptr(), dom.omega_inv.ctypes.data, k, dom.ifft_divisor.ctypes.data, ncol, n, None))
         lap("lagrange_to_coeff")
         first_prover_poly = qc.sigma + len(perm_cols)                               # z sets, lookup product, permuted pair
@@ -214,7 +215,7 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True):
         checks = {"permutation_product_closes": perm_closes, "lookup_product_closes": lookup_closes, "quotient_is_a_polynomial": top_is_zero and low_nonzero,
                   "commit_lagrange_equals_commit_coeff": commit_agrees}
         n_msm = len(adv_commit) + len(prod_commit) + 1 + len(h_commit)
-        prove_ms = sum(v for kk, v in t.items() if kk not in ("setup_srs", "witness_columns"))
+        prove_ms = sum(v for kk, v in t.items() if kk not in ("setup_srs", "witness_columns", "stack_columns"))
         if verbose:
             print(f"k={k} gate_cols={G}: {ncol} columns, {n_msm} MSMs of 2^{k}, {ncol} iNTT 2^{k}, {ncol} NTT 2^{ek}, 1 iNTT 2^{ek}")
             for name, ms in t.items():
