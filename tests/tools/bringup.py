@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """First-light GPU checks against the Python big-int oracle (later superseded by tests/)."""
 import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import numpy as np
 from oracle import bn254 as O
 import zksnap_circuits_halo2_amd as Z

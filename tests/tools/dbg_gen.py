@@ -1,5 +1,5 @@
 import os, sys, ctypes as C
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import numpy as np, torch
 from oracle import bn254 as O, cpu_ref as Cr
 from zksnap_circuits_halo2_amd import _lib, fields as F

@@ -2,7 +2,7 @@
 """Randomised differential run of the C ABI against the oracles (test infrastructure: imports oracle/).  `fuzz_parity.py SECONDS [SEED] [large]`:
 random sizes, window overrides, scalar distributions and programs until the time is up; stops at the first mismatch with a repro line."""
 import ctypes as C, os, random, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import numpy as np, torch
 from oracle import bn254 as O, cpu_ref as Cr
 from zksnap_circuits_halo2_amd import _lib, arithmetic as A, evaluation as E, fields as F

@@ -2,7 +2,7 @@
 """MSM size sweep (prepared and general paths), uniform and witness-like scalars; checks every result against the
 structured identity MSM(a, (t0+i d)G) = [sum a_i (t0+i d)] G using the C oracle for the scalar sum."""
 import os, sys, time, ctypes as C
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import numpy as np, torch
 from oracle import cpu_ref as Cr
 from zksnap_circuits_halo2_amd import _lib, fields as F
