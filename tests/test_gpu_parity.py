@@ -933,3 +933,26 @@ def test_ntt_above_the_direct_twiddle_table_limit(lib, log_n):
     _lib.check(lib.zkhip_ifft_scaled_device(a.data_ptr(), omi.ctypes.data, log_n, div.ctypes.data, None))
     torch.cuda.synchronize()
     assert torch.equal(a, orig)
+
+
+def test_shutdown_and_lazy_reinit(lib, cref):
+    """zkhip_shutdown releases every device resource (tables, scratch, cached twiddles, the generator table); the next call
+    initialises lazily again and gives the same results"""
+    n = 3000
+    bases, t0, d = cref.gen_bases(99, n)
+    sc = cref.gen_scalars(98, n, 0)
+    before = aff(cref, Z.best_multiexp(sc, bases))
+    a = cref.gen_scalars(97, 1 << 10, 0)
+    f1 = a.copy(); Z.best_fft(f1, F.fr_encode([F.omega_for(10)])[0], 10)
+    params = Z.ParamsKZG.setup(6, 12345)
+    g_before = params.g.copy()
+    params.close()
+    lib.zkhip_shutdown()
+    lib.zkhip_shutdown()                                   # idempotent
+    assert np.array_equal(aff(cref, Z.best_multiexp(sc, bases)), before)
+    f2 = a.copy(); Z.best_fft(f2, F.fr_encode([F.omega_for(10)])[0], 10)
+    assert np.array_equal(f1, f2)
+    params = Z.ParamsKZG.setup(6, 12345)
+    assert np.array_equal(params.g, g_before)
+    params.close()
+    assert np.array_equal(before, structured_expect(cref, sc, t0, d))
