@@ -67,20 +67,14 @@ ZK_HD xyzz xyzz_dbl(const xyzz& A) {
 
 // acc += (x2, y2): mixed addition madd-2008-s.  x2, y2 are N-limbed and may be unreduced up to 64p
 // (the lazy external load gives < 32p, its negation < 64p).  The affine point must not be the identity.
-ZK_HD void xyzz_madd(xyzz& acc, const fe& x2, const fe& y2) {
-  if (xyzz_is_identity(acc)) {
-    fe one = fe_one<Fq>();
-    acc.X = fe_mul<Fq>(one, x2);                      // reduce: < 1.4p
-    acc.Y = fe_mul<Fq>(one, y2);
-    acc.ZZ = one;
-    acc.ZZZ = one;
-    return;
-  }
-  fe U2 = fe_mul<Fq>(acc.ZZ, x2);                     // 2*64/169 + 1 < 1.8p
-  fe S2 = fe_mul<Fq>(acc.ZZZ, y2);
+// CHAIN selects the multiply shape of the common path (fp29.hpp fe_mac).
+template <bool CHAIN = false>
+ZK_HD void xyzz_madd_nz(xyzz& acc, const fe& x2, const fe& y2) {   // acc is not the identity
+  fe U2 = fe_mul<Fq, CHAIN>(acc.ZZ, x2);                     // 2*64/169 + 1 < 1.8p
+  fe S2 = fe_mul<Fq, CHAIN>(acc.ZZZ, y2);
   fe P = fe_norm(fe_sub_red(U2, acc.X, Fq::P10_S1));  // X1 N < 9p;  P < 12p
   fe R = fe_norm(fe_sub_red(S2, acc.Y, Fq::P6_S1));   // Y1 N < 5p;  R < 8p
-  fe PP = fe_sqr<Fq>(P);                              // 144/169 + 1 < 1.86p
+  fe PP = fe_sqr<Fq, CHAIN>(P);                              // 144/169 + 1 < 1.86p
   if (fe_mulout_is_zero<Fq>(PP)) {                    // same x: doubling or inverse points (rare)
     fe RR0 = fe_sqr<Fq>(R);
     if (fe_mulout_is_zero<Fq>(RR0)) {
@@ -91,16 +85,36 @@ ZK_HD void xyzz_madd(xyzz& acc, const fe& x2, const fe& y2) {
     }
     return;
   }
-  fe PPP = fe_mul<Fq>(PP, P);                         // < 1.14p
-  fe Q = fe_mul<Fq>(PP, acc.X);                       // < 1.1p
-  fe RR = fe_sqr<Fq>(R);                              // < 1.4p
+  fe PPP = fe_mul<Fq, CHAIN>(PP, P);                         // < 1.14p
+  fe Q = fe_mul<Fq, CHAIN>(PP, acc.X);                       // < 1.1p
+  fe RR = fe_sqr<Fq, CHAIN>(R);                              // < 1.4p
   fe X3 = fe_norm(fe_sub_red(RR, fe_add(PPP, fe_dbl(Q)), Fq::P7_S3));  // subtrahend limbs < 3*2^29; X3 < 9p
   fe T = fe_sub_red(Q, X3, Fq::P10_S1);               // limbs < 1.5*2^30, < 12p
-  fe Y3 = fe_norm(fe_sub_red(fe_mul<Fq>(R, T), fe_mul<Fq>(PPP, acc.Y), Fq::P3_S1));  // < 5p
-  acc.ZZ = fe_mul<Fq>(acc.ZZ, PP);
-  acc.ZZZ = fe_mul<Fq>(acc.ZZZ, PPP);
+  fe Y3;
+  if constexpr (CHAIN) {
+    // R T + PPP (6p - Y1) under one reduction: columns 9 * (2^29 * 1.5 * 2^30 + 2^29 * 2^30) + 9 * 2^58 = 27 * 2^59 < 2^64;
+    // value < ((8 * 12 + 1.14 * 6) / 169 + 1) p < 1.7p
+    Y3 = fe_mul_add<Fq, true>(R, T, PPP, fe_neg_red(acc.Y, Fq::P6_S1));
+  } else {
+    Y3 = fe_norm(fe_sub_red(fe_mul<Fq>(R, T), fe_mul<Fq>(PPP, acc.Y), Fq::P3_S1));  // < 5p
+  }
+  acc.ZZ = fe_mul<Fq, CHAIN>(acc.ZZ, PP);
+  acc.ZZZ = fe_mul<Fq, CHAIN>(acc.ZZZ, PPP);
   acc.X = X3;
   acc.Y = Y3;
+}
+
+template <bool CHAIN = false>
+ZK_HD void xyzz_madd(xyzz& acc, const fe& x2, const fe& y2) {
+  if (xyzz_is_identity(acc)) {
+    fe one = fe_one<Fq>();
+    acc.X = fe_mul<Fq>(one, x2);                      // reduce: < 1.4p
+    acc.Y = fe_mul<Fq>(one, y2);
+    acc.ZZ = one;
+    acc.ZZZ = one;
+    return;
+  }
+  xyzz_madd_nz<CHAIN>(acc, x2, y2);
 }
 
 // A + B (general).  add-2008-s.

@@ -60,8 +60,23 @@ template <class P> ZK_HD fe fe_one() { fe r;
   for (int i = 0; i < NL; i++) r.l[i] = P::ONE[i];
   return r; }
 
+// acc += x * y.  With CHAIN the accumulator is pinned after every multiply-add so that the product column stays one chain of
+// v_mad_u64_u32 whose addend is the running sum.  Left alone, LLVM reassociates each column into partial sums that start from
+// 0 and joins them (and the carry of the previous column) with v_lshl_add_u64: 17-34 extra instructions per product.  The two
+// shapes suit different kernels (measured): the chain wins where many waves per SIMD hide its latency and
+// instruction issue is the bound (bucket accumulation: -5%); the compiler's shape wins in the latency-bound tail and, by a wide
+// margin, in the NTT, where independent butterflies want to interleave (the pin's inline asm also draws an s_nop from the
+// gfx950 hazard recogniser whenever the next instruction reads its result).  The pin itself emits nothing.
+template <bool CHAIN>
+ZK_HD void fe_mac(uint64_t& acc, uint32_t x, uint32_t y) {
+  acc += (uint64_t)x * y;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (CHAIN) asm("" : "+v"(acc));
+#endif
+}
+
 // Montgomery product a*b*2^-261 mod p (lazy: result in N form, value < p*(ab/(p 2^261) + 1)).
-template <class P>
+template <class P, bool CHAIN = false>
 ZK_HD fe fe_mul(const fe& a, const fe& b) {
   uint64_t acc = 0;
   uint32_t m[NL];
@@ -69,19 +84,54 @@ ZK_HD fe fe_mul(const fe& a, const fe& b) {
 #pragma unroll
   for (int k = 0; k < NL; k++) {
 #pragma unroll
-    for (int i = 0; i <= k; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+    for (int i = 0; i <= k; i++) fe_mac<CHAIN>(acc, a.l[i], b.l[k - i]);
 #pragma unroll
-    for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::P[k - i];
+    for (int i = 0; i < k; i++) fe_mac<CHAIN>(acc, m[i], P::P[k - i]);
     m[k] = ((uint32_t)acc * P::INV) & LMASK;
-    acc += (uint64_t)m[k] * P::P[0];
+    fe_mac<CHAIN>(acc, m[k], P::P[0]);
     acc >>= LB;
   }
 #pragma unroll
   for (int k = NL; k < 2 * NL - 1; k++) {
 #pragma unroll
-    for (int i = k - NL + 1; i < NL; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+    for (int i = k - NL + 1; i < NL; i++) fe_mac<CHAIN>(acc, a.l[i], b.l[k - i]);
 #pragma unroll
-    for (int i = k - NL + 1; i < NL; i++) acc += (uint64_t)m[i] * P::P[k - i];
+    for (int i = k - NL + 1; i < NL; i++) fe_mac<CHAIN>(acc, m[i], P::P[k - i]);
+    r.l[k - NL] = (uint32_t)acc & LMASK;
+    acc >>= LB;
+  }
+  r.l[NL - 1] = (uint32_t)acc;
+  return r;
+}
+
+// (a*b + c*d) * 2^-261 mod p with ONE reduction: the two product columns share the accumulator, so the 81 multiply-adds (and
+// the carry handling) of a second Montgomery reduction disappear.  Used for Y3 = R*T - PPP*Y1 with d = K p - Y1.
+// Needs 9 * (max a_i * max b_j + max c_i * max d_j) + 9 * 2^58 + 2^35 < 2^64; value < p * ((ab + cd) / (p 2^261) + 1).
+template <class P, bool CHAIN = false>
+ZK_HD fe fe_mul_add(const fe& a, const fe& b, const fe& c, const fe& d) {
+  uint64_t acc = 0;
+  uint32_t m[NL];
+  fe r;
+#pragma unroll
+  for (int k = 0; k < NL; k++) {
+#pragma unroll
+    for (int i = 0; i <= k; i++) fe_mac<CHAIN>(acc, a.l[i], b.l[k - i]);
+#pragma unroll
+    for (int i = 0; i <= k; i++) fe_mac<CHAIN>(acc, c.l[i], d.l[k - i]);
+#pragma unroll
+    for (int i = 0; i < k; i++) fe_mac<CHAIN>(acc, m[i], P::P[k - i]);
+    m[k] = ((uint32_t)acc * P::INV) & LMASK;
+    fe_mac<CHAIN>(acc, m[k], P::P[0]);
+    acc >>= LB;
+  }
+#pragma unroll
+  for (int k = NL; k < 2 * NL - 1; k++) {
+#pragma unroll
+    for (int i = k - NL + 1; i < NL; i++) fe_mac<CHAIN>(acc, a.l[i], b.l[k - i]);
+#pragma unroll
+    for (int i = k - NL + 1; i < NL; i++) fe_mac<CHAIN>(acc, c.l[i], d.l[k - i]);
+#pragma unroll
+    for (int i = k - NL + 1; i < NL; i++) fe_mac<CHAIN>(acc, m[i], P::P[k - i]);
     r.l[k - NL] = (uint32_t)acc & LMASK;
     acc >>= LB;
   }
@@ -90,7 +140,7 @@ ZK_HD fe fe_mul(const fe& a, const fe& b) {
 }
 
 // Montgomery square (45 distinct products instead of 81).  Needs limbs < 2^30.3.
-template <class P>
+template <class P, bool CHAIN = false>
 ZK_HD fe fe_sqr(const fe& a) {
   uint64_t acc = 0;
   uint32_t m[NL], d[NL];
@@ -100,21 +150,21 @@ ZK_HD fe fe_sqr(const fe& a) {
 #pragma unroll
   for (int k = 0; k < NL; k++) {
 #pragma unroll
-    for (int i = 0; 2 * i < k; i++) acc += (uint64_t)d[i] * a.l[k - i];
-    if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
+    for (int i = 0; 2 * i < k; i++) fe_mac<CHAIN>(acc, d[i], a.l[k - i]);
+    if ((k & 1) == 0) fe_mac<CHAIN>(acc, a.l[k / 2], a.l[k / 2]);
 #pragma unroll
-    for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::P[k - i];
+    for (int i = 0; i < k; i++) fe_mac<CHAIN>(acc, m[i], P::P[k - i]);
     m[k] = ((uint32_t)acc * P::INV) & LMASK;
-    acc += (uint64_t)m[k] * P::P[0];
+    fe_mac<CHAIN>(acc, m[k], P::P[0]);
     acc >>= LB;
   }
 #pragma unroll
   for (int k = NL; k < 2 * NL - 1; k++) {
 #pragma unroll
-    for (int i = k - NL + 1; 2 * i < k; i++) acc += (uint64_t)d[i] * a.l[k - i];
-    if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
+    for (int i = k - NL + 1; 2 * i < k; i++) fe_mac<CHAIN>(acc, d[i], a.l[k - i]);
+    if ((k & 1) == 0) fe_mac<CHAIN>(acc, a.l[k / 2], a.l[k / 2]);
 #pragma unroll
-    for (int i = k - NL + 1; i < NL; i++) acc += (uint64_t)m[i] * P::P[k - i];
+    for (int i = k - NL + 1; i < NL; i++) fe_mac<CHAIN>(acc, m[i], P::P[k - i]);
     r.l[k - NL] = (uint32_t)acc & LMASK;
     acc >>= LB;
   }

@@ -451,17 +451,18 @@ __global__ void k_order_offsets(const uint32_t* __restrict__ len_count, uint32_t
 
 __global__ void __launch_bounds__(256) k_make_order(const uint32_t* __restrict__ offset, const uint32_t* __restrict__ task_off,
                                                     uint32_t nbuckets, uint32_t task_shift, uint32_t* __restrict__ len_cursor,
-                                                    uint32_t* __restrict__ order) {
+                                                    const uint32_t* __restrict__ sorted, uint4* __restrict__ order) {
   __shared__ uint32_t lh[65];
   if (threadIdx.x < 65) lh[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t nt = 0, t = 0, full = 1u << task_shift, rem = 0;
+  uint32_t nt = 0, t = 0, full = 1u << task_shift, rem = 0, s0 = 0;
   if (k < nbuckets) {
     t = task_off[k];
     nt = task_off[k + 1] - t;
     if (nt) {
-      rem = (offset[k + 1] - offset[k]) - ((nt - 1) << task_shift);
+      s0 = offset[k];
+      rem = (offset[k + 1] - s0) - ((nt - 1) << task_shift);
       if (nt > 1) atomicAdd(&lh[full], nt - 1);
       atomicAdd(&lh[rem], 1u);
     }
@@ -470,29 +471,54 @@ __global__ void __launch_bounds__(256) k_make_order(const uint32_t* __restrict__
   if (threadIdx.x < 65) { const uint32_t v = lh[threadIdx.x]; lh[threadIdx.x] = v ? atomicAdd(&len_cursor[threadIdx.x], v) : 0u; }
   __syncthreads();
   if (nt) {
+    // the record a task starts from, in execution order: (task, first entry, length, first point reference) -- one coalesced
+    // 16-byte load in k_accumulate instead of the chain order -> task -> sorted before the first point can be fetched
     if (nt > 1) {
       const uint32_t pos = atomicAdd(&lh[full], nt - 1);
-      for (uint32_t j = 0; j + 1 < nt; j++) order[pos + j] = t + j;
+      for (uint32_t j = 0; j + 1 < nt; j++) {
+        const uint32_t st = s0 + (j << task_shift);
+        order[pos + j] = make_uint4(t + j, st, full, sorted[st]);
+      }
     }
-    order[atomicAdd(&lh[rem], 1u)] = t + nt - 1;
+    const uint32_t st = s0 + ((nt - 1) << task_shift);
+    order[atomicAdd(&lh[rem], 1u)] = make_uint4(t + nt - 1, st, rem, sorted[st]);
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// 6. accumulate: one thread per task
+// 6. accumulate: one thread per task.  TABLE: the points come from a prepared table (k_build_table), whose coordinates are
+// stored reduced, in the internal Montgomery form: the first point of a bucket is then a copy, where a caller's point (radix
+// 2^256, unpacked lazily to < 32p) costs two multiplications by one to reduce.  With the ~2 points per bucket and window of
+// the wide-window path that is one multiplication in seven.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(128) k_accumulate(const task_t* __restrict__ tasks, const uint32_t* __restrict__ ntasks_p,
-                                                    const uint32_t* __restrict__ order, const uint32_t* __restrict__ sorted,
+template <bool TABLE>
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) k_accumulate(const task_t* __restrict__ tasks, const uint32_t* __restrict__ ntasks_p,
+                                                    const uint4* __restrict__ order, const uint32_t* __restrict__ sorted,
                                                     const uint32_t* __restrict__ bases, uint32_t* __restrict__ partials) {
   const uint32_t ntasks = *ntasks_p;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ntasks; i += gridDim.x * blockDim.x) {
-    const uint32_t t = order[i];           // tasks run longest-first; partial t stays in bucket order
-    task_t tk = tasks[t];
+    const uint4 rec = order[i];            // tasks run longest-first; partial t stays in bucket order
+    const uint32_t t = rec.x;
+    struct { uint32_t start, len; } tk = {rec.y, rec.z};
     xyzz acc = xyzz_identity();
     const uint32_t* refs = sorted + tk.start;
-    uint32_t ref = refs[0];
+    uint32_t ref = rec.w;
     affine_words pt = load_affine(bases, ref & 0x7fffffffu);
-    for (uint32_t j = 0; j < tk.len; j++) {
+    uint32_t j = 0;
+    if constexpr (TABLE) {             // the first point is a copy (peeled: merging it with the addition in one loop body costs 30 VGPRs)
+      if (!affine_is_identity(pt)) {
+        acc.X = fe_unpack<0>(pt.x);     // < p, N form
+        acc.Y = fe_unpack<0>(pt.y);
+        if (ref >> 31) acc.Y = fe_norm(fe_neg_red(acc.Y, Fq::P2_S1));   // -y: 2p - y
+        acc.ZZ = acc.ZZZ = fe_one<Fq>();
+      }
+      if (tk.len > 1) {
+        ref = refs[1];
+        pt = load_affine(bases, ref & 0x7fffffffu);
+      }
+      j = 1;
+    }
+    for (; j < tk.len; j++) {
       affine_words cur = pt;
       uint32_t cref = ref;
       if (j + 1 < tk.len) {            // prefetch the next point under the current addition
@@ -500,10 +526,17 @@ __global__ void __launch_bounds__(128) k_accumulate(const task_t* __restrict__ t
         pt = load_affine(bases, ref & 0x7fffffffu);
       }
       if (affine_is_identity(cur)) continue;
-      fe x2 = fe_from_ext_lazy(cur.x);   // < 32p
-      fe y2 = fe_from_ext_lazy(cur.y);
-      if (cref >> 31) y2 = fe_neg_red(y2, Fq::P64_S1);   // -y: 64p - y < 64p, limbs < 2^30
-      xyzz_madd(acc, x2, y2);
+      fe x2, y2;
+      if constexpr (TABLE) {
+        x2 = fe_unpack<0>(cur.x);
+        y2 = fe_unpack<0>(cur.y);
+        if (cref >> 31) y2 = fe_neg_red(y2, Fq::P2_S1);   // limbs < 2^30, < 2p
+      } else {
+        x2 = fe_from_ext_lazy(cur.x);   // < 32p
+        y2 = fe_from_ext_lazy(cur.y);
+        if (cref >> 31) y2 = fe_neg_red(y2, Fq::P64_S1);   // -y: 64p - y < 64p, limbs < 2^30
+      }
+      xyzz_madd<true>(acc, x2, y2);
     }
     store_xyzz(partials, t, acc);
   }
@@ -782,7 +815,7 @@ size_t msm_workspace_bytes(size_t n_one, int c, bool prepared, size_t batch) {
   total += 4 * align_up((NB + 1) * sizeof(uint32_t), 256);  // count, offset, cursor, task_off
   total += 2 * align_up((NB / SCAN_TILE + 2) * sizeof(uint32_t), 256);  // scan block sums x2
   total += align_up(max_tasks * sizeof(task_t), 256);
-  total += align_up(max_tasks * sizeof(uint32_t), 256);     // execution order
+  total += align_up(max_tasks * sizeof(uint4), 256);        // execution order: one record per task
   total += align_up(max_tasks * 144, 256);                  // partials
   total += 2 * align_up((size_t)WB * B * 144, 256);         // pyramid ping-pong (state never exceeds B elements per bucket set)
   total += align_up((W + batch) * 144, 256);                // window / bucket-set sums
@@ -853,7 +886,7 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   uint32_t* bsum1 = (uint32_t*)carve((NB / SCAN_TILE + 2) * sizeof(uint32_t));
   uint32_t* bsum2 = (uint32_t*)carve((NB / SCAN_TILE + 2) * sizeof(uint32_t));
   task_t* tasks = (task_t*)carve(max_tasks * sizeof(task_t));
-  uint32_t* order = (uint32_t*)carve(max_tasks * sizeof(uint32_t));
+  uint4* order = (uint4*)carve(max_tasks * sizeof(uint4));
   uint32_t* partials = (uint32_t*)carve(max_tasks * 144);
   const size_t pyr_elems = B;   // per window: N + (s-1) N/2 <= B at every step
   uint32_t* pyrA = (uint32_t*)carve((size_t)WB * pyr_elems * 144);
@@ -918,13 +951,14 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   hipLaunchKernelGGL(k_scan_apply<1>, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, count, NB, bsum2, counters + 1, task_off, (uint32_t*)nullptr, task_shift);
   hipLaunchKernelGGL(k_make_tasks, dim3((NB + 255) / 256), dim3(256), 0, stream, offset, task_off, NB, tasks, task_shift, counters + 2, counters + 64);
   hipLaunchKernelGGL(k_order_offsets, dim3(1), dim3(64), 0, stream, counters + 64, counters + 160);
-  hipLaunchKernelGGL(k_make_order, dim3((NB + 255) / 256), dim3(256), 0, stream, offset, task_off, NB, task_shift, counters + 160, order);
+  hipLaunchKernelGGL(k_make_order, dim3((NB + 255) / 256), dim3(256), 0, stream, offset, task_off, NB, task_shift, counters + 160, sorted, order);
   prof_mark(stream, "tasks");
   // 6. accumulate (grid-stride over the device-side task count)
   {
     uint32_t blocks = (uint32_t)((max_tasks + 127) / 128);
     if (blocks > 256 * 64) blocks = 256 * 64;
-    hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(128), 0, stream, tasks, counters + 1, order, sorted, d_bases, partials);
+    if (prepared) hipLaunchKernelGGL(k_accumulate<true>, dim3(blocks), dim3(128), 0, stream, tasks, counters + 1, order, sorted, d_bases, partials);
+    else hipLaunchKernelGGL(k_accumulate<false>, dim3(blocks), dim3(128), 0, stream, tasks, counters + 1, order, sorted, d_bases, partials);
   }
   prof_mark(stream, "accumulate");
   // 7. combine
@@ -1227,29 +1261,36 @@ int g1_fixed_base_mul_device(const uint32_t* d_scalars, size_t n, const uint32_t
 }
 
 // ------------------------------------------------------------------------------------------------
-// prepared bases: table[w * n + i] = 2^(c w) * P_i (affine, external format), w < W.  One thread per point walks the
-// doubling chain, parks the XYZZ multiples in `tmp`, then normalises its W-1 points with one inversion.
+// prepared bases: table[w * n + i] = 2^(c w) * P_i, w < W, affine, each coordinate the canonical internal-form value
+// (x * 2^261 mod p) packed into 8 words -- the library's own format, read only by k_accumulate<true>; (0, 0) = identity.
+// One thread per point walks the doubling chain, parks the XYZZ multiples in `tmp`, then normalises its W-1 points with one
+// inversion.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void store_table_point(uint32_t* table, size_t idx, const fe& x, const fe& y) {   // x, y < 2p
+  uint32_t wx[8], wy[8];
+  fe_pack(fe_canon_lt2p<Fq>(x), wx);
+  fe_pack(fe_canon_lt2p<Fq>(y), wy);
+  uint4* q = reinterpret_cast<uint4*>(table + idx * 16);
+  q[0] = make_uint4(wx[0], wx[1], wx[2], wx[3]); q[1] = make_uint4(wx[4], wx[5], wx[6], wx[7]);
+  q[2] = make_uint4(wy[0], wy[1], wy[2], wy[3]); q[3] = make_uint4(wy[4], wy[5], wy[6], wy[7]);
+}
+
 __global__ void __launch_bounds__(64) k_build_table(const uint32_t* __restrict__ bases, uint32_t n, int c, int W,
                                                     uint32_t* __restrict__ table, uint32_t* __restrict__ tmp_pts,
                                                     uint32_t* __restrict__ tmp_pref) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   affine_words pt = load_affine(bases, i);
-  {
-    uint4* q = reinterpret_cast<uint4*>(table + (size_t)i * 16);
-    q[0] = make_uint4(pt.x[0], pt.x[1], pt.x[2], pt.x[3]); q[1] = make_uint4(pt.x[4], pt.x[5], pt.x[6], pt.x[7]);
-    q[2] = make_uint4(pt.y[0], pt.y[1], pt.y[2], pt.y[3]); q[3] = make_uint4(pt.y[4], pt.y[5], pt.y[6], pt.y[7]);
-  }
   if (affine_is_identity(pt)) {
-    for (int w = 1; w < W; w++) {
+    for (int w = 0; w < W; w++) {
       uint4* q = reinterpret_cast<uint4*>(table + ((size_t)w * n + i) * 16);
       q[0] = q[1] = q[2] = q[3] = make_uint4(0, 0, 0, 0);
     }
     return;
   }
   xyzz P = xyzz_identity();
-  xyzz_madd(P, fe_from_ext_lazy(pt.x), fe_from_ext_lazy(pt.y));
+  xyzz_madd(P, fe_from_ext_lazy(pt.x), fe_from_ext_lazy(pt.y));     // X, Y reduced (< 1.4p), internal form
+  store_table_point(table, i, P.X, P.Y);
   fe pref = fe_one<Fq>();
   for (int w = 1; w < W; w++) {
     for (int k = 0; k < c; k++) P = xyzz_dbl(P);
@@ -1265,12 +1306,7 @@ __global__ void __launch_bounds__(64) k_build_table(const uint32_t* __restrict__
     inv = fe_mul<Fq>(inv, fe_mul<Fq>(Q.ZZ, Q.ZZZ));
     fe x = fe_mul<Fq>(fe_mul<Fq>(winv, Q.ZZZ), Q.X);
     fe y = fe_mul<Fq>(fe_mul<Fq>(winv, Q.ZZ), Q.Y);
-    uint32_t wx[8], wy[8];
-    fe_to_ext<Fq>(x, wx);
-    fe_to_ext<Fq>(y, wy);
-    uint4* q = reinterpret_cast<uint4*>(table + ((size_t)w * n + i) * 16);
-    q[0] = make_uint4(wx[0], wx[1], wx[2], wx[3]); q[1] = make_uint4(wx[4], wx[5], wx[6], wx[7]);
-    q[2] = make_uint4(wy[0], wy[1], wy[2], wy[3]); q[3] = make_uint4(wy[4], wy[5], wy[6], wy[7]);
+    store_table_point(table, (size_t)w * n + i, x, y);
   }
 }
 
