@@ -180,14 +180,15 @@ def main() -> None:
                               "avg_launch_ms": round(t_acc, 4), "algorithmic_bytes_per_launch": alg_bytes,
                               "whole_msm_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / 8000.0, 5),
                               "note": "256-bit modular-integer work: ALU-bound, not HBM-bound (DESIGN.md)"}
-        # issue-rate view of the same kernel: 8M + 2S mixed addition = 8*162 + 2*126 v_mad_u64_u32 (ISA count),
+        # issue-rate view of the same kernel: 8M + 2S mixed addition with Y3's two products under one reduction
+        # = 6*162 + (2*81 + 81) + 2*126 = 1467 v_mad_u64_u32 (ISA count of the loop body),
         # W*n additions per launch (W = ceil(256 / c) windows of the prepared table); peak = the v_mad_u64_u32-only issue rate measured by tools/isa_rate.hip at 4 waves/SIMD
         c_bits = lib.zkhip_prepared_window_bits(handle)
         windows = (256 + c_bits - 1) // c_bits
-        imads = (8 * 162 + 2 * 126) * float(windows) * n
+        imads = 1467.0 * float(windows) * n
         result["valu_roofline"] = {"kernel": "k_accumulate", "window_bits": c_bits, "windows": windows, "unit": "T v_mad_u64_u32 lane-ops/s", "achieved": round(imads / (t_acc * 1e-3) / 1e12, 2),
                                    "peak": 27.95, "frac": round(imads / (t_acc * 1e-3) / 1e12 / 27.95, 3),
-                                   "note": "the other ~1/3 of the kernel's instructions (carry splits, masks, adds) share the same issue slots"}
+                                   "note": "the other 31% of the loop body's 2123 instructions (carry shifts, masks, limb adds) share the same issue slots"}
         result["phases_ms"] = {k: round(v, 4) for k, v in acc.items()}
 
     if rank == 0 and world == 1 and not args.no_extras:

@@ -796,7 +796,7 @@ int msm_pick_window_prepared(size_t n) {
     double W = (256 + c - 1) / c;
     double cost = W * 10.0 * (double)n + 28.0 * (double)(1u << (c - 1)) + (c > 16 ? W * 1.0 * (double)n : 0.0);
     if (msm_top_window_is_degenerate(c)) continue;
-    if (c > 16 && n < ((size_t)1 << 20)) continue;   // measured with the quad-cooperative tail: c = 20 loses at 2^19 (1.47 vs 1.34 ms), wins from 2^20 (1.84 vs 1.94 ms)
+    if (c > 16 && n < ((size_t)1 << 22)) continue;   // measured (median of 60): c = 16 / c = 20 at 2^20 1.73 / 1.77 ms, 2^21 3.32 / 3.37, 2^22 6.48 / 6.05, 2^23 13.1 / 11.3
     if (cost < best_cost) { best_cost = cost; best = c; }
   }
   if (const char* e = getenv("ZKHIP_MAX_WINDOW")) { int m = atoi(e); if (m >= 2 && best > m) best = m; }   // A/B knob
