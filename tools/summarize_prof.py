@@ -53,8 +53,11 @@ else:
     for k, (n, v) in sorted(write.items(), key=lambda kv: -kv[1][1])[:16]:
         lines.append(f"  {k:44s} dispatches={n:4d}  avg = {v:12.1f} KiB = {v*1024/1e6:9.1f} MB")
     open(sys.argv[4], "w").write("\n".join(lines) + "\n")
+    def pick(table, k):   # exact name, or the template instance with the most dispatches (k_accumulate<true> on the prepared path)
+        hits = [v for name, v in table.items() if name == k or name.startswith(k + "<")]
+        return max(hits, key=lambda v: v[0]) if hits else (0, 0.0)
     def entry(k):
-        fr = fetch.get(k, (0, 0.0))[1] * 1024; wr = write.get(k, (0, 0.0))[1] * 1024
+        fr = pick(fetch, k)[1] * 1024; wr = pick(write, k)[1] * 1024
         return {"fetch_bytes_raw": round(fr), "fetch_bytes_corrected": round(2 * fr), "write_bytes": round(wr), "hbm_bytes_per_launch": round(2 * fr + wr)}
     out = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, --kernel-trace), python3 bench.py --steps 3 --warmup 1 --no-extras --no-cpu-baseline --no-general-path",
            "workload": "prepared MSM 2^20 (bench headline configuration)",
