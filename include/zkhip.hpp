@@ -18,6 +18,8 @@
 #include <array>
 #include <cstdint>
 #include <cstring>
+#include <istream>
+#include <ostream>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -361,7 +363,45 @@ class ParamsKZG {
     std::vector<G1Affine> g = points(pw), gl = points(den);
     return ParamsKZG(k, std::move(g), std::move(gl));
   }
-  ParamsKZG(ParamsKZG&& o) noexcept : k_(o.k_), n_(o.n_), g_(std::move(o.g_)), g_lagrange_(std::move(o.g_lagrange_)) {}   // the registered arrays keep their addresses
+  ParamsKZG(ParamsKZG&& o) noexcept : k_(o.k_), n_(o.n_), g_(std::move(o.g_)), g_lagrange_(std::move(o.g_lagrange_)), g2_(o.g2_), s_g2_(o.s_g2_) {}   // the registered arrays keep their addresses
+
+  // G2Affine memory (x.c0 || x.c1 || y.c0 || y.c1, Montgomery limbs): carried for the verifying key and the SRS file only -- no G2
+  // arithmetic exists on this path (/root/reference/aggregator/src/wrapper.rs:1143-1144 only reads g2() / s_g2())
+  using G2Bytes = std::array<uint64_t, 16>;
+  void set_g2(const G2Bytes& g2, const G2Bytes& s_g2) { g2_ = g2; s_g2_ = s_g2; }
+  const G2Bytes& g2() const { return g2_; }
+  const G2Bytes& s_g2() const { return s_g2_; }
+
+  // `ParamsKZG::write` / `read` [DEP halo2-axiom poly/kzg/commitment.rs, SerdeFormat::RawBytes], the format of the
+  // `kzg_bn254_{k}.srs` files `gen_srs` keeps (/root/reference/aggregator/benches/wrapper_circuit.rs:35):
+  //   k u32 LE | g: 2^k x 64 B | g_lagrange: 2^k x 64 B | g2 128 B | s_g2 128 B      (raw = the in-memory Montgomery limbs)
+  // Restated from the published layout; no reference file pins it.  Little-endian hosts only.
+  void write(std::ostream& out) const {
+    if (g_lagrange_.size() != n_) throw std::invalid_argument("ParamsKZG::write: no Lagrange basis");
+    out.write(reinterpret_cast<const char*>(&k_), 4);
+    out.write(reinterpret_cast<const char*>(g_.data()), (std::streamsize)(n_ * sizeof(G1Affine)));
+    out.write(reinterpret_cast<const char*>(g_lagrange_.data()), (std::streamsize)(n_ * sizeof(G1Affine)));
+    out.write(reinterpret_cast<const char*>(g2_.data()), 128);
+    out.write(reinterpret_cast<const char*>(s_g2_.data()), 128);
+    if (!out) throw std::runtime_error("ParamsKZG::write: stream error");
+  }
+  // points are taken as they are (the reference's RawBytesUnchecked); the Python mirror's reader samples curve membership
+  static ParamsKZG read(std::istream& in) {
+    uint32_t k = 0;
+    in.read(reinterpret_cast<char*>(&k), 4);
+    if (!in || k > 28) throw std::runtime_error("ParamsKZG::read: not a RawBytes KZG parameter file");
+    const uint64_t n = (uint64_t)1 << k;
+    std::vector<G1Affine> g(n), gl(n);
+    G2Bytes g2{}, s_g2{};
+    in.read(reinterpret_cast<char*>(g.data()), (std::streamsize)(n * sizeof(G1Affine)));
+    in.read(reinterpret_cast<char*>(gl.data()), (std::streamsize)(n * sizeof(G1Affine)));
+    in.read(reinterpret_cast<char*>(g2.data()), 128);
+    in.read(reinterpret_cast<char*>(s_g2.data()), 128);
+    if (!in) throw std::runtime_error("ParamsKZG::read: truncated file");
+    ParamsKZG p(k, std::move(g), std::move(gl));
+    p.set_g2(g2, s_g2);
+    return p;
+  }
 
   uint32_t k() const { return k_; }
   uint64_t n() const { return n_; }
@@ -391,6 +431,7 @@ class ParamsKZG {
   uint32_t k_;
   uint64_t n_;
   std::vector<G1Affine> g_, g_lagrange_;
+  G2Bytes g2_{}, s_g2_{};
 };
 
 }  // namespace halo2

@@ -7,6 +7,7 @@
 //        grand_product, permute_expression_pair (2 vectors of 2^k - 6), a row program's output column,
 //        setup(k, s): g[0..4), commit(poly), commit_lagrange(poly)
 #include <cstdio>
+#include <sstream>
 #include <vector>
 #include "zkhip.hpp"
 
@@ -77,6 +78,25 @@ int main(int argc, char** argv) {
       G1 c1 = ps.commit(poly), c2 = ps.commit_lagrange(poly);
       fwrite(&c1, sizeof(G1), 1, out);
       fwrite(&c2, sizeof(G1), 1, out);
+      // ParamsKZG::write -> read: the same bytes come back, and the re-read parameters commit to the same point
+      ParamsKZG::G2Bytes g2{}, s_g2{};
+      for (int i = 0; i < 16; i++) { g2[i] = 0x1111111111111111ULL * (uint64_t)(i + 1); s_g2[i] = ~g2[i]; }
+      ps.set_g2(g2, s_g2);
+      std::stringstream file;
+      ps.write(file);
+      const std::string bytes = file.str();
+      ParamsKZG again = ParamsKZG::read(file);
+      std::stringstream file2;
+      again.write(file2);
+      const uint64_t same = (bytes == file2.str() && bytes.size() == 4 + 2 * n * sizeof(G1Affine) + 256 && again.s_g2() == s_g2) ? 1 : 0;
+      fwrite(&same, 8, 1, out);
+      G1 c3 = again.commit_lagrange(poly);
+      fwrite(&c3, sizeof(G1), 1, out);
+      bool threw_trunc = false;
+      std::stringstream cut(bytes.substr(0, bytes.size() - 1));
+      try { ParamsKZG::read(cut); } catch (const std::runtime_error&) { threw_trunc = true; }
+      const uint64_t trunc = threw_trunc ? 1 : 0;
+      fwrite(&trunc, 8, 1, out);
     }
     fclose(out);
     // error behaviour: the reference's assert_eq!(coeffs.len(), bases.len())

@@ -640,6 +640,10 @@ def test_cpp_host_mirror(cref, tmp_path):
     c1, c2 = take(1, 12)[0], take(1, 12)[0]
     assert F.g1_decode_jacobian(c1) == O.scalar_mul(O.eval_polynomial(pv, s_trap), O.G1_GEN)
     assert F.g1_decode_jacobian(c2) == O.scalar_mul(O.eval_polynomial(dom.lagrange_to_coeff(pv), s_trap), O.G1_GEN)
+    # ParamsKZG::write -> read -> write gives identical bytes of the RawBytes size; the re-read SRS commits alike; truncation throws
+    assert int(take(1, 1)[0, 0]) == 1
+    assert F.g1_decode_jacobian(take(1, 12)[0]) == F.g1_decode_jacobian(c2)
+    assert int(take(1, 1)[0, 0]) == 1
     assert pos == raw.size
 
 
@@ -830,6 +834,34 @@ def test_params_kzg_setup_small_vs_oracle(lib):
             assert O.affine_from_limbs([int(x) for x in params.g_lagrange[i]]) == O.scalar_mul(li, O.G1_GEN), i
     finally:
         params.close()
+
+
+def test_params_kzg_write_read_round_trip(lib, cref, tmp_path):
+    """ParamsKZG::write / read (RawBytes layout, srs.py): a file written from a set-up SRS reads back to the same tables, G2 points
+    included, and the re-read parameters commit to the same point (their tables are registered afresh)"""
+    from zksnap_circuits_halo2_amd import srs as S
+
+    k, s = 9, 0x0BADC0DE_5EED_0001_0002_0003
+    params = Z.ParamsKZG.setup(k, s)
+    path = tmp_path / f"kzg_bn254_{k}.srs"
+    try:
+        assert S.g2_decode(params.get_g2()) == S.G2_GENERATOR and S.g2_decode(params.get_s_g2()) == S.g2_mul(s)
+        with open(path, "wb") as f:
+            params.write(f)
+        assert path.stat().st_size == 4 + 2 * (1 << k) * 64 + 256
+        poly = cref.gen_scalars(77, 1 << k, 0)
+        c_before = aff(cref, params.commit(poly)), aff(cref, params.commit_lagrange(poly))
+    finally:
+        params.close()
+    with open(path, "rb") as f:
+        again = Z.ParamsKZG.read(f)
+    try:
+        assert again.k == k and np.array_equal(again.g, params.g) and np.array_equal(again.g_lagrange, params.g_lagrange)
+        assert np.array_equal(again.g2, params.g2) and np.array_equal(again.s_g2, params.s_g2)
+        c_after = aff(cref, again.commit(poly)), aff(cref, again.commit_lagrange(poly))
+        assert all(np.array_equal(a, b) for a, b in zip(c_before, c_after))
+    finally:
+        again.close()
 
 
 @pytest.mark.parametrize("k", [10, 15])

@@ -1,0 +1,29 @@
+#!/bin/bash
+# Collects everything profiles/README.md lists for the final state, on the GPU box (run through gpurun from the repo root):
+#   bash tools/collect_profiles.sh <tag>        -> gpurun_out/<tag>_*
+# rocprofv3 passes: kernel stats of the bench command, kernel stats of the full bench, FETCH_SIZE / WRITE_SIZE (separate passes),
+# SQ issue/wait counters of the MSM + NTT workload (separate passes, --kernel-trace only).
+set -e
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+BENCH_MSM="python3 $R/bench.py --steps 10 --warmup 2 --no-extras --no-cpu-baseline --no-general-path"
+BENCH_PMC="python3 $R/bench.py --steps 3 --warmup 1 --no-extras --no-cpu-baseline --no-general-path"
+rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof_msm -- $BENCH_MSM > $O/${TAG}_prof_msm.log 2>&1
+echo "stats msm done"
+rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof_full -- python3 $R/bench.py --no-cpu-baseline > $O/${TAG}_prof_full.log 2>&1
+echo "stats full done"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/${TAG}_pmc_fetch -- $BENCH_PMC > $O/${TAG}_pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/${TAG}_pmc_write -- $BENCH_PMC > $O/${TAG}_pmc_write.log 2>&1
+echo "pmc hbm done"
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $O/${TAG}_pmc_sq_a -- python3 $R/tools/prof_msm.py 20 3 24 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVES -d $O/${TAG}_pmc_sq_b -- python3 $R/tools/prof_msm.py 20 3 24 > /dev/null 2>&1
+echo "pmc sq done"
+cd $R
+python3 tools/summarize_prof.py stats $O/${TAG}_prof_msm $O/${TAG}_kernel_stats_bench_msm2p20.csv
+python3 tools/summarize_prof.py stats $O/${TAG}_prof_full $O/${TAG}_kernel_stats_bench_full.csv
+python3 tools/summarize_prof.py pmc $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write $O/${TAG}_pmc_hbm_bytes_bench.txt $O/${TAG}_pmc_traffic.json
+python3 tools/summarize_prof.py sq $O/${TAG}_pmc_sq_a $O/${TAG}_pmc_sq_b $O/${TAG}_pmc_sq_issue.txt
+rm -rf $O/${TAG}_prof_msm $O/${TAG}_prof_full $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write $O/${TAG}_pmc_sq_a $O/${TAG}_pmc_sq_b
+echo "summaries written"

@@ -2,6 +2,7 @@
 """Turn rocprofv3 output directories into the summaries committed under profiles/.
   summarize_prof.py stats <dir> <out.csv>            copy the --stats kernel table (largest first)
   summarize_prof.py pmc <fetch_dir> <write_dir> <out.txt> <out.json>   per-kernel averages of FETCH_SIZE / WRITE_SIZE (KiB per dispatch)
+  summarize_prof.py sq <dir_a> <dir_b> <out.txt>     per-kernel averages of the SQ issue / wait counters (tools/collect_profiles.sh)
 FETCH_SIZE gets the gfx950 x2 correction the MI355X guide prescribes for wide coalesced streams; both figures are listed."""
 import csv, glob, json, os, re, sqlite3, sys
 from collections import defaultdict
@@ -42,6 +43,20 @@ def kernel_stats(d):
 if sys.argv[1] == "stats":
     rows = kernel_stats(sys.argv[2])
     with open(sys.argv[3], "w", newline="") as f: csv.writer(f, quoting=csv.QUOTE_NONNUMERIC).writerows(rows)
+elif sys.argv[1] == "sq":
+    names = {sys.argv[2]: ["SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY"], sys.argv[3]: ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_VMEM", "SQ_INSTS_LDS"]}
+    tab = defaultdict(dict)
+    for d, cs in names.items():
+        for c in cs:
+            for k, (n, v) in counters(d, c).items(): tab[k][c] = v; tab[k]["dispatches"] = n
+    lines = ["rocprofv3 --kernel-trace --pmc <4 SQ counters> (two separate passes), workload tools/prof_msm.py 20 3 24 (3 prepared MSMs 2^20, 3 NTTs 2^24).",
+             "Per-dispatch averages.  SQ_WAVE_CYCLES = SQ_ACTIVE_INST_ANY + SQ_WAIT_INST_ANY (issue stall: the pipe is taken by another wave) + SQ_WAIT_ANY",
+             "(parked at s_waitcnt / barrier), in quad-cycles summed over waves (MI355X_MICROARCH.md).  active% x (waves per SIMD) ~ VALU occupancy.", ""]
+    for k, v in sorted(tab.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0))[:14]:
+        wc = v.get("SQ_WAVE_CYCLES", 0) or 1
+        lines.append(f"  {k:40s} n={v.get('dispatches', 0):3d} waves={v.get('SQ_WAVES', 0):9.0f} valu_insts={v.get('SQ_INSTS_VALU', 0):13.0f} vmem={v.get('SQ_INSTS_VMEM', 0):10.0f} lds={v.get('SQ_INSTS_LDS', 0):10.0f}"
+                     f"  active={100 * v.get('SQ_ACTIVE_INST_ANY', 0) / wc:5.1f}% issue_stall={100 * v.get('SQ_WAIT_INST_ANY', 0) / wc:5.1f}% parked={100 * v.get('SQ_WAIT_ANY', 0) / wc:5.1f}%")
+    open(sys.argv[4], "w").write("\n".join(lines) + "\n")
 else:
     fetch, write = counters(sys.argv[2], "FETCH_SIZE"), counters(sys.argv[3], "WRITE_SIZE")
     lines = ["rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), same command as the bench line:",

@@ -1,4 +1,4 @@
-"""`ParamsKZG<Bn256>` commit surface mirror [DEP halo2-axiom poly/kzg/commitment.rs]:
+"""`ParamsKZG<Bn256>` mirror [DEP halo2-axiom poly/kzg/commitment.rs] (setup / read / write: section 8(f) row 4):
 owns `g` / `g_lagrange`, pins them in HBM once (`zkhip_register_bases`) and commits with the GPU MSM."""
 from __future__ import annotations
 
@@ -9,10 +9,13 @@ from .arithmetic import best_multiexp
 
 
 class ParamsKZG:
-    def __init__(self, k: int, g: np.ndarray, g_lagrange: np.ndarray | None = None):
+    def __init__(self, k: int, g: np.ndarray, g_lagrange: np.ndarray | None = None, g2: np.ndarray | None = None, s_g2: np.ndarray | None = None):
         self.k, self.n = k, 1 << k
         self.g = np.ascontiguousarray(g, dtype=np.uint64).reshape(self.n, 8)
         self.g_lagrange = None if g_lagrange is None else np.ascontiguousarray(g_lagrange, dtype=np.uint64).reshape(self.n, 8)
+        # G2Affine memory (16 u64), carried for the verifying key and the SRS file only (srs.py)
+        self.g2 = None if g2 is None else np.ascontiguousarray(g2, dtype=np.uint64).reshape(16)
+        self.s_g2 = None if s_g2 is None else np.ascontiguousarray(s_g2, dtype=np.uint64).reshape(16)
         lib = _lib.load()
         _lib.check(lib.zkhip_register_bases(self.g.ctypes.data, self.n))
         if self.g_lagrange is not None:
@@ -62,7 +65,31 @@ class ParamsKZG:
         finally:
             for ptr in (d_sc, d_tmp, d_pts):
                 lib.zkhip_free(ptr)
-        return cls(k, g, g_lagrange)
+        from . import srs
+
+        return cls(k, g, g_lagrange, srs.g2_encode(srs.G2_GENERATOR), srs.g2_encode(srs.g2_mul(s)))
+
+    def write(self, f) -> None:
+        """`ParamsKZG::write` (SerdeFormat::RawBytes) [DEP]; layout in srs.py"""
+        from . import srs
+
+        if self.g_lagrange is None or self.g2 is None or self.s_g2 is None:
+            raise ValueError("write needs g_lagrange, g2 and s_g2")
+        srs.write_params(f, self.k, self.g, self.g_lagrange, self.g2, self.s_g2)
+
+    @classmethod
+    def read(cls, f, check_points: int = 64) -> "ParamsKZG":
+        """`ParamsKZG::read` [DEP]: parses the file and pins both tables in HBM"""
+        from . import srs
+
+        k, g, g_lagrange, g2, s_g2 = srs.read_params(f, check_points)
+        return cls(k, g, g_lagrange, g2, s_g2)
+
+    def get_g2(self) -> np.ndarray:
+        return self.g2
+
+    def get_s_g2(self) -> np.ndarray:
+        return self.s_g2
 
     def get_g(self) -> np.ndarray:
         return self.g

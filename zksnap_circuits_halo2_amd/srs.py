@@ -1,0 +1,172 @@
+"""`ParamsKZG::{write, read}` file format and the G2 half of `ParamsKZG::setup`.
+
+[DEP] halo2-axiom poly/kzg/commitment.rs `write_custom` / `read_custom` with `SerdeFormat::RawBytes` (what `write` / `read` use), reached
+from `gen_srs` (/root/reference/aggregator/benches/wrapper_circuit.rs:35,49,69, /root/reference/aggregator/src/wrapper.rs:961) and from the
+browser worker that fetches `kzg_bn254_{k}.srs` (/root/reference/voter/frontend/app/worker.js:218-225).  The dependency is un-vendored, so
+the layout below is the published one restated, not checked against a reference file (parity unpinned):
+
+    k            u32 little-endian
+    g            2^k   x 64 B   G1Affine, x || y, each 4 x u64 LE limbs in Montgomery form -- the memory of `&[G1Affine]`
+    g_lagrange   2^k   x 64 B   the same
+    g2           128 B          G2Affine, x.c0 || x.c1 || y.c0 || y.c1, Montgomery limbs
+    s_g2         128 B          the same
+
+Raw bytes are the in-memory representation, which is also what the C ABI takes: a file maps straight onto `zkhip_register_bases`.
+The compressed `SerdeFormat::Processed` form is not handled (its flag bits differ between halo2curves releases and no reference file pins
+them).  G2 never reaches the GPU (the prover only carries g2 / s_g2 into the verifying key: /root/reference/aggregator/src/wrapper.rs:1143-1144);
+its arithmetic here is host big-int code for the single multiplication [s]G2 that `setup` needs."""
+from __future__ import annotations
+
+import io
+import struct
+from typing import BinaryIO, Optional, Tuple
+
+import numpy as np
+
+from .fields import MONT, Q_MOD, R_MOD
+
+Fq2 = Tuple[int, int]
+# generator of the order-r subgroup of the sextic twist y^2 = x^3 + 3 / (9 + i)  (the alt_bn128 G2 generator, as in halo2curves bn256::G2)
+G2_GENERATOR = (
+    (10857046999023057135944570762232829481370756359578518086990519993285655852781,
+     11559732032986387107991004021392285783925812861821192530917403151452391805634),
+    (8495653923123431417604973247489272438418190587263600148770280649306958101930,
+     4082367875863433681332203403145435568316851327593401208105741076214120093531),
+)
+
+
+def _f2mul(a: Fq2, b: Fq2) -> Fq2:
+    return ((a[0] * b[0] - a[1] * b[1]) % Q_MOD, (a[0] * b[1] + a[1] * b[0]) % Q_MOD)
+
+
+def _f2sub(a: Fq2, b: Fq2) -> Fq2:
+    return ((a[0] - b[0]) % Q_MOD, (a[1] - b[1]) % Q_MOD)
+
+
+def _f2inv(a: Fq2) -> Fq2:
+    d = pow(a[0] * a[0] + a[1] * a[1], -1, Q_MOD)
+    return (a[0] * d % Q_MOD, -a[1] * d % Q_MOD)
+
+
+G2_B = _f2mul((3, 0), _f2inv((9, 1)))
+
+
+def g2_is_on_curve(P) -> bool:
+    if P is None:
+        return True
+    x, y = P
+    x3 = _f2mul(_f2mul(x, x), x)
+    return _f2mul(y, y) == ((x3[0] + G2_B[0]) % Q_MOD, (x3[1] + G2_B[1]) % Q_MOD)
+
+
+def g2_add(P, Q):
+    if P is None:
+        return Q
+    if Q is None:
+        return P
+    if P[0] == Q[0]:
+        if ((P[1][0] + Q[1][0]) % Q_MOD, (P[1][1] + Q[1][1]) % Q_MOD) == (0, 0):
+            return None
+        lam = _f2mul(_f2mul((3, 0), _f2mul(P[0], P[0])), _f2inv(_f2mul((2, 0), P[1])))
+    else:
+        lam = _f2mul(_f2sub(Q[1], P[1]), _f2inv(_f2sub(Q[0], P[0])))
+    x3 = _f2sub(_f2sub(_f2mul(lam, lam), P[0]), Q[0])
+    return (x3, _f2sub(_f2mul(lam, _f2sub(P[0], x3)), P[1]))
+
+
+def g2_mul(k: int, P=G2_GENERATOR):
+    k %= R_MOD
+    acc = None
+    for bit in bin(k)[2:] if k else "":
+        acc = g2_add(acc, acc)
+        if bit == "1":
+            acc = g2_add(acc, P)
+    return acc
+
+
+def g2_encode(P) -> np.ndarray:
+    """affine G2 point (None = identity) -> (16,) uint64, the memory of `G2Affine`"""
+    out = np.zeros(16, dtype=np.uint64)
+    if P is not None:
+        for c, v in enumerate((P[0][0], P[0][1], P[1][0], P[1][1])):
+            m = v * MONT % Q_MOD
+            out[4 * c:4 * c + 4] = [(m >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(4)]
+    return out
+
+
+def g2_decode(arr: np.ndarray):
+    a = np.asarray(arr, dtype=np.uint64).reshape(16)
+    inv = pow(MONT, -1, Q_MOD)
+    v = []
+    for c in range(4):
+        m = sum(int(a[4 * c + j]) << (64 * j) for j in range(4))
+        if m >= Q_MOD:
+            raise ValueError("G2 coordinate limbs are not a canonical Montgomery residue")
+        v.append(m * inv % Q_MOD)
+    if not any(v):
+        return None
+    return ((v[0], v[1]), (v[2], v[3]))
+
+
+def _g1_sample_on_curve(points: np.ndarray, sample: int) -> None:
+    """y^2 = x^3 + 3 on up to `sample` evenly spaced points (host big-int arithmetic; a whole-file check would be a GPU pass)"""
+    n = points.shape[0]
+    inv = pow(MONT, -1, Q_MOD)
+    for i in sorted(set(np.linspace(0, n - 1, min(sample, n), dtype=np.int64).tolist())):
+        w = [sum(int(points[i, 4 * c + j]) << (64 * j) for j in range(4)) for c in range(2)]
+        if w[0] >= Q_MOD or w[1] >= Q_MOD:
+            raise ValueError(f"point {i}: limbs are not a canonical Montgomery residue")
+        x, y = w[0] * inv % Q_MOD, w[1] * inv % Q_MOD
+        if (x, y) != (0, 0) and (y * y - x * x * x - 3) % Q_MOD:
+            raise ValueError(f"point {i} is not on the curve")
+
+
+def write_params(f: BinaryIO, k: int, g: np.ndarray, g_lagrange: np.ndarray, g2: np.ndarray, s_g2: np.ndarray) -> None:
+    n = 1 << k
+    g = np.ascontiguousarray(g, dtype="<u8").reshape(-1, 8)
+    g_lagrange = np.ascontiguousarray(g_lagrange, dtype="<u8").reshape(-1, 8)
+    if g.shape[0] != n or g_lagrange.shape[0] != n:
+        raise ValueError(f"g / g_lagrange must hold 2^{k} points")
+    f.write(struct.pack("<I", k))
+    f.write(g.tobytes())
+    f.write(g_lagrange.tobytes())
+    f.write(np.ascontiguousarray(g2, dtype="<u8").reshape(16).tobytes())
+    f.write(np.ascontiguousarray(s_g2, dtype="<u8").reshape(16).tobytes())
+
+
+def read_params(f: BinaryIO, check_points: int = 64, max_k: int = 28):
+    """-> (k, g, g_lagrange, g2, s_g2).  `check_points`: curve membership is verified on that many evenly spaced points of each table and
+    on both G2 points (the reference's RawBytes reader checks every point; 0 = its RawBytesUnchecked)."""
+    head = f.read(4)
+    if len(head) != 4:
+        raise ValueError("truncated SRS file: no header")
+    (k,) = struct.unpack("<I", head)
+    if k > max_k:
+        raise ValueError(f"SRS header says k = {k} (> {max_k}): not a RawBytes KZG parameter file")
+    n = 1 << k
+
+    def table(name: str) -> np.ndarray:
+        buf = f.read(n * 64)
+        if len(buf) != n * 64:
+            raise ValueError(f"truncated SRS file: {name} holds {len(buf) // 64} of {n} points")
+        return np.frombuffer(buf, dtype="<u8").reshape(n, 8).astype(np.uint64)
+
+    g, g_lagrange = table("g"), table("g_lagrange")
+    tail = f.read(256)
+    if len(tail) != 256:
+        raise ValueError("truncated SRS file: g2 / s_g2 missing")
+    g2 = np.frombuffer(tail[:128], dtype="<u8").astype(np.uint64)
+    s_g2 = np.frombuffer(tail[128:], dtype="<u8").astype(np.uint64)
+    if check_points:
+        _g1_sample_on_curve(g, check_points)
+        _g1_sample_on_curve(g_lagrange, check_points)
+        for name, p in (("g2", g2), ("s_g2", s_g2)):
+            if not g2_is_on_curve(g2_decode(p)):
+                raise ValueError(f"{name} is not on the twist curve")
+    return k, g, g_lagrange, g2, s_g2
+
+
+def params_to_bytes(k: int, g, g_lagrange, g2, s_g2) -> bytes:
+    buf = io.BytesIO()
+    write_params(buf, k, g, g_lagrange, g2, s_g2)
+    return buf.getvalue()
