@@ -206,6 +206,13 @@ int zkhip_g1_gen_walk_device(const uint64_t t0[4], const uint64_t d[4], size_t n
  * G1Affine for the BN254 generator G = (1, 2), i < n -- g = [s^i] G and g_lagrange = [L_i(s)] G are two such calls on scalar vectors
  * the Fr primitives above produce on the device.  The first call builds a 32 MiB table of generator multiples. */
 int zkhip_g1_fixed_base_mul_device(const void *d_scalars, size_t n, void *d_out, void *stream);
+/* `best_fft::<G1>(a, omega, log_n)` [DEP arithmetic.rs: the FftGroup instance for curve points]: in place on 2^log_n Jacobian points
+ * (96 B each, the memory of `G1`), natural order in and out, a[i] <- sum_j omega^(i j) a[j]; omega: Fr in Montgomery form.
+ * Each butterfly holds one 254-bit scalar multiplication: ~1 s at log_n = 22.  log_n <= 26. */
+int zkhip_g1_fft_device(void *d_points_xyz, const uint64_t omega[4], uint32_t log_n, void *stream);
+/* `g_to_lagrange(g, k)` [DEP poly/kzg/commitment.rs, used by ParamsKZG::setup / from_parts for an SRS whose trapdoor is not known]:
+ * d_g_lagrange[i] = (1/n) sum_j omega_k^(-i j) d_g[j], both arrays 2^k G1Affine points (64 B); may not alias. */
+int zkhip_g_to_lagrange_device(const void *d_g, uint32_t k, void *d_g_lagrange, void *stream);
 /* Per-phase timing with HIP events on the stream the kernels run on.  enable(1), run one call, then
  * zkhip_profile_read synchronises and returns the number of phases of the last profiled call, writing up to
  * `max` durations (milliseconds) and names (63 chars + NUL each). */

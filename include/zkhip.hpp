@@ -309,6 +309,24 @@ class EvaluationDomain {
 };
 
 // ---- halo2_proofs::poly::kzg::commitment::ParamsKZG (commit surface) ----------------------------------------------
+// `g_to_lagrange(g, k)` [DEP poly/kzg/commitment.rs]: the Lagrange-basis SRS of a monomial-basis SRS with unknown trapdoor -- an inverse
+// FFT over the G1 points on the device (zkhip_g_to_lagrange_device)
+inline std::vector<G1Affine> g_to_lagrange(const std::vector<G1Affine>& g, uint32_t k) {
+  const uint64_t n = (uint64_t)1 << k;
+  if (g.size() != n) throw std::invalid_argument("g_to_lagrange: length != 2^k");
+  void *d_in = nullptr, *d_out = nullptr;
+  check(zkhip_alloc(n * sizeof(G1Affine), &d_in), "g_to_lagrange alloc");
+  int rc = zkhip_alloc(n * sizeof(G1Affine), &d_out);
+  std::vector<G1Affine> out(n);
+  if (rc == ZKHIP_OK) rc = zkhip_upload(d_in, g.data(), n * sizeof(G1Affine));
+  if (rc == ZKHIP_OK) rc = zkhip_g_to_lagrange_device(d_in, k, d_out, nullptr);
+  if (rc == ZKHIP_OK) rc = zkhip_download(out.data(), d_out, n * sizeof(G1Affine));
+  (void)zkhip_free(d_in);
+  if (d_out) (void)zkhip_free(d_out);
+  check(rc, "g_to_lagrange");
+  return out;
+}
+
 class ParamsKZG {
  public:
   // takes ownership of the SRS arrays and pins them in HBM (prepared fixed-base tables)
@@ -406,6 +424,12 @@ class ParamsKZG {
   uint32_t k() const { return k_; }
   uint64_t n() const { return n_; }
   const std::vector<G1Affine>& get_g() const { return g_; }
+  const std::vector<G1Affine>& get_g_lagrange() const { return g_lagrange_; }
+  // `ParamsKZG::from_parts` with the Lagrange basis derived from g
+  static ParamsKZG from_parts(uint32_t k, std::vector<G1Affine> g) {
+    std::vector<G1Affine> gl = g_to_lagrange(g, k);
+    return ParamsKZG(k, std::move(g), std::move(gl));
+  }
   // commit(poly) = best_multiexp(poly.coeffs, g[..len]); blinding is ignored for KZG, as in the reference
   G1 commit(const std::vector<Fr>& poly) const {
     if (poly.size() > n_) throw std::invalid_argument("commit: polynomial longer than the SRS");

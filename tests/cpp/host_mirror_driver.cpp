@@ -7,6 +7,7 @@
 //        grand_product, permute_expression_pair (2 vectors of 2^k - 6), a row program's output column,
 //        setup(k, s): g[0..4), commit(poly), commit_lagrange(poly)
 #include <cstdio>
+#include <cstring>
 #include <sstream>
 #include <vector>
 #include "zkhip.hpp"
@@ -97,6 +98,10 @@ int main(int argc, char** argv) {
       try { ParamsKZG::read(cut); } catch (const std::runtime_error&) { threw_trunc = true; }
       const uint64_t trunc = threw_trunc ? 1 : 0;
       fwrite(&trunc, 8, 1, out);
+      // g_to_lagrange(g) reproduces the Lagrange basis that setup built from the trapdoor
+      const std::vector<G1Affine> gl = g_to_lagrange(ps.get_g(), k);
+      const uint64_t same_gl = std::memcmp(gl.data(), ps.get_g_lagrange().data(), n * sizeof(G1Affine)) == 0 ? 1 : 0;
+      fwrite(&same_gl, 8, 1, out);
     }
     fclose(out);
     // error behaviour: the reference's assert_eq!(coeffs.len(), bases.len())

@@ -2,6 +2,7 @@
 compared limb for limb, MSM outputs after affine normalisation (Jacobian representatives are not unique)."""
 import json
 import os
+import random
 
 import numpy as np
 import pytest
@@ -644,6 +645,7 @@ def test_cpp_host_mirror(cref, tmp_path):
     assert int(take(1, 1)[0, 0]) == 1
     assert F.g1_decode_jacobian(take(1, 12)[0]) == F.g1_decode_jacobian(c2)
     assert int(take(1, 1)[0, 0]) == 1
+    assert int(take(1, 1)[0, 0]) == 1                        # g_to_lagrange(setup.g) == setup.g_lagrange
     assert pos == raw.size
 
 
@@ -834,6 +836,72 @@ def test_params_kzg_setup_small_vs_oracle(lib):
             assert O.affine_from_limbs([int(x) for x in params.g_lagrange[i]]) == O.scalar_mul(li, O.G1_GEN), i
     finally:
         params.close()
+
+
+@pytest.mark.parametrize("log_n", [0, 1, 2, 5, 7])
+def test_g1_fft_matches_the_scalar_transform(lib, log_n):
+    """best_fft::<G1>: for points a_j G the transform is [NTT(a)_i] G -- the scalar transform comes from the big-int oracle, the
+    points from its scalar multiplication; input includes the identity and a repeated point"""
+    import ctypes as C
+
+    n = 1 << log_n
+    rng = random.Random(90 + log_n)
+    a = [rng.randrange(O.R_MOD) for _ in range(n)]
+    if n >= 4:
+        a[1] = 0                                              # the identity among the inputs
+        a[3] = a[2]                                           # equal points meet in a butterfly (doubling inside the addition)
+    omega = O.omega_for(log_n)
+    pts = [O.to_jac(O.scalar_mul(v, O.G1_GEN)) if v else O.JAC_ID for v in a]
+    buf = np.array([[lim for c in P for lim in O.limbs4(O.to_mont(c, O.Q_MOD))] for P in pts], dtype=np.uint64).reshape(n, 12)
+    d = C.c_void_p()
+    _lib.check(lib.zkhip_alloc(n * 96, C.byref(d)))
+    try:
+        _lib.check(lib.zkhip_upload(d, buf.ctypes.data, n * 96))
+        om = F.fr_encode([omega])[0]
+        _lib.check(lib.zkhip_g1_fft_device(d, om.ctypes.data, log_n, None))
+        out = np.zeros((n, 12), dtype=np.uint64)
+        _lib.check(lib.zkhip_download(out.ctypes.data, d, n * 96))
+    finally:
+        lib.zkhip_free(d)
+    expect = O.best_fft(a, omega, log_n)
+    for i in range(n):
+        assert F.g1_decode_jacobian(out[i]) == (O.scalar_mul(expect[i], O.G1_GEN) if expect[i] else None), i
+
+
+@pytest.mark.parametrize("k", [3, 9])
+def test_g_to_lagrange_agrees_with_the_trapdoor_formula(lib, cref, k):
+    """two routes to the Lagrange-basis SRS: setup's closed form [L_i(s)] G (fixed-base multiplications) and g_to_lagrange's inverse
+    FFT over the points of g -- different kernels, same points; then from_parts commits like setup"""
+    from zksnap_circuits_halo2_amd import kzg
+
+    s = 0x6C61_6772_616E_6765_0000_0000_0000_0001_0203
+    params = Z.ParamsKZG.setup(k, s)
+    try:
+        assert np.array_equal(kzg.g_to_lagrange(params.g, k), params.g_lagrange)
+        evals = cref.gen_scalars(4242 + k, 1 << k, 0)
+        expected = aff(cref, params.commit_lagrange(evals))
+    finally:
+        params.close()
+    derived = Z.ParamsKZG.from_parts(k, params.g, None, params.g2, params.s_g2)
+    try:
+        assert np.array_equal(aff(cref, derived.commit_lagrange(evals)), expected)
+    finally:
+        derived.close()
+
+
+def test_g1_fft_bad_arguments(lib):
+    import ctypes as C
+
+    om = F.fr_encode([1])[0]
+    d = C.c_void_p()
+    _lib.check(lib.zkhip_alloc(96, C.byref(d)))
+    try:
+        assert lib.zkhip_g1_fft_device(None, om.ctypes.data, 0, None) == -1
+        assert lib.zkhip_g1_fft_device(d, om.ctypes.data, 27, None) == -1
+        assert lib.zkhip_g_to_lagrange_device(d, 0, d, None) == -1          # aliasing
+        assert lib.zkhip_g_to_lagrange_device(None, 0, d, None) == -1
+    finally:
+        lib.zkhip_free(d)
 
 
 def test_params_kzg_write_read_round_trip(lib, cref, tmp_path):

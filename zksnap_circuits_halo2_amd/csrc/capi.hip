@@ -847,6 +847,35 @@ int zkhip_g1_fixed_base_mul_device(const void* d_scalars, size_t n, void* d_out,
   return g1_fixed_base_mul_device((const uint32_t*)d_scalars, n, (const uint32_t*)g_ctx.fixed_table.p, (uint32_t*)d_out, g_ctx.ws.p, g_ctx.ws.cap, s);
 }
 
+int zkhip_g1_fft_device(void* d_points_xyz, const uint64_t omega[4], uint32_t log_n, void* stream) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (!d_points_xyz || !omega) { set_error("g1_fft: null pointer"); return ZKHIP_EINVAL; }
+  if (log_n > 26) { set_error("g1_fft: log_n = %u out of range", log_n); return ZKHIP_EINVAL; }
+  const size_t n = (size_t)1 << log_n;
+  if ((rc = g_ctx.ws.reserve(g1_fft_workspace(n))) != ZKHIP_OK) return rc;
+  return g1_fft_device((const uint32_t*)d_points_xyz, 1, (uint32_t*)d_points_xyz, 1, log_n, (const uint32_t*)omega, nullptr, g_ctx.ws.p, g_ctx.ws.cap,
+                       caller_stream(stream));
+}
+
+int zkhip_g_to_lagrange_device(const void* d_g, uint32_t k, void* d_g_lagrange, void* stream) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (!d_g || !d_g_lagrange) { set_error("g_to_lagrange: null pointer"); return ZKHIP_EINVAL; }
+  if (d_g == d_g_lagrange) { set_error("g_to_lagrange: the arrays may not alias"); return ZKHIP_EINVAL; }
+  if (k > 26) { set_error("g_to_lagrange: k = %u out of range", k); return ZKHIP_EINVAL; }
+  const size_t n = (size_t)1 << k;
+  if ((rc = g_ctx.ws.reserve(g1_fft_workspace(n))) != ZKHIP_OK) return rc;
+  namespace H = zkhip::halo2;
+  H::Fr omega = H::fr_root_of_unity();
+  for (uint32_t i = k; i < 28; i++) omega = H::detail::mul(omega, omega);
+  const H::Fr omega_inv = H::detail::invert(omega), n_inv = H::detail::invert(H::detail::from_u64((uint64_t)n));
+  return g1_fft_device((const uint32_t*)d_g, 0, (uint32_t*)d_g_lagrange, 0, k, (const uint32_t*)omega_inv.l, (const uint32_t*)n_inv.l, g_ctx.ws.p,
+                       g_ctx.ws.cap, caller_stream(stream));
+}
+
 int zkhip_g1_gen_walk_device(const uint64_t t0[4], const uint64_t d[4], size_t n, void* d_out, void* stream) {
   guard_t g(g_mu);
   int rc = ensure_init();

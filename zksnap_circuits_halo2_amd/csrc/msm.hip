@@ -1339,6 +1339,168 @@ void release_prepared(prepared_bases* pb) {
   delete pb;
 }
 
+// ------------------------------------------------------------------------------------------------
+// FFT over G1 points: `best_fft::<G1>` [DEP halo2-axiom arithmetic.rs, FftGroup for the curve group] as `g_to_lagrange` uses it
+// (ParamsKZG::setup / from_parts [DEP poly/kzg/commitment.rs], reached from /root/reference/voter/benches/voter_circuit.rs:60;
+// SURVEY.md section 8(f) row 4): a[i] <- sum_j omega^(i j) a[j], natural order in and out.  Same radix-2 structure as the scalar
+// transform, but a butterfly's twiddle product is a 254-bit scalar multiplication (~254 doublings + ~127 additions), so the kernel
+// is pure field arithmetic: one thread per butterfly, one launch per level, points kept as XYZZ (144 B) in a work array between
+// levels.  Thread t handles twiddle index j = t / (n/m) of block t % (n/m): for all but the last six levels the 64 lanes of a
+// wavefront share j, hence the scalar's bits, and the add-or-not branch of the double-and-add loop is uniform.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ xyzz xyzz_negate(const xyzz& a) {
+  xyzz r = a;
+  r.Y = fe_norm(fe_neg_red(a.Y, Fq::P6_S1));      // Y N < 5p -> 6p - Y
+  return r;
+}
+
+// k * B for a canonical 254-bit integer k (8 words), B in XYZZ form; MSB-first double-and-add
+__device__ __forceinline__ xyzz xyzz_scalar_mul(const xyzz& B, const uint32_t (&kw)[8]) {
+  xyzz acc = xyzz_identity();
+  if (xyzz_is_identity(B)) return acc;
+  int bit = 253;
+  while (bit >= 0 && !((kw[bit >> 5] >> (bit & 31)) & 1)) bit--;
+#pragma unroll 1
+  for (; bit >= 0; bit--) {
+    acc = xyzz_dbl(acc);
+    if ((kw[bit >> 5] >> (bit & 31)) & 1) acc = xyzz_add(acc, B);
+  }
+  return acc;
+}
+
+// Fr element in external Montgomery words -> canonical integer words
+__device__ __forceinline__ void fr_ext_to_integer(const fe& internal_reduced, uint32_t (&kw)[8]) {
+  fe raw1;
+#pragma unroll
+  for (int i = 0; i < NL; i++) raw1.l[i] = FrParams::RAW_ONE[i];
+  fe_pack(fe_canon_lt2p<FrParams>(fe_mul<FrParams>(raw1, internal_reduced)), kw);
+}
+
+__device__ __forceinline__ fe fr_ext_to_internal(const uint32_t* ext_words) {   // x * 2^256 -> x * 2^261, reduced
+  fe k;
+#pragma unroll
+  for (int i = 0; i < NL; i++) k.l[i] = FrParams::FROM_EXT[i];
+  uint32_t w[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) w[i] = ext_words[i];
+  return fe_mul<FrParams>(k, fe_unpack<0>(w));
+}
+
+__device__ __forceinline__ fe fr_pow_small(fe base, uint32_t e) {
+  fe acc = fe_one<FrParams>();
+  while (e) {
+    if (e & 1) acc = fe_mul<FrParams>(acc, base);
+    base = fe_sqr<FrParams>(base);
+    e >>= 1;
+  }
+  return acc;
+}
+
+struct fr_words { uint32_t w[8]; };
+
+// work[bitrev(i)] = scale * in[i]   (FORMAT 0: affine 64 B points, 1: Jacobian 96 B points; scale = nullptr-equivalent: has_scale = 0)
+template <int FORMAT>
+__global__ void __launch_bounds__(64) k_g1fft_load(const uint32_t* __restrict__ in, uint32_t n, int log_n, fr_words scale, int has_scale,
+                                                   uint32_t* __restrict__ work) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  xyzz P;
+  if (FORMAT == 0) {
+    const affine_words pt = load_affine(in, i);
+    P = xyzz_identity();
+    if (!affine_is_identity(pt)) xyzz_madd(P, fe_from_ext_lazy(pt.x), fe_from_ext_lazy(pt.y));
+  } else {
+    P = load_jacobian(in + (size_t)i * 24);
+  }
+  if (has_scale) {
+    uint32_t kw[8];
+    fr_ext_to_integer(fr_ext_to_internal(scale.w), kw);
+    P = xyzz_scalar_mul(P, kw);
+  }
+  store_xyzz(work, log_n ? (__brev(i) >> (32 - log_n)) : 0u, P);
+}
+
+// level s = 1 .. log_n of the decimation-in-time transform on bit-reversed input: m = 2^s, butterflies (i0, i0 + m/2)
+__global__ void __launch_bounds__(64) k_g1fft_level(uint32_t* __restrict__ work, uint32_t n, int s, int log_n, fr_words omega) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n / 2) return;
+  const uint32_t blocks = n >> s, half = 1u << (s - 1);          // n/m blocks of m points
+  const uint32_t j = t / blocks, blk = t - j * blocks;           // lanes of a wavefront share j while blocks >= 64
+  const uint32_t i0 = (blk << s) + j, i1 = i0 + half;
+  xyzz T = load_xyzz(work, i1);
+  if (j) {                                                        // twiddle omega^(j n/m); j = 0: 1
+    uint32_t kw[8];
+    fr_ext_to_integer(fr_pow_small(fr_ext_to_internal(omega.w), j * blocks), kw);
+    T = xyzz_scalar_mul(T, kw);
+  }
+  const xyzz A = load_xyzz(work, i0);                             // after the multiplication: one point less alive during it
+  store_xyzz(work, i0, xyzz_add(A, T));
+  store_xyzz(work, i1, xyzz_add(A, xyzz_negate(T)));
+}
+
+__global__ void __launch_bounds__(64) k_g1fft_store_jacobian(const uint32_t* __restrict__ work, uint32_t n, uint32_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) store_jacobian(load_xyzz(work, i), out + (size_t)i * 24);
+}
+
+// XYZZ work array -> affine points, one inversion per thread chunk (as k_fixed_base_mul)
+constexpr int AFFINE_CHUNK = 32;
+__global__ void __launch_bounds__(64) k_xyzz_to_affine(const uint32_t* __restrict__ work, uint32_t n, uint32_t* __restrict__ out,
+                                                       uint32_t* __restrict__ tmp_pref) {
+  const uint32_t lo = (blockIdx.x * blockDim.x + threadIdx.x) * AFFINE_CHUNK;
+  if (lo >= n) return;
+  const uint32_t cnt = min((uint32_t)AFFINE_CHUNK, n - lo);
+  fe pref = fe_one<Fq>();
+  for (uint32_t i = 0; i < cnt; i++) {
+    const xyzz Q = load_xyzz(work, lo + i);
+    store_fe9_generic(tmp_pref, lo + i, pref);
+    if (!xyzz_is_identity(Q)) pref = fe_mul<Fq>(pref, fe_mul<Fq>(Q.ZZ, Q.ZZZ));
+  }
+  fe inv = fq_inverse(pref);
+  for (uint32_t ii = cnt; ii-- > 0;) {
+    const xyzz Q = load_xyzz(work, lo + ii);
+    uint32_t* o = out + (size_t)(lo + ii) * 16;
+    if (xyzz_is_identity(Q)) {
+#pragma unroll
+      for (int t = 0; t < 16; t++) o[t] = 0;
+      continue;
+    }
+    const fe pre = load_fe9_generic(tmp_pref, lo + ii);
+    const fe winv = fe_mul<Fq>(inv, pre);
+    inv = fe_mul<Fq>(inv, fe_mul<Fq>(Q.ZZ, Q.ZZZ));
+    const fe x = fe_mul<Fq>(fe_mul<Fq>(winv, Q.ZZZ), Q.X);
+    const fe y = fe_mul<Fq>(fe_mul<Fq>(winv, Q.ZZ), Q.Y);
+    uint32_t wx[8], wy[8];
+    fe_to_ext<Fq>(x, wx);
+    fe_to_ext<Fq>(y, wy);
+#pragma unroll
+    for (int t = 0; t < 8; t++) { o[t] = wx[t]; o[8 + t] = wy[t]; }
+  }
+}
+
+size_t g1_fft_workspace(size_t n) { return align_up(n * 144, 256) + align_up(n * 36, 256) + 256; }
+
+// in_format / out_format: 0 = affine (64 B), 1 = Jacobian (96 B).  scale_ext: optional factor applied to every input point.
+int g1_fft_device(const uint32_t* d_in, int in_format, uint32_t* d_out, int out_format, uint32_t log_n, const uint32_t omega_ext[8],
+                  const uint32_t* scale_ext, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (log_n > 26) { set_error("g1_fft: log_n = %u out of range", log_n); return ZKHIP_EINVAL; }
+  const size_t n = (size_t)1 << log_n;
+  if (ws_bytes < g1_fft_workspace(n)) { set_error("g1_fft: workspace too small"); return ZKHIP_EINVAL; }
+  uint32_t* work = (uint32_t*)ws;
+  uint32_t* pref = (uint32_t*)((char*)ws + align_up(n * 144, 256));
+  fr_words om, sc;
+  for (int i = 0; i < 8; i++) { om.w[i] = omega_ext[i]; sc.w[i] = scale_ext ? scale_ext[i] : 0u; }
+  const unsigned gb = (unsigned)((n + 63) / 64);
+  if (in_format == 0) hipLaunchKernelGGL(k_g1fft_load<0>, dim3(gb), dim3(64), 0, stream, d_in, (uint32_t)n, (int)log_n, sc, scale_ext ? 1 : 0, work);
+  else hipLaunchKernelGGL(k_g1fft_load<1>, dim3(gb), dim3(64), 0, stream, d_in, (uint32_t)n, (int)log_n, sc, scale_ext ? 1 : 0, work);
+  for (uint32_t s = 1; s <= log_n; s++)
+    hipLaunchKernelGGL(k_g1fft_level, dim3((unsigned)((n / 2 + 63) / 64)), dim3(64), 0, stream, work, (uint32_t)n, (int)s, (int)log_n, om);
+  if (out_format == 1) hipLaunchKernelGGL(k_g1fft_store_jacobian, dim3(gb), dim3(64), 0, stream, work, (uint32_t)n, d_out);
+  else hipLaunchKernelGGL(k_xyzz_to_affine, dim3((unsigned)(((n + AFFINE_CHUNK - 1) / AFFINE_CHUNK + 63) / 64)), dim3(64), 0, stream, work, (uint32_t)n, d_out, pref);
+  HIPCHK(hipGetLastError());
+  return ZKHIP_OK;
+}
+
 int sum_jacobian_device(const uint32_t* d_in, int m, uint32_t* d_out, hipStream_t stream) {
   hipLaunchKernelGGL(k_sum_jacobian, dim3(1), dim3(64), 0, stream, d_in, m, d_out);
   HIPCHK(hipGetLastError());

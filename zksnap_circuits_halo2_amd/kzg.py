@@ -8,6 +8,30 @@ from . import _lib
 from .arithmetic import best_multiexp
 
 
+def g_to_lagrange(g: np.ndarray, k: int) -> np.ndarray:
+    """`g_to_lagrange(g_projective, k)` [DEP poly/kzg/commitment.rs]: the Lagrange-basis SRS of a monomial-basis SRS whose trapdoor is not
+    known, g_lagrange[i] = (1/n) sum_j omega^(-i j) g[j] -- an inverse FFT over G1 points on the GPU (`zkhip_g_to_lagrange_device`)."""
+    import ctypes as C
+
+    n = 1 << k
+    g = np.ascontiguousarray(g, dtype=np.uint64).reshape(n, 8)
+    lib = _lib.load()
+    d_in, d_out = C.c_void_p(), C.c_void_p()
+    _lib.check(lib.zkhip_alloc(n * 64, C.byref(d_in)))
+    try:
+        _lib.check(lib.zkhip_alloc(n * 64, C.byref(d_out)))
+        try:
+            _lib.check(lib.zkhip_upload(d_in, g.ctypes.data, n * 64))
+            _lib.check(lib.zkhip_g_to_lagrange_device(d_in, k, d_out, None))
+            out = np.zeros((n, 8), dtype=np.uint64)
+            _lib.check(lib.zkhip_download(out.ctypes.data, d_out, n * 64))
+            return out
+        finally:
+            lib.zkhip_free(d_out)
+    finally:
+        lib.zkhip_free(d_in)
+
+
 class ParamsKZG:
     def __init__(self, k: int, g: np.ndarray, g_lagrange: np.ndarray | None = None, g2: np.ndarray | None = None, s_g2: np.ndarray | None = None):
         self.k, self.n = k, 1 << k
@@ -68,6 +92,11 @@ class ParamsKZG:
         from . import srs
 
         return cls(k, g, g_lagrange, srs.g2_encode(srs.G2_GENERATOR), srs.g2_encode(srs.g2_mul(s)))
+
+    @classmethod
+    def from_parts(cls, k: int, g: np.ndarray, g_lagrange: np.ndarray | None = None, g2: np.ndarray | None = None, s_g2: np.ndarray | None = None) -> "ParamsKZG":
+        """`ParamsKZG::from_parts` [DEP]: the Lagrange basis is derived from g when it is not supplied"""
+        return cls(k, g, g_to_lagrange(g, k) if g_lagrange is None else g_lagrange, g2, s_g2)
 
     def write(self, f) -> None:
         """`ParamsKZG::write` (SerdeFormat::RawBytes) [DEP]; layout in srs.py"""
