@@ -449,11 +449,18 @@ __global__ void k_order_offsets(const uint32_t* __restrict__ len_count, uint32_t
   for (int L = 64; L >= 1; L--) { len_cursor[L] = run; run += len_count[L]; }
 }
 
+// Within the class of full-length tasks the order is j-major per workgroup of 256 buckets (j = the task's index inside its
+// bucket): a wavefront of k_accumulate then runs 64 tasks that sit at the same depth of 64 neighbouring buckets.  The sort fills
+// every bucket roughly window by window, so those 64 tasks gather their points from the same one or two window slices of the
+// prepared table instead of from all of it -- the table of a 2^24-point MSM is 13 GiB, and the gathers' address-translation
+// footprint, not their bandwidth, is what costs (an emulated dense 16 GiB footprint slows the 2^20 accumulation by 11 %).
+constexpr int ORDER_JMAX = 64;
 __global__ void __launch_bounds__(256) k_make_order(const uint32_t* __restrict__ offset, const uint32_t* __restrict__ task_off,
                                                     uint32_t nbuckets, uint32_t task_shift, uint32_t* __restrict__ len_cursor,
                                                     const uint32_t* __restrict__ sorted, uint4* __restrict__ order) {
   __shared__ uint32_t lh[65];
-  if (threadIdx.x < 65) lh[threadIdx.x] = 0;
+  __shared__ uint32_t jcnt[ORDER_JMAX + 1], joff[ORDER_JMAX + 1];
+  if (threadIdx.x < 65) { lh[threadIdx.x] = 0; jcnt[threadIdx.x] = 0; }
   __syncthreads();
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t nt = 0, t = 0, full = 1u << task_shift, rem = 0, s0 = 0;
@@ -463,21 +470,36 @@ __global__ void __launch_bounds__(256) k_make_order(const uint32_t* __restrict__
     if (nt) {
       s0 = offset[k];
       rem = (offset[k + 1] - s0) - ((nt - 1) << task_shift);
-      if (nt > 1) atomicAdd(&lh[full], nt - 1);
       atomicAdd(&lh[rem], 1u);
+      const uint32_t nfull = nt - 1, head = min(nfull, (uint32_t)ORDER_JMAX);
+      for (uint32_t j = 0; j < head; j++) atomicAdd(&jcnt[j], 1u);
+      if (nfull > head) atomicAdd(&jcnt[ORDER_JMAX], nfull - head);
     }
   }
   __syncthreads();
-  if (threadIdx.x < 65) { const uint32_t v = lh[threadIdx.x]; lh[threadIdx.x] = v ? atomicAdd(&len_cursor[threadIdx.x], v) : 0u; }
+  if (threadIdx.x == 0) {                      // offsets of the depth classes inside this workgroup's range of full tasks
+    uint32_t run = 0;
+    for (int j = 0; j <= ORDER_JMAX; j++) { joff[j] = run; run += jcnt[j]; }
+    const uint32_t base = run ? atomicAdd(&len_cursor[full], run) : 0u;
+    for (int j = 0; j <= ORDER_JMAX; j++) joff[j] += base;
+  }
+  if (threadIdx.x < 65 && threadIdx.x != full) { const uint32_t v = lh[threadIdx.x]; lh[threadIdx.x] = v ? atomicAdd(&len_cursor[threadIdx.x], v) : 0u; }
+  __syncthreads();
+  if (threadIdx.x == 0 && lh[full]) lh[full] = atomicAdd(&len_cursor[full], lh[full]);     // remainder tasks of full length, after the depth classes
   __syncthreads();
   if (nt) {
     // the record a task starts from, in execution order: (task, first entry, length, first point reference) -- one coalesced
     // 16-byte load in k_accumulate instead of the chain order -> task -> sorted before the first point can be fetched
-    if (nt > 1) {
-      const uint32_t pos = atomicAdd(&lh[full], nt - 1);
-      for (uint32_t j = 0; j + 1 < nt; j++) {
+    const uint32_t nfull = nt - 1, head = min(nfull, (uint32_t)ORDER_JMAX);
+    for (uint32_t j = 0; j < head; j++) {
+      const uint32_t st = s0 + (j << task_shift);
+      order[atomicAdd(&joff[j], 1u)] = make_uint4(t + j, st, full, sorted[st]);
+    }
+    if (nfull > head) {
+      const uint32_t pos = atomicAdd(&joff[ORDER_JMAX], nfull - head);
+      for (uint32_t j = head; j < nfull; j++) {
         const uint32_t st = s0 + (j << task_shift);
-        order[pos + j] = make_uint4(t + j, st, full, sorted[st]);
+        order[pos + j - head] = make_uint4(t + j, st, full, sorted[st]);
       }
     }
     const uint32_t st = s0 + ((nt - 1) << task_shift);
