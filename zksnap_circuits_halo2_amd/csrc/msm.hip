@@ -416,22 +416,23 @@ __global__ void __launch_bounds__(256) k_make_tasks(const uint32_t* __restrict__
   __shared__ uint32_t lh[65];
   if (threadIdx.x < 65) lh[threadIdx.x] = 0;
   __syncthreads();
-  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  // a capped grid walks the buckets: the length histogram costs one global atomic per (workgroup, length) on the same 65 words,
+  // and with one workgroup per 256 buckets those were 2048 x 65 contended atomics at 2^19 buckets (99 us of a 6 ms MSM)
   uint32_t nt = 0;
-  if (k < nbuckets) {
-    uint32_t s = offset[k], e = offset[k + 1], t = task_off[k];
-    nt = task_off[k + 1] - t;
-    for (uint32_t j = 0; j < nt; j++) {
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nbuckets; k += gridDim.x * blockDim.x) {
+    const uint32_t s = offset[k], e = offset[k + 1], t = task_off[k], m = task_off[k + 1] - t;
+    for (uint32_t j = 0; j < m; j++) {
       task_t tk;
       tk.bucket = k;
       tk.start = s + (j << task_shift);
       tk.len = min(1u << task_shift, e - tk.start);
       tasks[t + j] = tk;
     }
-    if (nt) {   // nt - 1 full tasks and one of the remaining length
-      if (nt > 1) atomicAdd(&lh[1u << task_shift], nt - 1);
-      atomicAdd(&lh[(e - s) - ((nt - 1) << task_shift)], 1u);
+    if (m) {   // m - 1 full tasks and one of the remaining length
+      if (m > 1) atomicAdd(&lh[1u << task_shift], m - 1);
+      atomicAdd(&lh[(e - s) - ((m - 1) << task_shift)], 1u);
     }
+    nt = max(nt, m);
   }
   __syncthreads();
   if (threadIdx.x < 65 && lh[threadIdx.x]) atomicAdd(&len_count[threadIdx.x], lh[threadIdx.x]);
@@ -449,7 +450,7 @@ __global__ void k_order_offsets(const uint32_t* __restrict__ len_count, uint32_t
   for (int L = 64; L >= 1; L--) { len_cursor[L] = run; run += len_count[L]; }
 }
 
-// Within the class of full-length tasks the order is j-major per workgroup of 256 buckets (j = the task's index inside its
+// Within the class of full-length tasks the order is j-major per workgroup (j = the task's index inside its
 // bucket): a wavefront of k_accumulate then runs 64 tasks that sit at the same depth of 64 neighbouring buckets.  The sort fills
 // every bucket roughly window by window, so those 64 tasks gather their points from the same one or two window slices of the
 // prepared table instead of from all of it -- the table of a 2^24-point MSM is 13 GiB, and the gathers' address-translation
@@ -462,14 +463,11 @@ __global__ void __launch_bounds__(256) k_make_order(const uint32_t* __restrict__
   __shared__ uint32_t jcnt[ORDER_JMAX + 1], joff[ORDER_JMAX + 1];
   if (threadIdx.x < 65) { lh[threadIdx.x] = 0; jcnt[threadIdx.x] = 0; }
   __syncthreads();
-  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t nt = 0, t = 0, full = 1u << task_shift, rem = 0, s0 = 0;
-  if (k < nbuckets) {
-    t = task_off[k];
-    nt = task_off[k + 1] - t;
+  const uint32_t full = 1u << task_shift, step = gridDim.x * blockDim.x;     // capped grid, as k_make_tasks
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nbuckets; k += step) {
+    const uint32_t nt = task_off[k + 1] - task_off[k];
     if (nt) {
-      s0 = offset[k];
-      rem = (offset[k + 1] - s0) - ((nt - 1) << task_shift);
+      const uint32_t rem = (offset[k + 1] - offset[k]) - ((nt - 1) << task_shift);
       atomicAdd(&lh[rem], 1u);
       const uint32_t nfull = nt - 1, head = min(nfull, (uint32_t)ORDER_JMAX);
       for (uint32_t j = 0; j < head; j++) atomicAdd(&jcnt[j], 1u);
@@ -487,9 +485,12 @@ __global__ void __launch_bounds__(256) k_make_order(const uint32_t* __restrict__
   __syncthreads();
   if (threadIdx.x == 0 && lh[full]) lh[full] = atomicAdd(&len_cursor[full], lh[full]);     // remainder tasks of full length, after the depth classes
   __syncthreads();
-  if (nt) {
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nbuckets; k += step) {
+    const uint32_t t = task_off[k], nt = task_off[k + 1] - t;
+    if (!nt) continue;
     // the record a task starts from, in execution order: (task, first entry, length, first point reference) -- one coalesced
     // 16-byte load in k_accumulate instead of the chain order -> task -> sorted before the first point can be fetched
+    const uint32_t s0 = offset[k], rem = (offset[k + 1] - s0) - ((nt - 1) << task_shift);
     const uint32_t nfull = nt - 1, head = min(nfull, (uint32_t)ORDER_JMAX);
     for (uint32_t j = 0; j < head; j++) {
       const uint32_t st = s0 + (j << task_shift);
@@ -968,12 +969,13 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   else hipLaunchKernelGGL(k_sort_pass<true>, dim3(chunks, W, K), dim3(1024), lds, stream, (const int16_t*)digits, n_pad, chunk, c, cursor, sorted, wb_stride, ref_base, ref_stride);
   prof_mark(stream, "scatter");
   // 5. tasks
+  const unsigned task_blocks = (unsigned)std::min<size_t>((NB + 255) / 256, 256);
   hipLaunchKernelGGL(k_scan_sums<1>, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, count, NB, bsum2, task_shift);
   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_BLOCK), 0, stream, bsum2, nblk, counters + 1);
   hipLaunchKernelGGL(k_scan_apply<1>, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, count, NB, bsum2, counters + 1, task_off, (uint32_t*)nullptr, task_shift);
-  hipLaunchKernelGGL(k_make_tasks, dim3((NB + 255) / 256), dim3(256), 0, stream, offset, task_off, NB, tasks, task_shift, counters + 2, counters + 64);
+  hipLaunchKernelGGL(k_make_tasks, dim3(task_blocks), dim3(256), 0, stream, offset, task_off, NB, tasks, task_shift, counters + 2, counters + 64);
   hipLaunchKernelGGL(k_order_offsets, dim3(1), dim3(64), 0, stream, counters + 64, counters + 160);
-  hipLaunchKernelGGL(k_make_order, dim3((NB + 255) / 256), dim3(256), 0, stream, offset, task_off, NB, task_shift, counters + 160, sorted, order);
+  hipLaunchKernelGGL(k_make_order, dim3(task_blocks), dim3(256), 0, stream, offset, task_off, NB, task_shift, counters + 160, sorted, order);
   prof_mark(stream, "tasks");
   // 6. accumulate (grid-stride over the device-side task count)
   {
