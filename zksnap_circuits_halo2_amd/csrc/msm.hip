@@ -993,7 +993,7 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   const uint32_t seq_parts = 16u * (uint32_t)combine_lanes;
   {
     uint32_t blocks = (uint32_t)((max_tasks + 127) / 128);
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 256) blocks = 256;                 // grid-stride kernels; usually no bucket needs a level, and an idle launch costs by its wave count
     // a bucket holds at most max_tasks partials: levels beyond ceil(log4(max_tasks / seq_parts)) can never be needed
     int levels = 0;
     while (levels < COMBINE_LEVELS && (((uint64_t)max_tasks + ((uint64_t)1 << (2 * levels)) - 1) >> (2 * levels)) > seq_parts) levels++;
