@@ -92,14 +92,18 @@ def main() -> None:
     torch.cuda.synchronize()
     t_prep = time.perf_counter() - t_prep
     d_scalars = torch.from_numpy(synth_scalars(n, 0x5A4B534E41500003 + rank).view(np.int64)).to(dev)
-    d_out = torch.zeros(16, dtype=torch.int64, device=dev)          # 96-byte result in a 128-byte slot
-    d_gather = torch.zeros(16 * world, dtype=torch.int64, device=dev)
-    d_final = torch.zeros(16, dtype=torch.int64, device=dev)
+    d_out = torch.zeros(12, dtype=torch.int64, device=dev)          # 96-byte Jacobian result
+    # Exchange per step: one 96-byte all_gather + a fold of the N partials, enqueued behind the MSM on the same stream.  (Running it on a
+    # side stream under the next step's MSM was measured at N = 1 with the gather degenerated to a copy -- ZKHIP_BENCH_FORCE_EXCHANGE=1
+    # -- and is slower: 599 vs 612 Mpoints/s, against 616 without any exchange; the cross-stream events cost more than the fold.)
+    exchange = world > 1 or os.environ.get("ZKHIP_BENCH_FORCE_EXCHANGE") == "1"
+    d_gather = torch.zeros(12 * world, dtype=torch.int64, device=dev)
+    d_final = torch.zeros(12, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
 
     def step():
         _lib.check(lib.zkhip_msm_g1_prepared_device(handle, 0, d_scalars.data_ptr(), n, d_out.data_ptr(), stream))
-        if world > 1:   # every rank gathers the 128-byte slots and folds the partials
+        if exchange:   # every rank gathers the partials and folds them
             gather_fold_device(d_out, d_gather, d_final, stream)
 
     for _ in range(args.warmup):
@@ -123,6 +127,8 @@ def main() -> None:
 
     ms_per_step = elapsed / args.steps * 1e3
     mpoints = world * n * args.steps / elapsed / 1e6
+    if exchange and world == 1:   # forced exchange at N = 1: the fold of one partial must be that partial (as an affine point)
+        assert F.g1_decode_jacobian(d_final.cpu().numpy().view(np.uint64)[:12]) == F.g1_decode_jacobian(d_out.cpu().numpy().view(np.uint64)[:12])
 
     result = {
         "metric": "BN254 G1 MSM Mpoints/sec",

@@ -61,23 +61,26 @@ def sharded_msm(scalars_shard: np.ndarray, bases_shard: np.ndarray, group=None,
 
 
 def gather_fold_device(d_partial, d_gather, d_final, stream: int = 0, group=None) -> None:
-    """Device-resident form of the exchange (what `bench.py` times): `d_partial` is this rank's 96-byte Jacobian partial sum in
-    a 128-byte slot (torch int64[16] on the GPU), `d_gather` int64[16 * world], `d_final` int64[16] receives the fold.
-    Backend "nccl" (RCCL) gathers device to device; "gloo" (CPU rehearsals of the N > 1 path) stages through the host."""
+    """Device-resident form of the exchange (what `bench.py` times): `d_partial` is this rank's 96-byte Jacobian partial sum (torch
+    int64[12] on the GPU; int64[16] = the same in a 128-byte slot is accepted too), `d_gather` int64[width * world], `d_final` receives
+    the fold in its first 12 words.  Backend "nccl" (RCCL) gathers device to device; "gloo" (CPU rehearsals of the N > 1 path) stages
+    through the host.  Everything is enqueued on the current torch stream / `stream` (pass the same one)."""
     import torch.distributed as dist
 
     from . import _lib
 
+    width = d_partial.numel()
+    assert width in (12, 16) and d_gather.numel() >= width
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
-        d_gather[:16].copy_(d_partial)
+        d_gather[:width].copy_(d_partial)
     elif dist.get_backend(group) == "nccl":
         dist.all_gather_into_tensor(d_gather, d_partial, group=group)
     else:
         import torch
 
-        host = torch.empty(16 * world, dtype=torch.int64)
+        host = torch.empty(width * world, dtype=torch.int64)
         dist.all_gather_into_tensor(host, d_partial.cpu(), group=group)
         d_gather.copy_(host)
-    parts = d_gather.view(world, 16)[:, :12].contiguous()        # compact the 128-byte slots to 96-byte points
+    parts = d_gather if width == 12 else d_gather.view(world, 16)[:, :12].contiguous()   # 128-byte slots are compacted to 96-byte points
     _lib.check(_lib.load().zkhip_g1_sum_device(parts.data_ptr(), world, d_final.data_ptr(), stream))
