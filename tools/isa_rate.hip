@@ -44,6 +44,10 @@ __global__ void k(uint32_t* out, uint32_t seed) {
       if (OP == 18) { asm volatile("v_mad_u32_u16 %0, %1, %2, %0" : "+v"(w[i]) : "v"(a), "v"(b)); }
       if (OP == 19) { asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(d[i]) : "v"(w[i])); }
       if (OP == 20) { asm volatile("v_cvt_u32_f64 %0, %1" : "=v"(w[i]) : "v"(d[i])); }
+      // one dependent chain (the pinned product column of fe_mac<true>), without and with the s_nop the hazard recogniser puts after
+      // the pin's inline asm; counted as one multiply-add each
+      if (OP == 21) { asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[0]) : "v"(a), "v"(b) : "vcc"); }
+      if (OP == 22) { asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\ts_nop 0" : "+v"(acc[0]) : "v"(a), "v"(b) : "vcc"); }
     }
   }
   uint64_t s = 0; double ds = 0; uint32_t ws = 0;
@@ -58,9 +62,10 @@ int main() {
   const char* names[] = {"v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u32_u24", "v_mul_hi_u32_u24",
                          "v_fma_f64", "v_add_co_u32", "v_add_co+v_addc(2)", "v_add3_u32", "v_lshl_add_u64",
                          "v_fma_f32", "v_mad_i64_i32", "v_mul_u32_u24", "v_lshrrev_b64", "v_and_b32",
-                         "v_mul_f64", "v_add_f64", "v_dot4_u32_u8", "v_mad_u32_u16", "v_cvt_f64_u32", "v_cvt_u32_f64"};
+                         "v_mul_f64", "v_add_f64", "v_dot4_u32_u8", "v_mad_u32_u16", "v_cvt_f64_u32", "v_cvt_u32_f64",
+                         "v_mad_u64_u32 dependent chain", "v_mad_u64_u32 dependent + s_nop 0"};
   kern_t ks[] = {k<0>, k<1>, k<2>, k<3>, k<4>, k<5>, k<6>, k<7>, k<8>, k<9>, k<10>, k<11>, k<12>, k<13>, k<14>,
-                 k<15>, k<16>, k<17>, k<18>, k<19>, k<20>};
+                 k<15>, k<16>, k<17>, k<18>, k<19>, k<20>, k<21>, k<22>};
   const int nops = sizeof(ks) / sizeof(ks[0]);
   hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
   int cus = prop.multiProcessorCount;
@@ -69,7 +74,7 @@ int main() {
   hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   // waves per SIMD: 1, 2, 4 (block 256 = one wave per SIMD; blocks per CU 1, 2, 4)
   for (int op = 0; op < nops; op++) {
-    for (int wps : {1, 2, 4}) {
+    for (int wps : {1, 2, 4, 8}) {
       int blocks = cus * wps;
       hipLaunchKernelGGL(ks[op], dim3(blocks), dim3(256), 0, 0, out, 1u);
       CHECK(hipDeviceSynchronize());

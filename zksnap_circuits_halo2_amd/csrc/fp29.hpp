@@ -21,6 +21,10 @@
 #pragma once
 #include <cstdint>
 #include "bn254_constants.hpp"
+#if defined(__HIPCC__)
+#include <type_traits>
+#include "mac_blocks.hpp"
+#endif
 
 #if defined(__HIPCC__)
 #define ZK_HD __host__ __device__ __forceinline__
@@ -60,13 +64,13 @@ template <class P> ZK_HD fe fe_one() { fe r;
   for (int i = 0; i < NL; i++) r.l[i] = P::ONE[i];
   return r; }
 
-// acc += x * y.  With CHAIN the accumulator is pinned after every multiply-add so that the product column stays one chain of
-// v_mad_u64_u32 whose addend is the running sum.  Left alone, LLVM reassociates each column into partial sums that start from
-// 0 and joins them (and the carry of the previous column) with v_lshl_add_u64: 17-34 extra instructions per product.  The two
-// shapes suit different kernels (measured): the chain wins where many waves per SIMD hide its latency and
-// instruction issue is the bound (bucket accumulation: -5%); the compiler's shape wins in the latency-bound tail and, by a wide
-// margin, in the NTT, where independent butterflies want to interleave (the pin's inline asm also draws an s_nop from the
-// gfx950 hazard recogniser whenever the next instruction reads its result).  The pin itself emits nothing.
+// acc += x * y.  CHAIN keeps a product column one chain of v_mad_u64_u32 whose addend is the running sum.  Left alone, LLVM
+// reassociates each column into partial sums that start from 0 and joins them (and the carry of the previous column) with
+// v_lshl_add_u64: 17-34 extra instructions per product.  The two shapes suit different kernels (measured):
+// the chain wins where many waves per SIMD hide its latency and instruction issue is the bound (bucket accumulation: -5 %); the
+// compiler's shape wins in the latency-bound tail and, by a wide margin, in the NTT, where independent butterflies want to
+// interleave.  On the device the chain is written as asm blocks of whole column runs (fe_mul_blocks below, mac_blocks.hpp); this
+// per-product pin (an empty asm that emits nothing but makes the value opaque) is its portable statement and what the host pass sees.
 template <bool CHAIN>
 ZK_HD void fe_mac(uint64_t& acc, uint32_t x, uint32_t y) {
   acc += (uint64_t)x * y;
@@ -75,9 +79,106 @@ ZK_HD void fe_mac(uint64_t& acc, uint32_t x, uint32_t y) {
 #endif
 }
 
+#if defined(__HIPCC__)
+// compile-time loop: f(std::integral_constant<int, K>) for K = BEGIN .. END - 1 (the block sizes below are template arguments)
+template <int K, int END, class F>
+ZK_D void static_for(F&& f) {
+  if constexpr (K < END) {
+    f(std::integral_constant<int, K>{});
+    static_for<K + 1, END>(f);
+  }
+}
+
+// The CHAIN shape of fe_mul / fe_sqr / fe_mul_add with each run of multiply-adds of a column as one asm block (mac_blocks.hpp):
+// same values as the plain code, column by column.  `second`: an optional second product c*d under the same reduction.
+template <class P, bool SECOND>
+ZK_D fe fe_mul_blocks(const fe& a, const fe& b, const fe& c, const fe& d) {
+  uint64_t acc = 0;
+  uint32_t m[NL];
+  fe r;
+  static_for<0, NL>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    uint32_t x[NL], y[NL];
+#pragma unroll
+    for (int i = 0; i <= k; i++) { x[i] = a.l[i]; y[i] = b.l[k - i]; }
+    mac_vv<k + 1>(acc, x, y);
+    if constexpr (SECOND) {
+#pragma unroll
+      for (int i = 0; i <= k; i++) { x[i] = c.l[i]; y[i] = d.l[k - i]; }
+      mac_vv<k + 1>(acc, x, y);
+    }
+    if constexpr (k > 0) {
+#pragma unroll
+      for (int i = 0; i < k; i++) { x[i] = m[i]; y[i] = P::P[k - i]; }
+      mac_vs<k>(acc, x, y);
+    }
+    m[k] = ((uint32_t)acc * P::INV) & LMASK;
+    acc += (uint64_t)m[k] * P::P[0];
+    acc >>= LB;
+  });
+  static_for<NL, 2 * NL - 1>([&](auto kc) {
+    constexpr int k = decltype(kc)::value, lo = k - NL + 1, n = NL - lo;
+    uint32_t x[NL], y[NL];
+#pragma unroll
+    for (int i = 0; i < n; i++) { x[i] = a.l[lo + i]; y[i] = b.l[k - lo - i]; }
+    mac_vv<n>(acc, x, y);
+    if constexpr (SECOND) {
+#pragma unroll
+      for (int i = 0; i < n; i++) { x[i] = c.l[lo + i]; y[i] = d.l[k - lo - i]; }
+      mac_vv<n>(acc, x, y);
+    }
+#pragma unroll
+    for (int i = 0; i < n; i++) { x[i] = m[lo + i]; y[i] = P::P[k - lo - i]; }
+    mac_vs<n>(acc, x, y);
+    r.l[k - NL] = (uint32_t)acc & LMASK;
+    acc >>= LB;
+  });
+  r.l[NL - 1] = (uint32_t)acc;
+  return r;
+}
+
+template <class P>
+ZK_D fe fe_sqr_blocks(const fe& a) {
+  uint64_t acc = 0;
+  uint32_t m[NL], dbl[NL];
+  fe r;
+#pragma unroll
+  for (int i = 0; i < NL; i++) dbl[i] = a.l[i] << 1;
+  static_for<0, 2 * NL - 1>([&](auto kc) {
+    constexpr int k = decltype(kc)::value, lo = k < NL ? 0 : k - NL + 1;
+    constexpr int cross = (k + 1) / 2 - lo;                  // products 2 a_i a_(k-i), lo <= i, 2 i < k
+    uint32_t x[NL], y[NL];
+    if constexpr (cross > 0) {
+#pragma unroll
+      for (int i = 0; i < cross; i++) { x[i] = dbl[lo + i]; y[i] = a.l[k - lo - i]; }
+      mac_vv<cross>(acc, x, y);
+    }
+    if constexpr ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
+    constexpr int nm = k < NL ? k : NL - lo;                 // m_i p_(k-i): i < k (first half), lo <= i < NL (second half)
+    if constexpr (nm > 0) {
+#pragma unroll
+      for (int i = 0; i < nm; i++) { x[i] = m[lo + i]; y[i] = P::P[k - lo - i]; }
+      mac_vs<nm>(acc, x, y);
+    }
+    if constexpr (k < NL) {
+      m[k] = ((uint32_t)acc * P::INV) & LMASK;
+      acc += (uint64_t)m[k] * P::P[0];
+    } else {
+      r.l[k - NL] = (uint32_t)acc & LMASK;
+    }
+    acc >>= LB;
+  });
+  r.l[NL - 1] = (uint32_t)acc;
+  return r;
+}
+#endif
+
 // Montgomery product a*b*2^-261 mod p (lazy: result in N form, value < p*(ab/(p 2^261) + 1)).
 template <class P, bool CHAIN = false>
 ZK_HD fe fe_mul(const fe& a, const fe& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (CHAIN) return fe_mul_blocks<P, false>(a, b, a, b);
+#endif
   uint64_t acc = 0;
   uint32_t m[NL];
   fe r;
@@ -109,6 +210,9 @@ ZK_HD fe fe_mul(const fe& a, const fe& b) {
 // Needs 9 * (max a_i * max b_j + max c_i * max d_j) + 9 * 2^58 + 2^35 < 2^64; value < p * ((ab + cd) / (p 2^261) + 1).
 template <class P, bool CHAIN = false>
 ZK_HD fe fe_mul_add(const fe& a, const fe& b, const fe& c, const fe& d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (CHAIN) return fe_mul_blocks<P, true>(a, b, c, d);
+#endif
   uint64_t acc = 0;
   uint32_t m[NL];
   fe r;
@@ -142,6 +246,9 @@ ZK_HD fe fe_mul_add(const fe& a, const fe& b, const fe& c, const fe& d) {
 // Montgomery square (45 distinct products instead of 81).  Needs limbs < 2^30.3.
 template <class P, bool CHAIN = false>
 ZK_HD fe fe_sqr(const fe& a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (CHAIN) return fe_sqr_blocks<P>(a);
+#endif
   uint64_t acc = 0;
   uint32_t m[NL], d[NL];
   fe r;
