@@ -194,7 +194,7 @@ def main() -> None:
         imads = 1467.0 * float(windows) * n
         result["valu_roofline"] = {"kernel": "k_accumulate", "window_bits": c_bits, "windows": windows, "unit": "T v_mad_u64_u32 lane-ops/s", "achieved": round(imads / (t_acc * 1e-3) / 1e12, 2),
                                    "peak": 27.95, "frac": round(imads / (t_acc * 1e-3) / 1e12 / 27.95, 3),
-                                   "note": "the other 31% of the loop body's 2123 instructions (carry shifts, masks, limb adds) share the same issue slots"}
+                                   "note": "the other 31% of the loop body's 2130 instructions (carry shifts, masks, limb adds) share the same issue slots"}
         result["phases_ms"] = {k: round(v, 4) for k, v in acc.items()}
 
     if rank == 0 and world == 1 and not args.no_extras:
