@@ -900,9 +900,14 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   void* digits = carve((size_t)W * K * n_pad * (wide ? sizeof(int32_t) : sizeof(int16_t)));
   uint32_t* stage_ref = wide ? (uint32_t*)carve((size_t)W * n * sizeof(uint32_t)) : nullptr;
   uint16_t* stage_fine = wide ? (uint16_t*)carve((size_t)W * n * sizeof(uint16_t)) : nullptr;
+  // everything that starts at zero sits together: one fill instead of three (each is its own ~5 us dispatch)
+  char* const zero_lo = p;
   uint32_t* gcounters = wide ? (uint32_t*)carve(1024) : nullptr;   // [0..32) group counts, [32..65) group offsets, [96..128) group cursors
-  uint32_t* sorted = (uint32_t*)carve((size_t)W * nk * sizeof(uint32_t));
+  uint32_t* counters = (uint32_t*)carve(1024);   // [0] total entries, [1] total tasks, [2] max task partials of one bucket,
+                                                 // [64..129) task-length histogram, [160..225) its cursors
   uint32_t* count = (uint32_t*)carve((NB + 1) * sizeof(uint32_t));
+  const size_t zero_bytes = (size_t)(p - zero_lo);
+  uint32_t* sorted = (uint32_t*)carve((size_t)W * nk * sizeof(uint32_t));
   uint32_t* offset = (uint32_t*)carve((NB + 1) * sizeof(uint32_t));
   uint32_t* cursor = (uint32_t*)carve((NB + 1) * sizeof(uint32_t));
   uint32_t* task_off = (uint32_t*)carve((NB + 1) * sizeof(uint32_t));
@@ -915,10 +920,9 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   uint32_t* pyrA = (uint32_t*)carve((size_t)WB * pyr_elems * 144);
   uint32_t* pyrB = (uint32_t*)carve((size_t)WB * pyr_elems * 144);
   uint32_t* winsum = (uint32_t*)carve((size_t)(W + K) * 144);
-  uint32_t* counters = (uint32_t*)carve(1024);   // [0] total entries, [1] total tasks, [2] max task partials of one bucket,
-                                                 // [64..129) task-length histogram, [160..225) its cursors
 
   prof_begin(stream);
+  HIPCHK(hipMemsetAsync(zero_lo, 0, zero_bytes, stream));
   // 1. digits
   const size_t sstride = K > 1 ? scalar_stride : n;
   const unsigned dblocks = (unsigned)(((size_t)K * n_pad + 255) / 256);
@@ -926,8 +930,6 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   else hipLaunchKernelGGL(k_digits<int16_t>, dim3(dblocks), dim3(256), 0, stream, d_scalars, (int16_t*)digits, (uint32_t)n, n_pad, c, W, K, sstride);
   prof_mark(stream, "digits");
   // 2. count
-  HIPCHK(hipMemsetAsync(count, 0, (NB + 1) * sizeof(uint32_t), stream));
-  HIPCHK(hipMemsetAsync(counters, 0, 1024, stream));
   uint32_t chunks = (uint32_t)((n + 65535) / 65536);
   while (chunks * (uint32_t)W * K < 256 && chunks < (n + 4095) / 4096) chunks *= 2;   // fill the chip
   if (chunks == 0) chunks = 1;
@@ -946,7 +948,6 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   const uint32_t wb_stride = prepared ? 0u : B;
   const uint32_t ref_base = prepared ? (uint32_t)prepared_off : 0u, ref_stride = prepared ? (uint32_t)prepared->n : 0u;
   if (wide) {
-    HIPCHK(hipMemsetAsync(gcounters, 0, 1024, stream));
     hipLaunchKernelGGL(k_coarse_pass<false>, dim3(chunks, W), dim3(1024), 0, stream, (const int32_t*)digits, n_pad, chunk, gcounters, (uint32_t*)nullptr,
                        (uint16_t*)nullptr, ref_base, ref_stride);
     hipLaunchKernelGGL(k_group_offsets, dim3(1), dim3(64), 0, stream, gcounters, G, gcounters + 32, gcounters + 96);
