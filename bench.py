@@ -310,7 +310,8 @@ def extras(lib, _lib, F, torch, dev, stream) -> dict:
         flow = min(flows, key=lambda f: f["prove_ms"])
         out["prover_flow_k22"] = {"prove_ms": round(flow["prove_ms"], 2), "columns": flow["columns"], "msms": flow["msms"], "checks": flow["checks"],
                                   "timings_ms": {kk: round(v, 2) for kk, v in flow["timings_ms"].items()},
-                                  "note": "no transcript (seeded challenges); every column, fixed ones included, is transformed"}
+                                  "proof_columns": flow["proof_columns"],
+                                  "note": "no transcript (seeded challenges); the proving key's columns (fixed, l_0/l_last/l_active, sigma) are transformed under keygen_* and not counted, as pk.fixed_cosets / pk.permutation.cosets are in the reference"}
     except Exception as exc:   # an extra: never fail the bench line
         out["prover_flow_k22"] = {"error": repr(exc)}
     tot = ms + out["prover_phases_k22"]["total_ms"]
