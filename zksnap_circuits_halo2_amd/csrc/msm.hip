@@ -33,6 +33,7 @@ namespace zkhip {
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+constexpr int MAX_TASK_LEN = 128;       // tasks are 2^task_shift entries, task_shift <= 7 (length histograms hold MAX_TASK_LEN + 1 counters)
 constexpr int TASK_SHIFT = 6;           // 64 entries per accumulate task: short tasks keep the tail of the launch balanced
                                         // (measured at 2^22: 5.9 ms with 64-entry tasks, 6.9 ms with 256, 8.1 ms with 512)
 constexpr int COMBINE_LEVELS = 10;      // radix-4 tree levels above the final step: covers 16 * 4^10 partials per bucket
@@ -414,8 +415,8 @@ __global__ void __launch_bounds__(1024) k_scan_single(const uint32_t* __restrict
                                                       uint32_t* __restrict__ out, uint32_t* __restrict__ out2, uint32_t task_shift,
                                                       uint32_t* __restrict__ len_cursor) {
   __shared__ uint32_t wsum[16];
-  __shared__ uint32_t lh[65];
-  if (MODE == 1 && threadIdx.x < 65) lh[threadIdx.x] = 0;
+  __shared__ uint32_t lh[MAX_TASK_LEN + 1];
+  if (MODE == 1 && threadIdx.x <= MAX_TASK_LEN) lh[threadIdx.x] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t full = 1u << task_shift;
@@ -463,7 +464,7 @@ __global__ void __launch_bounds__(1024) k_scan_single(const uint32_t* __restrict
     __syncthreads();
     if (threadIdx.x == 0) {
       uint32_t run = 0;
-      for (int L = 64; L >= 1; L--) { len_cursor[L] = run; run += lh[L]; }
+      for (int L = MAX_TASK_LEN; L >= 1; L--) { len_cursor[L] = run; run += lh[L]; }
     }
   }
 }
@@ -477,8 +478,8 @@ __global__ void __launch_bounds__(1024) k_scan_single(const uint32_t* __restrict
 __global__ void __launch_bounds__(256) k_make_tasks(const uint32_t* __restrict__ offset, const uint32_t* __restrict__ task_off,
                                                     uint32_t nbuckets, task_t* __restrict__ tasks, uint32_t task_shift,
                                                     uint32_t* __restrict__ max_parts, uint32_t* __restrict__ len_count) {
-  __shared__ uint32_t lh[65];
-  if (threadIdx.x < 65) lh[threadIdx.x] = 0;
+  __shared__ uint32_t lh[MAX_TASK_LEN + 1];
+  if (threadIdx.x <= MAX_TASK_LEN) lh[threadIdx.x] = 0;
   __syncthreads();
   // a capped grid walks the buckets: the length histogram costs one global atomic per (workgroup, length) on the same 65 words,
   // and with one workgroup per 256 buckets those were 2048 x 65 contended atomics at 2^19 buckets (99 us of a 6 ms MSM)
@@ -499,7 +500,7 @@ __global__ void __launch_bounds__(256) k_make_tasks(const uint32_t* __restrict__
     nt = max(nt, m);
   }
   __syncthreads();
-  if (len_count && threadIdx.x < 65 && lh[threadIdx.x]) atomicAdd(&len_count[threadIdx.x], lh[threadIdx.x]);   // nullptr: k_scan_single<1> made the histogram
+  if (len_count && threadIdx.x <= MAX_TASK_LEN && lh[threadIdx.x]) atomicAdd(&len_count[threadIdx.x], lh[threadIdx.x]);   // nullptr: k_scan_single<1> made the histogram
   // block max -> one atomic per wave
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) nt = max(nt, (uint32_t)__shfl_xor((int)nt, off, 64));
@@ -511,7 +512,7 @@ __global__ void __launch_bounds__(256) k_make_tasks(const uint32_t* __restrict__
 __global__ void k_order_offsets(const uint32_t* __restrict__ len_count, uint32_t* __restrict__ len_cursor) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   uint32_t run = 0;
-  for (int L = 64; L >= 1; L--) { len_cursor[L] = run; run += len_count[L]; }
+  for (int L = MAX_TASK_LEN; L >= 1; L--) { len_cursor[L] = run; run += len_count[L]; }
 }
 
 // Within the class of full-length tasks the order is j-major per workgroup (j = the task's index inside its
@@ -523,9 +524,10 @@ constexpr int ORDER_JMAX = 64;
 __global__ void __launch_bounds__(256) k_make_order(const uint32_t* __restrict__ offset, const uint32_t* __restrict__ task_off,
                                                     uint32_t nbuckets, uint32_t task_shift, uint32_t* __restrict__ len_cursor,
                                                     const uint32_t* __restrict__ sorted, uint4* __restrict__ order) {
-  __shared__ uint32_t lh[65];
+  __shared__ uint32_t lh[MAX_TASK_LEN + 1];
   __shared__ uint32_t jcnt[ORDER_JMAX + 1], joff[ORDER_JMAX + 1];
-  if (threadIdx.x < 65) { lh[threadIdx.x] = 0; jcnt[threadIdx.x] = 0; }
+  if (threadIdx.x <= MAX_TASK_LEN) lh[threadIdx.x] = 0;
+  if (threadIdx.x <= ORDER_JMAX) jcnt[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t full = 1u << task_shift, step = gridDim.x * blockDim.x;     // capped grid, as k_make_tasks
   for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nbuckets; k += step) {
@@ -545,7 +547,7 @@ __global__ void __launch_bounds__(256) k_make_order(const uint32_t* __restrict__
     const uint32_t base = run ? atomicAdd(&len_cursor[full], run) : 0u;
     for (int j = 0; j <= ORDER_JMAX; j++) joff[j] += base;
   }
-  if (threadIdx.x < 65 && threadIdx.x != full) { const uint32_t v = lh[threadIdx.x]; lh[threadIdx.x] = v ? atomicAdd(&len_cursor[threadIdx.x], v) : 0u; }
+  if (threadIdx.x <= MAX_TASK_LEN && threadIdx.x != full) { const uint32_t v = lh[threadIdx.x]; lh[threadIdx.x] = v ? atomicAdd(&len_cursor[threadIdx.x], v) : 0u; }
   __syncthreads();
   if (threadIdx.x == 0 && lh[full]) lh[full] = atomicAdd(&len_cursor[full], lh[full]);     // remainder tasks of full length, after the depth classes
   __syncthreads();
@@ -948,6 +950,13 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   // that the MSM is latency-bound: a task of L entries is L sequential mixed adds (~5 us each at low occupancy) and a bucket
   // of s entries leaves s/L partials to sum (~10 us each): pick L = 2^shift minimising 5 L + 10 (s/L - 1).
   uint32_t task_shift = TASK_SHIFT;
+  {
+    // 128-entry tasks halve the partials the combine step has to add, and pay once the launch is many rounds of waves deep even
+    // so: measured (6 / 7) 2^24 21.40 / 21.00 ms (combine 0.71 -> 0.27), but 2^22 6.00 / 6.07 and 2^20 1.72 / 1.85 (too few tasks).
+    static const int knob = [] { const char* e = getenv("ZKHIP_TASK_SHIFT"); return e ? atoi(e) : 0; }();
+    if (knob >= 2 && knob <= 7) task_shift = (uint32_t)knob;
+    else if ((((size_t)W * nk) >> 7) >= ((size_t)1 << 20)) task_shift = 7;
+  }
   if ((((size_t)W * nk) >> TASK_SHIFT) < ((size_t)1 << 17)) {
     const double occ = (double)W * (double)nk / (double)NB;
     double best = 1e300;
@@ -967,8 +976,8 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   // everything that starts at zero sits together: one fill instead of three (each is its own ~5 us dispatch)
   char* const zero_lo = p;
   uint32_t* gcounters = wide ? (uint32_t*)carve(1024) : nullptr;   // [0..32) group counts, [32..65) group offsets, [96..128) group cursors
-  uint32_t* counters = (uint32_t*)carve(1024);   // [0] total entries, [1] total tasks, [2] max task partials of one bucket,
-                                                 // [64..129) task-length histogram, [160..225) its cursors
+  uint32_t* counters = (uint32_t*)carve(2048);   // [0] total entries, [1] total tasks, [2] max task partials of one bucket,
+                                                 // [32..161) task-length histogram (MAX_TASK_LEN + 1), [192..321) its cursors
   uint32_t* count = (uint32_t*)carve((NB + 1) * sizeof(uint32_t));
   const size_t zero_bytes = (size_t)(p - zero_lo);
   uint32_t* sorted = (uint32_t*)carve((size_t)W * nk * sizeof(uint32_t));
@@ -1041,16 +1050,16 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   // 5. tasks
   const unsigned task_blocks = (unsigned)std::min<size_t>((NB + 255) / 256, 256);
   if (scan_single) {
-    hipLaunchKernelGGL(k_scan_single<1>, dim3(1), dim3(1024), 0, stream, count, (uint32_t)NB, counters + 1, task_off, (uint32_t*)nullptr, task_shift, counters + 160);
+    hipLaunchKernelGGL(k_scan_single<1>, dim3(1), dim3(1024), 0, stream, count, (uint32_t)NB, counters + 1, task_off, (uint32_t*)nullptr, task_shift, counters + 192);
     hipLaunchKernelGGL(k_make_tasks, dim3(task_blocks), dim3(256), 0, stream, offset, task_off, NB, tasks, task_shift, counters + 2, (uint32_t*)nullptr);
   } else {
     hipLaunchKernelGGL(k_scan_sums<1>, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, count, NB, bsum2, task_shift);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_BLOCK), 0, stream, bsum2, nblk, counters + 1);
     hipLaunchKernelGGL(k_scan_apply<1>, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, count, NB, bsum2, counters + 1, task_off, (uint32_t*)nullptr, task_shift);
-    hipLaunchKernelGGL(k_make_tasks, dim3(task_blocks), dim3(256), 0, stream, offset, task_off, NB, tasks, task_shift, counters + 2, counters + 64);
-    hipLaunchKernelGGL(k_order_offsets, dim3(1), dim3(64), 0, stream, counters + 64, counters + 160);
+    hipLaunchKernelGGL(k_make_tasks, dim3(task_blocks), dim3(256), 0, stream, offset, task_off, NB, tasks, task_shift, counters + 2, counters + 32);
+    hipLaunchKernelGGL(k_order_offsets, dim3(1), dim3(64), 0, stream, counters + 32, counters + 192);
   }
-  hipLaunchKernelGGL(k_make_order, dim3(task_blocks), dim3(256), 0, stream, offset, task_off, NB, task_shift, counters + 160, sorted, order);
+  hipLaunchKernelGGL(k_make_order, dim3(task_blocks), dim3(256), 0, stream, offset, task_off, NB, task_shift, counters + 192, sorted, order);
   prof_mark(stream, "tasks");
   // 6. accumulate (grid-stride over the device-side task count)
   {
