@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B helper: median / min time of the prepared MSM (2^L) over many runs, and the median of every phase (in-library HIP events).
-  ab_time_msm.py [log_n=20] [reps=100] [label]      knobs: ZKHIP_MAX_WINDOW
+  ab_time_msm.py [log_n=20] [reps=100] [label]      knobs: ZKHIP_MAX_WINDOW (cap the prepared window), ZKHIP_TASK_SHIFT (task length 2^s)
 Run the variants alternately in one gpurun call: box-to-box differences (+-4 %) exceed most single-kernel effects."""
 import os, sys, ctypes as C, statistics as st
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
