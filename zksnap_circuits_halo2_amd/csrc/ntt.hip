@@ -70,6 +70,25 @@ __device__ __forceinline__ void store_fe9(uint32_t* p, uint32_t idx, const fe& a
   for (int i = 0; i < 9; i++) q[i] = a.l[i];
 }
 
+// LDS tile: element E lives at word 9 E + 8 (E >> 6) + (E >> 8).  With the plain 9-word stride the first round's accesses
+// (element 64 m + 8 e + jj over the lanes' (m, jj)) and the bit-reversed initial stores hit 8 banks out of 64; the two pad terms
+// make those patterns (nearly) conflict-free and leave the contiguous ones as they were.
+__device__ __forceinline__ uint32_t lds_word(uint32_t e) { return 9u * e + 8u * (e >> 6) + (e >> 8); }
+constexpr uint32_t NTT_LDS_WORDS = 9u * 2048u + 8u * 32u + 8u + 16u;   // NTT_TILE = 2048
+static inline uint32_t lds_word_host(uint32_t e) { return 9u * e + 8u * (e >> 6) + (e >> 8); }
+__device__ __forceinline__ fe load_lds9(const uint32_t* p, uint32_t idx) {
+  fe r;
+  const uint32_t* q = p + lds_word(idx);
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = q[i];
+  return r;
+}
+__device__ __forceinline__ void store_lds9(uint32_t* p, uint32_t idx, const fe& a) {
+  uint32_t* q = p + lds_word(idx);
+#pragma unroll
+  for (int i = 0; i < 9; i++) q[i] = a.l[i];
+}
+
 // external constant c*2^256 -> internal c*2^261 (reduced)
 __device__ __forceinline__ fe fr_ext_to_internal(const uint32_t (&w)[8]) {
   fe k;
@@ -130,7 +149,7 @@ __global__ void __launch_bounds__(256, 2) k_ntt_pass(pass_args a) {
       x = fe_mul<Fr>(tw, x);
     }
     const uint32_t i = __brev(r) >> (32 - B);
-    store_fe9(lds, i * J + jj, x);
+    store_lds9(lds, i * J + jj, x);
   }
   __syncthreads();
 
@@ -147,7 +166,7 @@ __global__ void __launch_bounds__(256, 2) k_ntt_pass(pass_args a) {
         const uint32_t rest = (m << (3 - v)) | ((uint32_t)e >> v);
         const uint32_t lo = rest & ((1u << s) - 1), hi = rest >> s;
         pos[e] = (hi << (s + v)) | (((uint32_t)e & ((1u << v) - 1)) << s) | lo;
-        x[e] = load_fe9(lds, pos[e] * J + jj);
+        x[e] = load_lds9(lds, pos[e] * J + jj);
       }
       if (s == 0) {
         // First round (v == 3, lo == 0): twiddles depend only on the register index and 7 of the 12 are w^0 = 1, so
@@ -201,7 +220,7 @@ __global__ void __launch_bounds__(256, 2) k_ntt_pass(pass_args a) {
         }
       }
 #pragma unroll
-      for (int e = 0; e < 8; e++) store_fe9(lds, pos[e] * J + jj, fe_norm(x[e]));
+      for (int e = 0; e < 8; e++) store_lds9(lds, pos[e] * J + jj, fe_norm(x[e]));
       __syncthreads();
       s += v;
     }
@@ -215,7 +234,7 @@ __global__ void __launch_bounds__(256, 2) k_ntt_pass(pass_args a) {
     const uint32_t jj = aa * q + b;
     const uint32_t j = j0 + jj;
     const uint32_t d = ((j >> a.S) << (a.S + B)) + (j & (Ns - 1)) + (rp << a.S);
-    fe x = load_fe9(lds, rp * J + jj);
+    fe x = load_lds9(lds, rp * J + jj);
     uint32_t w[8];
     if (a.last) {
       if (d >= a.out_len) continue;
@@ -443,7 +462,7 @@ int ntt_transform(const uint32_t* d_in, uint32_t in_len, uint32_t in_stride, uin
   }
   static std::once_flag attr_once;
   std::call_once(attr_once, [] {
-    (void)hipFuncSetAttribute((const void*)k_ntt_pass, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_TILE * 36);
+    (void)hipFuncSetAttribute((const void*)k_ntt_pass, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_LDS_WORDS * 4);
   });
   const uint32_t tile = N < NTT_TILE ? N : NTT_TILE;
   if ((p->npass >= 2 && !tmp0) || (p->npass >= 3 && !tmp1)) { set_error("ntt: missing scratch buffer"); return ZKHIP_EINVAL; }
@@ -462,7 +481,7 @@ int ntt_transform(const uint32_t* d_in, uint32_t in_len, uint32_t in_stride, uin
     a.dst = a.last ? d_out : tmp[i & 1];
     a.src_stride = i == 0 ? in_stride : N;
     a.dst_stride = a.last ? out_stride : N;
-    hipLaunchKernelGGL(k_ntt_pass, dim3(N / tile, batch), dim3(tile / 8), (size_t)tile * 36, stream, a);
+    hipLaunchKernelGGL(k_ntt_pass, dim3(N / tile, batch), dim3(tile / 8), (size_t)(lds_word_host(tile) + 16) * 4, stream, a);
     prof_mark(stream, i == 0 ? "ntt_pass0" : (i == 1 ? "ntt_pass1" : (i == 2 ? "ntt_pass2" : "ntt_pass3")));
   }
   HIPCHK(hipGetLastError());
