@@ -113,3 +113,21 @@ def test_header_is_plain_c99_and_links(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
                            "-L", lib_dir, "-lzkhip", "-Wl,-rpath," + lib_dir])
     assert subprocess.call([str(exe)]) == 0
+
+
+def test_generated_mac_blocks_header_is_current(tmp_path):
+    """zksnap_circuits_halo2_amd/csrc/mac_blocks.hpp is generated by tools/gen_mac_blocks.py: the committed file must be what the
+    generator writes (the asm blocks are the shape of the bucket-accumulation kernel's field products)"""
+    import importlib.util
+    import shutil
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    committed = open(os.path.join(root, "zksnap_circuits_halo2_amd", "csrc", "mac_blocks.hpp")).read()
+    # run the generator on a copy of the tree layout it expects
+    tools = tmp_path / "tools"; csrc = tmp_path / "zksnap_circuits_halo2_amd" / "csrc"
+    tools.mkdir(); csrc.mkdir(parents=True)
+    shutil.copy(os.path.join(root, "tools", "gen_mac_blocks.py"), tools / "gen_mac_blocks.py")
+    spec = importlib.util.spec_from_file_location("gen_mac_blocks", tools / "gen_mac_blocks.py")
+    spec.loader.exec_module(importlib.util.module_from_spec(spec))
+    assert (csrc / "mac_blocks.hpp").read_text() == committed
+    assert committed.count("v_mad_u64_u32") >= 2 * sum(range(1, 10))
