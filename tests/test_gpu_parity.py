@@ -649,7 +649,7 @@ def test_cpp_host_mirror(cref, tmp_path):
     assert pos == raw.size
 
 
-def _gather_fold_worker(rank, world, port, n, q):
+def _gather_fold_worker(rank, world, port, n, q, rank_width=12):
     """one of `world` processes sharing the single GPU of the test box; gloo stands in for RCCL"""
     import ctypes as C
 
@@ -667,9 +667,10 @@ def _gather_fold_worker(rank, world, port, n, q):
     lo, hi = shard_range(n, rank, world)
     d_b = torch.from_numpy(np.ascontiguousarray(bases[lo:hi]).view(np.int64)).cuda()
     d_s = torch.from_numpy(np.ascontiguousarray(sc[lo:hi]).view(np.int64)).cuda()
-    d_out = torch.zeros(16, dtype=torch.int64, device="cuda")
-    d_gather = torch.zeros(16 * world, dtype=torch.int64, device="cuda")
-    d_final = torch.zeros(16, dtype=torch.int64, device="cuda")
+    width = 12 if rank_width == 12 else 16          # bench.py exchanges the bare 96-byte points; 128-byte slots are accepted too
+    d_out = torch.zeros(width, dtype=torch.int64, device="cuda")
+    d_gather = torch.zeros(width * world, dtype=torch.int64, device="cuda")
+    d_final = torch.zeros(width, dtype=torch.int64, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     h = C.c_uint64(0)
     L.check(lib.zkhip_prepare_bases_device(d_b.data_ptr(), hi - lo, C.byref(h)))
@@ -685,8 +686,9 @@ def _gather_fold_worker(rank, world, port, n, q):
     dist.destroy_process_group()
 
 
-def test_bench_exchange_path_two_ranks_on_one_gpu():
-    """the N > 1 step of bench.py (prepared MSM on the rank's shard -> gather 128-byte slots -> fold) with two processes on this
+@pytest.mark.parametrize("width", [12, 16])
+def test_bench_exchange_path_two_ranks_on_one_gpu(width):
+    """the N > 1 step of bench.py (prepared MSM on the rank's shard -> gather the 96-byte partials -> fold) with two processes on this
     box's single GPU and gloo in place of RCCL"""
     import socket
 
@@ -699,7 +701,7 @@ def test_bench_exchange_path_two_ranks_on_one_gpu():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     world, n = 2, 5001
-    procs = [ctx.Process(target=_gather_fold_worker, args=(r, world, port, n, q)) for r in range(world)]
+    procs = [ctx.Process(target=_gather_fold_worker, args=(r, world, port, n, q, width)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in range(world)]
