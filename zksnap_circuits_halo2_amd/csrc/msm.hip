@@ -203,14 +203,14 @@ __global__ void __launch_bounds__(1024) k_sort_pass(const int16_t* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 // 2'/4'. wide windows (16 < c <= 21, prepared path only).  Fewer windows = fewer additions (c = 20: 13 instead of 16),
 //     but 2^(c-1) buckets no longer fit an LDS histogram.  Two levels:
-//       coarse  bucket >> 15 selects one of G = 2^(c-16) groups; a (window, chunk) workgroup counts / places its entries
-//               per group (G LDS counters, one ranged global atomic per group) into a staging array (ref u32 + fine u16);
-//       fine    per group, the 2^15 "fine" buckets are handled exactly like the one-level path: LDS histogram, contiguous
-//               atomics into the global counts, scan, reservation, placement.
+//       coarse  bucket >> 12 selects one of G = 2^(c-13) groups (128 at c = 20); a (window, chunk) workgroup counts / places its
+//               entries per group (G LDS counters, one ranged global atomic per group) into a staging array (ref u32 + fine u16);
+//       fine    per group, the 2^12 "fine" buckets: LDS histogram, atomics into the global counts (k_fine_count), scan, then
+//               k_fine_sorted: reservation and a counting sort of the chunk inside LDS, so that bucket runs leave as runs.
 // ------------------------------------------------------------------------------------------------
-constexpr int FINE_BITS = 15;
+constexpr int FINE_BITS = 12;
 constexpr uint32_t FINE_CHUNK = 65536;
-constexpr int MAX_GROUPS = 32;
+constexpr int MAX_GROUPS = 128;
 
 // (Recomputing the digits from the scalars in both passes instead of storing them as int32 was tried and measured slower:
 // 0.139 vs 0.117 ms at 2^20, 1.75 vs 1.3 ms at 2^24.)
@@ -261,12 +261,105 @@ __global__ void __launch_bounds__(1024) k_coarse_pass(const int32_t* __restrict_
   }
 }
 
-// goff[g] = start of group g in the staging array (exclusive scan of the group counts), gcursor = copy
-__global__ void k_group_offsets(const uint32_t* __restrict__ gcount, int G, uint32_t* __restrict__ goff, uint32_t* __restrict__ gcursor) {
+constexpr uint32_t SORT_CHUNK = 28672;   // entries per workgroup of the sorted fine scatter: 112 KiB of references in LDS
+
+// goff[g] = start of group g in the staging array (exclusive scan of the group counts), gcursor = copy; cstart[g] = index of the
+// group's first SORT_CHUNK-sized chunk in the numbering of k_fine_sorted's workgroups
+__global__ void k_group_offsets(const uint32_t* __restrict__ gcount, int G, uint32_t* __restrict__ goff, uint32_t* __restrict__ gcursor,
+                                uint32_t* __restrict__ cstart) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  uint32_t run = 0;
-  for (int g = 0; g < G; g++) { goff[g] = run; gcursor[g] = run; run += gcount[g]; }
+  uint32_t run = 0, crun = 0;
+  for (int g = 0; g < G; g++) {
+    goff[g] = run; gcursor[g] = run; cstart[g] = crun;
+    run += gcount[g];
+    crun += (gcount[g] + SORT_CHUNK - 1) / SORT_CHUNK;
+  }
   goff[G] = run;
+  cstart[G] = crun;
+}
+
+// Fine scatter with the chunk sorted in LDS first.  The plain placement (k_fine_pass<true>) stores every reference with its own
+// 4-byte write, and PMC shows what that costs: 8.7 bytes reach memory per byte of payload (32-byte sectors).  Here a workgroup
+// owns SORT_CHUNK staged entries of one group of 2^FINE_BITS buckets, counting-sorts their references by bucket inside LDS, and
+// writes bucket runs: neighbouring lanes store neighbouring words (~7 entries per bucket and chunk).
+//   LDS: cur[FB] (histogram -> run starts -> run ends) | delta[FB] (global slot of a run minus its LDS position) | refs[SORT_CHUNK]
+__global__ void __launch_bounds__(1024) k_fine_sorted(const uint16_t* __restrict__ stage_fine, const uint32_t* __restrict__ stage_ref,
+                                                      const uint32_t* __restrict__ goff, const uint32_t* __restrict__ cstart, int G,
+                                                      uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
+  extern __shared__ uint32_t hist[];
+  constexpr uint32_t FB = 1u << FINE_BITS;
+  static_assert(FB == 4096, "one thread owns four buckets in the scan");
+  __shared__ uint32_t wsum[16];
+  uint32_t* cur = hist;
+  uint32_t* delta = hist + FB;
+  uint32_t* refs = hist + 2 * FB;
+  const uint32_t w = blockIdx.x;
+  if (w >= cstart[G]) return;
+  uint32_t glo = 0, ghi = (uint32_t)G;                      // group of chunk w: last g with cstart[g] <= w
+  while (ghi - glo > 1) { const uint32_t mid = (glo + ghi) >> 1; if (cstart[mid] <= w) glo = mid; else ghi = mid; }
+  const uint32_t g = glo;
+  const uint32_t start = goff[g] + (w - cstart[g]) * SORT_CHUNK, end = min(goff[g + 1], start + SORT_CHUNK), cnt_n = end - start;
+  for (uint32_t b = threadIdx.x; b < FB; b += blockDim.x) cur[b] = 0;
+  __syncthreads();
+  for (uint32_t p = start + threadIdx.x; p < end; p += blockDim.x) atomicAdd(&cur[stage_fine[p]], 1u);
+  __syncthreads();
+  // exclusive scan over the 4096 counts: thread t owns buckets 4t .. 4t + 3
+  uint32_t c[4], l[4], s = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { c[k] = cur[4 * threadIdx.x + k]; s += c[k]; }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t x = s;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t y = __shfl_up(x, off, 64);
+    if (lane >= off) x += y;
+  }
+  if (lane == 63) wsum[wave] = x;
+  __syncthreads();
+  uint32_t before = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++) if (i < wave) before += wsum[i];
+  uint32_t run = before + x - s;
+  uint32_t* gl = cursor + (size_t)g * FB;
+  uint32_t gb[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) { l[k] = run; run += c[k]; }
+#pragma unroll
+  for (int k = 0; k < 4; k++) gb[k] = c[k] ? atomicAdd(&gl[4 * threadIdx.x + k], c[k]) : 0u;      // reserve the runs' slots
+#pragma unroll
+  for (int k = 0; k < 4; k++) { cur[4 * threadIdx.x + k] = l[k]; delta[4 * threadIdx.x + k] = gb[k] - l[k]; }
+  __syncthreads();
+  for (uint32_t p = start + threadIdx.x; p < end; p += blockDim.x) refs[atomicAdd(&cur[stage_fine[p]], 1u)] = stage_ref[p];
+  __syncthreads();
+  // cur[b] is now the end of bucket b's run; entry i belongs to the first bucket whose run ends after i
+  for (uint32_t i = threadIdx.x; i < cnt_n; i += blockDim.x) {
+    uint32_t lo = 0, hi = FB - 1;                             // invariant: answer in [lo, hi]; 12 LDS reads (a proportional first guess
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (cur[mid] > i) hi = mid; else lo = mid + 1; }   // with linear probing measured slower)
+    sorted[delta[lo] + i] = refs[i];
+  }
+}
+
+// count pass of the same tiling (one workgroup per SORT_CHUNK entries of a group): LDS histogram, non-empty counts merged into the
+// global per-bucket counts
+__global__ void __launch_bounds__(1024) k_fine_count(const uint16_t* __restrict__ stage_fine, const uint32_t* __restrict__ goff,
+                                                     const uint32_t* __restrict__ cstart, int G, uint32_t* __restrict__ count) {
+  constexpr uint32_t FB = 1u << FINE_BITS;
+  __shared__ uint32_t cur[FB];
+  const uint32_t w = blockIdx.x;
+  if (w >= cstart[G]) return;
+  uint32_t glo = 0, ghi = (uint32_t)G;
+  while (ghi - glo > 1) { const uint32_t mid = (glo + ghi) >> 1; if (cstart[mid] <= w) glo = mid; else ghi = mid; }
+  const uint32_t g = glo;
+  const uint32_t start = goff[g] + (w - cstart[g]) * SORT_CHUNK, end = min(goff[g + 1], start + SORT_CHUNK);
+  for (uint32_t b = threadIdx.x; b < FB; b += blockDim.x) cur[b] = 0;
+  __syncthreads();
+  for (uint32_t p = start + threadIdx.x; p < end; p += blockDim.x) atomicAdd(&cur[stage_fine[p]], 1u);
+  __syncthreads();
+  uint32_t* gl = count + (size_t)g * FB;
+  for (uint32_t b = threadIdx.x; b < FB; b += blockDim.x) {
+    const uint32_t v = cur[b];
+    if (v) atomicAdd(&gl[b], v);
+  }
 }
 
 template <bool SCATTER>
@@ -874,7 +967,7 @@ int msm_pick_window(size_t n) {
 }
 
 
-constexpr int MAX_WINDOW_PREPARED = 20;   // 2^19 buckets = 16 groups of 2^15
+constexpr int MAX_WINDOW_PREPARED = 20;   // 2^19 buckets = 128 groups of 2^12
 
 int msm_pick_window_prepared(size_t n) {
   // one shared bucket set: W * 10 n multiplications of accumulation + 2 * 14 * 2^(c-1) of bucket reduction.  Windows above
@@ -899,7 +992,7 @@ size_t msm_workspace_bytes(size_t n_one, int c, bool prepared, size_t batch) {
   const size_t max_tasks = ((W * n) >> TASK_SHIFT) >= ((size_t)1 << 17) ? ((W * n) >> TASK_SHIFT) + NB + 1 : W * n / 4 + NB + 1;
   size_t total = 0;
   total += align_up(W * (n + 8) * (c > 16 ? sizeof(int32_t) : sizeof(int16_t)), 256);    // digits (rows padded to a multiple of 8)
-  if (c > 16) total += align_up(W * n * sizeof(uint32_t), 256) + align_up(W * n * sizeof(uint16_t), 256) + 1024;   // staging (ref, fine) + group counters
+  if (c > 16) total += align_up(W * n * sizeof(uint32_t), 256) + align_up(W * n * sizeof(uint16_t), 256) + 4096;   // staging (ref, fine) + group counters
   total += align_up(W * n * sizeof(uint32_t), 256);         // sorted
   total += 4 * align_up((NB + 1) * sizeof(uint32_t), 256);  // count, offset, cursor, task_off
   total += 2 * align_up((NB / SCAN_TILE + 2) * sizeof(uint32_t), 256);  // scan block sums x2
@@ -975,7 +1068,7 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   uint16_t* stage_fine = wide ? (uint16_t*)carve((size_t)W * n * sizeof(uint16_t)) : nullptr;
   // everything that starts at zero sits together: one fill instead of three (each is its own ~5 us dispatch)
   char* const zero_lo = p;
-  uint32_t* gcounters = wide ? (uint32_t*)carve(1024) : nullptr;   // [0..32) group counts, [32..65) group offsets, [96..128) group cursors
+  uint32_t* gcounters = wide ? (uint32_t*)carve(4096) : nullptr;   // [0..128) group counts, [128..257) group offsets, [384..512) group cursors, [512..641) chunk starts
   uint32_t* counters = (uint32_t*)carve(2048);   // [0] total entries, [1] total tasks, [2] max task partials of one bucket,
                                                  // [32..161) task-length histogram (MAX_TASK_LEN + 1), [192..321) its cursors
   uint32_t* count = (uint32_t*)carve((NB + 1) * sizeof(uint32_t));
@@ -1014,20 +1107,21 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
     HIPCHK(hipFuncSetAttribute((const void*)k_sort_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)k_fine_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)k_fine_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)k_fine_sorted, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * (1 << FINE_BITS) + SORT_CHUNK) * 4));
     attr_set = true;
   }
   const int G = wide ? (int)(B >> FINE_BITS) : 1;                      // coarse groups
-  const uint32_t fine_chunks = (uint32_t)(((size_t)W * n + FINE_CHUNK - 1) / FINE_CHUNK);   // worst case: one group holds everything
+  const uint32_t sort_chunks = (uint32_t)(((size_t)W * n + SORT_CHUNK - 1) / SORT_CHUNK) + (uint32_t)G;     // upper bound of the fine passes' chunks; surplus workgroups return at once
   const uint32_t wb_stride = prepared ? 0u : B;
   const uint32_t ref_base = prepared ? (uint32_t)prepared_off : 0u, ref_stride = prepared ? (uint32_t)prepared->n : 0u;
   if (wide) {
     hipLaunchKernelGGL(k_coarse_pass<false>, dim3(chunks, W), dim3(1024), 0, stream, (const int32_t*)digits, n_pad, chunk, gcounters, (uint32_t*)nullptr,
                        (uint16_t*)nullptr, ref_base, ref_stride);
-    hipLaunchKernelGGL(k_group_offsets, dim3(1), dim3(64), 0, stream, gcounters, G, gcounters + 32, gcounters + 96);
-    hipLaunchKernelGGL(k_coarse_pass<true>, dim3(chunks, W), dim3(1024), 0, stream, (const int32_t*)digits, n_pad, chunk, gcounters + 96, stage_ref,
+    hipLaunchKernelGGL(k_group_offsets, dim3(1), dim3(64), 0, stream, gcounters, G, gcounters + 128, gcounters + 384, gcounters + 512);
+    hipLaunchKernelGGL(k_coarse_pass<true>, dim3(chunks, W), dim3(1024), 0, stream, (const int32_t*)digits, n_pad, chunk, gcounters + 384, stage_ref,
                        stage_fine, ref_base, ref_stride);
     prof_mark(stream, "coarse");
-    hipLaunchKernelGGL(k_fine_pass<false>, dim3(fine_chunks, G), dim3(1024), lds, stream, stage_fine, stage_ref, gcounters + 32, count, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_fine_count, dim3(sort_chunks), dim3(1024), 0, stream, stage_fine, gcounters + 128, gcounters + 512, G, count);
   } else {
     hipLaunchKernelGGL(k_sort_pass<false>, dim3(chunks, W, K), dim3(1024), lds, stream, (const int16_t*)digits, n_pad, chunk, c, count, (uint32_t*)nullptr, wb_stride, ref_base, ref_stride);
   }
@@ -1044,7 +1138,10 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   }
   prof_mark(stream, "scan");
   // 4. scatter
-  if (wide) hipLaunchKernelGGL(k_fine_pass<true>, dim3(fine_chunks, G), dim3(1024), lds, stream, stage_fine, stage_ref, gcounters + 32, cursor, sorted);
+  if (wide) {
+    hipLaunchKernelGGL(k_fine_sorted, dim3(sort_chunks), dim3(1024), (size_t)(2u * (1u << FINE_BITS) + SORT_CHUNK) * 4, stream, stage_fine, stage_ref,
+                       gcounters + 128, gcounters + 512, G, cursor, sorted);
+  }
   else hipLaunchKernelGGL(k_sort_pass<true>, dim3(chunks, W, K), dim3(1024), lds, stream, (const int16_t*)digits, n_pad, chunk, c, cursor, sorted, wb_stride, ref_base, ref_stride);
   prof_mark(stream, "scatter");
   // 5. tasks
