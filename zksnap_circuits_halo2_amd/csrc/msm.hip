@@ -209,7 +209,6 @@ __global__ void __launch_bounds__(1024) k_sort_pass(const int16_t* __restrict__ 
 //               k_fine_sorted: reservation and a counting sort of the chunk inside LDS, so that bucket runs leave as runs.
 // ------------------------------------------------------------------------------------------------
 constexpr int FINE_BITS = 12;
-constexpr uint32_t FINE_CHUNK = 65536;
 constexpr int MAX_GROUPS = 128;
 
 // (Recomputing the digits from the scalars in both passes instead of storing them as int32 was tried and measured slower:
@@ -261,6 +260,73 @@ __global__ void __launch_bounds__(1024) k_coarse_pass(const int32_t* __restrict_
   }
 }
 
+// Coarse placement with the chunk sorted by group in LDS first (same reasoning as k_fine_sorted below): a workgroup takes
+// COARSE_CHUNK digits of one window, counting-sorts (reference, fine bucket) by group inside LDS and writes each group's run --
+// COARSE_CHUNK / G = 64 entries on average -- as neighbouring words.  LDS: cur[G] | delta[G] | refs[CH] | fines[CH].
+constexpr uint32_t COARSE_CHUNK = 8192;
+__global__ void __launch_bounds__(1024) k_coarse_sorted(const int32_t* __restrict__ digits, uint32_t n_pad, uint32_t* __restrict__ gcursor,
+                                                        uint32_t* __restrict__ stage_ref, uint16_t* __restrict__ stage_fine,
+                                                        uint32_t ref_base, uint32_t ref_stride) {
+  __shared__ uint32_t cur[MAX_GROUPS], delta[MAX_GROUPS];
+  __shared__ uint32_t refs[COARSE_CHUNK];
+  __shared__ uint16_t fines[COARSE_CHUNK];
+  const int win = blockIdx.y;
+  const uint32_t lo = blockIdx.x * COARSE_CHUNK, hi = min(n_pad, lo + COARSE_CHUNK);   // multiples of 8
+  if (lo >= hi) return;
+  if (threadIdx.x < MAX_GROUPS) cur[threadIdx.x] = 0;
+  __syncthreads();
+  const uint4* dv = reinterpret_cast<const uint4*>(digits + (size_t)win * n_pad);
+  const uint32_t v_lo = lo >> 2, v_hi = hi >> 2;
+  for (uint32_t vi = v_lo + threadIdx.x; vi < v_hi; vi += blockDim.x) {
+    const uint4 q = dv[vi];
+    const int32_t d4[4] = {(int32_t)q.x, (int32_t)q.y, (int32_t)q.z, (int32_t)q.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int32_t d = d4[k];
+      if (d != 0) atomicAdd(&cur[((uint32_t)(d < 0 ? -d : d) - 1) >> FINE_BITS], 1u);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {            // one wavefront: exclusive scan of the MAX_GROUPS = 128 counts (two per lane), then the reservations
+    const uint32_t c0 = cur[2 * threadIdx.x], c1 = cur[2 * threadIdx.x + 1], s = c0 + c1;
+    uint32_t x = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t y = __shfl_up(x, off, 64);
+      if ((int)threadIdx.x >= off) x += y;
+    }
+    const uint32_t l0 = x - s, l1 = l0 + c0;
+    const uint32_t g0 = c0 ? atomicAdd(&gcursor[2 * threadIdx.x], c0) : 0u, g1 = c1 ? atomicAdd(&gcursor[2 * threadIdx.x + 1], c1) : 0u;
+    cur[2 * threadIdx.x] = l0; cur[2 * threadIdx.x + 1] = l1;
+    delta[2 * threadIdx.x] = g0 - l0; delta[2 * threadIdx.x + 1] = g1 - l1;
+  }
+  __syncthreads();
+  const uint32_t rbase = ref_base + (uint32_t)win * ref_stride;
+  for (uint32_t vi = v_lo + threadIdx.x; vi < v_hi; vi += blockDim.x) {
+    const uint4 q = dv[vi];
+    const int32_t d4[4] = {(int32_t)q.x, (int32_t)q.y, (int32_t)q.z, (int32_t)q.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int32_t d = d4[k];
+      if (d != 0) {
+        const uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1;
+        const uint32_t pos = atomicAdd(&cur[b >> FINE_BITS], 1u);
+        refs[pos] = (rbase + vi * 4 + k) | (d < 0 ? 0x80000000u : 0u);
+        fines[pos] = (uint16_t)(b & ((1u << FINE_BITS) - 1));
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t total = cur[MAX_GROUPS - 1];                  // cur[g] = end of group g's run
+  for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) {
+    uint32_t glo = 0, ghi = MAX_GROUPS - 1;
+    while (glo < ghi) { const uint32_t mid = (glo + ghi) >> 1; if (cur[mid] > i) ghi = mid; else glo = mid + 1; }
+    const uint32_t pos = delta[glo] + i;
+    stage_ref[pos] = refs[i];
+    stage_fine[pos] = fines[i];
+  }
+}
+
 constexpr uint32_t SORT_CHUNK = 28672;   // entries per workgroup of the sorted fine scatter: 112 KiB of references in LDS
 
 // goff[g] = start of group g in the staging array (exclusive scan of the group counts), gcursor = copy; cstart[g] = index of the
@@ -278,7 +344,7 @@ __global__ void k_group_offsets(const uint32_t* __restrict__ gcount, int G, uint
   cstart[G] = crun;
 }
 
-// Fine scatter with the chunk sorted in LDS first.  The plain placement (k_fine_pass<true>) stores every reference with its own
+// Fine scatter with the chunk sorted in LDS first.  A plain placement (as in k_sort_pass<true>) stores every reference with its own
 // 4-byte write, and PMC shows what that costs: 8.7 bytes reach memory per byte of payload (32-byte sectors).  Here a workgroup
 // owns SORT_CHUNK staged entries of one group of 2^FINE_BITS buckets, counting-sorts their references by bucket inside LDS, and
 // writes bucket runs: neighbouring lanes store neighbouring words (~7 entries per bucket and chunk).
@@ -359,61 +425,6 @@ __global__ void __launch_bounds__(1024) k_fine_count(const uint16_t* __restrict_
   for (uint32_t b = threadIdx.x; b < FB; b += blockDim.x) {
     const uint32_t v = cur[b];
     if (v) atomicAdd(&gl[b], v);
-  }
-}
-
-template <bool SCATTER>
-__global__ void __launch_bounds__(1024) k_fine_pass(const uint16_t* __restrict__ stage_fine, const uint32_t* __restrict__ stage_ref,
-                                                    const uint32_t* __restrict__ goff, uint32_t* __restrict__ count_or_cursor,
-                                                    uint32_t* __restrict__ sorted) {
-  extern __shared__ uint32_t hist[];
-  constexpr uint32_t FB = 1u << FINE_BITS;
-  const uint32_t g = blockIdx.y;
-  const uint32_t gend = goff[g + 1];
-  const uint64_t start64 = (uint64_t)goff[g] + (uint64_t)blockIdx.x * FINE_CHUNK;
-  if (start64 >= gend) return;
-  const uint32_t start = (uint32_t)start64, end = (uint32_t)min((uint64_t)gend, start64 + FINE_CHUNK);
-  for (uint32_t b = threadIdx.x; b < FB; b += blockDim.x) hist[b] = 0;
-  __syncthreads();
-  // [start, end) = unaligned head | 8-entry vectors | tail
-  const uint32_t a_lo = min(end, (start + 7) & ~7u), a_hi = max(a_lo, end & ~7u);
-  const uint4* fv = reinterpret_cast<const uint4*>(stage_fine);
-  for (uint32_t p = start + threadIdx.x; p < a_lo; p += blockDim.x) atomicAdd(&hist[stage_fine[p]], 1u);
-  for (uint32_t p = a_hi + threadIdx.x; p < end; p += blockDim.x) atomicAdd(&hist[stage_fine[p]], 1u);
-  for (uint32_t vi = (a_lo >> 3) + threadIdx.x; vi < (a_hi >> 3); vi += blockDim.x) {
-    const uint4 q = fv[vi];
-    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-    for (int k = 0; k < 8; k++) atomicAdd(&hist[(w[k >> 1] >> ((k & 1) * 16)) & 0xffffu], 1u);
-  }
-  __syncthreads();
-  uint32_t* gl = count_or_cursor + (size_t)g * FB;
-  if (!SCATTER) {
-    for (uint32_t b = threadIdx.x; b < FB; b += blockDim.x) {
-      const uint32_t v = hist[b];
-      if (v) atomicAdd(&gl[b], v);
-    }
-    return;
-  }
-  for (uint32_t b0 = threadIdx.x; b0 < FB; b0 += 8 * blockDim.x) {
-    uint32_t v[8], r[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) { const uint32_t b = b0 + k * blockDim.x; v[k] = b < FB ? hist[b] : 0u; }
-#pragma unroll
-    for (int k = 0; k < 8; k++) r[k] = v[k] ? atomicAdd(&gl[b0 + k * blockDim.x], v[k]) : 0u;
-#pragma unroll
-    for (int k = 0; k < 8; k++) { const uint32_t b = b0 + k * blockDim.x; if (b < FB) hist[b] = r[k]; }
-  }
-  __syncthreads();
-  for (uint32_t p = start + threadIdx.x; p < a_lo; p += blockDim.x) sorted[atomicAdd(&hist[stage_fine[p]], 1u)] = stage_ref[p];
-  for (uint32_t p = a_hi + threadIdx.x; p < end; p += blockDim.x) sorted[atomicAdd(&hist[stage_fine[p]], 1u)] = stage_ref[p];
-  const uint4* rv = reinterpret_cast<const uint4*>(stage_ref);
-  for (uint32_t vi = (a_lo >> 3) + threadIdx.x; vi < (a_hi >> 3); vi += blockDim.x) {
-    const uint4 q = fv[vi], r0 = rv[2 * vi], r1 = rv[2 * vi + 1];
-    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-    const uint32_t r[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
-#pragma unroll
-    for (int k = 0; k < 8; k++) sorted[atomicAdd(&hist[(w[k >> 1] >> ((k & 1) * 16)) & 0xffffu], 1u)] = r[k];
   }
 }
 
@@ -978,7 +989,7 @@ int msm_pick_window_prepared(size_t n) {
     double W = (256 + c - 1) / c;
     double cost = W * 10.0 * (double)n + 28.0 * (double)(1u << (c - 1)) + (c > 16 ? W * 1.0 * (double)n : 0.0);
     if (msm_top_window_is_degenerate(c)) continue;
-    if (c > 16 && n < ((size_t)1 << 22)) continue;   // measured (median of 60): c = 16 / c = 20 at 2^20 1.73 / 1.77 ms, 2^21 3.32 / 3.37, 2^22 6.48 / 6.05, 2^23 13.1 / 11.3
+    if (c > 16 && n < ((size_t)1 << 20)) continue;   // measured (median of 60, c = 16 / c = 20): 2^20 1.83 / 1.67 ms, 2^21 3.32 / 2.95 on one box; the crossover was at 2^22 before the wide sort wrote bucket runs
     if (cost < best_cost) { best_cost = cost; best = c; }
   }
   if (const char* e = getenv("ZKHIP_MAX_WINDOW")) { int m = atoi(e); if (m >= 2 && best > m) best = m; }   // A/B knob
@@ -1105,8 +1116,6 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   if (!attr_set) {
     HIPCHK(hipFuncSetAttribute((const void*)k_sort_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)k_sort_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void*)k_fine_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void*)k_fine_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)k_fine_sorted, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * (1 << FINE_BITS) + SORT_CHUNK) * 4));
     attr_set = true;
   }
@@ -1118,8 +1127,9 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
     hipLaunchKernelGGL(k_coarse_pass<false>, dim3(chunks, W), dim3(1024), 0, stream, (const int32_t*)digits, n_pad, chunk, gcounters, (uint32_t*)nullptr,
                        (uint16_t*)nullptr, ref_base, ref_stride);
     hipLaunchKernelGGL(k_group_offsets, dim3(1), dim3(64), 0, stream, gcounters, G, gcounters + 128, gcounters + 384, gcounters + 512);
-    hipLaunchKernelGGL(k_coarse_pass<true>, dim3(chunks, W), dim3(1024), 0, stream, (const int32_t*)digits, n_pad, chunk, gcounters + 384, stage_ref,
-                       stage_fine, ref_base, ref_stride);
+    static_assert(MAX_GROUPS == 128, "k_coarse_sorted scans two groups per lane of one wavefront");
+    hipLaunchKernelGGL(k_coarse_sorted, dim3((n_pad + COARSE_CHUNK - 1) / COARSE_CHUNK, W), dim3(1024), 0, stream, (const int32_t*)digits, n_pad, gcounters + 384,
+                       stage_ref, stage_fine, ref_base, ref_stride);
     prof_mark(stream, "coarse");
     hipLaunchKernelGGL(k_fine_count, dim3(sort_chunks), dim3(1024), 0, stream, stage_fine, gcounters + 128, gcounters + 512, G, count);
   } else {
