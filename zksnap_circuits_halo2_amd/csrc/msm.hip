@@ -674,7 +674,8 @@ __global__ void __launch_bounds__(256) k_make_order(const uint32_t* __restrict__
       }
     }
     const uint32_t st = s0 + ((nt - 1) << task_shift);
-    order[atomicAdd(&lh[rem], 1u)] = make_uint4(t + nt - 1, st, rem, sorted[st]);
+    // a bucket that is a single task needs no combining: its sum goes straight to the bucket array (bit 31 = "x is the bucket")
+    order[atomicAdd(&lh[rem], 1u)] = make_uint4(nt == 1 ? (0x80000000u | k) : t + nt - 1, st, rem, sorted[st]);
   }
 }
 
@@ -687,7 +688,8 @@ __global__ void __launch_bounds__(256) k_make_order(const uint32_t* __restrict__
 template <bool TABLE>
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) k_accumulate(const task_t* __restrict__ tasks, const uint32_t* __restrict__ ntasks_p,
                                                     const uint4* __restrict__ order, const uint32_t* __restrict__ sorted,
-                                                    const uint32_t* __restrict__ bases, uint32_t* __restrict__ partials) {
+                                                    const uint32_t* __restrict__ bases, uint32_t* __restrict__ partials,
+                                                    uint32_t* __restrict__ buckets) {
   const uint32_t ntasks = *ntasks_p;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ntasks; i += gridDim.x * blockDim.x) {
     const uint4 rec = order[i];            // tasks run longest-first; partial t stays in bucket order
@@ -731,7 +733,8 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))
       }
       xyzz_madd<true>(acc, x2, y2);
     }
-    store_xyzz(partials, t, acc);
+    if (t >> 31) store_xyzz(buckets, t & 0x7fffffffu, acc);     // the bucket's only task (k_make_order)
+    else store_xyzz(partials, t, acc);
   }
 }
 
@@ -781,16 +784,18 @@ __global__ void __launch_bounds__(128) k_combine_seq(const uint32_t* __restrict_
   const uint32_t k = gid / COMBINE_LANES, q = gid % COMBINE_LANES;
   const bool live = k < nbuckets;                  // whole lane groups are live or dead together (128 % 8 == 0)
   xyzz acc = xyzz_identity();
+  uint32_t m = 0;
   if (live) {
-    const uint32_t t = task_off[k], m = task_off[k + 1] - t;
+    const uint32_t t = task_off[k];
+    m = task_off[k + 1] - t;
     const uint32_t stride = 1u << (2 * tree_levels_for(m, seq_parts));
-    const uint32_t left = (m + stride - 1) / stride;              // partials still to be summed
+    const uint32_t left = m == 1 ? 0u : (m + stride - 1) / stride;   // partials still to be summed; a single task wrote its bucket itself
 #pragma unroll 1
     for (uint32_t j = q; j < left; j += COMBINE_LANES) acc = xyzz_add(acc, load_xyzz(partials, t + j * stride));
   }
 #pragma unroll 1
   for (int mask = 1; mask < COMBINE_LANES; mask <<= 1) acc = xyzz_add(acc, xyzz_shfl_xor(acc, mask));
-  if (live && q == 0) store_xyzz(buckets, k, acc);
+  if (live && q == 0 && m != 1) store_xyzz(buckets, k, acc);
 }
 
 // the same with a quad per lane of the above (small MSMs: the bucket count is far below the chip's lane count and the step is
@@ -803,16 +808,18 @@ __global__ void __launch_bounds__(128) k_combine_seq_quad(const uint32_t* __rest
   const uint32_t q = gid & 3, lane = (gid >> 2) % COMBINE_LANES, k = (gid >> 2) / COMBINE_LANES;
   const bool live = k < nbuckets;                  // whole groups of 4 * COMBINE_LANES lanes are live or dead together
   xyzz acc = xyzz_identity();
+  uint32_t m = 0;
   if (live) {
-    const uint32_t t = task_off[k], m = task_off[k + 1] - t;
+    const uint32_t t = task_off[k];
+    m = task_off[k + 1] - t;
     const uint32_t stride = 1u << (2 * tree_levels_for(m, seq_parts));
-    const uint32_t left = (m + stride - 1) / stride;
+    const uint32_t left = m == 1 ? 0u : (m + stride - 1) / stride;   // a single task wrote its bucket itself
 #pragma unroll 1
     for (uint32_t j = lane; j < left; j += COMBINE_LANES) acc = xyzz_add_quad(acc, load_xyzz(partials, t + j * stride), q);
   }
 #pragma unroll 1
   for (int mask = 1; mask < COMBINE_LANES; mask <<= 1) acc = xyzz_add_quad(acc, xyzz_shfl_xor(acc, 4 * mask), q);
-  if (live && lane == 0 && q == 0) store_xyzz(buckets, k, acc);
+  if (live && lane == 0 && q == 0 && m != 1) store_xyzz(buckets, k, acc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1172,8 +1179,8 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   {
     uint32_t blocks = (uint32_t)((max_tasks + 127) / 128);
     if (blocks > 256 * 64) blocks = 256 * 64;
-    if (prepared) hipLaunchKernelGGL(k_accumulate<true>, dim3(blocks), dim3(128), 0, stream, tasks, counters + 1, order, sorted, d_bases, partials);
-    else hipLaunchKernelGGL(k_accumulate<false>, dim3(blocks), dim3(128), 0, stream, tasks, counters + 1, order, sorted, d_bases, partials);
+    if (prepared) hipLaunchKernelGGL(k_accumulate<true>, dim3(blocks), dim3(128), 0, stream, tasks, counters + 1, order, sorted, d_bases, partials, pyrA);
+    else hipLaunchKernelGGL(k_accumulate<false>, dim3(blocks), dim3(128), 0, stream, tasks, counters + 1, order, sorted, d_bases, partials, pyrA);
   }
   prof_mark(stream, "accumulate");
   // 7. combine
