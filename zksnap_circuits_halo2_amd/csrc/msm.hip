@@ -328,17 +328,21 @@ __global__ void __launch_bounds__(1024) k_coarse_sorted(const int32_t* __restric
 }
 
 constexpr uint32_t SORT_CHUNK = 28672;   // entries per workgroup of the sorted fine scatter: 112 KiB of references in LDS
+// second shape for small groups (< 2^17 staged entries per group, i.e. 2^20 points): 20 Ki references + their 16-bit bucket ids
+// (120 KiB), no search on the way out.  Measured: 2^20 scatter 0.152 -> 0.110 ms; 2^21 0.240 -> 0.262, 2^22 0.509 -> 0.524 (shorter
+// runs, more reservations), so only the smallest wide-window size uses it.
+constexpr uint32_t SORT_CHUNK_IDS = 20480;
 
 // goff[g] = start of group g in the staging array (exclusive scan of the group counts), gcursor = copy; cstart[g] = index of the
 // group's first SORT_CHUNK-sized chunk in the numbering of k_fine_sorted's workgroups
 __global__ void k_group_offsets(const uint32_t* __restrict__ gcount, int G, uint32_t* __restrict__ goff, uint32_t* __restrict__ gcursor,
-                                uint32_t* __restrict__ cstart) {
+                                uint32_t* __restrict__ cstart, uint32_t chunk) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   uint32_t run = 0, crun = 0;
   for (int g = 0; g < G; g++) {
     goff[g] = run; gcursor[g] = run; cstart[g] = crun;
     run += gcount[g];
-    crun += (gcount[g] + SORT_CHUNK - 1) / SORT_CHUNK;
+    crun += (gcount[g] + chunk - 1) / chunk;
   }
   goff[G] = run;
   cstart[G] = crun;
@@ -405,10 +409,67 @@ __global__ void __launch_bounds__(1024) k_fine_sorted(const uint16_t* __restrict
   }
 }
 
+// the same with the bucket id of every sorted entry kept in LDS (SORT_CHUNK_IDS above)
+__global__ void __launch_bounds__(1024) k_fine_sorted_ids(const uint16_t* __restrict__ stage_fine, const uint32_t* __restrict__ stage_ref,
+                                                      const uint32_t* __restrict__ goff, const uint32_t* __restrict__ cstart, int G,
+                                                      uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
+  extern __shared__ uint32_t hist[];
+  constexpr uint32_t FB = 1u << FINE_BITS;
+  static_assert(FB == 4096, "one thread owns four buckets in the scan");
+  __shared__ uint32_t wsum[16];
+  uint32_t* cur = hist;
+  uint32_t* delta = hist + FB;
+  uint32_t* refs = hist + 2 * FB;
+  const uint32_t w = blockIdx.x;
+  if (w >= cstart[G]) return;
+  uint32_t glo = 0, ghi = (uint32_t)G;                      // group of chunk w: last g with cstart[g] <= w
+  while (ghi - glo > 1) { const uint32_t mid = (glo + ghi) >> 1; if (cstart[mid] <= w) glo = mid; else ghi = mid; }
+  const uint32_t g = glo;
+  const uint32_t start = goff[g] + (w - cstart[g]) * SORT_CHUNK_IDS, end = min(goff[g + 1], start + SORT_CHUNK_IDS), cnt_n = end - start;
+  for (uint32_t b = threadIdx.x; b < FB; b += blockDim.x) cur[b] = 0;
+  __syncthreads();
+  for (uint32_t p = start + threadIdx.x; p < end; p += blockDim.x) atomicAdd(&cur[stage_fine[p]], 1u);
+  __syncthreads();
+  // exclusive scan over the 4096 counts: thread t owns buckets 4t .. 4t + 3
+  uint32_t c[4], l[4], s = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { c[k] = cur[4 * threadIdx.x + k]; s += c[k]; }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t x = s;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t y = __shfl_up(x, off, 64);
+    if (lane >= off) x += y;
+  }
+  if (lane == 63) wsum[wave] = x;
+  __syncthreads();
+  uint32_t before = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++) if (i < wave) before += wsum[i];
+  uint32_t run = before + x - s;
+  uint32_t* gl = cursor + (size_t)g * FB;
+  uint32_t gb[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) { l[k] = run; run += c[k]; }
+#pragma unroll
+  for (int k = 0; k < 4; k++) gb[k] = c[k] ? atomicAdd(&gl[4 * threadIdx.x + k], c[k]) : 0u;      // reserve the runs' slots
+#pragma unroll
+  for (int k = 0; k < 4; k++) { cur[4 * threadIdx.x + k] = l[k]; delta[4 * threadIdx.x + k] = gb[k] - l[k]; }
+  __syncthreads();
+  uint16_t* ids = reinterpret_cast<uint16_t*>(refs + SORT_CHUNK_IDS);
+  for (uint32_t p = start + threadIdx.x; p < end; p += blockDim.x) {
+    const uint32_t f = stage_fine[p], pos = atomicAdd(&cur[f], 1u);
+    refs[pos] = stage_ref[p];
+    ids[pos] = (uint16_t)f;
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < cnt_n; i += blockDim.x) sorted[delta[ids[i]] + i] = refs[i];
+}
+
 // count pass of the same tiling (one workgroup per SORT_CHUNK entries of a group): LDS histogram, non-empty counts merged into the
 // global per-bucket counts
 __global__ void __launch_bounds__(1024) k_fine_count(const uint16_t* __restrict__ stage_fine, const uint32_t* __restrict__ goff,
-                                                     const uint32_t* __restrict__ cstart, int G, uint32_t* __restrict__ count) {
+                                                     const uint32_t* __restrict__ cstart, int G, uint32_t* __restrict__ count, uint32_t chunk) {
   constexpr uint32_t FB = 1u << FINE_BITS;
   __shared__ uint32_t cur[FB];
   const uint32_t w = blockIdx.x;
@@ -416,7 +477,7 @@ __global__ void __launch_bounds__(1024) k_fine_count(const uint16_t* __restrict_
   uint32_t glo = 0, ghi = (uint32_t)G;
   while (ghi - glo > 1) { const uint32_t mid = (glo + ghi) >> 1; if (cstart[mid] <= w) glo = mid; else ghi = mid; }
   const uint32_t g = glo;
-  const uint32_t start = goff[g] + (w - cstart[g]) * SORT_CHUNK, end = min(goff[g + 1], start + SORT_CHUNK);
+  const uint32_t start = goff[g] + (w - cstart[g]) * chunk, end = min(goff[g + 1], start + chunk);
   for (uint32_t b = threadIdx.x; b < FB; b += blockDim.x) cur[b] = 0;
   __syncthreads();
   for (uint32_t p = start + threadIdx.x; p < end; p += blockDim.x) atomicAdd(&cur[stage_fine[p]], 1u);
@@ -1124,21 +1185,24 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
     HIPCHK(hipFuncSetAttribute((const void*)k_sort_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)k_sort_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)k_fine_sorted, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * (1 << FINE_BITS) + SORT_CHUNK) * 4));
+    HIPCHK(hipFuncSetAttribute((const void*)k_fine_sorted_ids, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * (1 << FINE_BITS) + SORT_CHUNK_IDS) * 4 + SORT_CHUNK_IDS * 2));
     attr_set = true;
   }
   const int G = wide ? (int)(B >> FINE_BITS) : 1;                      // coarse groups
-  const uint32_t sort_chunks = (uint32_t)(((size_t)W * n + SORT_CHUNK - 1) / SORT_CHUNK) + (uint32_t)G;     // upper bound of the fine passes' chunks; surplus workgroups return at once
+  const bool sort_ids = (size_t)W * n < ((size_t)G << 17);           // fewer than 2^17 staged entries per group on average
+  const uint32_t sort_chunk = sort_ids ? SORT_CHUNK_IDS : SORT_CHUNK;
+  const uint32_t sort_chunks = (uint32_t)(((size_t)W * n + sort_chunk - 1) / sort_chunk) + (uint32_t)G;     // upper bound of the fine passes' chunks; surplus workgroups return at once
   const uint32_t wb_stride = prepared ? 0u : B;
   const uint32_t ref_base = prepared ? (uint32_t)prepared_off : 0u, ref_stride = prepared ? (uint32_t)prepared->n : 0u;
   if (wide) {
     hipLaunchKernelGGL(k_coarse_pass<false>, dim3(chunks, W), dim3(1024), 0, stream, (const int32_t*)digits, n_pad, chunk, gcounters, (uint32_t*)nullptr,
                        (uint16_t*)nullptr, ref_base, ref_stride);
-    hipLaunchKernelGGL(k_group_offsets, dim3(1), dim3(64), 0, stream, gcounters, G, gcounters + 128, gcounters + 384, gcounters + 512);
+    hipLaunchKernelGGL(k_group_offsets, dim3(1), dim3(64), 0, stream, gcounters, G, gcounters + 128, gcounters + 384, gcounters + 512, sort_chunk);
     static_assert(MAX_GROUPS == 128, "k_coarse_sorted scans two groups per lane of one wavefront");
     hipLaunchKernelGGL(k_coarse_sorted, dim3((n_pad + COARSE_CHUNK - 1) / COARSE_CHUNK, W), dim3(1024), 0, stream, (const int32_t*)digits, n_pad, gcounters + 384,
                        stage_ref, stage_fine, ref_base, ref_stride);
     prof_mark(stream, "coarse");
-    hipLaunchKernelGGL(k_fine_count, dim3(sort_chunks), dim3(1024), 0, stream, stage_fine, gcounters + 128, gcounters + 512, G, count);
+    hipLaunchKernelGGL(k_fine_count, dim3(sort_chunks), dim3(1024), 0, stream, stage_fine, gcounters + 128, gcounters + 512, G, count, sort_chunk);
   } else {
     hipLaunchKernelGGL(k_sort_pass<false>, dim3(chunks, W, K), dim3(1024), lds, stream, (const int16_t*)digits, n_pad, chunk, c, count, (uint32_t*)nullptr, wb_stride, ref_base, ref_stride);
   }
@@ -1156,8 +1220,10 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   prof_mark(stream, "scan");
   // 4. scatter
   if (wide) {
-    hipLaunchKernelGGL(k_fine_sorted, dim3(sort_chunks), dim3(1024), (size_t)(2u * (1u << FINE_BITS) + SORT_CHUNK) * 4, stream, stage_fine, stage_ref,
-                       gcounters + 128, gcounters + 512, G, cursor, sorted);
+    if (sort_ids) hipLaunchKernelGGL(k_fine_sorted_ids, dim3(sort_chunks), dim3(1024), (size_t)(2u * (1u << FINE_BITS) + SORT_CHUNK_IDS) * 4 + SORT_CHUNK_IDS * 2, stream,
+                                     stage_fine, stage_ref, gcounters + 128, gcounters + 512, G, cursor, sorted);
+    else hipLaunchKernelGGL(k_fine_sorted, dim3(sort_chunks), dim3(1024), (size_t)(2u * (1u << FINE_BITS) + SORT_CHUNK) * 4, stream, stage_fine, stage_ref,
+                            gcounters + 128, gcounters + 512, G, cursor, sorted);
   }
   else hipLaunchKernelGGL(k_sort_pass<true>, dim3(chunks, W, K), dim3(1024), lds, stream, (const int16_t*)digits, n_pad, chunk, c, cursor, sorted, wb_stride, ref_base, ref_stride);
   prof_mark(stream, "scatter");
