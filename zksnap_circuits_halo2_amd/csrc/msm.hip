@@ -1258,9 +1258,11 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   {
     uint32_t blocks = (uint32_t)((max_tasks + 127) / 128);
     if (blocks > 256) blocks = 256;                 // grid-stride kernels; usually no bucket needs a level, and an idle launch costs by its wave count
-    // a bucket holds at most max_tasks partials: levels beyond ceil(log4(max_tasks / seq_parts)) can never be needed
+    // a bucket holds at most all W n entries of one MSM, i.e. (W n >> task_shift) + 1 partials: levels beyond ceil(log4(that / seq_parts))
+    // can never be needed (every level that is launched and not needed still costs ~3 us)
+    const uint64_t max_parts_bound = (((uint64_t)W * n) >> task_shift) + 1;
     int levels = 0;
-    while (levels < COMBINE_LEVELS && (((uint64_t)max_tasks + ((uint64_t)1 << (2 * levels)) - 1) >> (2 * levels)) > seq_parts) levels++;
+    while (levels < COMBINE_LEVELS && ((max_parts_bound + ((uint64_t)1 << (2 * levels)) - 1) >> (2 * levels)) > seq_parts) levels++;
     for (int level = 0; level < levels; level++)
       hipLaunchKernelGGL(k_combine_tree, dim3(blocks), dim3(128), 0, stream, tasks, counters + 1, task_off, counters + 2, partials, level, seq_parts);
   }
