@@ -472,6 +472,38 @@ void ref_eval_polynomial(const u64* poly, size_t n, const u64 point[4], u64 out[
   }
   memcpy(out, acc, 32);
 }
+/* `eval_polynomial` as halo2-axiom runs it on a multi-core host [DEP arithmetic.rs]: the coefficients are cut into `threads`
+ * contiguous chunks, each chunk is evaluated by Horner (`evaluate`) and scaled by point^(chunk start), the parts are summed.
+ * Same value as the serial form; used by the large-size NTT spot checks (a(w^i) for sampled i) and timed in bench.py. */
+typedef struct { const u64* poly; size_t n; const u64* point; size_t start; u64 out[4]; } evalp_job_t;
+static void* evalp_worker(void* arg) {
+  evalp_job_t* j = (evalp_job_t*)arg;
+  u64 acc[4], e[4] = {(u64)j->start, 0, 0, 0}, pw[4];
+  ref_eval_polynomial(j->poly, j->n, j->point, acc);
+  f_pow(&FR, pw, j->point, e);
+  f_mul(&FR, j->out, acc, pw);
+  return NULL;
+}
+void ref_eval_polynomial_mt(const u64* poly, size_t n, const u64 point[4], int threads, u64 out[4]) {
+  if (threads < 1) threads = 1;
+  if (n < 2 * (size_t)threads || threads == 1) { ref_eval_polynomial(poly, n, point, out); return; }
+  size_t chunk = n / (size_t)threads, nchunks = (n + chunk - 1) / chunk;
+  evalp_job_t* jobs = (evalp_job_t*)malloc(nchunks * sizeof(evalp_job_t));
+  pthread_t* th = (pthread_t*)malloc(nchunks * sizeof(pthread_t));
+  for (size_t k = 0; k < nchunks; k++) {
+    size_t lo = k * chunk, hi = lo + chunk > n ? n : lo + chunk;
+    jobs[k].poly = poly + 4 * lo; jobs[k].n = hi - lo; jobs[k].point = point; jobs[k].start = lo;
+    pthread_create(&th[k], NULL, evalp_worker, &jobs[k]);
+  }
+  u64 acc[4] = {0, 0, 0, 0};
+  for (size_t k = 0; k < nchunks; k++) {
+    pthread_join(th[k], NULL);
+    f_add(&FR, acc, acc, jobs[k].out);
+  }
+  memcpy(out, acc, 32);
+  free(jobs);
+  free(th);
+}
 void ref_kate_division(const u64* a, size_t n, const u64 b[4], u64* q) { /* b = -b; q[i-1] = a[i] - tmp; tmp = q[i-1] * b */
   if (n < 2) return;
   u64 nb[4], zero[4] = {0, 0, 0, 0}, tmp[4] = {0, 0, 0, 0};

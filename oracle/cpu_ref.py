@@ -67,6 +67,34 @@ def eval_polynomial(poly: np.ndarray, point: np.ndarray) -> np.ndarray:
     return out
 
 
+def eval_polynomial_mt(poly: np.ndarray, point: np.ndarray, threads: int) -> np.ndarray:
+    """halo2's multi-core `eval_polynomial` (chunk per thread, parts scaled by point^start and summed)"""
+    out = np.zeros(4, dtype=np.uint64)
+    load().ref_eval_polynomial_mt(_p(poly), C.c_size_t(poly.shape[0]), _p(point), int(threads), _p(out))
+    return out
+
+
+def usable_cores() -> int:
+    """host threads this process may actually run at once: the scheduler affinity mask capped by the cgroup CPU quota
+    (what rayon's default pool size -- std::thread::available_parallelism -- reports on the same box)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except Exception:   # noqa: BLE001
+            continue
+    return max(1, n)
+
+
 def kate_division(a: np.ndarray, b: np.ndarray) -> np.ndarray:
     q = np.zeros((max(a.shape[0] - 1, 0), 4), dtype=np.uint64)
     load().ref_kate_division(_p(a), C.c_size_t(a.shape[0]), _p(b), _p(q))

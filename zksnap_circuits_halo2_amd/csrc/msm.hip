@@ -1064,24 +1064,81 @@ int msm_pick_window_prepared(size_t n) {
   return best;
 }
 
+// Workspace layout.  ONE routine lays the regions out, and it serves both the size query (base == nullptr) and the launcher, so
+// the two can never disagree (they once did: the estimator padded n before applying the task-count switch below and the
+// launcher did not, which undersized the workspace for n just below 2^19).
+struct msm_layout {
+  uint32_t task_shift;          // log2 of the task length
+  size_t max_tasks;             // upper bound of the task count for that length
+  void* digits;
+  uint32_t* stage_ref; uint16_t* stage_fine;
+  char* zero_lo; size_t zero_bytes;   // everything that starts at zero sits together: one fill instead of three
+  uint32_t *gcounters, *counters, *count, *sorted, *offset, *cursor, *task_off, *bsum1, *bsum2;
+  task_t* tasks; uint4* order;
+  uint32_t *partials, *pyrA, *pyrB, *winsum;
+  size_t total;                 // bytes from the base to the end of the last region
+};
+
+// Task length.  With >= 2^17 tasks of 64 entries the chip is full and 64 is best (throughput-bound, see TASK_SHIFT).  Below
+// that the MSM is latency-bound: a task of L entries is L sequential mixed adds (~5 us each at low occupancy) and a bucket
+// of s entries leaves s/L partials to sum (~10 us each): pick L = 2^shift minimising 5 L + 10 (s/L - 1).
+static uint32_t msm_task_shift(size_t entries /* W n K */, size_t NB) {
+  uint32_t task_shift = TASK_SHIFT;
+  // 128-entry tasks halve the partials the combine step has to add, and pay once the launch is many rounds of waves deep even
+  // so: measured (6 / 7) 2^24 21.40 / 21.00 ms (combine 0.71 -> 0.27), but 2^22 6.00 / 6.07 and 2^20 1.72 / 1.85 (too few tasks).
+  static const int knob = [] { const char* e = getenv("ZKHIP_TASK_SHIFT"); return e ? atoi(e) : 0; }();
+  if (knob >= 2 && knob <= 7) task_shift = (uint32_t)knob;
+  else if ((entries >> 7) >= ((size_t)1 << 20)) task_shift = 7;
+  if ((entries >> TASK_SHIFT) < ((size_t)1 << 17)) {
+    const double occ = (double)entries / (double)NB;
+    double best = 1e300;
+    for (uint32_t sh = 2; sh <= (uint32_t)TASK_SHIFT; sh++) {
+      const double L = (double)(1u << sh), parts = occ / L;
+      const double est = 5.0 * L + 10.0 * (parts > 1.0 ? parts - 1.0 : 0.0);
+      if (est < best) { best = est; task_shift = sh; }
+    }
+  }
+  return task_shift;
+}
+
+static msm_layout msm_lay_out(char* base, size_t n, size_t K, int c, bool prepared) {
+  msm_layout L;
+  const size_t W = (256 + c - 1) / c, B = (size_t)1 << (c - 1), WB = prepared ? K : W, NB = WB * B;
+  const bool wide = c > 16;
+  const size_t nk = n * K, entries = W * nk;
+  const size_t n_pad = (n + 7) & ~(size_t)7;
+  L.task_shift = msm_task_shift(entries, NB);
+  L.max_tasks = (entries >> L.task_shift) + NB + 1;        // every bucket adds at most one task that is not full
+  char* p = base;
+  auto carve = [&](size_t bytes) { void* r = p; p += align_up(bytes, 256); return r; };
+  L.digits = carve(W * K * n_pad * (wide ? sizeof(int32_t) : sizeof(int16_t)));
+  L.stage_ref = wide ? (uint32_t*)carve(entries * sizeof(uint32_t)) : nullptr;
+  L.stage_fine = wide ? (uint16_t*)carve(entries * sizeof(uint16_t)) : nullptr;
+  L.zero_lo = p;
+  L.gcounters = wide ? (uint32_t*)carve(4096) : nullptr;   // [0..128) group counts, [128..257) group offsets, [384..512) group cursors, [512..641) chunk starts
+  L.counters = (uint32_t*)carve(2048);                     // [0] total entries, [1] total tasks, [2] max task partials of one bucket,
+                                                           // [32..161) task-length histogram (MAX_TASK_LEN + 1), [192..321) its cursors
+  L.count = (uint32_t*)carve((NB + 1) * sizeof(uint32_t));
+  L.zero_bytes = (size_t)(p - L.zero_lo);
+  L.sorted = (uint32_t*)carve(entries * sizeof(uint32_t));
+  L.offset = (uint32_t*)carve((NB + 1) * sizeof(uint32_t));
+  L.cursor = (uint32_t*)carve((NB + 1) * sizeof(uint32_t));
+  L.task_off = (uint32_t*)carve((NB + 1) * sizeof(uint32_t));
+  L.bsum1 = (uint32_t*)carve((NB / SCAN_TILE + 2) * sizeof(uint32_t));
+  L.bsum2 = (uint32_t*)carve((NB / SCAN_TILE + 2) * sizeof(uint32_t));
+  L.tasks = (task_t*)carve(L.max_tasks * sizeof(task_t));
+  L.order = (uint4*)carve(L.max_tasks * sizeof(uint4));    // execution order: one record per task
+  L.partials = (uint32_t*)carve(L.max_tasks * 144);
+  L.pyrA = (uint32_t*)carve(WB * B * 144);                 // pyramid ping-pong: per bucket set N + (s-1) N/2 <= B elements at every step
+  L.pyrB = (uint32_t*)carve(WB * B * 144);
+  L.winsum = (uint32_t*)carve((W + K) * 144);              // window / bucket-set sums
+  L.total = (size_t)(p - base);
+  return L;
+}
+
 size_t msm_workspace_bytes(size_t n_one, int c, bool prepared, size_t batch) {
-  const size_t n = n_one * batch + 8 * batch;   // entries scale with the batch (rows padded per MSM)
-  const size_t W = (256 + c - 1) / c, B = (size_t)1 << (c - 1), WB = prepared ? batch : W, NB = WB * B;
-  // 64-entry tasks when the chip is full, else as short as 4 entries (see the task-length choice in msm_g1_device)
-  const size_t max_tasks = ((W * n) >> TASK_SHIFT) >= ((size_t)1 << 17) ? ((W * n) >> TASK_SHIFT) + NB + 1 : W * n / 4 + NB + 1;
-  size_t total = 0;
-  total += align_up(W * (n + 8) * (c > 16 ? sizeof(int32_t) : sizeof(int16_t)), 256);    // digits (rows padded to a multiple of 8)
-  if (c > 16) total += align_up(W * n * sizeof(uint32_t), 256) + align_up(W * n * sizeof(uint16_t), 256) + 4096;   // staging (ref, fine) + group counters
-  total += align_up(W * n * sizeof(uint32_t), 256);         // sorted
-  total += 4 * align_up((NB + 1) * sizeof(uint32_t), 256);  // count, offset, cursor, task_off
-  total += 2 * align_up((NB / SCAN_TILE + 2) * sizeof(uint32_t), 256);  // scan block sums x2
-  total += align_up(max_tasks * sizeof(task_t), 256);
-  total += align_up(max_tasks * sizeof(uint4), 256);        // execution order: one record per task
-  total += align_up(max_tasks * 144, 256);                  // partials
-  total += 2 * align_up((size_t)WB * B * 144, 256);         // pyramid ping-pong (state never exceeds B elements per bucket set)
-  total += align_up((W + batch) * 144, 256);                // window / bucket-set sums
-  total += 4096;                                            // counters + result
-  return total;
+  if (n_one == 0 || batch == 0) return 0;
+  return msm_lay_out(nullptr, n_one, batch, c, prepared).total;
 }
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s failed: %s", #x, hipGetErrorString(e_)); return ZKHIP_EHIP; } } while (0)
@@ -1115,56 +1172,22 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
     d_bases = prepared->table;
   }
   if ((size_t)W * n * K >= (1ull << 32) || (size_t)WB * B >= (1ull << 31)) { set_error("msm: W*n*batch overflows 32-bit slot index"); return ZKHIP_EINVAL; }
-  if (ws_bytes < msm_workspace_bytes(n, c, prepared != nullptr, K)) { set_error("msm: workspace too small"); return ZKHIP_EINVAL; }
   const size_t nk = n * K;                          // scalars in the whole batch
-  const size_t max_tasks = (((size_t)W * nk) >> TASK_SHIFT) >= ((size_t)1 << 17) ? (((size_t)W * nk) >> TASK_SHIFT) + NB + 1 : (size_t)W * nk / 4 + NB + 1;
-  // Task length.  With >= 2^17 tasks of 64 entries the chip is full and 64 is best (throughput-bound, see TASK_SHIFT).  Below
-  // that the MSM is latency-bound: a task of L entries is L sequential mixed adds (~5 us each at low occupancy) and a bucket
-  // of s entries leaves s/L partials to sum (~10 us each): pick L = 2^shift minimising 5 L + 10 (s/L - 1).
-  uint32_t task_shift = TASK_SHIFT;
-  {
-    // 128-entry tasks halve the partials the combine step has to add, and pay once the launch is many rounds of waves deep even
-    // so: measured (6 / 7) 2^24 21.40 / 21.00 ms (combine 0.71 -> 0.27), but 2^22 6.00 / 6.07 and 2^20 1.72 / 1.85 (too few tasks).
-    static const int knob = [] { const char* e = getenv("ZKHIP_TASK_SHIFT"); return e ? atoi(e) : 0; }();
-    if (knob >= 2 && knob <= 7) task_shift = (uint32_t)knob;
-    else if ((((size_t)W * nk) >> 7) >= ((size_t)1 << 20)) task_shift = 7;
-  }
-  if ((((size_t)W * nk) >> TASK_SHIFT) < ((size_t)1 << 17)) {
-    const double occ = (double)W * (double)nk / (double)NB;
-    double best = 1e300;
-    for (uint32_t sh = 2; sh <= (uint32_t)TASK_SHIFT; sh++) {
-      const double L = (double)(1u << sh), parts = occ / L;
-      const double est = 5.0 * L + 10.0 * (parts > 1.0 ? parts - 1.0 : 0.0);
-      if (est < best) { best = est; task_shift = sh; }
-    }
-  }
-
-  char* p = (char*)ws;
-  auto carve = [&](size_t bytes) { void* r = p; p += align_up(bytes, 256); return r; };
+  const msm_layout lay = msm_lay_out((char*)ws, n, K, c, prepared != nullptr);
+  if (ws_bytes < lay.total) { set_error("msm: workspace too small (%zu < %zu bytes)", ws_bytes, lay.total); return ZKHIP_EINVAL; }
+  const uint32_t task_shift = lay.task_shift;
+  const size_t max_tasks = lay.max_tasks;
   const uint32_t n_pad = (uint32_t)((n + 7) & ~(size_t)7);
-  void* digits = carve((size_t)W * K * n_pad * (wide ? sizeof(int32_t) : sizeof(int16_t)));
-  uint32_t* stage_ref = wide ? (uint32_t*)carve((size_t)W * n * sizeof(uint32_t)) : nullptr;
-  uint16_t* stage_fine = wide ? (uint16_t*)carve((size_t)W * n * sizeof(uint16_t)) : nullptr;
-  // everything that starts at zero sits together: one fill instead of three (each is its own ~5 us dispatch)
-  char* const zero_lo = p;
-  uint32_t* gcounters = wide ? (uint32_t*)carve(4096) : nullptr;   // [0..128) group counts, [128..257) group offsets, [384..512) group cursors, [512..641) chunk starts
-  uint32_t* counters = (uint32_t*)carve(2048);   // [0] total entries, [1] total tasks, [2] max task partials of one bucket,
-                                                 // [32..161) task-length histogram (MAX_TASK_LEN + 1), [192..321) its cursors
-  uint32_t* count = (uint32_t*)carve((NB + 1) * sizeof(uint32_t));
-  const size_t zero_bytes = (size_t)(p - zero_lo);
-  uint32_t* sorted = (uint32_t*)carve((size_t)W * nk * sizeof(uint32_t));
-  uint32_t* offset = (uint32_t*)carve((NB + 1) * sizeof(uint32_t));
-  uint32_t* cursor = (uint32_t*)carve((NB + 1) * sizeof(uint32_t));
-  uint32_t* task_off = (uint32_t*)carve((NB + 1) * sizeof(uint32_t));
-  uint32_t* bsum1 = (uint32_t*)carve((NB / SCAN_TILE + 2) * sizeof(uint32_t));
-  uint32_t* bsum2 = (uint32_t*)carve((NB / SCAN_TILE + 2) * sizeof(uint32_t));
-  task_t* tasks = (task_t*)carve(max_tasks * sizeof(task_t));
-  uint4* order = (uint4*)carve(max_tasks * sizeof(uint4));
-  uint32_t* partials = (uint32_t*)carve(max_tasks * 144);
-  const size_t pyr_elems = B;   // per window: N + (s-1) N/2 <= B at every step
-  uint32_t* pyrA = (uint32_t*)carve((size_t)WB * pyr_elems * 144);
-  uint32_t* pyrB = (uint32_t*)carve((size_t)WB * pyr_elems * 144);
-  uint32_t* winsum = (uint32_t*)carve((size_t)(W + K) * 144);
+  void* const digits = lay.digits;
+  uint32_t* const stage_ref = lay.stage_ref;
+  uint16_t* const stage_fine = lay.stage_fine;
+  char* const zero_lo = lay.zero_lo;
+  const size_t zero_bytes = lay.zero_bytes;
+  uint32_t *const gcounters = lay.gcounters, *const counters = lay.counters, *const count = lay.count, *const sorted = lay.sorted,
+           *const offset = lay.offset, *const cursor = lay.cursor, *const task_off = lay.task_off, *const bsum1 = lay.bsum1, *const bsum2 = lay.bsum2;
+  task_t* const tasks = lay.tasks;
+  uint4* const order = lay.order;
+  uint32_t *const partials = lay.partials, *const pyrA = lay.pyrA, *const pyrB = lay.pyrB, *const winsum = lay.winsum;
 
   prof_begin(stream);
   HIPCHK(hipMemsetAsync(zero_lo, 0, zero_bytes, stream));
