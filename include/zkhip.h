@@ -29,13 +29,35 @@ extern "C" {
 #define ZKHIP_ENOMEM (-4)  /* device allocation failed */
 
 /* ---- lifecycle ----------------------------------------------------------------------------------- */
-/* Select the HIP device this process drives (one process per GPU).  devices == NULL: device 0 (or
- * $ZKHIP_DEVICE).  Lazy init on first use is allowed.  ndev > 1 is rejected: multi-GPU = multi-process. */
+/* Name the HIP devices this process drives (`zkhip_init(const int *devices, int ndev)`).  devices == NULL
+ * or ndev == 0: device 0 (or $ZKHIP_DEVICE).  devices[0] is the PRIMARY device: every `_device` entry point, every NTT and every
+ * other vector operation runs there, and `_device` pointers are pointers into its memory.  With ndev > 1 the MSM over registered
+ * bases is sharded by point range over all the devices (zkhip_register_bases below) -- the 8 GPUs of one node behind one
+ * `create_proof` process (/root/reference/aggregator/src/wrapper.rs:129).  Lazy init on first use is allowed (device 0).
+ * Calling it again with the same list is a no-op; with a different list it shuts the library down first.
+ * Environment: ZKHIP_DEVICE (default device), ZKHIP_SHARDS (see zkhip_set_msm_shards), ZKHIP_HOST_LANES (1..4, default 2: host-buffer
+ * calls that may be in flight at once, each with its own stream and scratch memory). */
 int zkhip_init(const int *devices, int ndev);
 void zkhip_shutdown(void);
 const char *zkhip_last_error(void);
-/* library / device identification, for logs: writes a NUL-terminated string */
+/* library / device identification, for logs: writes a NUL-terminated string (the primary device) */
 int zkhip_device_name(char *buf, size_t len);
+/* number of devices the library drives (0 when it cannot initialise) */
+int zkhip_device_count(void);
+/* Number of point-range shards zkhip_register_bases cuts an array into from now on: shard s of S covers points
+ * [s n / S, (s + 1) n / S) (the first n % S shards one point more) and lives on device s % ndev.  Default: one shard per device.
+ * More shards than devices ("virtual shards", also $ZKHIP_SHARDS) run the whole multi-GPU path -- per-shard tables, per-shard
+ * Pippenger, gather of the 96-byte Jacobian partials, fold -- on fewer devices; the result is the same group element for every
+ * shard count.  0 restores the default. */
+int zkhip_set_msm_shards(int shards);
+int zkhip_msm_shards(void);
+
+/* Threads and streams.  Every entry point may be called from any host thread.  Host-buffer calls (no `_device` suffix) borrow one of
+ * the library's lanes for the duration of the call, so up to ZKHIP_HOST_LANES of them run concurrently (one call's PCIe transfer
+ * under another's kernels); further callers wait.  `_device` calls are asynchronous on the caller's stream and use scratch memory
+ * that belongs to that stream: calls on different streams never share scratch, calls on one stream are ordered by the stream.  Two
+ * host threads must not enqueue on the SAME stream at the same time (as with any HIP stream).  The profiling hooks
+ * (zkhip_profile_*) are a single-caller debugging aid. */
 
 /* ---- MSM: replaces `best_multiexp(coeffs: &[Fr], bases: &[G1Affine]) -> G1` ------------------------- */
 /* [DEP] halo2_proofs/src/arithmetic.rs; called by ParamsKZG::commit / commit_lagrange.  n may be any value
@@ -47,9 +69,13 @@ int zkhip_msm_g1(const uint64_t *scalars, const uint64_t *bases, size_t n, uint6
 int zkhip_msm_g1_batch(const uint64_t *scalars, const uint64_t *bases, size_t n, size_t batch, uint64_t *out_xyz);
 
 /* Residency for `ParamsKZG::{g, g_lagrange}` (static per params object): upload once and build the prepared table
- * (2^(c w) * P_i for every window w: W * 64 bytes per point of HBM, one-time ~25 ms per 2^20 points); zkhip_msm_g1
- * recognises `bases` pointers inside a registered range (any sub-range), skips the upload and runs the prepared
- * path: one shared bucket set, no window fold. */
+ * (2^(c w) * P_i for every window w: W * 64 bytes per point of HBM, one-time ~25 ms per 2^20 points) on every shard's device;
+ * zkhip_msm_g1 recognises `bases` pointers inside a registered range (any sub-range), skips the upload and runs the prepared
+ * path: one shared bucket set per shard, no window fold, one gather + fold of the shards' partial sums.
+ * Contract: the caller keeps [bases, bases + 8 n) alive AND UNCHANGED until zkhip_unregister_bases -- the table is built from the
+ * contents at registration.  Recognition is by address, so memory that was freed without unregistering and later reused for other
+ * points would alias a stale table; as a guard the library keeps 8 sampled points of the registered array and treats a range whose
+ * samples no longer match as not registered (correct result through the general path, slower).  Always unregister before freeing. */
 int zkhip_register_bases(const uint64_t *bases, size_t n);
 int zkhip_unregister_bases(const uint64_t *bases);
 

@@ -52,7 +52,9 @@ def test_compute_fails_loudly_without_gpu(lib):
 
 
 def test_argument_validation_has_no_side_effects(lib):
-    assert lib.zkhip_init(None, 2) == -1   # one process drives one GPU
+    assert lib.zkhip_init(None, -1) == -1 and lib.zkhip_init(None, 65) == -1   # ZKHIP_EINVAL before any device is touched
+    two = (__import__("ctypes").c_int * 2)(0, 0)
+    assert lib.zkhip_init(two, 2) in (-1, -2)   # a device named twice (or, on a box without a GPU, no device at all)
     assert lib.zkhip_msm_window_bits(1 << 20) == 16
     assert 2 <= lib.zkhip_msm_window_bits(1) <= 16
 

@@ -89,7 +89,8 @@ def test_coeff_to_extended_wrapper_size_equals_coset_evaluation(lib, cref):
 
 def _walk_bases(lib, torch, n, T0, D):
     bases = torch.empty(n * 8, dtype=torch.int64, device="cuda")
-    _lib.check(lib.zkhip_g1_gen_walk_device(F.fr_encode([T0])[0].ctypes.data, F.fr_encode([D])[0].ctypes.data, n, bases.data_ptr(), None))
+    t0m, dm = F.fr_encode([T0])[0], F.fr_encode([D])[0]          # named: `.ctypes.data` of a temporary would dangle
+    _lib.check(lib.zkhip_g1_gen_walk_device(t0m.ctypes.data, dm.ctypes.data, n, bases.data_ptr(), None))
     return bases
 
 

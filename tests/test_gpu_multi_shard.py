@@ -1,0 +1,237 @@
+"""GPU (-m gpu): the multi-GPU MSM and the thread / stream rules of the C ABI.
+
+One process, `zkhip_init(devices, ndev)`, `zkhip_register_bases` sharding the SRS by point range, `zkhip_msm_g1` fanning the scalar
+slices out, gathering the 96-byte partials and folding them.  The test box has ONE card, so the path is rehearsed two ways:
+virtual shards (`zkhip_set_msm_shards`: S tables, S Pippenger runs, gather, fold on one device) and duplicate device contexts
+(`ZKHIP_TEST_DUPLICATE_DEVICES=1` + `zkhip_init([0, 0, 0], 3)`: the worker threads, per-device lanes and peer copies of the real
+multi-device path, all landing on the same card).  A sum of points is a unique group element, so every shard count must give the
+same affine point as the unsharded MSM and as the structured-SRS identity."""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import bn254 as O
+from zksnap_circuits_halo2_amd import _lib, fields as F
+
+pytestmark = pytest.mark.gpu
+D = 0x9E3779B97F4A7C15F39CC0605CEDC835
+T0 = 0x5A4B534E41500002 + 1001
+
+
+def _walk_host(lib, n, t0=T0):
+    """host copy of the structured SRS (t0 + i D) G, generated on the device"""
+    import torch
+
+    bases = torch.empty(n * 8, dtype=torch.int64, device="cuda")
+    t0m, dm = F.fr_encode([t0])[0], F.fr_encode([D])[0]
+    _lib.check(lib.zkhip_g1_gen_walk_device(t0m.ctypes.data, dm.ctypes.data, n, bases.data_ptr(), None))
+    torch.cuda.synchronize()
+    return np.ascontiguousarray(bases.cpu().numpy().view(np.uint64).reshape(n, 8))
+
+
+def _expect(cref, sc, t0):
+    return cref.jac_to_affine(cref.scalar_mul(cref.expected_scalar(sc, t0, D), cref.generator()))
+
+
+def _msm(lib, sc, bases):
+    out = np.zeros(12, dtype=np.uint64)
+    _lib.check(lib.zkhip_msm_g1(sc.ctypes.data, bases.ctypes.data, sc.shape[0], out.ctypes.data))
+    return out
+
+
+@pytest.fixture
+def restore_shards(lib):
+    yield
+    lib.zkhip_set_msm_shards(0)
+
+
+@pytest.mark.parametrize("n", [10007, (1 << 17) + 3])
+def test_virtual_shards_equal_unsharded(lib, cref, restore_shards, n):
+    bases = _walk_host(lib, n)
+    sc = cref.gen_scalars(9100 + n % 13, n, 0)
+    sc[5] = 0
+    bases_with_id = bases.copy(); bases_with_id[17] = 0          # an identity base inside shard 0
+    exp = _expect(cref, sc, T0)
+    results = {}
+    for S in (1, 3, 8):
+        _lib.check(lib.zkhip_set_msm_shards(S))
+        assert lib.zkhip_msm_shards() == S
+        _lib.check(lib.zkhip_register_bases(bases.ctypes.data, n))
+        try:
+            full = cref.jac_to_affine(_msm(lib, sc, bases))
+            assert np.array_equal(full, exp), S
+            # sub-ranges: inside one shard, across a shard boundary, a prefix (what ParamsKZG::commit of a short polynomial passes)
+            for lo, hi in ((3, 100), (n // 8 - 50, n // 8 + 60), (0, n - 1), (n // 3 - 1, 2 * n // 3 + 5), (n - 9, n)):
+                part = cref.jac_to_affine(_msm(lib, np.ascontiguousarray(sc[lo:hi]), bases[lo:hi]))
+                assert np.array_equal(part, _expect(cref, np.ascontiguousarray(sc[lo:hi]), (T0 + lo * D) % O.R_MOD)), (S, lo, hi)
+            results[S] = full
+        finally:
+            _lib.check(lib.zkhip_unregister_bases(bases.ctypes.data))
+    assert np.array_equal(results[1], results[3]) and np.array_equal(results[1], results[8])
+    # fewer points than shards, and the empty MSM
+    _lib.check(lib.zkhip_set_msm_shards(8))
+    _lib.check(lib.zkhip_register_bases(bases.ctypes.data, 5))
+    try:
+        assert np.array_equal(cref.jac_to_affine(_msm(lib, np.ascontiguousarray(sc[:5]), bases[:5])), _expect(cref, np.ascontiguousarray(sc[:5]), T0))
+        assert F.g1_decode_jacobian(_msm(lib, np.zeros((0, 4), dtype=np.uint64), bases[:0])) is None
+    finally:
+        _lib.check(lib.zkhip_unregister_bases(bases.ctypes.data))
+    del bases_with_id
+
+
+def test_config4_rehearsal_8_shards_of_2p21(lib, cref, restore_shards):
+    """BASELINE configs[4]: the wrapper circuit at k + 2 = 24, MSM sharded over 8 GPUs = 2^21 points per shard -- here 8 shards on the
+    one card, through the same register / fan-out / gather / fold code the 8-GPU host runs"""
+    n = 1 << 24
+    bases = _walk_host(lib, n)
+    sc = cref.gen_scalars(92400, n, 0)
+    _lib.check(lib.zkhip_set_msm_shards(8))
+    _lib.check(lib.zkhip_register_bases(bases.ctypes.data, n))
+    try:
+        assert np.array_equal(cref.jac_to_affine(_msm(lib, sc, bases)), _expect(cref, sc, T0))
+    finally:
+        _lib.check(lib.zkhip_unregister_bases(bases.ctypes.data))
+
+
+def test_stale_registration_is_not_trusted(lib, cref):
+    """memory that still carries a registration but no longer the registered points (freed and reused, or modified in place) must not
+    be multiplied against the stale table: the sampled-point guard sends the call down the general path"""
+    n = 5000
+    bases = _walk_host(lib, n)
+    sc = cref.gen_scalars(9300, n, 0)
+    _lib.check(lib.zkhip_register_bases(bases.ctypes.data, n))
+    try:
+        assert np.array_equal(cref.jac_to_affine(_msm(lib, sc, bases)), _expect(cref, sc, T0))
+        other = _walk_host(lib, n, T0 + 77)
+        bases[:] = other                                          # same address, different points
+        assert np.array_equal(cref.jac_to_affine(_msm(lib, sc, bases)), _expect(cref, sc, T0 + 77))
+    finally:
+        _lib.check(lib.zkhip_unregister_bases(bases.ctypes.data))
+
+
+def test_two_host_threads_on_two_streams(lib, cref):
+    """`_device` calls from two host threads, each on its own stream, at the same time: scratch memory belongs to the stream, so the MSMs,
+    transforms and row-a7 passes of one thread must not disturb the other's"""
+    import torch
+
+    n, L = 1 << 16, 16
+    errors, ok = [], {}
+    t0m, dm = F.fr_encode([T0])[0], F.fr_encode([D])[0]
+    bases = torch.empty(n * 8, dtype=torch.int64, device="cuda")
+    _lib.check(lib.zkhip_g1_gen_walk_device(t0m.ctypes.data, dm.ctypes.data, n, bases.data_ptr(), None))
+    h = C.c_uint64(0)
+    _lib.check(lib.zkhip_prepare_bases_device(bases.data_ptr(), n, C.byref(h)))
+    om = F.fr_encode([F.omega_for(L)])[0]
+    omi = F.fr_encode([pow(F.omega_for(L), -1, F.R_MOD)])[0]
+    div = F.fr_encode([pow(n, -1, F.R_MOD)])[0]
+    torch.cuda.synchronize()
+
+    def work(tid):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for rep in range(6):
+                    sc = cref.gen_scalars(9400 + 16 * tid + rep, n, rep % 2)
+                    dsc = torch.from_numpy(sc.view(np.int64)).cuda()
+                    out = torch.zeros(12, dtype=torch.int64, device="cuda")
+                    out2 = torch.zeros(12, dtype=torch.int64, device="cuda")
+                    poly = dsc.clone()
+                    st.synchronize()
+                    s = st.cuda_stream
+                    _lib.check(lib.zkhip_msm_g1_prepared_device(h, 0, dsc.data_ptr(), n, out.data_ptr(), s))
+                    _lib.check(lib.zkhip_ntt_fr_device(poly.data_ptr(), om.ctypes.data, L, s))
+                    _lib.check(lib.zkhip_msm_g1_device(dsc.data_ptr(), bases.data_ptr(), n, out2.data_ptr(), s))
+                    _lib.check(lib.zkhip_ifft_scaled_device(poly.data_ptr(), omi.ctypes.data, L, div.ctypes.data, s))
+                    st.synchronize()
+                    exp = cref.jac_to_affine(cref.scalar_mul(cref.expected_scalar(sc, T0, D), cref.generator()))
+                    a = cref.jac_to_affine(np.ascontiguousarray(out.cpu().numpy().view(np.uint64)))
+                    b = cref.jac_to_affine(np.ascontiguousarray(out2.cpu().numpy().view(np.uint64)))
+                    ok[(tid, rep)] = bool(np.array_equal(a, exp) and np.array_equal(b, exp) and torch.equal(poly, dsc))
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    _lib.check(lib.zkhip_release_bases(h))
+    assert not errors, errors
+    assert len(ok) == 12 and all(ok.values()), ok
+
+
+def test_host_calls_overlap_on_lanes(lib, cref):
+    """host-buffer calls from four threads: each borrows a lane (two by default), none holds the library lock while it waits for
+    the device; all results right"""
+    n = 1 << 15
+    bases = _walk_host(lib, n)
+    _lib.check(lib.zkhip_register_bases(bases.ctypes.data, n))
+    res, errors = {}, []
+
+    def work(tid):
+        try:
+            for rep in range(5):
+                sc = cref.gen_scalars(9500 + 8 * tid + rep, n, 0)
+                got = cref.jac_to_affine(_msm(lib, sc, bases))
+                a = cref.gen_scalars(9600 + 8 * tid + rep, 1 << 14, 0)
+                ref = a.copy()
+                om = F.fr_encode([F.omega_for(14)])[0]
+                cref.best_fft(ref, om, 14, 1)
+                _lib.check(lib.zkhip_ntt_fr(a.ctypes.data, om.ctypes.data, 14))
+                res[(tid, rep)] = bool(np.array_equal(got, _expect(cref, sc, T0)) and np.array_equal(a, ref))
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    try:
+        threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    finally:
+        _lib.check(lib.zkhip_unregister_bases(bases.ctypes.data))
+    assert not errors, errors
+    assert len(res) == 20 and all(res.values())
+
+
+def test_multi_device_path_on_duplicate_contexts(lib, cref):
+    """zkhip_init with three device contexts (the same card three times under ZKHIP_TEST_DUPLICATE_DEVICES): registered bases are cut
+    into one shard per context, the secondary contexts run on their worker threads and send their partials with peer copies.
+    Also the unregistered case, which splits bases and scalars evenly over the devices."""
+    n = (1 << 16) + 11
+    lib.zkhip_shutdown()
+    os.environ["ZKHIP_TEST_DUPLICATE_DEVICES"] = "1"
+    try:
+        devs = (C.c_int * 3)(0, 0, 0)
+        _lib.check(lib.zkhip_init(devs, 3))
+        assert lib.zkhip_device_count() == 3 and lib.zkhip_msm_shards() == 3
+        bases = _walk_host(lib, n)
+        sc = cref.gen_scalars(9700, n, 0)
+        exp = _expect(cref, sc, T0)
+        assert np.array_equal(cref.jac_to_affine(_msm(lib, sc, bases)), exp)          # not registered: even split, general path per device
+        _lib.check(lib.zkhip_register_bases(bases.ctypes.data, n))
+        try:
+            for rep in range(3):
+                assert np.array_equal(cref.jac_to_affine(_msm(lib, sc, bases)), exp), rep
+            lo, hi = n // 3 - 100, n // 3 + 100                                        # two shards, two devices
+            assert np.array_equal(cref.jac_to_affine(_msm(lib, np.ascontiguousarray(sc[lo:hi]), bases[lo:hi])),
+                                  _expect(cref, np.ascontiguousarray(sc[lo:hi]), (T0 + lo * D) % O.R_MOD))
+            _lib.check(lib.zkhip_set_msm_shards(7))                                    # more shards than devices: round robin
+            _lib.check(lib.zkhip_register_bases(bases.ctypes.data, n))                 # re-registration replaces the tables
+            assert np.array_equal(cref.jac_to_affine(_msm(lib, sc, bases)), exp)
+        finally:
+            _lib.check(lib.zkhip_unregister_bases(bases.ctypes.data))
+        # the `_device` entry points keep working on the primary context
+        a = cref.gen_scalars(9701, 1 << 12, 0)
+        ref = a.copy()
+        om = F.fr_encode([F.omega_for(12)])[0]
+        cref.best_fft(ref, om, 12, 1)
+        _lib.check(lib.zkhip_ntt_fr(a.ctypes.data, om.ctypes.data, 12))
+        assert np.array_equal(a, ref)
+    finally:
+        lib.zkhip_shutdown()
+        del os.environ["ZKHIP_TEST_DUPLICATE_DEVICES"]
+        _lib.check(lib.zkhip_init(None, 0))

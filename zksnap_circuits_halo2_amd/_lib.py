@@ -14,6 +14,9 @@ _SIGS = {
     "zkhip_shutdown": (None, []),
     "zkhip_last_error": (C.c_char_p, []),
     "zkhip_device_name": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "zkhip_device_count": (C.c_int, []),
+    "zkhip_set_msm_shards": (C.c_int, [C.c_int]),
+    "zkhip_msm_shards": (C.c_int, []),
     "zkhip_msm_g1": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "zkhip_msm_g1_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
     "zkhip_ntt_fr_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]),

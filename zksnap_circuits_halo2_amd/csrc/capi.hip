@@ -1,14 +1,31 @@
-// C ABI of libzkhip.so (include/zkhip.h): context, device buffers, registered-base residency, and the host-buffer
+// C ABI of libzkhip.so (include/zkhip.h): contexts, device buffers, registered-base residency, and the host-buffer
 // wrappers around the device paths in msm.hip / ntt.hip.  No CPU arithmetic lives here.
+//
+// Concurrency model (callers are the thread running create_proof and possibly rayon workers):
+//   * one context per HIP device named in zkhip_init; devs[0] is the PRIMARY device: every `_device` entry point, every NTT and every
+//     single-shard MSM runs there.  The other devices only ever run MSM shards.
+//   * scratch memory is keyed by stream.  A `_device` call uses the scratch set of the caller's stream (work on one stream is ordered,
+//     so its calls may share scratch; two streams never do).  Host-buffer calls borrow a LANE -- a library-owned stream with its own
+//     scratch set and pinned result buffer -- for the duration of the call and do NOT hold the library lock while they wait for the
+//     device: two host threads overlap one call's PCIe transfer with the other's kernels.
+//   * g_mu guards the context tables (registered bases, handles, scratch map, lanes) and the enqueue of `_device` calls.
+//   * an MSM over registered bases that span several shards (zkhip_init with ndev > 1, or ZKHIP_SHARDS / zkhip_set_msm_shards virtual
+//     shards on one device) fans the scalar slices out to the shards' devices, gathers the 96-byte Jacobian partials on the primary
+//     device (peer copies over xGMI) and folds them there (k_sum_jacobian) -- SURVEY.md section 8(e).
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
-#include <vector>
+#include <memory>
 #include <mutex>
+#include <thread>
+#include <vector>
 #include "zkhip_internal.hpp"
 #include "../../include/zkhip.hpp"   // host-side 4 x 64 Montgomery arithmetic for domain constants (zkhip::halo2::detail)
 
@@ -23,7 +40,7 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-// ---- profiler -------------------------------------------------------------------------------------
+// ---- profiler (one profiled call at a time: a debugging aid, not part of the concurrent surface) --------------------
 static bool g_prof_on = false;
 static const int PROF_MAX = 32;
 static hipEvent_t g_prof_ev[PROF_MAX + 1];
@@ -51,7 +68,7 @@ void prof_mark(hipStream_t stream, const char* name) {
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s failed: %s", #x, hipGetErrorString(e_)); return ZKHIP_EHIP; } } while (0)
 
-struct dev_buf {       // grow-only device scratch
+struct dev_buf {       // grow-only device scratch (hipFree waits for the device, so growing under queued work is safe)
   void* p = nullptr;
   size_t cap = 0;
   int reserve(size_t bytes) {
@@ -60,7 +77,8 @@ struct dev_buf {       // grow-only device scratch
     p = nullptr; cap = 0;
     size_t want = bytes + bytes / 8;
     if (hipMalloc(&p, want) != hipSuccess) {
-      if (hipMalloc(&p, bytes) != hipSuccess) { set_error("hipMalloc(%zu) failed", bytes); p = nullptr; return ZKHIP_ENOMEM; }
+      (void)hipGetLastError();
+      if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc(%zu) failed", bytes); p = nullptr; return ZKHIP_ENOMEM; }
       want = bytes;
     }
     cap = want;
@@ -69,40 +87,230 @@ struct dev_buf {       // grow-only device scratch
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+struct scratch {       // one user at a time: the calls of one stream
+  dev_buf ws, scalars, bases, poly, poly2, small, ntt_tmp, vm;
+  uint64_t last_use = 0;
+  void release() { ws.release(); scalars.release(); bases.release(); poly.release(); poly2.release(); small.release(); ntt_tmp.release(); vm.release(); }
+};
+
+struct lane {          // host-buffer calls: a library-owned stream + (through the stream) a scratch set + a pinned result buffer
+  hipStream_t stream = nullptr;
+  void* pinned = nullptr;              // LANE_PINNED bytes, hipHostMalloc
+  bool busy = false;
+};
+constexpr size_t LANE_PINNED = 64 * 1024;
+constexpr size_t MAX_STREAM_SCRATCH = 8;   // scratch sets kept per device (least recently used caller streams are dropped beyond that)
+
+// a host thread that drives one secondary device during a sharded MSM (its own PCIe link is fed by its own thread: a pageable
+// hipMemcpyAsync stages through the calling thread)
+struct worker {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::function<int()> job;
+  bool has_job = false, done = false, quit = false;
+  int rc = 0;
+  char err[512] = "";
+  void loop() {
+    for (;;) {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return has_job || quit; });
+      if (quit) return;
+      std::function<int()> j = std::move(job);
+      has_job = false;
+      lk.unlock();
+      const int r = j();
+      lk.lock();
+      rc = r;
+      snprintf(err, sizeof(err), "%s", g_err);     // the worker thread's error text, for the caller
+      done = true;
+      cv.notify_all();
+    }
+  }
+  void submit(std::function<int()> j) {
+    std::lock_guard<std::mutex> lk(mu);
+    job = std::move(j); has_job = true; done = false;
+    cv.notify_all();
+  }
+  int wait() {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return done; });
+    done = false;
+    if (rc != ZKHIP_OK) set_error("%s", err);
+    return rc;
+  }
+};
+
+struct device_ctx {
+  int device = 0;
+  std::vector<lane> lanes;
+  std::map<hipStream_t, scratch*> scratch_by_stream;
+  uint64_t use_clock = 0;
+  dev_buf fixed_table;                 // multiples of the generator for zkhip_g1_fixed_base_mul_device (primary only)
+  bool fixed_table_ready = false;
+  dev_buf gather;                      // primary: the shards' 96-byte partials, one 96-byte slot per shard
+  std::vector<hipEvent_t> shard_events;
+  worker* w = nullptr;                 // secondary devices only
+};
+
+struct shard_t {       // points [lo, lo + n) of a registered array, prepared on device `dev`
+  int dev = 0;         // index into g_ctx.devs
+  size_t lo = 0, n = 0;
+  prepared_bases* pb = nullptr;
+};
+
+constexpr int FINGER_POINTS = 8;
+struct registered_t {  // one zkhip_register_bases call
+  const uint64_t* host = nullptr;
+  size_t n = 0;
+  std::vector<shard_t> shards;
+  size_t finger_idx[FINGER_POINTS];
+  uint64_t finger[FINGER_POINTS][8];   // sampled points of the host array at registration: a stale or modified range is not trusted
+  ~registered_t();
+};
+
 struct context {
   bool ready = false;
-  int device = 0;
-  hipStream_t stream = nullptr;
-  dev_buf ws, scalars, bases, poly, poly2, small, ntt_tmp, vm, fixed_table;
-  bool fixed_table_ready = false;   // multiples of the generator for zkhip_g1_fixed_base_mul_device
-  std::map<const void*, prepared_bases*> registered;   // host ptr -> prepared table (slice 0 of the table = the bases themselves)
-  std::map<uint64_t, prepared_bases*> handles;          // zkhip_prepare_bases_device handles
+  std::vector<device_ctx*> devs;       // devs[0] = primary
+  int shards = 1;                      // MSM shards a registered array is cut into (default: one per device)
+  std::map<const void*, std::shared_ptr<registered_t>> registered;
+  std::map<uint64_t, prepared_bases*> handles;          // zkhip_prepare_bases_device handles (primary device)
   uint64_t next_handle = 1;
 };
 
 static std::recursive_mutex g_mu;
+static std::condition_variable_any g_lane_cv;
+static std::mutex g_fanout_mu;         // one multi-device MSM at a time (the secondary devices have one lane each)
 static context g_ctx;
 
-static int ensure_init() {
-  if (g_ctx.ready) return ZKHIP_OK;
-  return zkhip_init(nullptr, 0);
+static inline device_ctx& primary() { return *g_ctx.devs[0]; }
+
+registered_t::~registered_t() {
+  for (auto& sh : shards) {
+    if (!sh.pb) continue;
+    if (g_ctx.ready && sh.dev < (int)g_ctx.devs.size()) (void)hipSetDevice(g_ctx.devs[sh.dev]->device);
+    release_prepared(sh.pb);
+  }
+  if (g_ctx.ready) (void)hipSetDevice(primary().device);
 }
 
-// prepared table + point offset for `bases` if it lies inside a registered range with room for n points
-static const prepared_bases* find_registered(const uint64_t* bases, size_t n, size_t* off) {
-  for (auto& kv : g_ctx.registered) {
-    const char* lo = (const char*)kv.first;
-    const char* hi = lo + kv.second->n * 64;
-    const char* q = (const char*)bases;
-    if (q >= lo && q + n * 64 <= hi && ((q - lo) % 64) == 0) { *off = (size_t)(q - lo) / 64; return kv.second; }
+static int ensure_init() {
+  if (!g_ctx.ready) return zkhip_init(nullptr, 0);
+  // the current device is per host thread: a rayon worker that never touched HIP starts on device 0
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess || cur != primary().device) {
+    if (hipSetDevice(primary().device) != hipSuccess) { set_error("hipSetDevice(%d) failed", primary().device); return ZKHIP_ENODEV; }
   }
-  return nullptr;
+  return ZKHIP_OK;
+}
+
+// scratch set of `stream` on device d (g_mu held).  Beyond MAX_STREAM_SCRATCH sets the least recently used one that does not belong
+// to a library lane is dropped (after a device synchronisation: its stream may have been destroyed by the caller).
+static scratch* scratch_for(device_ctx& d, hipStream_t stream) {
+  auto it = d.scratch_by_stream.find(stream);
+  if (it != d.scratch_by_stream.end()) { it->second->last_use = ++d.use_clock; return it->second; }
+  if (d.scratch_by_stream.size() >= MAX_STREAM_SCRATCH + d.lanes.size()) {
+    auto victim = d.scratch_by_stream.end();
+    for (auto jt = d.scratch_by_stream.begin(); jt != d.scratch_by_stream.end(); ++jt) {
+      bool is_lane = false;
+      for (auto& L : d.lanes) is_lane |= (L.stream == jt->first);
+      if (is_lane) continue;
+      if (victim == d.scratch_by_stream.end() || jt->second->last_use < victim->second->last_use) victim = jt;
+    }
+    if (victim != d.scratch_by_stream.end()) {
+      (void)hipDeviceSynchronize();
+      victim->second->release();
+      delete victim->second;
+      d.scratch_by_stream.erase(victim);
+    }
+  }
+  scratch* sc = new scratch();
+  sc->last_use = ++d.use_clock;
+  d.scratch_by_stream[stream] = sc;
+  return sc;
 }
 
 // `stream` argument of the `_device` entry points: NULL is HIP's default (legacy) stream -- stream 0, which is what a caller
 // holding "the default stream" (e.g. torch.cuda.current_stream().cuda_stream == 0) passes, and which is ordered with that caller's
-// other default-stream work.  (The host-buffer entry points use the library's own non-blocking stream and synchronise it.)
+// other default-stream work.
 static inline hipStream_t caller_stream(void* stream) { return (hipStream_t)stream; }
+
+// ---- lanes -----------------------------------------------------------------------------------------------------------
+// RAII: borrows a free lane of the primary device (waits for one), resolves its scratch set.  Construct WITHOUT holding g_mu.
+struct lane_hold {
+  lane* L = nullptr;
+  scratch* sc = nullptr;
+  hipStream_t s = nullptr;
+  int rc = ZKHIP_OK;
+  lane_hold() {
+    std::unique_lock<std::recursive_mutex> lk(g_mu);
+    rc = ensure_init();
+    if (rc != ZKHIP_OK) return;
+    for (;;) {
+      for (auto& c : primary().lanes) if (!c.busy) { L = &c; break; }
+      if (L) break;
+      g_lane_cv.wait(lk);
+      if (!g_ctx.ready) { rc = ZKHIP_ENODEV; set_error("library shut down while a call was waiting"); return; }
+    }
+    L->busy = true;
+    s = L->stream;
+    sc = scratch_for(primary(), s);
+  }
+  ~lane_hold() {
+    if (!L) return;
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    L->busy = false;
+    g_lane_cv.notify_one();
+  }
+  lane_hold(const lane_hold&) = delete;
+  lane_hold& operator=(const lane_hold&) = delete;
+};
+
+// Contiguous point range of shard s of S over n points: the first n % S shards get one extra point (the partition the multi-process
+// path uses too: zksnap_circuits_halo2_amd/multi_gpu.py shard_range)
+static inline void shard_range(size_t n, int s, int S, size_t* lo, size_t* hi) {
+  const size_t base = n / (size_t)S, extra = n % (size_t)S;
+  *lo = (size_t)s * base + std::min<size_t>((size_t)s, extra);
+  *hi = *lo + base + ((size_t)s < extra ? 1 : 0);
+}
+
+// registered entry + point offset for `bases` if it lies inside a registered range with room for n points and the sampled points
+// of that range still hold what was registered (g_mu held)
+static std::shared_ptr<registered_t> find_registered(const uint64_t* bases, size_t n, size_t* off) {
+  for (auto& kv : g_ctx.registered) {
+    const char* lo = (const char*)kv.first;
+    const char* hi = lo + kv.second->n * 64;
+    const char* q = (const char*)bases;
+    if (q >= lo && q + n * 64 <= hi && ((q - lo) % 64) == 0) {
+      const registered_t& r = *kv.second;
+      for (int i = 0; i < FINGER_POINTS; i++)
+        if (memcmp(r.host + r.finger_idx[i] * 8, r.finger[i], 64) != 0) return nullptr;   // reused or modified memory: not the registered SRS
+      *off = (size_t)(q - lo) / 64;
+      return kv.second;
+    }
+  }
+  return nullptr;
+}
+
+static void destroy_device_ctx(device_ctx* d) {
+  (void)hipSetDevice(d->device);
+  (void)hipDeviceSynchronize();
+  if (d->w) {
+    { std::lock_guard<std::mutex> lk(d->w->mu); d->w->quit = true; d->w->cv.notify_all(); }
+    if (d->w->th.joinable()) d->w->th.join();
+    delete d->w;
+  }
+  for (auto& kv : d->scratch_by_stream) { kv.second->release(); delete kv.second; }
+  d->scratch_by_stream.clear();
+  for (auto& L : d->lanes) {
+    if (L.pinned) (void)hipHostFree(L.pinned);
+    if (L.stream) (void)hipStreamDestroy(L.stream);
+  }
+  for (auto e : d->shard_events) (void)hipEventDestroy(e);
+  d->fixed_table.release();
+  d->gather.release();
+  delete d;
+}
 
 }  // namespace zkhip
 
@@ -113,36 +321,83 @@ extern "C" {
 
 int zkhip_init(const int* devices, int ndev) {
   guard_t g(g_mu);
-  if (ndev > 1) { set_error("zkhip_init: one process drives one GPU (ndev = %d)", ndev); return ZKHIP_EINVAL; }
-  int dev = 0;
-  if (devices && ndev == 1) dev = devices[0];
-  else if (const char* e = getenv("ZKHIP_DEVICE")) dev = atoi(e);
+  if (ndev < 0 || ndev > 64) { set_error("zkhip_init: ndev = %d out of range", ndev); return ZKHIP_EINVAL; }
   int count = 0;
-  if (hipGetDeviceCount(&count) != hipSuccess || count == 0) { set_error("no HIP device available"); return ZKHIP_ENODEV; }
-  if (dev < 0 || dev >= count) { set_error("device %d out of range (%d devices)", dev, count); return ZKHIP_EINVAL; }
-  if (g_ctx.ready && g_ctx.device == dev) return ZKHIP_OK;
-  if (g_ctx.ready) zkhip_shutdown();
-  if (hipSetDevice(dev) != hipSuccess) { set_error("hipSetDevice(%d) failed", dev); return ZKHIP_ENODEV; }
-  if (hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); return ZKHIP_ENODEV; }
-  g_ctx.device = dev;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0) { (void)hipGetLastError(); set_error("no HIP device available"); return ZKHIP_ENODEV; }
+  std::vector<int> want;
+  if (devices && ndev >= 1) want.assign(devices, devices + ndev);
+  else if (const char* e = getenv("ZKHIP_DEVICE")) want.push_back(atoi(e));
+  else want.push_back(0);
+  for (size_t i = 0; i < want.size(); i++) {
+    if (want[i] < 0 || want[i] >= count) { set_error("device %d out of range (%d devices)", want[i], count); return ZKHIP_EINVAL; }
+    // a device named twice is an error -- except under ZKHIP_TEST_DUPLICATE_DEVICES=1, which lets a one-GPU box rehearse the
+    // multi-device machinery (worker threads, peer copies, gather + fold) with several contexts on the same card
+    const bool dup_ok = getenv("ZKHIP_TEST_DUPLICATE_DEVICES") != nullptr;
+    for (size_t j = 0; j < i && !dup_ok; j++) if (want[j] == want[i]) { set_error("zkhip_init: device %d named twice", want[i]); return ZKHIP_EINVAL; }
+  }
+  if (g_ctx.ready) {
+    bool same = g_ctx.devs.size() == want.size();
+    for (size_t i = 0; same && i < want.size(); i++) same = g_ctx.devs[i]->device == want[i];
+    if (same) return ensure_init();
+    zkhip_shutdown();
+  }
+  int lanes = 2;                                            // host-buffer calls that may be in flight at once
+  if (const char* e = getenv("ZKHIP_HOST_LANES")) { const int v = atoi(e); if (v >= 1 && v <= 4) lanes = v; }
+  for (size_t i = 0; i < want.size(); i++) {
+    if (hipSetDevice(want[i]) != hipSuccess) { (void)hipGetLastError(); set_error("hipSetDevice(%d) failed", want[i]); for (auto d : g_ctx.devs) destroy_device_ctx(d); g_ctx.devs.clear(); return ZKHIP_ENODEV; }
+    device_ctx* d = new device_ctx();
+    d->device = want[i];
+    d->lanes.resize(i == 0 ? (size_t)lanes : 1);
+    bool ok = true;
+    for (auto& L : d->lanes) {
+      ok = ok && hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) == hipSuccess;
+      ok = ok && hipHostMalloc(&L.pinned, LANE_PINNED, hipHostMallocDefault) == hipSuccess;
+    }
+    g_ctx.devs.push_back(d);
+    if (!ok) { (void)hipGetLastError(); set_error("zkhip_init: stream / pinned buffer creation failed on device %d", want[i]); for (auto dd : g_ctx.devs) destroy_device_ctx(dd); g_ctx.devs.clear(); return ZKHIP_ENODEV; }
+    if (i > 0) {
+      d->w = new worker();
+      const int devno = want[i];
+      worker* w = d->w;
+      w->th = std::thread([w, devno] { (void)hipSetDevice(devno); w->loop(); });
+    }
+  }
+  // partial sums travel device to device (xGMI); without peer access hipMemcpyPeerAsync stages through the host, which is also fine
+  for (size_t i = 1; i < want.size(); i++) {
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, want[i], want[0]) == hipSuccess && can) {
+      (void)hipSetDevice(want[i]);
+      (void)hipDeviceEnablePeerAccess(want[0], 0);
+    }
+    (void)hipGetLastError();
+  }
+  (void)hipSetDevice(want[0]);
+  g_ctx.shards = (int)want.size();
+  if (const char* e = getenv("ZKHIP_SHARDS")) { const int v = atoi(e); if (v >= 1 && v <= 64) g_ctx.shards = v; }
   g_ctx.ready = true;
   return ZKHIP_OK;
 }
 
 void zkhip_shutdown(void) {
-  guard_t g(g_mu);
+  std::unique_lock<std::recursive_mutex> lk(g_mu);
   if (!g_ctx.ready) return;
-  (void)hipSetDevice(g_ctx.device);
-  (void)hipStreamSynchronize(g_ctx.stream);
+  // host-buffer calls in flight hold a lane without the lock: let them finish
+  for (;;) {
+    bool busy = false;
+    for (auto& L : primary().lanes) busy |= L.busy;
+    if (!busy) break;
+    g_lane_cv.wait(lk);
+  }
+  (void)hipSetDevice(primary().device);
+  (void)hipDeviceSynchronize();
   ntt_clear_cache();
-  for (auto& kv : g_ctx.registered) release_prepared(kv.second);
-  g_ctx.registered.clear();
+  g_ctx.registered.clear();                                  // last references: tables are freed by ~registered_t
   for (auto& kv : g_ctx.handles) release_prepared(kv.second);
   g_ctx.handles.clear();
-  g_ctx.ws.release(); g_ctx.scalars.release(); g_ctx.bases.release(); g_ctx.poly.release(); g_ctx.poly2.release(); g_ctx.small.release(); g_ctx.ntt_tmp.release(); g_ctx.vm.release(); g_ctx.fixed_table.release(); g_ctx.fixed_table_ready = false;
-  (void)hipStreamDestroy(g_ctx.stream);
-  g_ctx.stream = nullptr;
+  for (auto d : g_ctx.devs) destroy_device_ctx(d);
+  g_ctx.devs.clear();
   g_ctx.ready = false;
+  g_lane_cv.notify_all();
 }
 
 const char* zkhip_last_error(void) { return g_err; }
@@ -152,9 +407,30 @@ int zkhip_device_name(char* buf, size_t len) {
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
   hipDeviceProp_t prop;
-  HIPCHK(hipGetDeviceProperties(&prop, g_ctx.device));
+  HIPCHK(hipGetDeviceProperties(&prop, primary().device));
   snprintf(buf, len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
   return ZKHIP_OK;
+}
+
+int zkhip_device_count(void) {
+  guard_t g(g_mu);
+  if (ensure_init() != ZKHIP_OK) return 0;
+  return (int)g_ctx.devs.size();
+}
+
+int zkhip_set_msm_shards(int shards) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (shards < 0 || shards > 64) { set_error("set_msm_shards: %d out of range [0, 64]", shards); return ZKHIP_EINVAL; }
+  g_ctx.shards = shards == 0 ? (int)g_ctx.devs.size() : shards;
+  return ZKHIP_OK;
+}
+
+int zkhip_msm_shards(void) {
+  guard_t g(g_mu);
+  if (ensure_init() != ZKHIP_OK) return 0;
+  return g_ctx.shards;
 }
 
 int zkhip_msm_window_bits(size_t n) { return msm_pick_window(n); }
@@ -166,90 +442,255 @@ int zkhip_msm_g1_device_c(const void* d_scalars, const void* d_bases, size_t n, 
   if (rc != ZKHIP_OK) return rc;
   if (!d_out_xyz || (n && (!d_scalars || !d_bases))) { set_error("msm: null pointer"); return ZKHIP_EINVAL; }
   const int c = window_bits > 0 ? window_bits : msm_pick_window(n ? n : 1);
-  const size_t need = n ? msm_workspace_bytes(n, c) : 0;
-  if ((rc = g_ctx.ws.reserve(need)) != ZKHIP_OK) return rc;
   hipStream_t s = caller_stream(stream);
-  return msm_g1_device((const uint32_t*)d_scalars, (const uint32_t*)d_bases, n, (uint32_t*)d_out_xyz, g_ctx.ws.p, g_ctx.ws.cap, c, s);
+  scratch* sc = scratch_for(primary(), s);
+  if ((rc = sc->ws.reserve(msm_workspace_bytes(n, c))) != ZKHIP_OK) return rc;
+  return msm_g1_device((const uint32_t*)d_scalars, (const uint32_t*)d_bases, n, (uint32_t*)d_out_xyz, sc->ws.p, sc->ws.cap, c, s);
 }
 
 int zkhip_msm_g1_device(const void* d_scalars, const void* d_bases, size_t n, void* d_out_xyz, void* stream) {
   return zkhip_msm_g1_device_c(d_scalars, d_bases, n, d_out_xyz, 0, stream);
 }
 
-int zkhip_msm_g1(const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t out_xyz[12]) {
-  guard_t g(g_mu);
-  int rc = ensure_init();
-  if (rc != ZKHIP_OK) return rc;
-  if (!out_xyz || (n && (!scalars || !bases))) { set_error("msm: null pointer"); return ZKHIP_EINVAL; }
-  hipStream_t s = g_ctx.stream;
-  if ((rc = g_ctx.small.reserve(4096)) != ZKHIP_OK) return rc;
-  const uint32_t* d_bases = nullptr;
-  const prepared_bases* pb = nullptr;
-  size_t off = 0;
-  if (n) {
-    if ((rc = g_ctx.scalars.reserve(n * 32)) != ZKHIP_OK) return rc;
-    HIPCHK(hipMemcpyAsync(g_ctx.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, s));
-    pb = find_registered(bases, n, &off);
-    if (!pb) {
-      if ((rc = g_ctx.bases.reserve(n * 64)) != ZKHIP_OK) return rc;
-      HIPCHK(hipMemcpyAsync(g_ctx.bases.p, bases, n * 64, hipMemcpyHostToDevice, s));
-      d_bases = (const uint32_t*)g_ctx.bases.p;
+}  // extern "C"
+
+namespace zkhip {
+
+// One shard's share of a host-buffer MSM on device `d` (current device = d.device, stream / scratch of its lane 0 or the borrowed
+// lane): uploads the scalar slice (and the base slice when there is no prepared table), runs the MSM, leaves the 96-byte partial at
+// d_partial (memory of device d).
+static int msm_shard_enqueue(scratch* sc, hipStream_t s, const uint64_t* scalars, const uint64_t* bases, size_t n, const prepared_bases* pb,
+                             size_t pb_off, uint32_t* d_partial) {
+  int rc;
+  if (n == 0) return msm_g1_device(nullptr, nullptr, 0, d_partial, nullptr, 0, 0, s);
+  if ((rc = sc->scalars.reserve(n * 32)) != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(sc->scalars.p, scalars, n * 32, hipMemcpyHostToDevice, s));
+  if (pb) {
+    if ((rc = sc->ws.reserve(msm_workspace_bytes(n, pb->c, true))) != ZKHIP_OK) return rc;
+    return msm_g1_device((const uint32_t*)sc->scalars.p, nullptr, n, d_partial, sc->ws.p, sc->ws.cap, 0, s, pb, pb_off);
+  }
+  if ((rc = sc->bases.reserve(n * 64)) != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(sc->bases.p, bases, n * 64, hipMemcpyHostToDevice, s));
+  const int c = msm_pick_window(n);
+  if ((rc = sc->ws.reserve(msm_workspace_bytes(n, c))) != ZKHIP_OK) return rc;
+  return msm_g1_device((const uint32_t*)sc->scalars.p, (const uint32_t*)sc->bases.p, n, d_partial, sc->ws.p, sc->ws.cap, c, s);
+}
+
+struct piece_t { int dev; size_t lo, n; const prepared_bases* pb; size_t pb_off; };   // points [lo, lo + n) of the call's range
+
+// Size the scratch for the largest of the pieces one device will run back to back: growing a buffer between two pieces would
+// free it (a device-wide wait) under the previous piece's kernels.
+static int reserve_for_pieces(scratch* sc, const std::vector<piece_t>& pieces, const std::vector<size_t>& mine) {
+  size_t sc_bytes = 0, bs_bytes = 0, ws_bytes = 0;
+  for (size_t i : mine) {
+    const piece_t& p = pieces[i];
+    if (p.n == 0) continue;
+    sc_bytes = std::max(sc_bytes, p.n * 32);
+    if (!p.pb) bs_bytes = std::max(bs_bytes, p.n * 64);
+    ws_bytes = std::max(ws_bytes, p.pb ? msm_workspace_bytes(p.n, p.pb->c, true) : msm_workspace_bytes(p.n, msm_pick_window(p.n)));
+  }
+  int rc;
+  if ((rc = sc->scalars.reserve(sc_bytes)) != ZKHIP_OK) return rc;
+  if ((rc = sc->bases.reserve(bs_bytes)) != ZKHIP_OK) return rc;
+  return sc->ws.reserve(ws_bytes);
+}
+
+// Host-buffer MSM on a borrowed lane: out = sum scalars[i] * bases[i].  `reg` (may be null) = the registered entry `bases` points
+// into at point offset `off`.  Pieces = the shards the range touches (registered) or an even split over the devices (not registered,
+// several devices); a single piece on the primary device is the plain path.
+static int host_msm(lane_hold& H, const uint64_t* scalars, const uint64_t* bases, size_t n, const std::shared_ptr<registered_t>& reg, size_t off,
+                    uint64_t* out_xyz) {
+  int rc;
+  std::vector<piece_t> pieces;
+  if (reg) {
+    for (auto& sh : reg->shards) {
+      const size_t lo = std::max(off, sh.lo), hi = std::min(off + n, sh.lo + sh.n);
+      if (lo < hi) pieces.push_back({sh.dev, lo - off, hi - lo, sh.pb, lo - sh.lo});
+    }
+  } else if (g_ctx.devs.size() > 1 && n >= 4096 * g_ctx.devs.size()) {
+    const int S = (int)g_ctx.devs.size();
+    for (int s = 0; s < S; s++) {
+      size_t lo, hi;
+      shard_range(n, s, S, &lo, &hi);
+      if (lo < hi) pieces.push_back({s, lo, hi - lo, nullptr, 0});
     }
   }
-  if (pb) {
-    if ((rc = g_ctx.ws.reserve(msm_workspace_bytes(n, pb->c, true))) != ZKHIP_OK) return rc;
-    rc = msm_g1_device((const uint32_t*)g_ctx.scalars.p, nullptr, n, (uint32_t*)g_ctx.small.p, g_ctx.ws.p, g_ctx.ws.cap, 0, s, pb, off);
+  if (pieces.empty()) pieces.push_back({0, 0, n, nullptr, 0});
+  hipStream_t s = H.s;
+  scratch* sc = H.sc;
+  if ((rc = sc->small.reserve(4096)) != ZKHIP_OK) return rc;
+  if (pieces.size() == 1 && pieces[0].dev == 0) {
+    const piece_t& p = pieces[0];
+    if ((rc = msm_shard_enqueue(sc, s, scalars + p.lo * 4, bases + p.lo * 8, p.n, p.pb, p.pb_off, (uint32_t*)sc->small.p)) != ZKHIP_OK) return rc;
   } else {
-    rc = zkhip_msm_g1_device_c(g_ctx.scalars.p, d_bases, n, g_ctx.small.p, 0, s);
+    // fan out: the primary device's pieces run on this thread's lane, one after another (virtual shards) -- the other devices'
+    // pieces on their worker threads, each device over its own PCIe link
+    device_ctx& P = primary();
+    std::unique_lock<std::mutex> fan(g_fanout_mu, std::defer_lock);
+    bool remote = false;
+    for (auto& p : pieces) remote |= p.dev != 0;
+    if (remote) fan.lock();
+    // gather slots live in the lane's scratch set: concurrent single-device fan-outs on different lanes do not share them
+    if ((rc = sc->poly2.reserve(pieces.size() * 96 + 256)) != ZKHIP_OK) return rc;
+    uint32_t* gather = (uint32_t*)sc->poly2.p;
+    std::vector<std::vector<size_t>> by_dev(g_ctx.devs.size());
+    for (size_t i = 0; i < pieces.size(); i++) by_dev[(size_t)pieces[i].dev].push_back(i);
+    if ((rc = reserve_for_pieces(sc, pieces, by_dev[0])) != ZKHIP_OK) return rc;
+    for (size_t d = 1; d < g_ctx.devs.size(); d++) {
+      if (by_dev[d].empty()) continue;
+      device_ctx* D = g_ctx.devs[d];
+      const std::vector<size_t> mine = by_dev[d];
+      const int primary_dev = P.device;
+      D->w->submit([D, mine, &pieces, scalars, bases, gather, primary_dev]() -> int {
+        hipStream_t ds = D->lanes[0].stream;
+        scratch* dsc;
+        { guard_t g(g_mu); dsc = scratch_for(*D, ds); }
+        int r;
+        if ((r = dsc->small.reserve(4096 + mine.size() * 96)) != ZKHIP_OK) return r;
+        if ((r = reserve_for_pieces(dsc, pieces, mine)) != ZKHIP_OK) return r;
+        for (size_t k = 0; k < mine.size(); k++) {
+          const piece_t& p = pieces[mine[k]];
+          uint32_t* part = (uint32_t*)((char*)dsc->small.p + 4096 + k * 96);
+          if ((r = msm_shard_enqueue(dsc, ds, scalars + p.lo * 4, bases + p.lo * 8, p.n, p.pb, p.pb_off, part)) != ZKHIP_OK) return r;
+          HIPCHK(hipMemcpyPeerAsync(gather + mine[k] * 24, primary_dev, part, D->device, 96, ds));
+        }
+        HIPCHK(hipStreamSynchronize(ds));                 // the partials have landed on the primary device
+        return ZKHIP_OK;
+      });
+    }
+    int rc_local = ZKHIP_OK;
+    for (size_t i : by_dev[0]) {
+      const piece_t& p = pieces[i];
+      if ((rc_local = msm_shard_enqueue(sc, s, scalars + p.lo * 4, bases + p.lo * 8, p.n, p.pb, p.pb_off, gather + i * 24)) != ZKHIP_OK) break;
+    }
+    int rc_remote = ZKHIP_OK;
+    for (size_t d = 1; d < g_ctx.devs.size(); d++) {
+      if (by_dev[d].empty()) continue;
+      const int r = g_ctx.devs[d]->w->wait();
+      if (r != ZKHIP_OK) rc_remote = r;
+    }
+    if (rc_local != ZKHIP_OK) return rc_local;
+    if (rc_remote != ZKHIP_OK) return rc_remote;
+    // the remote partials were written by other devices' streams, which this thread has waited for; the fold is ordered behind
+    // the local pieces on the lane's stream
+    if ((rc = sum_jacobian_device(gather, (int)pieces.size(), (uint32_t*)sc->small.p, s)) != ZKHIP_OK) return rc;
   }
-  if (rc != ZKHIP_OK) return rc;
-  HIPCHK(hipMemcpyAsync(out_xyz, g_ctx.small.p, 96, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(H.L->pinned, sc->small.p, 96, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
+  memcpy(out_xyz, H.L->pinned, 96);
   return ZKHIP_OK;
 }
 
+}  // namespace zkhip
+
+extern "C" {
+
+int zkhip_msm_g1(const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t out_xyz[12]) {
+  if (!out_xyz || (n && (!scalars || !bases))) { set_error("msm: null pointer"); return ZKHIP_EINVAL; }
+  lane_hold H;
+  if (H.rc != ZKHIP_OK) return H.rc;
+  std::shared_ptr<registered_t> reg;
+  size_t off = 0;
+  if (n) { guard_t g(g_mu); reg = find_registered(bases, n, &off); }
+  return host_msm(H, scalars, bases, n, reg, off, out_xyz);
+}
+
 // `batch` scalar vectors (contiguous, n elements each) against the same bases; out: batch Jacobian points.
-// Registered bases: one batched launch set; otherwise one general-path MSM per vector.
+// Registered bases in one shard with a window <= 16 bits: one batched launch set; otherwise one MSM per vector.
 int zkhip_msm_g1_batch(const uint64_t* scalars, const uint64_t* bases, size_t n, size_t batch, uint64_t* out_xyz) {
-  guard_t g(g_mu);
-  int rc = ensure_init();
-  if (rc != ZKHIP_OK) return rc;
   if (!out_xyz || (n && batch && (!scalars || !bases))) { set_error("msm_batch: null pointer"); return ZKHIP_EINVAL; }
   if (batch == 0) return ZKHIP_OK;
+  lane_hold H;
+  if (H.rc != ZKHIP_OK) return H.rc;
+  int rc;
+  std::shared_ptr<registered_t> reg;
   size_t off = 0;
-  const prepared_bases* pb = n ? find_registered(bases, n, &off) : nullptr;
-  if (!pb || pb->c > 16) {
+  if (n) { guard_t g(g_mu); reg = find_registered(bases, n, &off); }
+  const shard_t* one = nullptr;
+  if (reg) for (auto& sh : reg->shards) if (sh.dev == 0 && off >= sh.lo && off + n <= sh.lo + sh.n) one = &sh;
+  if (!one || one->pb->c > 16 || batch * 96 > LANE_PINNED) {
     for (size_t k = 0; k < batch; k++)
-      if ((rc = zkhip_msm_g1(scalars + k * n * 4, bases, n, out_xyz + k * 12)) != ZKHIP_OK) return rc;
+      if ((rc = host_msm(H, scalars + k * n * 4, bases, n, reg, off, out_xyz + k * 12)) != ZKHIP_OK) return rc;
     return ZKHIP_OK;
   }
-  hipStream_t s = g_ctx.stream;
-  if ((rc = g_ctx.scalars.reserve(n * batch * 32)) != ZKHIP_OK) return rc;
-  if ((rc = g_ctx.small.reserve(4096 + batch * 96)) != ZKHIP_OK) return rc;
-  HIPCHK(hipMemcpyAsync(g_ctx.scalars.p, scalars, n * batch * 32, hipMemcpyHostToDevice, s));
-  // reuse the handle-based entry point through a temporary handle for the registered table
-  const uint64_t tmp_handle = g_ctx.next_handle++;
-  g_ctx.handles[tmp_handle] = const_cast<prepared_bases*>(pb);
-  rc = zkhip_msm_g1_prepared_batch_device(tmp_handle, off, g_ctx.scalars.p, n, batch, n, g_ctx.small.p, s);
-  g_ctx.handles.erase(tmp_handle);
+  hipStream_t s = H.s;
+  scratch* sc = H.sc;
+  if ((rc = sc->scalars.reserve(n * batch * 32)) != ZKHIP_OK) return rc;
+  if ((rc = sc->small.reserve(4096 + batch * 96)) != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(sc->scalars.p, scalars, n * batch * 32, hipMemcpyHostToDevice, s));
+  {
+    // reuse the handle-based entry point through a temporary handle for the registered table
+    guard_t g(g_mu);
+    const uint64_t tmp_handle = g_ctx.next_handle++;
+    g_ctx.handles[tmp_handle] = one->pb;
+    rc = zkhip_msm_g1_prepared_batch_device(tmp_handle, off - one->lo, sc->scalars.p, n, batch, n, sc->small.p, s);
+    g_ctx.handles.erase(tmp_handle);
+  }
   if (rc != ZKHIP_OK) return rc;
-  HIPCHK(hipMemcpyAsync(out_xyz, g_ctx.small.p, batch * 96, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(H.L->pinned, sc->small.p, batch * 96, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
+  memcpy(out_xyz, H.L->pinned, batch * 96);
   return ZKHIP_OK;
 }
 
 int zkhip_register_bases(const uint64_t* bases, size_t n) {
-  guard_t g(g_mu);
-  int rc = ensure_init();
-  if (rc != ZKHIP_OK) return rc;
   if (!bases || n == 0) { set_error("register_bases: empty"); return ZKHIP_EINVAL; }
-  if (g_ctx.registered.count(bases)) zkhip_unregister_bases(bases);
-  if ((rc = g_ctx.bases.reserve(n * 64)) != ZKHIP_OK) return rc;
-  HIPCHK(hipMemcpyAsync(g_ctx.bases.p, bases, n * 64, hipMemcpyHostToDevice, g_ctx.stream));
-  prepared_bases* pb = nullptr;
-  if ((rc = prepare_bases_device((const uint32_t*)g_ctx.bases.p, n, g_ctx.stream, &pb)) != ZKHIP_OK) return rc;
-  g_ctx.registered[bases] = pb;
+  {
+    guard_t g(g_mu);
+    int rc = ensure_init();
+    if (rc != ZKHIP_OK) return rc;
+    if (g_ctx.registered.count(bases)) zkhip_unregister_bases(bases);
+  }
+  lane_hold H;                                        // the primary device's uploads run on a borrowed lane
+  if (H.rc != ZKHIP_OK) return H.rc;
+  int S, ndev;
+  { guard_t g(g_mu); S = g_ctx.shards; ndev = (int)g_ctx.devs.size(); }
+  if ((size_t)S > n) S = (int)n;
+  auto reg = std::make_shared<registered_t>();
+  reg->host = bases;
+  reg->n = n;
+  for (int i = 0; i < FINGER_POINTS; i++) {
+    reg->finger_idx[i] = (size_t)((unsigned __int128)(n - 1) * (unsigned)i / (FINGER_POINTS - 1));
+    memcpy(reg->finger[i], bases + reg->finger_idx[i] * 8, 64);
+  }
+  int rc = ZKHIP_OK;
+  for (int s = 0; s < S && rc == ZKHIP_OK; s++) {
+    size_t lo, hi;
+    shard_range(n, s, S, &lo, &hi);
+    if (lo >= hi) continue;
+    const int di = s % ndev;
+    device_ctx* D = g_ctx.devs[(size_t)di];
+    hipStream_t ds = di == 0 ? H.s : D->lanes[0].stream;
+    scratch* dsc;
+    { guard_t g(g_mu); dsc = di == 0 ? H.sc : scratch_for(*D, ds); }
+    if (hipSetDevice(D->device) != hipSuccess) { set_error("hipSetDevice(%d) failed", D->device); rc = ZKHIP_ENODEV; break; }
+    shard_t sh;
+    sh.dev = di; sh.lo = lo; sh.n = hi - lo;
+    if ((rc = dsc->bases.reserve(sh.n * 64)) == ZKHIP_OK) {
+      if (hipMemcpyAsync(dsc->bases.p, bases + lo * 8, sh.n * 64, hipMemcpyHostToDevice, ds) != hipSuccess) { set_error("register_bases: upload failed"); rc = ZKHIP_EHIP; }
+      else rc = prepare_bases_device((const uint32_t*)dsc->bases.p, sh.n, ds, &sh.pb);
+    }
+    if (rc == ZKHIP_OK) reg->shards.push_back(sh);
+  }
+  (void)hipSetDevice(primary().device);
+  if (rc != ZKHIP_OK) return rc;                      // ~registered_t frees the shards built so far
+  guard_t g(g_mu);
+  g_ctx.registered[bases] = reg;
   return ZKHIP_OK;
+}
+
+int zkhip_unregister_bases(const uint64_t* bases) {
+  std::shared_ptr<registered_t> reg;
+  {
+    guard_t g(g_mu);
+    auto it = g_ctx.registered.find(bases);
+    if (it == g_ctx.registered.end()) { set_error("unregister_bases: pointer not registered"); return ZKHIP_EINVAL; }
+    reg = it->second;
+    g_ctx.registered.erase(it);
+    for (auto d : g_ctx.devs) { (void)hipSetDevice(d->device); (void)hipDeviceSynchronize(); }   // the tables may still be in use on a stream
+    (void)hipSetDevice(primary().device);
+  }
+  return ZKHIP_OK;                                    // a host call still running holds its own reference; the last one frees the tables
 }
 
 int zkhip_prepare_bases_device(const void* d_bases, size_t n, uint64_t* handle) {
@@ -263,7 +704,7 @@ int zkhip_prepare_bases_device_c(const void* d_bases, size_t n, int window_bits,
   if (!d_bases || !handle || n == 0) { set_error("prepare_bases: bad argument"); return ZKHIP_EINVAL; }
   prepared_bases* pb = nullptr;
   HIPCHK(hipDeviceSynchronize());           // d_bases may still be being written on the caller's stream; one-time call
-  if ((rc = prepare_bases_device((const uint32_t*)d_bases, n, g_ctx.stream, &pb, window_bits)) != ZKHIP_OK) return rc;
+  if ((rc = prepare_bases_device((const uint32_t*)d_bases, n, nullptr, &pb, window_bits)) != ZKHIP_OK) return rc;
   *handle = g_ctx.next_handle++;
   g_ctx.handles[*handle] = pb;
   return ZKHIP_OK;
@@ -294,19 +735,10 @@ int zkhip_msm_g1_prepared_device(uint64_t handle, size_t offset, const void* d_s
   if (it == g_ctx.handles.end()) { set_error("msm_prepared: unknown handle"); return ZKHIP_EINVAL; }
   if (!d_out_xyz || (n && !d_scalars)) { set_error("msm_prepared: null pointer"); return ZKHIP_EINVAL; }
   const prepared_bases* pb = it->second;
-  if ((rc = g_ctx.ws.reserve(n ? msm_workspace_bytes(n, pb->c, true) : 0)) != ZKHIP_OK) return rc;
-  return msm_g1_device((const uint32_t*)d_scalars, nullptr, n, (uint32_t*)d_out_xyz, g_ctx.ws.p, g_ctx.ws.cap, 0,
-                       caller_stream(stream), pb, offset);
-}
-
-int zkhip_unregister_bases(const uint64_t* bases) {
-  guard_t g(g_mu);
-  auto it = g_ctx.registered.find(bases);
-  if (it == g_ctx.registered.end()) { set_error("unregister_bases: pointer not registered"); return ZKHIP_EINVAL; }
-  (void)hipDeviceSynchronize();             // the table may still be in use on a caller's stream
-  release_prepared(it->second);
-  g_ctx.registered.erase(it);
-  return ZKHIP_OK;
+  hipStream_t s = caller_stream(stream);
+  scratch* sc = scratch_for(primary(), s);
+  if ((rc = sc->ws.reserve(msm_workspace_bytes(n, pb->c, true))) != ZKHIP_OK) return rc;
+  return msm_g1_device((const uint32_t*)d_scalars, nullptr, n, (uint32_t*)d_out_xyz, sc->ws.p, sc->ws.cap, 0, s, pb, offset);
 }
 
 int zkhip_msm_g1_prepared_batch_device(uint64_t handle, size_t offset, const void* d_scalars, size_t n, size_t batch, size_t scalar_stride,
@@ -319,13 +751,14 @@ int zkhip_msm_g1_prepared_batch_device(uint64_t handle, size_t offset, const voi
   if (!d_out_xyz || (n && batch && !d_scalars) || (batch > 1 && scalar_stride < n)) { set_error("msm_prepared_batch: bad argument"); return ZKHIP_EINVAL; }
   const prepared_bases* pb = it->second;
   hipStream_t s = caller_stream(stream);
+  scratch* sc = scratch_for(primary(), s);
   // tables built for wide windows (n >= 2^20) do not batch: those MSMs are throughput-bound one at a time
   size_t group = (pb->c > 16 || batch <= 1) ? 1 : batch;
   while (group > 1 && ((size_t)((256 + pb->c - 1) / pb->c) * n * group >= (1ull << 31) || (group << (pb->c - 1)) > (1ull << 22))) group = (group + 1) / 2;   // <= 4 Mi buckets per launch set
   for (size_t k0 = 0; k0 < batch; k0 += group) {
     const size_t kk = batch - k0 < group ? batch - k0 : group;
-    if ((rc = g_ctx.ws.reserve(n ? msm_workspace_bytes(n, pb->c, true, kk) : 0)) != ZKHIP_OK) return rc;
-    rc = msm_g1_device((const uint32_t*)d_scalars + k0 * scalar_stride * 8, nullptr, n, (uint32_t*)d_out_xyz + k0 * 24, g_ctx.ws.p, g_ctx.ws.cap, 0, s, pb,
+    if ((rc = sc->ws.reserve(msm_workspace_bytes(n, pb->c, true, kk))) != ZKHIP_OK) return rc;
+    rc = msm_g1_device((const uint32_t*)d_scalars + k0 * scalar_stride * 8, nullptr, n, (uint32_t*)d_out_xyz + k0 * 24, sc->ws.p, sc->ws.cap, 0, s, pb,
                        offset, kk, scalar_stride);
     if (rc != ZKHIP_OK) return rc;
   }
@@ -341,22 +774,27 @@ int zkhip_g1_sum_device(const void* d_points_xyz, int m, void* d_out_xyz, void* 
 }
 
 int zkhip_g1_sum(const uint64_t* points_xyz, int m, uint64_t out_xyz[12]) {
-  guard_t g(g_mu);
-  int rc = ensure_init();
-  if (rc != ZKHIP_OK) return rc;
   if (m < 0 || !out_xyz || (m && !points_xyz)) { set_error("g1_sum: bad argument"); return ZKHIP_EINVAL; }
-  if ((rc = g_ctx.small.reserve(4096 + (size_t)m * 96)) != ZKHIP_OK) return rc;
-  char* d = (char*)g_ctx.small.p;
-  if (m) HIPCHK(hipMemcpyAsync(d + 4096, points_xyz, (size_t)m * 96, hipMemcpyHostToDevice, g_ctx.stream));
-  if ((rc = sum_jacobian_device((const uint32_t*)(d + 4096), m, (uint32_t*)d, g_ctx.stream)) != ZKHIP_OK) return rc;
-  HIPCHK(hipMemcpyAsync(out_xyz, d, 96, hipMemcpyDeviceToHost, g_ctx.stream));
-  HIPCHK(hipStreamSynchronize(g_ctx.stream));
+  lane_hold H;
+  if (H.rc != ZKHIP_OK) return H.rc;
+  int rc;
+  if ((rc = H.sc->small.reserve(4096 + (size_t)m * 96)) != ZKHIP_OK) return rc;
+  char* d = (char*)H.sc->small.p;
+  if (m) HIPCHK(hipMemcpyAsync(d + 4096, points_xyz, (size_t)m * 96, hipMemcpyHostToDevice, H.s));
+  if ((rc = sum_jacobian_device((const uint32_t*)(d + 4096), m, (uint32_t*)d, H.s)) != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(H.L->pinned, d, 96, hipMemcpyDeviceToHost, H.s));
+  HIPCHK(hipStreamSynchronize(H.s));
+  memcpy(out_xyz, H.L->pinned, 96);
   return ZKHIP_OK;
 }
 
+}  // extern "C"
+
+namespace zkhip {
+
 // ---- NTT / domain ----------------------------------------------------------------------------------
-// runs ntt_transform with scratch from the context (two buffers of batch * 2^L elements when the transform is multi-pass)
-static int run_transform(const uint32_t* d_in, uint32_t in_len, uint32_t in_stride, uint32_t* d_out, uint32_t out_len, uint32_t out_stride,
+// runs ntt_transform with scratch from the stream's set (two buffers of batch * 2^L elements when the transform is multi-pass)
+static int run_transform(scratch* sc, const uint32_t* d_in, uint32_t in_len, uint32_t in_stride, uint32_t* d_out, uint32_t out_len, uint32_t out_stride,
                          uint32_t batch, uint32_t L, const uint32_t* omega, const uint32_t* in_scale, uint32_t in_period,
                          const uint32_t* out_scale, uint32_t out_period, hipStream_t s) {
   if (L > 28) { set_error("ntt: log_n = %u > 28", L); return ZKHIP_EINVAL; }
@@ -369,9 +807,9 @@ static int run_transform(const uint32_t* d_in, uint32_t in_len, uint32_t in_stri
   const size_t one = (size_t)sub << L;     // elements per scratch copy
   uint32_t *t0 = nullptr, *t1 = nullptr;
   if (np >= 2) {
-    int rc = g_ctx.ntt_tmp.reserve(one * 32 * (np >= 3 ? 2 : 1));
+    int rc = sc->ntt_tmp.reserve(one * 32 * (np >= 3 ? 2 : 1));
     if (rc != ZKHIP_OK) return rc;
-    t0 = (uint32_t*)g_ctx.ntt_tmp.p;
+    t0 = (uint32_t*)sc->ntt_tmp.p;
     if (np >= 3) t1 = t0 + one * 8;
   }
   for (uint32_t b0 = 0; b0 < batch; b0 += sub) {
@@ -383,14 +821,25 @@ static int run_transform(const uint32_t* d_in, uint32_t in_len, uint32_t in_stri
   return ZKHIP_OK;
 }
 
+// a `_device` transform on the caller's stream (g_mu held by the caller)
+static int device_transform(const void* d_in, uint32_t in_len, size_t in_stride, void* d_out, uint32_t out_len, size_t out_stride, uint32_t batch, uint32_t L,
+                            const uint64_t* omega, const uint32_t* in_scale, uint32_t in_period, const uint32_t* out_scale, uint32_t out_period, void* stream) {
+  hipStream_t s = caller_stream(stream);
+  return run_transform(scratch_for(primary(), s), (const uint32_t*)d_in, in_len, (uint32_t)in_stride, (uint32_t*)d_out, out_len, (uint32_t)out_stride, batch, L,
+                       (const uint32_t*)omega, in_scale, in_period, out_scale, out_period, s);
+}
+
+}  // namespace zkhip
+
+extern "C" {
+
 int zkhip_ntt_fr_batch_device(void* d_a, const uint64_t omega[4], uint32_t log_n, uint32_t batch, size_t stride, void* stream) {
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
   if (!d_a || !omega || log_n > 28 || stride < ((size_t)1 << log_n) || stride >= ((size_t)1 << 32)) { set_error("ntt_batch: bad argument"); return ZKHIP_EINVAL; }
   const uint32_t N = 1u << log_n;
-  return run_transform((const uint32_t*)d_a, N, (uint32_t)stride, (uint32_t*)d_a, N, (uint32_t)stride, batch, log_n, (const uint32_t*)omega, nullptr, 0,
-                       nullptr, 0, caller_stream(stream));
+  return device_transform(d_a, N, stride, d_a, N, stride, batch, log_n, omega, nullptr, 0, nullptr, 0, stream);
 }
 
 int zkhip_ifft_scaled_batch_device(void* d_a, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4], uint32_t batch, size_t stride,
@@ -400,8 +849,7 @@ int zkhip_ifft_scaled_batch_device(void* d_a, const uint64_t omega_inv[4], uint3
   if (rc != ZKHIP_OK) return rc;
   if (!d_a || !omega_inv || !divisor || log_n > 28 || stride < ((size_t)1 << log_n) || stride >= ((size_t)1 << 32)) { set_error("ifft_batch: bad argument"); return ZKHIP_EINVAL; }
   const uint32_t N = 1u << log_n;
-  return run_transform((const uint32_t*)d_a, N, (uint32_t)stride, (uint32_t*)d_a, N, (uint32_t)stride, batch, log_n, (const uint32_t*)omega_inv, nullptr, 0,
-                       (const uint32_t*)divisor, 1, caller_stream(stream));
+  return device_transform(d_a, N, stride, d_a, N, stride, batch, log_n, omega_inv, nullptr, 0, (const uint32_t*)divisor, 1, stream);
 }
 
 int zkhip_ntt_fr_device(void* d_a, const uint64_t omega[4], uint32_t log_n, void* stream) {
@@ -411,7 +859,7 @@ int zkhip_ntt_fr_device(void* d_a, const uint64_t omega[4], uint32_t log_n, void
   if (!d_a || !omega) { set_error("ntt: null pointer"); return ZKHIP_EINVAL; }
   if (log_n > 28) { set_error("ntt: log_n = %u > 28", log_n); return ZKHIP_EINVAL; }
   const uint32_t N = 1u << log_n;
-  return run_transform((const uint32_t*)d_a, N, N, (uint32_t*)d_a, N, N, 1, log_n, (const uint32_t*)omega, nullptr, 0, nullptr, 0, caller_stream(stream));
+  return device_transform(d_a, N, N, d_a, N, N, 1, log_n, omega, nullptr, 0, nullptr, 0, stream);
 }
 
 int zkhip_ifft_scaled_device(void* d_a, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4], void* stream) {
@@ -421,8 +869,7 @@ int zkhip_ifft_scaled_device(void* d_a, const uint64_t omega_inv[4], uint32_t lo
   if (!d_a || !omega_inv || !divisor) { set_error("ifft: null pointer"); return ZKHIP_EINVAL; }
   if (log_n > 28) { set_error("ifft: log_n = %u > 28", log_n); return ZKHIP_EINVAL; }
   const uint32_t N = 1u << log_n;
-  return run_transform((const uint32_t*)d_a, N, N, (uint32_t*)d_a, N, N, 1, log_n, (const uint32_t*)omega_inv, nullptr, 0, (const uint32_t*)divisor, 1,
-                       caller_stream(stream));
+  return device_transform(d_a, N, N, d_a, N, N, 1, log_n, omega_inv, nullptr, 0, (const uint32_t*)divisor, 1, stream);
 }
 
 int zkhip_mul_periodic_device(void* d_a, size_t n, const void* d_table, uint32_t period, void* stream) {
@@ -433,55 +880,67 @@ int zkhip_mul_periodic_device(void* d_a, size_t n, const void* d_table, uint32_t
   return fr_mul_periodic_device((uint32_t*)d_a, n, (const uint32_t*)d_table, period, caller_stream(stream));
 }
 
+}  // extern "C"
+
+namespace zkhip {
+
 static int host_transform(const uint64_t* in, size_t in_len, uint64_t* out, size_t out_len, uint32_t log_n, const uint64_t* omega,
                           const uint32_t* in_scale, uint32_t in_period, const uint32_t* out_scale, uint32_t out_period) {
-  int rc = ensure_init();
-  if (rc != ZKHIP_OK) return rc;
   if (log_n > 28) { set_error("ntt: log_n = %u > 28", log_n); return ZKHIP_EINVAL; }
   if (!in || !out || !omega) { set_error("ntt: null pointer"); return ZKHIP_EINVAL; }
   const size_t N = (size_t)1 << log_n;
   if (in_len > N || out_len > N) { set_error("ntt: length exceeds domain"); return ZKHIP_EINVAL; }
-  hipStream_t s = g_ctx.stream;
-  if ((rc = g_ctx.poly.reserve(N * 32)) != ZKHIP_OK) return rc;
-  HIPCHK(hipMemcpyAsync(g_ctx.poly.p, in, in_len * 32, hipMemcpyHostToDevice, s));
-  rc = run_transform((const uint32_t*)g_ctx.poly.p, (uint32_t)in_len, (uint32_t)N, (uint32_t*)g_ctx.poly.p, (uint32_t)out_len, (uint32_t)N, 1, log_n,
+  lane_hold H;
+  if (H.rc != ZKHIP_OK) return H.rc;
+  int rc;
+  hipStream_t s = H.s;
+  if ((rc = H.sc->poly.reserve(N * 32)) != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(H.sc->poly.p, in, in_len * 32, hipMemcpyHostToDevice, s));
+  rc = run_transform(H.sc, (const uint32_t*)H.sc->poly.p, (uint32_t)in_len, (uint32_t)N, (uint32_t*)H.sc->poly.p, (uint32_t)out_len, (uint32_t)N, 1, log_n,
                      (const uint32_t*)omega, in_scale, in_period, out_scale, out_period, s);
   if (rc != ZKHIP_OK) return rc;
-  HIPCHK(hipMemcpyAsync(out, g_ctx.poly.p, out_len * 32, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(out, H.sc->poly.p, out_len * 32, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   return ZKHIP_OK;
 }
 
+}  // namespace zkhip
+
+extern "C" {
+
 // `batch` contiguous polynomials of 2^log_n elements, transformed in place in one launch set
 int zkhip_ntt_fr_batch(uint64_t* a, const uint64_t omega[4], uint32_t log_n, uint32_t batch) {
-  guard_t g(g_mu);
-  int rc = ensure_init();
-  if (rc != ZKHIP_OK) return rc;
   if (!a || !omega || log_n > 28) { set_error("ntt_batch: bad argument"); return ZKHIP_EINVAL; }
   if (batch == 0) return ZKHIP_OK;
+  lane_hold H;
+  if (H.rc != ZKHIP_OK) return H.rc;
+  int rc;
   const size_t N = (size_t)1 << log_n, total = N * batch;
-  hipStream_t s = g_ctx.stream;
-  if ((rc = g_ctx.poly.reserve(total * 32)) != ZKHIP_OK) return rc;
-  HIPCHK(hipMemcpyAsync(g_ctx.poly.p, a, total * 32, hipMemcpyHostToDevice, s));
-  if ((rc = zkhip_ntt_fr_batch_device(g_ctx.poly.p, omega, log_n, batch, N, s)) != ZKHIP_OK) return rc;
-  HIPCHK(hipMemcpyAsync(a, g_ctx.poly.p, total * 32, hipMemcpyDeviceToHost, s));
+  if (N >= ((size_t)1 << 32)) { set_error("ntt_batch: bad argument"); return ZKHIP_EINVAL; }
+  hipStream_t s = H.s;
+  if ((rc = H.sc->poly.reserve(total * 32)) != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(H.sc->poly.p, a, total * 32, hipMemcpyHostToDevice, s));
+  if ((rc = run_transform(H.sc, (const uint32_t*)H.sc->poly.p, (uint32_t)N, (uint32_t)N, (uint32_t*)H.sc->poly.p, (uint32_t)N, (uint32_t)N, batch, log_n,
+                          (const uint32_t*)omega, nullptr, 0, nullptr, 0, s)) != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(a, H.sc->poly.p, total * 32, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   return ZKHIP_OK;
 }
 
 int zkhip_ntt_fr(uint64_t* a, const uint64_t omega[4], uint32_t log_n) {
-  guard_t g(g_mu);
   const size_t N = (size_t)1 << (log_n > 28 ? 0 : log_n);
   return host_transform(a, N, a, N, log_n, omega, nullptr, 0, nullptr, 0);
 }
 
 int zkhip_ifft_scaled(uint64_t* a, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4]) {
-  guard_t g(g_mu);
   if (!divisor) { set_error("ifft: null divisor"); return ZKHIP_EINVAL; }
   const size_t N = (size_t)1 << (log_n > 28 ? 0 : log_n);
   return host_transform(a, N, a, N, log_n, omega_inv, nullptr, 0, (const uint32_t*)divisor, 1);
 }
 
+}  // extern "C"
+
+namespace zkhip {
 // scale triples of the coset transforms, computed on the host (4 x 64 Montgomery, include/zkhip.hpp):
 //   into the coset:   {1, zeta, zeta^2}                      (distribute_powers_zeta(.., true): [g_coset, g_coset_inv])
 //   out of the coset: divisor * {1, zeta^2, zeta}            (distribute_powers_zeta(.., false) + the ifft divisor)
@@ -499,9 +958,11 @@ static void coset_scales(const uint64_t zeta[4], const uint64_t* divisor, uint32
     memcpy(out, c0.l, 32); memcpy(out + 8, c1.l, 32); memcpy(out + 16, c2.l, 32);
   }
 }
+}  // namespace zkhip
+
+extern "C" {
 
 int zkhip_coeff_to_extended(const uint64_t* a, uint32_t k, uint64_t* out, uint32_t ext_k, const uint64_t ext_omega[4], const uint64_t zeta[4]) {
-  guard_t g(g_mu);
   if (!a || !out || !ext_omega || !zeta || k > ext_k || ext_k > 28) { set_error("coeff_to_extended: bad argument"); return ZKHIP_EINVAL; }
   uint32_t sc[24];
   coset_scales(zeta, nullptr, sc);
@@ -510,7 +971,6 @@ int zkhip_coeff_to_extended(const uint64_t* a, uint32_t k, uint64_t* out, uint32
 
 int zkhip_extended_to_coeff(uint64_t* a, uint32_t ext_k, const uint64_t ext_omega_inv[4], const uint64_t ext_divisor[4],
                             const uint64_t zeta[4], uint64_t* out, size_t out_len) {
-  guard_t g(g_mu);
   if (!a || !out || !ext_omega_inv || !ext_divisor || !zeta || ext_k > 28) { set_error("extended_to_coeff: bad argument"); return ZKHIP_EINVAL; }
   uint32_t sc[24];
   coset_scales(zeta, ext_divisor, sc);
@@ -528,8 +988,7 @@ int zkhip_coeff_to_extended_device(const void* d_a, size_t a_stride, uint32_t k,
   if (batch == 0) return ZKHIP_OK;
   uint32_t sc[24];
   coset_scales(zeta, nullptr, sc);
-  return run_transform((const uint32_t*)d_a, 1u << k, (uint32_t)a_stride, (uint32_t*)d_out, 1u << ext_k, (uint32_t)out_stride, batch, ext_k,
-                       (const uint32_t*)ext_omega, sc, 3, nullptr, 0, caller_stream(stream));
+  return device_transform(d_a, 1u << k, a_stride, d_out, 1u << ext_k, out_stride, batch, ext_k, ext_omega, sc, 3, nullptr, 0, stream);
 }
 
 int zkhip_extended_to_coeff_device(const void* d_a, size_t a_stride, uint32_t ext_k, const uint64_t ext_omega_inv[4], const uint64_t ext_divisor[4],
@@ -542,23 +1001,22 @@ int zkhip_extended_to_coeff_device(const void* d_a, size_t a_stride, uint32_t ex
   if (batch == 0 || out_len == 0) return ZKHIP_OK;
   uint32_t sc[24];
   coset_scales(zeta, ext_divisor, sc);
-  return run_transform((const uint32_t*)d_a, 1u << ext_k, (uint32_t)a_stride, (uint32_t*)d_out, (uint32_t)out_len, (uint32_t)out_stride, batch, ext_k,
-                       (const uint32_t*)ext_omega_inv, nullptr, 0, sc, 3, caller_stream(stream));
+  return device_transform(d_a, 1u << ext_k, a_stride, d_out, (uint32_t)out_len, out_stride, batch, ext_k, ext_omega_inv, nullptr, 0, sc, 3, stream);
 }
 
 int zkhip_mul_periodic(uint64_t* a, size_t n, const uint64_t* table, uint32_t period) {
-  guard_t g(g_mu);
-  int rc = ensure_init();
-  if (rc != ZKHIP_OK) return rc;
   if ((n && !a) || !table || period == 0) { set_error("mul_periodic: bad argument"); return ZKHIP_EINVAL; }
   if (n == 0) return ZKHIP_OK;
-  hipStream_t s = g_ctx.stream;
-  if ((rc = g_ctx.poly.reserve(n * 32)) != ZKHIP_OK) return rc;
-  if ((rc = g_ctx.poly2.reserve((size_t)period * 32)) != ZKHIP_OK) return rc;
-  HIPCHK(hipMemcpyAsync(g_ctx.poly.p, a, n * 32, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(g_ctx.poly2.p, table, (size_t)period * 32, hipMemcpyHostToDevice, s));
-  if ((rc = fr_mul_periodic_device((uint32_t*)g_ctx.poly.p, n, (const uint32_t*)g_ctx.poly2.p, period, s)) != ZKHIP_OK) return rc;
-  HIPCHK(hipMemcpyAsync(a, g_ctx.poly.p, n * 32, hipMemcpyDeviceToHost, s));
+  lane_hold H;
+  if (H.rc != ZKHIP_OK) return H.rc;
+  int rc;
+  hipStream_t s = H.s;
+  if ((rc = H.sc->poly.reserve(n * 32)) != ZKHIP_OK) return rc;
+  if ((rc = H.sc->poly2.reserve((size_t)period * 32)) != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(H.sc->poly.p, a, n * 32, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(H.sc->poly2.p, table, (size_t)period * 32, hipMemcpyHostToDevice, s));
+  if ((rc = fr_mul_periodic_device((uint32_t*)H.sc->poly.p, n, (const uint32_t*)H.sc->poly2.p, period, s)) != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(a, H.sc->poly.p, n * 32, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   return ZKHIP_OK;
 }
@@ -569,9 +1027,10 @@ int zkhip_fr_eval_polynomial_device(const void* d_poly, size_t n, const uint64_t
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
   if (!point || !d_out || (n && !d_poly)) { set_error("eval_polynomial: null pointer"); return ZKHIP_EINVAL; }
-  if ((rc = g_ctx.ws.reserve(poly_workspace_bytes(n))) != ZKHIP_OK) return rc;
-  return fr_eval_polynomial_device((const uint32_t*)d_poly, n, (const uint32_t*)point, (uint32_t*)d_out, g_ctx.ws.p, g_ctx.ws.cap,
-                                   caller_stream(stream));
+  hipStream_t s = caller_stream(stream);
+  scratch* sc = scratch_for(primary(), s);
+  if ((rc = sc->ws.reserve(poly_workspace_bytes(n))) != ZKHIP_OK) return rc;
+  return fr_eval_polynomial_device((const uint32_t*)d_poly, n, (const uint32_t*)point, (uint32_t*)d_out, sc->ws.p, sc->ws.cap, s);
 }
 
 int zkhip_fr_eval_polynomial_batch_device(const void* const* d_polys, size_t count, size_t n, const uint64_t point[4], void* d_out, void* stream) {
@@ -581,9 +1040,10 @@ int zkhip_fr_eval_polynomial_batch_device(const void* const* d_polys, size_t cou
   if (count && (!d_polys || !point || !d_out)) { set_error("eval_polynomial_batch: null pointer"); return ZKHIP_EINVAL; }
   for (size_t i = 0; i < count && n; i++)
     if (!d_polys[i]) { set_error("eval_polynomial_batch: polynomial %zu is null", i); return ZKHIP_EINVAL; }
-  if ((rc = g_ctx.ws.reserve(poly_batch_workspace_bytes(n, count))) != ZKHIP_OK) return rc;
-  return fr_eval_polynomial_batch_device(d_polys, count, n, (const uint32_t*)point, (uint32_t*)d_out, g_ctx.ws.p, g_ctx.ws.cap,
-                                         caller_stream(stream));
+  hipStream_t s = caller_stream(stream);
+  scratch* sc = scratch_for(primary(), s);
+  if ((rc = sc->ws.reserve(poly_batch_workspace_bytes(n, count))) != ZKHIP_OK) return rc;
+  return fr_eval_polynomial_batch_device(d_polys, count, n, (const uint32_t*)point, (uint32_t*)d_out, sc->ws.p, sc->ws.cap, s);
 }
 
 int zkhip_fr_kate_division_device(const void* d_a, size_t n, const uint64_t b[4], void* d_q, void* stream) {
@@ -591,9 +1051,10 @@ int zkhip_fr_kate_division_device(const void* d_a, size_t n, const uint64_t b[4]
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
   if (!b || (n > 1 && (!d_a || !d_q))) { set_error("kate_division: null pointer"); return ZKHIP_EINVAL; }
-  if ((rc = g_ctx.ws.reserve(poly_workspace_bytes(n))) != ZKHIP_OK) return rc;
-  return fr_kate_division_device((const uint32_t*)d_a, n, (const uint32_t*)b, (uint32_t*)d_q, g_ctx.ws.p, g_ctx.ws.cap,
-                                 caller_stream(stream));
+  hipStream_t s = caller_stream(stream);
+  scratch* sc = scratch_for(primary(), s);
+  if ((rc = sc->ws.reserve(poly_workspace_bytes(n))) != ZKHIP_OK) return rc;
+  return fr_kate_division_device((const uint32_t*)d_a, n, (const uint32_t*)b, (uint32_t*)d_q, sc->ws.p, sc->ws.cap, s);
 }
 
 int zkhip_fr_batch_invert_device(void* d_a, size_t n, void* stream) {
@@ -601,8 +1062,10 @@ int zkhip_fr_batch_invert_device(void* d_a, size_t n, void* stream) {
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
   if (n && !d_a) { set_error("batch_invert: null pointer"); return ZKHIP_EINVAL; }
-  if ((rc = g_ctx.ws.reserve(poly_workspace_bytes(n))) != ZKHIP_OK) return rc;
-  return fr_batch_invert_device((uint32_t*)d_a, n, g_ctx.ws.p, g_ctx.ws.cap, caller_stream(stream));
+  hipStream_t s = caller_stream(stream);
+  scratch* sc = scratch_for(primary(), s);
+  if ((rc = sc->ws.reserve(poly_workspace_bytes(n))) != ZKHIP_OK) return rc;
+  return fr_batch_invert_device((uint32_t*)d_a, n, sc->ws.p, sc->ws.cap, s);
 }
 
 int zkhip_fr_prefix_product_device(const void* d_v, size_t n, void* d_out, void* stream) {
@@ -610,52 +1073,57 @@ int zkhip_fr_prefix_product_device(const void* d_v, size_t n, void* d_out, void*
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
   if (n && (!d_v || !d_out)) { set_error("prefix_product: null pointer"); return ZKHIP_EINVAL; }
-  if ((rc = g_ctx.ws.reserve(poly_workspace_bytes(n))) != ZKHIP_OK) return rc;
-  return fr_prefix_product_device((const uint32_t*)d_v, n, (uint32_t*)d_out, g_ctx.ws.p, g_ctx.ws.cap, caller_stream(stream));
+  hipStream_t s = caller_stream(stream);
+  scratch* sc = scratch_for(primary(), s);
+  if ((rc = sc->ws.reserve(poly_workspace_bytes(n))) != ZKHIP_OK) return rc;
+  return fr_prefix_product_device((const uint32_t*)d_v, n, (uint32_t*)d_out, sc->ws.p, sc->ws.cap, s);
 }
 
-// host-buffer wrappers: upload to the poly scratch, run, download
+}  // extern "C"
+
+namespace zkhip {
+// host-buffer wrappers: upload to the lane's poly scratch, run on the lane's stream, download
 static int host_vec_op(int op, const uint64_t* in, size_t n_in, const uint64_t* c, uint64_t* out, size_t n_out) {
-  int rc = ensure_init();
-  if (rc != ZKHIP_OK) return rc;
-  hipStream_t s = g_ctx.stream;
-  if ((rc = g_ctx.poly.reserve((n_in + 1) * 32)) != ZKHIP_OK) return rc;
-  if ((rc = g_ctx.poly2.reserve((n_out + 1) * 32)) != ZKHIP_OK) return rc;
-  if (n_in) HIPCHK(hipMemcpyAsync(g_ctx.poly.p, in, n_in * 32, hipMemcpyHostToDevice, s));
+  lane_hold H;
+  if (H.rc != ZKHIP_OK) return H.rc;
+  int rc;
+  hipStream_t s = H.s;
+  if ((rc = H.sc->poly.reserve((n_in + 1) * 32)) != ZKHIP_OK) return rc;
+  if ((rc = H.sc->poly2.reserve((n_out + 1) * 32)) != ZKHIP_OK) return rc;
+  if (n_in) HIPCHK(hipMemcpyAsync(H.sc->poly.p, in, n_in * 32, hipMemcpyHostToDevice, s));
   switch (op) {
-    case 0: rc = zkhip_fr_eval_polynomial_device(g_ctx.poly.p, n_in, c, g_ctx.poly2.p, s); break;
-    case 1: rc = zkhip_fr_kate_division_device(g_ctx.poly.p, n_in, c, g_ctx.poly2.p, s); break;
-    case 2: rc = zkhip_fr_batch_invert_device(g_ctx.poly.p, n_in, s); break;
-    default: rc = zkhip_fr_prefix_product_device(g_ctx.poly.p, n_in, g_ctx.poly2.p, s); break;
+    case 0: rc = zkhip_fr_eval_polynomial_device(H.sc->poly.p, n_in, c, H.sc->poly2.p, s); break;
+    case 1: rc = zkhip_fr_kate_division_device(H.sc->poly.p, n_in, c, H.sc->poly2.p, s); break;
+    case 2: rc = zkhip_fr_batch_invert_device(H.sc->poly.p, n_in, s); break;
+    default: rc = zkhip_fr_prefix_product_device(H.sc->poly.p, n_in, H.sc->poly2.p, s); break;
   }
   if (rc != ZKHIP_OK) return rc;
-  if (n_out) HIPCHK(hipMemcpyAsync(out, op == 2 ? g_ctx.poly.p : g_ctx.poly2.p, n_out * 32, hipMemcpyDeviceToHost, s));
+  if (n_out) HIPCHK(hipMemcpyAsync(out, op == 2 ? H.sc->poly.p : H.sc->poly2.p, n_out * 32, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   return ZKHIP_OK;
 }
+}  // namespace zkhip
+
+extern "C" {
 
 int zkhip_fr_eval_polynomial(const uint64_t* poly, size_t n, const uint64_t point[4], uint64_t out[4]) {
-  guard_t g(g_mu);
   if (!point || !out || (n && !poly)) { set_error("eval_polynomial: null pointer"); return ZKHIP_EINVAL; }
   return host_vec_op(0, poly, n, point, out, 1);
 }
 
 int zkhip_fr_kate_division(const uint64_t* a, size_t n, const uint64_t b[4], uint64_t* q) {
-  guard_t g(g_mu);
   if (!b || (n > 1 && (!a || !q))) { set_error("kate_division: null pointer"); return ZKHIP_EINVAL; }
   if (n < 2) return ZKHIP_OK;
   return host_vec_op(1, a, n, b, q, n - 1);
 }
 
 int zkhip_fr_batch_invert(uint64_t* a, size_t n) {
-  guard_t g(g_mu);
   if (n && !a) { set_error("batch_invert: null pointer"); return ZKHIP_EINVAL; }
   if (n == 0) return ZKHIP_OK;
   return host_vec_op(2, a, n, nullptr, a, n);
 }
 
 int zkhip_fr_prefix_product(const uint64_t* v, size_t n, uint64_t* out) {
-  guard_t g(g_mu);
   if (n && (!v || !out)) { set_error("prefix_product: null pointer"); return ZKHIP_EINVAL; }
   if (n == 0) return ZKHIP_OK;
   return host_vec_op(3, v, n, nullptr, out, n);
@@ -669,23 +1137,25 @@ int zkhip_lookup_permute_device(const void* d_input, const void* d_table, size_t
   if (rc != ZKHIP_OK) return rc;
   if (usable_rows && (!d_input || !d_table || !d_permuted_input || !d_permuted_table)) { set_error("lookup_permute: null pointer"); return ZKHIP_EINVAL; }
   if (usable_rows == 0) return ZKHIP_OK;
-  if ((rc = g_ctx.vm.reserve(lookup_permute_workspace_bytes(usable_rows))) != ZKHIP_OK) return rc;
+  hipStream_t s = caller_stream(stream);
+  scratch* sc = scratch_for(primary(), s);
+  if ((rc = sc->vm.reserve(lookup_permute_workspace_bytes(usable_rows))) != ZKHIP_OK) return rc;
   return lookup_permute_device((const uint32_t*)d_input, (const uint32_t*)d_table, usable_rows, (uint32_t*)d_permuted_input,
-                               (uint32_t*)d_permuted_table, g_ctx.vm.p, g_ctx.vm.cap, caller_stream(stream));
+                               (uint32_t*)d_permuted_table, sc->vm.p, sc->vm.cap, s);
 }
 
 int zkhip_lookup_permute(const uint64_t* input, const uint64_t* table, size_t usable_rows, uint64_t* permuted_input, uint64_t* permuted_table) {
-  guard_t g(g_mu);
-  int rc = ensure_init();
-  if (rc != ZKHIP_OK) return rc;
   if (usable_rows && (!input || !table || !permuted_input || !permuted_table)) { set_error("lookup_permute: null pointer"); return ZKHIP_EINVAL; }
   if (usable_rows == 0) return ZKHIP_OK;
+  lane_hold H;
+  if (H.rc != ZKHIP_OK) return H.rc;
+  int rc;
   const size_t bytes = usable_rows * 32;
-  hipStream_t s = g_ctx.stream;
-  if ((rc = g_ctx.poly.reserve(2 * bytes)) != ZKHIP_OK) return rc;
-  if ((rc = g_ctx.poly2.reserve(2 * bytes)) != ZKHIP_OK) return rc;
-  char* in = (char*)g_ctx.poly.p;
-  char* out = (char*)g_ctx.poly2.p;
+  hipStream_t s = H.s;
+  if ((rc = H.sc->poly.reserve(2 * bytes)) != ZKHIP_OK) return rc;
+  if ((rc = H.sc->poly2.reserve(2 * bytes)) != ZKHIP_OK) return rc;
+  char* in = (char*)H.sc->poly.p;
+  char* out = (char*)H.sc->poly2.p;
   HIPCHK(hipMemcpyAsync(in, input, bytes, hipMemcpyHostToDevice, s));
   HIPCHK(hipMemcpyAsync(in + bytes, table, bytes, hipMemcpyHostToDevice, s));
   if ((rc = zkhip_lookup_permute_device(in, in + bytes, usable_rows, out, out + bytes, s)) != ZKHIP_OK) return rc;
@@ -718,9 +1188,7 @@ int zkhip_free(void* d_ptr) {
 }
 
 int zkhip_upload(void* d_dst, const void* src, size_t bytes) {
-  guard_t g(g_mu);
-  int rc = ensure_init();
-  if (rc != ZKHIP_OK) return rc;
+  { guard_t g(g_mu); int rc = ensure_init(); if (rc != ZKHIP_OK) return rc; }
   if (bytes && (!d_dst || !src)) { set_error("upload: null pointer"); return ZKHIP_EINVAL; }
   if (bytes == 0) return ZKHIP_OK;
   HIPCHK(hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));      // default stream, blocking
@@ -728,9 +1196,7 @@ int zkhip_upload(void* d_dst, const void* src, size_t bytes) {
 }
 
 int zkhip_download(void* dst, const void* d_src, size_t bytes) {
-  guard_t g(g_mu);
-  int rc = ensure_init();
-  if (rc != ZKHIP_OK) return rc;
+  { guard_t g(g_mu); int rc = ensure_init(); if (rc != ZKHIP_OK) return rc; }
   if (bytes && (!dst || !d_src)) { set_error("download: null pointer"); return ZKHIP_EINVAL; }
   if (bytes == 0) return ZKHIP_OK;
   HIPCHK(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
@@ -738,9 +1204,7 @@ int zkhip_download(void* dst, const void* d_src, size_t bytes) {
 }
 
 int zkhip_sync(void) {
-  guard_t g(g_mu);
-  int rc = ensure_init();
-  if (rc != ZKHIP_OK) return rc;
+  { guard_t g(g_mu); int rc = ensure_init(); if (rc != ZKHIP_OK) return rc; }
   HIPCHK(hipDeviceSynchronize());
   return ZKHIP_OK;
 }
@@ -753,31 +1217,32 @@ int zkhip_fr_eval_rows_device(const zkhip_vm_program* prog, const void* const* d
   if (rc != ZKHIP_OK) return rc;
   if ((rc = row_vm_validate(prog, n_columns, log_rows, accumulate)) != ZKHIP_OK) return rc;
   if (!d_out || (n_columns && !d_columns)) { set_error("eval_rows: null pointer"); return ZKHIP_EINVAL; }
-  if ((rc = g_ctx.vm.reserve(row_vm_workspace_bytes(prog, n_columns, log_rows))) != ZKHIP_OK) return rc;
-  return row_vm_device(prog, d_columns, n_columns, log_rows, accumulate, (uint32_t*)d_out, g_ctx.vm.p, g_ctx.vm.cap,
-                       caller_stream(stream));
+  hipStream_t s = caller_stream(stream);
+  scratch* sc = scratch_for(primary(), s);
+  if ((rc = sc->vm.reserve(row_vm_workspace_bytes(prog, n_columns, log_rows))) != ZKHIP_OK) return rc;
+  return row_vm_device(prog, d_columns, n_columns, log_rows, accumulate, (uint32_t*)d_out, sc->vm.p, sc->vm.cap, s);
 }
 
 int zkhip_fr_eval_rows(const zkhip_vm_program* prog, const uint64_t* const* columns, uint32_t n_columns, uint32_t log_rows,
                        int accumulate, uint64_t* out) {
-  guard_t g(g_mu);
-  int rc = ensure_init();
-  if (rc != ZKHIP_OK) return rc;
+  int rc;
   if ((rc = row_vm_validate(prog, n_columns, log_rows, accumulate)) != ZKHIP_OK) return rc;
   if (!out || (n_columns && !columns)) { set_error("eval_rows: null pointer"); return ZKHIP_EINVAL; }
+  lane_hold H;
+  if (H.rc != ZKHIP_OK) return H.rc;
   const size_t rows = (size_t)1 << log_rows, bytes = rows * 32;
-  hipStream_t s = g_ctx.stream;
-  if ((rc = g_ctx.poly.reserve((size_t)(n_columns ? n_columns : 1) * bytes)) != ZKHIP_OK) return rc;
-  if ((rc = g_ctx.poly2.reserve(bytes)) != ZKHIP_OK) return rc;
+  hipStream_t s = H.s;
+  if ((rc = H.sc->poly.reserve((size_t)(n_columns ? n_columns : 1) * bytes)) != ZKHIP_OK) return rc;
+  if ((rc = H.sc->poly2.reserve(bytes)) != ZKHIP_OK) return rc;
   std::vector<const void*> d_cols(n_columns);
   for (uint32_t i = 0; i < n_columns; i++) {
     if (!columns[i]) { set_error("eval_rows: column %u is null", i); return ZKHIP_EINVAL; }
-    d_cols[i] = (char*)g_ctx.poly.p + (size_t)i * bytes;
+    d_cols[i] = (char*)H.sc->poly.p + (size_t)i * bytes;
     HIPCHK(hipMemcpyAsync((void*)d_cols[i], columns[i], bytes, hipMemcpyHostToDevice, s));
   }
-  if (accumulate) HIPCHK(hipMemcpyAsync(g_ctx.poly2.p, out, bytes, hipMemcpyHostToDevice, s));
-  if ((rc = zkhip_fr_eval_rows_device(prog, d_cols.data(), n_columns, log_rows, accumulate, g_ctx.poly2.p, s)) != ZKHIP_OK) return rc;
-  HIPCHK(hipMemcpyAsync(out, g_ctx.poly2.p, bytes, hipMemcpyDeviceToHost, s));
+  if (accumulate) HIPCHK(hipMemcpyAsync(H.sc->poly2.p, out, bytes, hipMemcpyHostToDevice, s));
+  if ((rc = zkhip_fr_eval_rows_device(prog, d_cols.data(), n_columns, log_rows, accumulate, H.sc->poly2.p, s)) != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(out, H.sc->poly2.p, bytes, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   return ZKHIP_OK;
 }
@@ -795,18 +1260,18 @@ int zkhip_fr_grand_product_device(const void* d_num, void* d_den, size_t n, void
 }
 
 int zkhip_fr_grand_product(const uint64_t* num, const uint64_t* den, size_t n, uint64_t* z) {
-  guard_t g(g_mu);
-  int rc = ensure_init();
-  if (rc != ZKHIP_OK) return rc;
   if (n && (!num || !den || !z)) { set_error("grand_product: null pointer"); return ZKHIP_EINVAL; }
   if (n == 0) return ZKHIP_OK;
-  hipStream_t s = g_ctx.stream;
-  if ((rc = g_ctx.poly.reserve(n * 32)) != ZKHIP_OK) return rc;
-  if ((rc = g_ctx.poly2.reserve(n * 32)) != ZKHIP_OK) return rc;
-  HIPCHK(hipMemcpyAsync(g_ctx.poly.p, num, n * 32, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(g_ctx.poly2.p, den, n * 32, hipMemcpyHostToDevice, s));
-  if ((rc = zkhip_fr_grand_product_device(g_ctx.poly.p, g_ctx.poly2.p, n, g_ctx.poly.p, s)) != ZKHIP_OK) return rc;
-  HIPCHK(hipMemcpyAsync(z, g_ctx.poly.p, n * 32, hipMemcpyDeviceToHost, s));
+  lane_hold H;
+  if (H.rc != ZKHIP_OK) return H.rc;
+  int rc;
+  hipStream_t s = H.s;
+  if ((rc = H.sc->poly.reserve(n * 32)) != ZKHIP_OK) return rc;
+  if ((rc = H.sc->poly2.reserve(n * 32)) != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(H.sc->poly.p, num, n * 32, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(H.sc->poly2.p, den, n * 32, hipMemcpyHostToDevice, s));
+  if ((rc = zkhip_fr_grand_product_device(H.sc->poly.p, H.sc->poly2.p, n, H.sc->poly.p, s)) != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(z, H.sc->poly.p, n * 32, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   return ZKHIP_OK;
 }
@@ -838,13 +1303,16 @@ int zkhip_g1_fixed_base_mul_device(const void* d_scalars, size_t n, void* d_out,
   if (n && (!d_scalars || !d_out)) { set_error("fixed_base_mul: null pointer"); return ZKHIP_EINVAL; }
   if (n == 0) return ZKHIP_OK;
   hipStream_t s = caller_stream(stream);
-  if ((rc = g_ctx.ws.reserve(g1_fixed_base_workspace(n))) != ZKHIP_OK) return rc;
-  if (!g_ctx.fixed_table_ready) {              // one-time: 16 windows x 2^15 multiples of the generator (32 MiB)
-    if ((rc = g_ctx.fixed_table.reserve(g1_fixed_base_table_bytes())) != ZKHIP_OK) return rc;
-    if ((rc = g1_fixed_base_table_build((uint32_t*)g_ctx.fixed_table.p, g_ctx.ws.p, g_ctx.ws.cap, s)) != ZKHIP_OK) return rc;
-    g_ctx.fixed_table_ready = true;
+  scratch* sc = scratch_for(primary(), s);
+  device_ctx& P = primary();
+  if ((rc = sc->ws.reserve(g1_fixed_base_workspace(n))) != ZKHIP_OK) return rc;
+  if (!P.fixed_table_ready) {              // one-time: 16 windows x 2^15 multiples of the generator (32 MiB), shared by every stream
+    if ((rc = P.fixed_table.reserve(g1_fixed_base_table_bytes())) != ZKHIP_OK) return rc;
+    if ((rc = g1_fixed_base_table_build((uint32_t*)P.fixed_table.p, sc->ws.p, sc->ws.cap, s)) != ZKHIP_OK) return rc;
+    HIPCHK(hipStreamSynchronize(s));
+    P.fixed_table_ready = true;
   }
-  return g1_fixed_base_mul_device((const uint32_t*)d_scalars, n, (const uint32_t*)g_ctx.fixed_table.p, (uint32_t*)d_out, g_ctx.ws.p, g_ctx.ws.cap, s);
+  return g1_fixed_base_mul_device((const uint32_t*)d_scalars, n, (const uint32_t*)P.fixed_table.p, (uint32_t*)d_out, sc->ws.p, sc->ws.cap, s);
 }
 
 int zkhip_g1_fft_device(void* d_points_xyz, const uint64_t omega[4], uint32_t log_n, void* stream) {
@@ -854,9 +1322,10 @@ int zkhip_g1_fft_device(void* d_points_xyz, const uint64_t omega[4], uint32_t lo
   if (!d_points_xyz || !omega) { set_error("g1_fft: null pointer"); return ZKHIP_EINVAL; }
   if (log_n > 26) { set_error("g1_fft: log_n = %u out of range", log_n); return ZKHIP_EINVAL; }
   const size_t n = (size_t)1 << log_n;
-  if ((rc = g_ctx.ws.reserve(g1_fft_workspace(n))) != ZKHIP_OK) return rc;
-  return g1_fft_device((const uint32_t*)d_points_xyz, 1, (uint32_t*)d_points_xyz, 1, log_n, (const uint32_t*)omega, nullptr, g_ctx.ws.p, g_ctx.ws.cap,
-                       caller_stream(stream));
+  hipStream_t s = caller_stream(stream);
+  scratch* sc = scratch_for(primary(), s);
+  if ((rc = sc->ws.reserve(g1_fft_workspace(n))) != ZKHIP_OK) return rc;
+  return g1_fft_device((const uint32_t*)d_points_xyz, 1, (uint32_t*)d_points_xyz, 1, log_n, (const uint32_t*)omega, nullptr, sc->ws.p, sc->ws.cap, s);
 }
 
 int zkhip_g_to_lagrange_device(const void* d_g, uint32_t k, void* d_g_lagrange, void* stream) {
@@ -867,13 +1336,14 @@ int zkhip_g_to_lagrange_device(const void* d_g, uint32_t k, void* d_g_lagrange, 
   if (d_g == d_g_lagrange) { set_error("g_to_lagrange: the arrays may not alias"); return ZKHIP_EINVAL; }
   if (k > 26) { set_error("g_to_lagrange: k = %u out of range", k); return ZKHIP_EINVAL; }
   const size_t n = (size_t)1 << k;
-  if ((rc = g_ctx.ws.reserve(g1_fft_workspace(n))) != ZKHIP_OK) return rc;
+  hipStream_t s = caller_stream(stream);
+  scratch* sc = scratch_for(primary(), s);
+  if ((rc = sc->ws.reserve(g1_fft_workspace(n))) != ZKHIP_OK) return rc;
   namespace H = zkhip::halo2;
   H::Fr omega = H::fr_root_of_unity();
   for (uint32_t i = k; i < 28; i++) omega = H::detail::mul(omega, omega);
   const H::Fr omega_inv = H::detail::invert(omega), n_inv = H::detail::invert(H::detail::from_u64((uint64_t)n));
-  return g1_fft_device((const uint32_t*)d_g, 0, (uint32_t*)d_g_lagrange, 0, k, (const uint32_t*)omega_inv.l, (const uint32_t*)n_inv.l, g_ctx.ws.p,
-                       g_ctx.ws.cap, caller_stream(stream));
+  return g1_fft_device((const uint32_t*)d_g, 0, (uint32_t*)d_g_lagrange, 0, k, (const uint32_t*)omega_inv.l, (const uint32_t*)n_inv.l, sc->ws.p, sc->ws.cap, s);
 }
 
 int zkhip_g1_gen_walk_device(const uint64_t t0[4], const uint64_t d[4], size_t n, void* d_out, void* stream) {
@@ -881,50 +1351,45 @@ int zkhip_g1_gen_walk_device(const uint64_t t0[4], const uint64_t d[4], size_t n
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
   if (!t0 || !d || (n && !d_out)) { set_error("gen_walk: null pointer"); return ZKHIP_EINVAL; }
-  if ((rc = g_ctx.ws.reserve(g1_gen_walk_workspace(n))) != ZKHIP_OK) return rc;
-  return g1_gen_walk_device((const uint32_t*)t0, (const uint32_t*)d, n, (uint32_t*)d_out, g_ctx.ws.p, g_ctx.ws.cap,
-                            caller_stream(stream));
+  hipStream_t s = caller_stream(stream);
+  scratch* sc = scratch_for(primary(), s);
+  if ((rc = sc->ws.reserve(g1_gen_walk_workspace(n))) != ZKHIP_OK) return rc;
+  return g1_gen_walk_device((const uint32_t*)t0, (const uint32_t*)d, n, (uint32_t*)d_out, sc->ws.p, sc->ws.cap, s);
 }
 
 // ---- parity hooks ----------------------------------------------------------------------------------
 int zkhip_test_field_op(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
-  guard_t g(g_mu);
-  int rc = ensure_init();
-  if (rc != ZKHIP_OK) return rc;
   if (field < 0 || field > 1 || op < 0 || op > 3 || (n && (!a || !b || !out))) { set_error("test_field_op: bad argument"); return ZKHIP_EINVAL; }
   if (n == 0) return ZKHIP_OK;
-  hipStream_t s = g_ctx.stream;
-  dev_buf tmp;
-  if ((rc = tmp.reserve(n * 96)) != ZKHIP_OK) return rc;
-  char* d = (char*)tmp.p;
-  hipError_t e = hipMemcpyAsync(d, a, n * 32, hipMemcpyHostToDevice, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(d + n * 32, b, n * 32, hipMemcpyHostToDevice, s);
-  if (e == hipSuccess) rc = test_field_op(field, op, (uint32_t*)d, (uint32_t*)(d + n * 32), (uint32_t*)(d + n * 64), n, s);
-  if (e == hipSuccess && rc == ZKHIP_OK) e = hipMemcpyAsync(out, d + n * 64, n * 32, hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);
-  tmp.release();
-  if (e != hipSuccess) { set_error("test_field_op: %s", hipGetErrorString(e)); return ZKHIP_EHIP; }
-  return rc;
+  lane_hold H;
+  if (H.rc != ZKHIP_OK) return H.rc;
+  int rc;
+  hipStream_t s = H.s;
+  if ((rc = H.sc->poly.reserve(n * 96)) != ZKHIP_OK) return rc;
+  char* d = (char*)H.sc->poly.p;
+  HIPCHK(hipMemcpyAsync(d, a, n * 32, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d + n * 32, b, n * 32, hipMemcpyHostToDevice, s));
+  if ((rc = test_field_op(field, op, (uint32_t*)d, (uint32_t*)(d + n * 32), (uint32_t*)(d + n * 64), n, s)) != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(out, d + n * 64, n * 32, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return ZKHIP_OK;
 }
 
 int zkhip_test_g1_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out_xyz, size_t n) {
-  guard_t g(g_mu);
-  int rc = ensure_init();
-  if (rc != ZKHIP_OK) return rc;
   if (op < 0 || op > 4 || (n && (!a || !b || !out_xyz))) { set_error("test_g1_op: bad argument"); return ZKHIP_EINVAL; }
   if (n == 0) return ZKHIP_OK;
-  hipStream_t s = g_ctx.stream;
-  dev_buf tmp;
-  if ((rc = tmp.reserve(n * (64 + 64 + 96))) != ZKHIP_OK) return rc;
-  char* d = (char*)tmp.p;
-  hipError_t e = hipMemcpyAsync(d, a, n * 64, hipMemcpyHostToDevice, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(d + n * 64, b, n * 64, hipMemcpyHostToDevice, s);
-  if (e == hipSuccess) rc = test_g1_op(op, (uint32_t*)d, (uint32_t*)(d + n * 64), (uint32_t*)(d + n * 128), n, s);
-  if (e == hipSuccess && rc == ZKHIP_OK) e = hipMemcpyAsync(out_xyz, d + n * 128, n * 96, hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);
-  tmp.release();
-  if (e != hipSuccess) { set_error("test_g1_op: %s", hipGetErrorString(e)); return ZKHIP_EHIP; }
-  return rc;
+  lane_hold H;
+  if (H.rc != ZKHIP_OK) return H.rc;
+  int rc;
+  hipStream_t s = H.s;
+  if ((rc = H.sc->poly.reserve(n * (64 + 64 + 96))) != ZKHIP_OK) return rc;
+  char* d = (char*)H.sc->poly.p;
+  HIPCHK(hipMemcpyAsync(d, a, n * 64, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d + n * 64, b, n * 64, hipMemcpyHostToDevice, s));
+  if ((rc = test_g1_op(op, (uint32_t*)d, (uint32_t*)(d + n * 64), (uint32_t*)(d + n * 128), n, s)) != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(out_xyz, d + n * 128, n * 96, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return ZKHIP_OK;
 }
 
 }  // extern "C"

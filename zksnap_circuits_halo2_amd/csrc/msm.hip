@@ -1203,7 +1203,12 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   if (chunks == 0) chunks = 1;
   const uint32_t chunk = (uint32_t)((((n + chunks - 1) / chunks) + 7) & ~(size_t)7);   // multiple of 8 (vector loads)
   const size_t lds = wide ? ((size_t)4 << FINE_BITS) : (size_t)B * sizeof(uint32_t);
-  static bool attr_set = false;
+  // function attributes belong to the device's copy of the kernel: once per device (callers serialise the enqueue: capi.hip g_mu;
+  // the worker threads of a sharded MSM touch distinct devices)
+  static bool attr_set_dev[64] = {};
+  int cur_dev = 0;
+  HIPCHK(hipGetDevice(&cur_dev));
+  bool& attr_set = attr_set_dev[cur_dev & 63];
   if (!attr_set) {
     HIPCHK(hipFuncSetAttribute((const void*)k_sort_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)k_sort_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));

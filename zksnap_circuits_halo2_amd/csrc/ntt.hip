@@ -460,10 +460,17 @@ int ntt_transform(const uint32_t* d_in, uint32_t in_len, uint32_t in_stride, uin
     HIPCHK(hipGetLastError());
     return ZKHIP_OK;
   }
-  static std::once_flag attr_once;
-  std::call_once(attr_once, [] {
-    (void)hipFuncSetAttribute((const void*)k_ntt_pass, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_LDS_WORDS * 4);
-  });
+  {
+    static std::mutex attr_mu;
+    static bool attr_set_dev[64] = {};
+    int cur_dev = 0;
+    HIPCHK(hipGetDevice(&cur_dev));
+    std::lock_guard<std::mutex> ag(attr_mu);
+    if (!attr_set_dev[cur_dev & 63]) {
+      HIPCHK(hipFuncSetAttribute((const void*)k_ntt_pass, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_LDS_WORDS * 4));
+      attr_set_dev[cur_dev & 63] = true;
+    }
+  }
   const uint32_t tile = N < NTT_TILE ? N : NTT_TILE;
   if ((p->npass >= 2 && !tmp0) || (p->npass >= 3 && !tmp1)) { set_error("ntt: missing scratch buffer"); return ZKHIP_EINVAL; }
   uint32_t* tmp[2] = {tmp0, tmp1};
