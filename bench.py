@@ -168,21 +168,32 @@ def main() -> None:
         lib.zkhip_profile_enable(0)
         # arbitrary (unregistered) bases: per-window bucket sets + window fold
         if gen:
+            # the equal-work replacement of best_multiexp (arbitrary, unregistered bases: per-window bucket sets + window fold), next to the
+            # headline, which is the ParamsKZG::commit case (bases fixed per params object -> prepared table built once, outside the timed region)
+            result["value_general_path"] = round(n / sum(gen.values()) / 1e3, 2)
             result["general_path"] = {"ms": round(sum(gen.values()), 4), "Mpoints_per_s": round(n / sum(gen.values()) / 1e3, 2),
-                                      "phases_ms": {k: round(v, 4) for k, v in gen.items()}}
+                                      "phases_ms": {k: round(v, 4) for k, v in gen.items()},
+                                      "note": "in-library HIP events around one call, bases device-resident but not prepared"}
         _lib.check(lib.zkhip_msm_g1_prepared_device(handle, 0, d_scalars.data_ptr(), n, d_out.data_ptr(), stream))
         torch.cuda.synchronize()
         t_acc = acc.get("accumulate", float("nan"))
         alg_bytes = 96.0 * n                                       # 64 B affine base + 32 B scalar per point
         achieved = alg_bytes / (t_acc * 1e-3) / 1e9
-        traffic = None
-        try:   # PMC-measured HBM bytes of this kernel at this size (collected in separate rocprofv3 --pmc passes, committed)
+        traffic, traffic_source = None, None
+        try:   # PMC-measured HBM bytes of this kernel at this size: NOT measured by this run -- collected in separate rocprofv3 --pmc passes of
+               # this same command (tools/collect_profiles.sh) and committed; the file names the commit it was collected at
             if args.log_n == 20:
-                traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["k_accumulate"]["hbm_bytes_per_launch"]
+                for cand in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+                    path = os.path.join(ROOT, "profiles", cand)
+                    if os.path.exists(path):
+                        rec = json.load(open(path))
+                        traffic = rec["k_accumulate"]["hbm_bytes_per_launch"]
+                        traffic_source = f"profiles/{cand}@{rec.get('commit', 'round-1 head')} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch; a committed constant, not a live counter)"
+                        break
         except Exception:
-            traffic = None
+            traffic, traffic_source = None, None
         result["roofline"] = {"bound": "hbm", "kernel": "k_accumulate", "achieved": round(achieved, 2), "peak": 8000.0,
-                              "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic,
+                              "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": traffic_source,
                               "avg_launch_ms": round(t_acc, 4), "algorithmic_bytes_per_launch": alg_bytes,
                               "whole_msm_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / 8000.0, 5),
                               "note": "256-bit modular-integer work: ALU-bound, not HBM-bound (DESIGN.md)"}
@@ -197,6 +208,18 @@ def main() -> None:
                                    "note": "the other 31% of the loop body's 2130 instructions (carry shifts, masks, limb adds) share the same issue slots"}
         result["phases_ms"] = {k: round(v, 4) for k, v in acc.items()}
 
+    # ---- BASELINE configs[4]: the wrapper circuit at k + 2 (2^24 points) sharded over the GPUs of the node -------------------------
+    # N > 1: every rank takes 2^24 / N points (2^21 at N = 8) -- the stated config, next to the weak-scaling headline above.
+    # N = 1: the same 2^24-point MSM through the C ABI's own multi-GPU path with 8 virtual shards of 2^21 points on the one card.
+    if not args.no_extras:
+        try:
+            c4 = config4_leg(lib, _lib, F, torch, dist, dev, stream, rank, world, gather_fold_device)
+            if rank == 0:
+                result["config4_wrapper_k24_msm"] = c4
+        except Exception as exc:   # an extra: never fail the bench line
+            if rank == 0:
+                result["config4_wrapper_k24_msm"] = {"error": repr(exc)}
+
     if rank == 0 and world == 1 and not args.no_extras:
         result.update(extras(lib, _lib, F, torch, dev, stream))
 
@@ -207,6 +230,110 @@ def main() -> None:
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def config4_leg(lib, _lib, F, torch, dist, dev, stream, rank, world, gather_fold_device) -> dict:
+    """BASELINE configs[4] (wrapper_circuit at bench-k + 2: one 2^24-point MSM over the node's GPUs, partial sums exchanged and folded).
+    world > 1: strong-scaling leg -- rank g holds points [g n / N, (g + 1) n / N) of the 2^24 (device-resident, prepared), the step is its
+    MSM + the all_gather(96 B) + fold, timed like the headline (barrier + synchronize on both sides, max over ranks).
+    world == 1: the C ABI's multi-GPU path rehearsed on one card: zkhip_set_msm_shards(8), zkhip_register_bases on the 2^24-point SRS
+    (eight tables of 2^21 points), zkhip_msm_g1 with host scalars (PCIe-inclusive: this is the host-buffer boundary) and, for the
+    kernel-side number, the eight shard MSMs + fold device-resident."""
+    total = 1 << 24
+    per = total // world
+    T0, D = 0x5A4B534E41500002 + 424242, 0x9E3779B97F4A7C15F39CC0605CEDC835
+    dd = F.fr_encode([D])[0]
+    steps = 5
+    if world > 1:
+        t0 = F.fr_encode([(T0 + rank * per * D) % F.R_MOD])[0]
+        g = torch.empty(per * 8, dtype=torch.int64, device=dev)
+        _lib.check(lib.zkhip_g1_gen_walk_device(t0.ctypes.data, dd.ctypes.data, per, g.data_ptr(), stream))
+        torch.cuda.synchronize()
+        h = C.c_uint64(0)
+        _lib.check(lib.zkhip_prepare_bases_device(g.data_ptr(), per, C.byref(h)))
+        sc = torch.from_numpy(synth_scalars(per, 0x5A4B534E41500103 + rank).view(np.int64)).to(dev)
+        part = torch.zeros(12, dtype=torch.int64, device=dev)
+        gat = torch.zeros(12 * world, dtype=torch.int64, device=dev)
+        fin = torch.zeros(12, dtype=torch.int64, device=dev)
+
+        def step():
+            _lib.check(lib.zkhip_msm_g1_prepared_device(h, 0, sc.data_ptr(), per, part.data_ptr(), stream))
+            gather_fold_device(part, gat, fin, stream)
+
+        step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        el = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device=dev)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        ms = float(el.item()) / steps * 1e3
+        lib.zkhip_release_bases(h)
+        return {"workload": f"BASELINE configs[4]: 2^24-point MSM, 2^{per.bit_length() - 1} points per GPU x {world} GPUs, all_gather(96 B) + fold, device-resident",
+                "scaling": "strong", "ms_per_msm": round(ms, 4), "Mpoints_per_s": round(total / ms / 1e3, 1), "steps": steps}
+    # one card: 8 virtual shards through the C ABI
+    g = torch.empty(total * 8, dtype=torch.int64, device=dev)
+    t0 = F.fr_encode([T0])[0]
+    _lib.check(lib.zkhip_g1_gen_walk_device(t0.ctypes.data, dd.ctypes.data, total, g.data_ptr(), stream))
+    torch.cuda.synchronize()
+    h_g = g.cpu().numpy().view(np.uint64).reshape(total, 8).copy()
+    h_sc = synth_scalars(total, 0x5A4B534E41500103)
+    out = np.zeros(12, dtype=np.uint64)
+    res = {"workload": "BASELINE configs[4] rehearsed on one card: 2^24-point MSM as 8 virtual shards of 2^21 points (zkhip_set_msm_shards(8) + "
+                       "zkhip_register_bases + zkhip_msm_g1: per-shard tables, per-shard Pippenger, gather of the 96-byte partials, fold)"}
+    _lib.check(lib.zkhip_set_msm_shards(8))
+    try:
+        t = time.perf_counter()
+        _lib.check(lib.zkhip_register_bases(h_g.ctypes.data, total))
+        res["register_bases_s_one_time"] = round(time.perf_counter() - t, 3)
+        _lib.check(lib.zkhip_msm_g1(h_sc.ctypes.data, h_g.ctypes.data, total, out.ctypes.data))
+        t = time.perf_counter()
+        for _ in range(3):
+            _lib.check(lib.zkhip_msm_g1(h_sc.ctypes.data, h_g.ctypes.data, total, out.ctypes.data))
+        ms_host = (time.perf_counter() - t) / 3 * 1e3
+        res["host_buffers_ms_per_msm"] = round(ms_host, 2)        # scalars cross PCIe (512 MiB per call)
+        res["host_buffers_Mpoints_per_s"] = round(total / ms_host / 1e3, 1)
+    finally:
+        lib.zkhip_unregister_bases(h_g.ctypes.data)
+        lib.zkhip_set_msm_shards(0)
+    del h_g
+    # kernel side of the same partition: eight prepared shards, device-resident scalars, partials folded on the device
+    per = total // 8
+    hs = []
+    for s_i in range(8):
+        hh = C.c_uint64(0)
+        _lib.check(lib.zkhip_prepare_bases_device(g.data_ptr() + s_i * per * 64, per, C.byref(hh)))
+        hs.append(hh)
+    sc = torch.from_numpy(h_sc.view(np.int64)).to(dev)
+    parts = torch.zeros(12 * 8, dtype=torch.int64, device=dev)
+    fin = torch.zeros(12, dtype=torch.int64, device=dev)
+
+    def step():
+        for s_i in range(8):
+            _lib.check(lib.zkhip_msm_g1_prepared_device(hs[s_i], 0, sc.data_ptr() + s_i * per * 32, per, parts.data_ptr() + s_i * 96, stream))
+        _lib.check(lib.zkhip_g1_sum_device(parts.data_ptr(), 8, fin.data_ptr(), stream))
+
+    step()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t) / 3 * 1e3
+    same = F.g1_decode_jacobian(fin.cpu().numpy().view(np.uint64)[:12]) == F.g1_decode_jacobian(out)
+    for hh in hs:
+        lib.zkhip_release_bases(hh)
+    res.update({"device_resident_ms_per_msm": round(ms, 3), "device_resident_Mpoints_per_s": round(total / ms / 1e3, 1),
+                "per_shard_ms": round(ms / 8, 3), "host_and_device_paths_agree": bool(same),
+                "note": "on 8 GPUs the eight shards run concurrently: expected time ~ per_shard_ms + exchange; measured on one card here"})
+    del g, sc
+    torch.cuda.empty_cache()
+    return res
 
 
 def extras(lib, _lib, F, torch, dev, stream) -> dict:
@@ -234,7 +361,26 @@ def extras(lib, _lib, F, torch, dev, stream) -> dict:
         ms = timed(lambda: _lib.check(lib.zkhip_ntt_fr_device(a.data_ptr(), om.ctypes.data, L, stream)), 5)
         ntt[f"2^{L}"] = {"ms": round(ms, 4), "Melem_per_s": round(N / ms / 1e3, 1),
                          "hbm_frac_algorithmic": round(64.0 * N / (ms * 1e-3) / 8e12, 5)}
+        # per-pass durations of the same transform: HIP events the library drops on the launch stream between its passes
+        lib.zkhip_profile_enable(1)
+        per_pass = {}
+        for _ in range(3):
+            _lib.check(lib.zkhip_ntt_fr_device(a.data_ptr(), om.ctypes.data, L, stream))
+            for name, t_ms in profile_read(lib):
+                per_pass[name] = per_pass.get(name, 0.0) + t_ms / 3
+        lib.zkhip_profile_enable(0)
+        ntt[f"2^{L}"]["passes_ms"] = {kk: round(v, 4) for kk, v in per_pass.items()}
     out["ntt"] = ntt
+    # roofline object of the NTT's kernel (64 B per element per transform, one 32-byte read and one 32-byte write;
+    # a pass moves N x 32 B in and N x 32 B out, PMC-confirmed, so a transform of p passes has p x 64 B per element of traffic)
+    p24 = ntt["2^24"]["passes_ms"]
+    if p24:
+        avg_pass = sum(p24.values()) / len(p24)
+        out["roofline_ntt"] = {"bound": "hbm", "kernel": "k_ntt_pass", "workload": "NTT 2^24 (three passes)", "avg_pass_ms": round(avg_pass, 4),
+                               "algorithmic_bytes_per_launch": 64.0 * (1 << 24), "achieved": round(64.0 * (1 << 24) / (avg_pass * 1e-3) / 1e9, 1),
+                               "peak": 8000.0, "unit": "GB/s", "frac": round(64.0 * (1 << 24) / (avg_pass * 1e-3) / 1e9 / 8000.0, 4),
+                               "whole_transform_frac": ntt["2^24"]["hbm_frac_algorithmic"],
+                               "note": "per launch = one pass over the 2^24 elements (N x 32 B read + N x 32 B written); the kernel is bound by VALU issue (254-bit modular multiplies), DESIGN.md section 4"}
 
     k = 22
     n = 1 << k
@@ -463,31 +609,72 @@ def small_replays(lib, _lib, F, torch, dev, stream, timed) -> dict:
 
 
 def cpu_baseline(log_n, d_scalars, d_bases, d_out, n) -> dict:
-    """The reference's algorithm (oracle/cpu_ref.c restatement of best_multiexp) on the host cores, same inputs."""
+    """The reference's algorithm (oracle/cpu_ref.c: restatement of halo2-axiom's best_multiexp / best_fft, since `cargo bench`
+    cannot run in this pipeline: /root/reference/README.md:64-73 names the commands being stood in for) on the host cores of the
+    GPU box.  `value` is the 2^20 MSM at T = the cores this process may use (scheduler affinity capped by the cgroup CPU quota:
+    what rayon's default pool would be sized to); a thread sweep and the NTT / wrapper-shape rows of BASELINE.md section 3 follow."""
     from oracle import cpu_ref as Cr
 
-    threads = os.cpu_count() or 1
+    from zksnap_circuits_halo2_amd import fields as F
+
+    usable = Cr.usable_cores()
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None
+    try:
+        quota = open("/sys/fs/cgroup/cpu.max").read().strip()
+    except OSError:
+        quota = None
     log_s = min(log_n, 20)
     m = 1 << log_s
     sc = np.ascontiguousarray(d_scalars.cpu().numpy().view(np.uint64).reshape(-1, 4)[:m])
     bs = np.ascontiguousarray(d_bases.cpu().numpy().view(np.uint64).reshape(-1, 8)[:m])
-    t = time.perf_counter()
-    ref = Cr.best_multiexp(sc, bs, threads)
-    dt = time.perf_counter() - t
+
+    def msm_s(s_, b_, t_):
+        t = time.perf_counter()
+        r = Cr.best_multiexp(s_, b_, t_)
+        return time.perf_counter() - t, r
+
+    dt, ref = msm_s(sc, bs, usable)
     agree = None
     if m == n:
         got = d_out.cpu().numpy().view(np.uint64)[:12]
         agree = bool(np.array_equal(Cr.jac_to_affine(np.ascontiguousarray(got)), Cr.jac_to_affine(ref)))
-    # one host thread (SURVEY.md 8(d): "plus a T=1 run"), on a 2^17-point prefix of the same inputs
+    # thread sweep on the same 2^20 inputs (one thread: a 2^17 prefix, scaled per point)
+    sweep = {}
     m1 = min(m, 1 << 17)
-    t = time.perf_counter()
-    Cr.best_multiexp(np.ascontiguousarray(sc[:m1]), np.ascontiguousarray(bs[:m1]), 1)
-    dt1 = time.perf_counter() - t
-    return {"value": round(m / dt / 1e6, 4), "unit": "Mpoints/s", "cores": threads, "kind": "port",
-            "sample": f"one 2^{log_s}-point MSM, same inputs as the GPU run, {threads} threads, {dt:.2f} s wall",
-            "gpu_result_matches": agree,
-            "single_thread": {"value": round(m1 / dt1 / 1e6, 5), "unit": "Mpoints/s", "cores": 1,
-                              "sample": f"one 2^{m1.bit_length() - 1}-point MSM, {dt1:.2f} s wall"}}
+    dt1, _ = msm_s(np.ascontiguousarray(sc[:m1]), np.ascontiguousarray(bs[:m1]), 1)
+    sweep["1"] = {"Mpoints_per_s": round(m1 / dt1 / 1e6, 5), "sample": f"2^{m1.bit_length() - 1} points, {dt1:.2f} s"}
+    for t_ in sorted({8, 16, 32, 64, usable, os.cpu_count() or usable}):
+        if t_ == usable:
+            sweep[str(t_)] = {"Mpoints_per_s": round(m / dt / 1e6, 4), "sample": f"2^{log_s} points, {dt:.2f} s"}
+            continue
+        d_, _ = msm_s(sc, bs, t_)
+        sweep[str(t_)] = {"Mpoints_per_s": round(m / d_ / 1e6, 4), "sample": f"2^{log_s} points, {d_:.2f} s"}
+    # NTT rows (best_fft restatement, T = usable) and the wrapper-shape op mix, extrapolated from one op of each kind
+    ntt = {}
+    for L in (22, 24):
+        a = synth_scalars(1 << L, 4000 + L)
+        om = F.fr_encode([F.omega_for(L)])[0]
+        t = time.perf_counter()
+        Cr.best_fft(a, om, L, usable)
+        ntt[f"2^{L}"] = {"s": round(time.perf_counter() - t, 3), "threads": usable}
+        del a
+    m22 = 1 << 22
+    sc22 = synth_scalars(m22, 4100)
+    reps = m22 // m
+    dt22 = 0.0
+    for r in range(reps):        # 2^22-point MSM = best_multiexp over 4 x the 2^20 bases (the chunk-per-thread structure makes its time linear in n at fixed window size; c moves from 12 to 13)
+        d_, _ = msm_s(np.ascontiguousarray(sc22[r * m:(r + 1) * m]), bs, usable)
+        dt22 += d_
+    mix = 18 * dt22 + 13 * ntt["2^22"]["s"] + 14 * ntt["2^24"]["s"]
+    return {"value": round(m / dt / 1e6, 4), "unit": "Mpoints/s", "cores": usable, "kind": "port",
+            "sample": f"one 2^{log_s}-point MSM (the GPU run's inputs), oracle/cpu_ref.c best_multiexp with {usable} threads, {dt:.2f} s wall",
+            "cores_usable": usable, "sched_affinity": affinity, "cgroup_cpu_max": quota, "os_cpu_count": os.cpu_count(),
+            "gpu_result_matches": agree, "thread_sweep_msm_2^20": sweep, "ntt_best_fft": ntt,
+            "msm_2^22_s": round(dt22, 3),
+            "wrapper_shape_mix": {"s": round(mix, 2), "proofs_per_s_msm_ntt_portion": round(1.0 / mix, 4),
+                                  "how": "18 x (2^22 MSM, timed as 4 x 2^20) + 13 x (2^22 best_fft) + 14 x (2^24 best_fft), one op of each kind timed and multiplied",
+                                  "note": "restatement of the reference's CPU algorithms, not `cargo bench`: no witness generation, no transcript, and the 4x64 field multiply here is plain C (halo2curves uses assembly, roughly 2x faster per multiply)"},
+            "note": "a reported baseline, not the target: the roofline fraction above is what describes the kernel"}
 
 
 if __name__ == "__main__":
