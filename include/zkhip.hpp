@@ -403,8 +403,9 @@ class ParamsKZG {
     out.write(reinterpret_cast<const char*>(s_g2_.data()), 128);
     if (!out) throw std::runtime_error("ParamsKZG::write: stream error");
   }
-  // points are taken as they are (the reference's RawBytesUnchecked); the Python mirror's reader samples curve membership
-  static ParamsKZG read(std::istream& in) {
+  // `check` (default): every point of both tables is verified on the GPU (zkhip_g1_check_points), as the reference's
+  // SerdeFormat::RawBytes reader does; false = RawBytesUnchecked
+  static ParamsKZG read(std::istream& in, bool check = true) {
     uint32_t k = 0;
     in.read(reinterpret_cast<char*>(&k), 4);
     if (!in || k > 28) throw std::runtime_error("ParamsKZG::read: not a RawBytes KZG parameter file");
@@ -416,6 +417,13 @@ class ParamsKZG {
     in.read(reinterpret_cast<char*>(g2.data()), 128);
     in.read(reinterpret_cast<char*>(s_g2.data()), 128);
     if (!in) throw std::runtime_error("ParamsKZG::read: truncated file");
+    if (check) {
+      uint64_t bad = 0;
+      detail::check(zkhip_g1_check_points(reinterpret_cast<const uint64_t*>(g.data()), (size_t)n, &bad), "zkhip_g1_check_points");
+      if (bad < n) throw std::runtime_error("ParamsKZG::read: g holds a point that is not on the curve");
+      detail::check(zkhip_g1_check_points(reinterpret_cast<const uint64_t*>(gl.data()), (size_t)n, &bad), "zkhip_g1_check_points");
+      if (bad < n) throw std::runtime_error("ParamsKZG::read: g_lagrange holds a point that is not on the curve");
+    }
     ParamsKZG p(k, std::move(g), std::move(gl));
     p.set_g2(g2, s_g2);
     return p;

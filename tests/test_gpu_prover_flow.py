@@ -160,3 +160,96 @@ def test_device_resident_prover_flow(lib, k, gate_cols):
     assert not bad["quotient_is_a_polynomial"] and bad["permutation_product_closes"] and bad["commit_lagrange_equals_commit_coeff"]
     bad = prove_flow.run(k, gate_cols, seed=5 + k, corrupt="copy", verbose=False)["checks"]
     assert not bad["quotient_is_a_polynomial"] and not bad["permutation_product_closes"]
+
+
+# ---------------------------------------------------------------- keygen_vk / keygen_pk, ProvingKey files
+def test_keygen_against_the_oracle(lib, cref):
+    """keygen.py on the toy circuit: sigma columns = the cycles' delta^col * omega^row; the verifying key's commitments = the oracle's
+    MSM of the Lagrange columns; fixed_polys / fixed_cosets / permutation cosets = the oracle's `lagrange_to_coeff` / `coeff_to_extended`;
+    l_active_row = 1 - (l_last + l_blind) on the extended coset, the formula `keygen_pk` [DEP plonk/keygen.rs] evaluates"""
+    from zksnap_circuits_halo2_amd import keygen as KG
+
+    rng = random.Random(31)
+    circ = toy_circuit(rng)
+    cs = E.ConstraintSystem(num_fixed=3, num_advice=2, gates=[[E.Fixed(0) * (E.Advice(0, 0) + E.Advice(0, 1) * E.Advice(0, 2) - E.Advice(0, 3))]],
+                            lookups=[E.Lookup([E.Advice(1)], [E.Fixed(2)])], permutation_columns=PERM_COLUMNS, blinding_factors=BLIND, degree=4)
+    asm = KG.Assembly(N, 3)
+    for cyc in [[(0, 1), (2, 2)], [(1, 10), (1, 20)], [(0, 13), (1, 30)], [(0, 17), (0, 21), (2, 5)]]:
+        for (c1, r1), (c2, r2) in zip(cyc, cyc[1:]):
+            asm.copy(c1, r1, c2, r2)
+    fixed = [enc(c) for c in circ["fixed"]]
+    with Z.ParamsKZG.setup(K, 0xC0FFEE) as params:
+        vk = KG.keygen_vk(params, cs, fixed, asm)
+        pk = KG.keygen_pk(params, vk, cs, fixed, asm)
+        gl = params.g_lagrange.copy()
+    for c in range(3):
+        assert F.fr_decode(pk.permutations[c]) == circ["sigma"][c], c
+    for cols, commits in ((fixed, vk.fixed_commitments), (pk.permutations, vk.permutation_commitments)):
+        for col, cm in zip(cols, commits):
+            assert np.array_equal(cm, cref.jac_to_affine(cref.best_multiexp(np.ascontiguousarray(col), gl, 2)))
+    dom = Z.EvaluationDomain(4, K)
+
+    def to_coeff(col):
+        a = np.ascontiguousarray(col).copy()
+        cref.best_fft(a, dom.omega_inv, K, 1)
+        cref.scale(a, dom.ifft_divisor)
+        return a
+
+    def to_ext(coeff):
+        ext = np.zeros((dom.extended_len(), 4), dtype=np.uint64)
+        ext[:N] = coeff
+        cref.distribute_powers_zeta(ext[:N], dom.g_coset, dom.g_coset_inv)
+        cref.best_fft(ext, dom.extended_omega, dom.extended_k, 1)
+        return ext
+
+    for lag, poly, coset in list(zip(fixed, pk.fixed_polys, pk.fixed_cosets)) + list(zip(pk.permutations, pk.permutation_polys, pk.permutation_cosets)):
+        assert np.array_equal(poly, to_coeff(lag))
+        assert np.array_equal(coset, to_ext(poly))
+    ind = lambda rows: enc([1 if i in rows else 0 for i in range(N)])
+    assert np.array_equal(pk.l0, to_ext(to_coeff(ind({0}))))
+    l_last, l_blind = to_ext(to_coeff(ind({U}))), to_ext(to_coeff(ind(set(range(U + 1, N)))))
+    assert np.array_equal(pk.l_last, l_last)
+    want = [(1 - a - b) % R for a, b in zip(F.fr_decode(l_last), F.fr_decode(l_blind))]
+    assert F.fr_decode(pk.l_active_row) == want
+
+
+@pytest.mark.parametrize("k,gate_cols", [(7, 1), (10, 3)])
+def test_prover_flow_from_a_proving_key_file(lib, tmp_path, k, gate_cols):
+    """keygen -> `ProvingKey::write(RawBytesUnchecked)` -> `ProvingKey::read` -> the prover runs on the key that was READ (what the
+    reference's wrapper does through build/*_pk.bin: /root/reference/aggregator/src/wrapper.rs:967-989, :1007-1034); the prover's
+    invariants hold, and still break with the witness"""
+    from tools import prove_flow
+
+    path = str(tmp_path / "toy_pk.bin")
+    res = prove_flow.run(k, gate_cols, seed=40 + k, verbose=False, pk_file=path)
+    assert all(res["checks"].values()), res["checks"]
+    n, en, nf, npc = 1 << k, 1 << (k + 2), gate_cols + 2, gate_cols + 2
+    want = (8 + nf * 64 + npc * 64) + 3 * (4 + en * 32) + 2 * (4 + nf * (4 + n * 32)) + (4 + nf * (4 + en * 32)) + 2 * (4 + npc * (4 + n * 32)) + (4 + npc * (4 + en * 32))
+    assert res["pk_file_bytes"] == want
+    bad = prove_flow.run(k, gate_cols, seed=40 + k, corrupt="copy", verbose=False, pk_file=path)["checks"]
+    assert not bad["quotient_is_a_polynomial"] and not bad["permutation_product_closes"]
+
+
+def test_params_file_reader_checks_every_point(lib, cref, tmp_path):
+    """`ParamsKZG::read` (SerdeFormat::RawBytes) verifies every point: one off-curve point anywhere in either table is refused by the
+    default reader (a GPU pass over the whole file), found at its index, and accepted only by the explicit unchecked mode"""
+    import io
+
+    from zksnap_circuits_halo2_amd import srs
+
+    k = 9
+    with Z.ParamsKZG.setup(k, 777) as params:
+        buf = io.BytesIO()
+        params.write(buf)
+    raw = bytearray(buf.getvalue())
+    srs.read_params(io.BytesIO(bytes(raw)))                                    # intact file: accepted
+    idx = 301                                                                  # not one of 64 evenly spaced samples
+    off = 4 + (1 << k) * 64 + idx * 64 + 32                                    # y of g_lagrange[idx]
+    raw[off] ^= 1
+    with pytest.raises(ValueError, match=r"g_lagrange: point 301"):
+        srs.read_params(io.BytesIO(bytes(raw)))
+    srs.read_params(io.BytesIO(bytes(raw)), check_points=0)                    # RawBytesUnchecked
+    pts = np.frombuffer(bytes(raw[4:4 + (1 << k) * 64]), dtype="<u8").reshape(-1, 8).astype(np.uint64)
+    assert srs.g1_first_invalid(pts) is None
+    pts[7, 0:4] = np.array([(O.Q_MOD >> (64 * j)) & ((1 << 64) - 1) for j in range(4)], dtype=np.uint64)     # x = q: not canonical
+    assert srs.g1_first_invalid(pts) == 7

@@ -1,7 +1,7 @@
 """CPU: the SRS file layer (zksnap_circuits_halo2_amd/srs.py) -- RawBytes layout, truncation / corruption errors, and the host G2
 arithmetic behind `ParamsKZG::setup`'s s_g2, checked against the oracle's independent G1 code where a shared structure exists
 (group laws) and against the curve equation / subgroup order otherwise."""
-import io
+import io  # the default reader checks every point on the GPU; these CPU tests use the host-side sampling mode (check_points=64)
 import random
 import struct
 
@@ -55,7 +55,7 @@ def test_raw_bytes_layout_and_round_trip():
     assert blob[4:4 + 64] == g[0].astype("<u8").tobytes()                    # the memory of G1Affine, untouched
     assert blob[4 + n * 64:4 + n * 64 + 64] == gl[0].astype("<u8").tobytes()
     assert blob[-256:-128] == g2.astype("<u8").tobytes() and blob[-128:] == s_g2.astype("<u8").tobytes()
-    k2, ga, gla, g2a, s_g2a = srs.read_params(io.BytesIO(blob))
+    k2, ga, gla, g2a, s_g2a = srs.read_params(io.BytesIO(blob), check_points=64)
     assert k2 == k and np.array_equal(ga, g) and np.array_equal(gla, gl) and np.array_equal(g2a, g2) and np.array_equal(s_g2a, s_g2)
     assert ga.dtype == np.uint64 and ga.flags["C_CONTIGUOUS"]
 
@@ -64,7 +64,7 @@ def test_raw_bytes_layout_and_round_trip():
 def test_truncated_file_is_reported(cut):
     blob = srs.params_to_bytes(*small_params())
     with pytest.raises(ValueError, match="truncated"):
-        srs.read_params(io.BytesIO(blob[:cut]))
+        srs.read_params(io.BytesIO(blob[:cut]), check_points=64)
 
 
 def test_corruption_is_reported():
@@ -72,14 +72,14 @@ def test_corruption_is_reported():
     blob = bytearray(srs.params_to_bytes(k, g, gl, g2, s_g2))
     bad = bytearray(blob); bad[0:4] = struct.pack("<I", 77)
     with pytest.raises(ValueError, match="k = 77"):
-        srs.read_params(io.BytesIO(bytes(bad)))
+        srs.read_params(io.BytesIO(bytes(bad)), check_points=64)
     bad = bytearray(blob); bad[4 + 64 * 2 + 5] ^= 1                          # one bit of g[2].x
     with pytest.raises(ValueError, match="point 2"):
-        srs.read_params(io.BytesIO(bytes(bad)))
+        srs.read_params(io.BytesIO(bytes(bad)), check_points=64)
     srs.read_params(io.BytesIO(bytes(bad)), check_points=0)                  # RawBytesUnchecked: accepted as is
     bad = bytearray(blob); bad[-100] ^= 1
     with pytest.raises(ValueError, match="s_g2"):
-        srs.read_params(io.BytesIO(bytes(bad)))
+        srs.read_params(io.BytesIO(bytes(bad)), check_points=64)
     with pytest.raises(ValueError):
         srs.write_params(io.BytesIO(), k + 1, g, gl, g2, s_g2)
 
@@ -87,5 +87,5 @@ def test_corruption_is_reported():
 def test_identity_points_are_accepted():
     k, g, gl, g2, s_g2 = small_params()
     g[1] = 0                                                                 # (0, 0) = the identity in G1Affine memory
-    out = srs.read_params(io.BytesIO(srs.params_to_bytes(k, g, gl, g2, s_g2)))
+    out = srs.read_params(io.BytesIO(srs.params_to_bytes(k, g, gl, g2, s_g2)), check_points=64)
     assert not out[1][1].any()

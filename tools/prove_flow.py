@@ -28,7 +28,11 @@ R = F.R_MOD
 BLIND = 5
 
 
-def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True):
+def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk_file=None):
+    """pk_file: path -- the proving key is written there (`ProvingKey::write`, RawBytesUnchecked), read back, and the READ key is what the
+    prover uses (the reference's wrapper does the same through build/*_pk.bin: /root/reference/aggregator/src/wrapper.rs:967-989, :1007-1034)"""
+    from zksnap_circuits_halo2_amd import keygen as KG
+
     lib = _lib.load()
     dev = torch.device("cuda", 0)
     n, u = 1 << k, (1 << k) - (BLIND + 1)
@@ -78,7 +82,6 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True):
     params = Z.ParamsKZG.setup(k, s)
     d_g = torch.from_numpy(params.g.view(np.int64)).to(dev)
     d_gl = torch.from_numpy(params.g_lagrange.view(np.int64)).to(dev)
-    params.close()
     h_g, h_gl = C.c_uint64(0), C.c_uint64(0)
     _lib.check(lib.zkhip_prepare_bases_device(d_g.data_ptr(), n, C.byref(h_g)))
     _lib.check(lib.zkhip_prepare_bases_device(d_gl.data_ptr(), n, C.byref(h_gl)))
@@ -126,21 +129,38 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True):
         adv_commit = [commit(h_gl, a) for a in advice]                             # advice is committed in the Lagrange basis
         lap("commit_advice")
 
-        # ---- permutation argument --------------------------------------------------------------------------------------------
+        # ---- keygen: the circuit's fixed columns and copy constraints -> verifying key, proving key -----------------------------------
         omega = F.omega_for(k)
-        sigma = []
-        for j in range(len(perm_cols)):
-            p = E.RowProgram(omega=omega)
-            p.emit(E.OP_MUL, 0, E.RowProgram.ROWPOW, p.constant(pow(E.DELTA, j, R)))
-            sigma.append(run_prog(p, [], k))
-        for cyc in cycles:
-            for idx, (c, r) in enumerate(cyc):
-                c2, r2 = cyc[(idx + 1) % len(cyc)]
-                sigma[c][r] = words([pow(E.DELTA, c2, R) * pow(omega, r2, R) % R])[0]
         cs = E.ConstraintSystem(
             num_fixed=G + 2, num_advice=G + 1, num_instance=0,
             gates=[[E.Fixed(i) * (E.Advice(i, 0) + E.Advice(i, 1) * E.Advice(i, 2) - E.Advice(i, 3))] for i in range(G)],
             lookups=[E.Lookup([E.Advice(G)], [E.Fixed(G + 1)])], permutation_columns=perm_cols, blinding_factors=BLIND, degree=4)
+        assembly = KG.Assembly(n, len(perm_cols))
+        for cyc in cycles:
+            for (c1, r1), (c2, r2) in zip(cyc, cyc[1:]):
+                assembly.copy(c1, r1, c2, r2)
+        host = lambda tns: tns.cpu().numpy().view(np.uint64).reshape(-1, 4)
+        lap("witness_columns")
+        vk = KG.keygen_vk(params, cs, [host(f) for f in fixed], assembly)
+        lap("keygen_vk")
+        pk = KG.keygen_pk(params, vk, cs, [host(f) for f in fixed], assembly)
+        lap("keygen_pk")
+        pk_bytes = None
+        if pk_file is not None:
+            with open(pk_file, "wb") as fh:
+                pk.write(fh, KG.RAW_BYTES_UNCHECKED)
+            with open(pk_file, "rb") as fh:
+                pk2 = KG.ProvingKey.read(fh, KG.RAW_BYTES_UNCHECKED, cs)
+            pk_bytes = os.path.getsize(pk_file)
+            same = all(np.array_equal(x, y) for x, y in zip(
+                [pk.l0, pk.l_last, pk.l_active_row, pk.vk.fixed_commitments, pk.vk.permutation_commitments] + pk.fixed_values + pk.fixed_polys + pk.fixed_cosets + pk.permutations + pk.permutation_polys + pk.permutation_cosets,
+                [pk2.l0, pk2.l_last, pk2.l_active_row, pk2.vk.fixed_commitments, pk2.vk.permutation_commitments] + pk2.fixed_values + pk2.fixed_polys + pk2.fixed_cosets + pk2.permutations + pk2.permutation_polys + pk2.permutation_cosets))
+            assert same, "ProvingKey::read(ProvingKey::write(pk)) differs from pk"
+            pk = pk2
+            lap("pk_file_round_trip")
+        params.close()
+        dev_t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(dev)
+        sigma = [dev_t(p_) for p_ in pk.permutations]
         z_sets, last_z = [], 1
         for si in range(cs.num_permutation_sets):
             lo, hi = si * cs.chunk_len, min((si + 1) * cs.chunk_len, len(perm_cols))
@@ -178,6 +198,9 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True):
         assert len(lagrange) == qc.total
         ncol = len(lagrange)
         coeff = torch.stack(lagrange).contiguous()                                  # [ncol][n][4]
+        # the proving key's columns arrive transformed: coefficients (for the evaluations at x) and extended cosets (for the quotient)
+        key_polys = pk.fixed_polys + [None] * (qc.l0 - qc.advice) + [None, None, None] + pk.permutation_polys
+        key_cosets = pk.fixed_cosets + [None] * (qc.l0 - qc.advice) + [pk.l0, pk.l_last, pk.l_active_row] + pk.permutation_cosets
         lap("stack_columns")
         # Columns of the proving key (fixed, l_0 / l_last / l_active, the permutation's sigma polynomials) are transformed once per
         # circuit by keygen and their extended cosets are kept (pk.fixed_cosets, pk.permutation.cosets [DEP]); only the witness-dependent
@@ -190,8 +213,12 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True):
             if hi > lo:
                 _lib.check(lib.zkhip_ifft_scaled_batch_device(coeff[lo].data_ptr(), dom.omega_inv.ctypes.data, k, dom.ifft_divisor.ctypes.data, hi - lo, n, None))
 
-        for lo, hi in pk_ranges:
-            ifft_range(lo, hi)
+        for lo, hi in pk_ranges:                 # l0 / l_last / l_active_row have no stored coefficient form in the key: transformed here, outside the proof time
+            for i in range(lo, hi):
+                if key_polys[i] is not None:
+                    coeff[i] = dev_t(key_polys[i])
+                else:
+                    ifft_range(i, i + 1)
         lap("keygen_lagrange_to_coeff")
         for lo, hi in proof_ranges:
             ifft_range(lo, hi)
@@ -208,7 +235,8 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True):
                                                               dom.g_coset.ctypes.data, None))
 
         for lo, hi in pk_ranges:
-            extend_range(lo, hi)
+            for i in range(lo, hi):
+                ext[i] = dev_t(key_cosets[i])
         lap("keygen_coeff_to_extended")
         for lo, hi in proof_ranges:
             extend_range(lo, hi)
@@ -239,7 +267,7 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True):
         checks = {"permutation_product_closes": perm_closes, "lookup_product_closes": lookup_closes, "quotient_is_a_polynomial": top_is_zero and low_nonzero,
                   "commit_lagrange_equals_commit_coeff": commit_agrees}
         n_msm = len(adv_commit) + len(prod_commit) + 1 + len(h_commit)
-        prove_ms = sum(v for kk, v in t.items() if kk not in ("setup_srs", "witness_columns", "stack_columns") and not kk.startswith("keygen_"))
+        prove_ms = sum(v for kk, v in t.items() if kk not in ("setup_srs", "witness_columns", "stack_columns", "pk_file_round_trip") and not kk.startswith("keygen_"))
         n_proof_cols = sum(hi - lo for lo, hi in proof_ranges)
         if verbose:
             print(f"k={k} gate_cols={G}: {ncol} columns ({n_proof_cols} witness-dependent, {ncol - n_proof_cols} of the proving key), {n_msm} MSMs of 2^{k}, "
@@ -248,7 +276,8 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True):
                 print(f"  {name:28s} {ms:9.3f} ms")
             print(f"  {'prover steps (no setup/witness)':28s} {prove_ms:9.3f} ms")
             print("  checks:", checks)
-        return {"timings_ms": t, "prove_ms": prove_ms, "checks": checks, "columns": ncol, "proof_columns": n_proof_cols, "msms": n_msm}
+        return {"timings_ms": t, "prove_ms": prove_ms, "checks": checks, "columns": ncol, "proof_columns": n_proof_cols, "msms": n_msm,
+                "keygen_ms": t.get("keygen_vk", 0.0) + t.get("keygen_pk", 0.0), "pk_file_bytes": pk_bytes}
     finally:
         torch.cuda.synchronize()
         lib.zkhip_release_bases(h_g)

@@ -1357,6 +1357,44 @@ int zkhip_g1_gen_walk_device(const uint64_t t0[4], const uint64_t d[4], size_t n
   return g1_gen_walk_device((const uint32_t*)t0, (const uint32_t*)d, n, (uint32_t*)d_out, sc->ws.p, sc->ws.cap, s);
 }
 
+// ---- SRS / key-file validation: every point canonical and on the curve (RawBytes readers) ------------------------------
+int zkhip_g1_check_points_device(const void* d_points, size_t n, uint64_t* first_bad, void* stream) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (!first_bad || (n && !d_points)) { set_error("g1_check_points: null pointer"); return ZKHIP_EINVAL; }
+  hipStream_t s = caller_stream(stream);
+  scratch* sc = scratch_for(primary(), s);
+  if ((rc = sc->small.reserve(4096)) != ZKHIP_OK) return rc;
+  if ((rc = g1_check_points_device((const uint32_t*)d_points, n, (unsigned long long*)sc->small.p, s)) != ZKHIP_OK) return rc;
+  unsigned long long v = 0;
+  HIPCHK(hipMemcpyAsync(&v, sc->small.p, 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  *first_bad = (uint64_t)v;
+  return ZKHIP_OK;
+}
+
+int zkhip_g1_check_points(const uint64_t* points, size_t n, uint64_t* first_bad) {
+  if (!first_bad || (n && !points)) { set_error("g1_check_points: null pointer"); return ZKHIP_EINVAL; }
+  lane_hold H;
+  if (H.rc != ZKHIP_OK) return H.rc;
+  int rc;
+  *first_bad = n;
+  const size_t chunk = (size_t)1 << 24;                  // 1 GiB of points per upload
+  if ((rc = H.sc->bases.reserve(std::min(n, chunk) * 64)) != ZKHIP_OK) return rc;
+  if ((rc = H.sc->small.reserve(4096)) != ZKHIP_OK) return rc;
+  for (size_t lo = 0; lo < n; lo += chunk) {
+    const size_t m = std::min(chunk, n - lo);
+    HIPCHK(hipMemcpyAsync(H.sc->bases.p, points + lo * 8, m * 64, hipMemcpyHostToDevice, H.s));
+    if ((rc = g1_check_points_device((const uint32_t*)H.sc->bases.p, m, (unsigned long long*)H.sc->small.p, H.s)) != ZKHIP_OK) return rc;
+    HIPCHK(hipMemcpyAsync(H.L->pinned, H.sc->small.p, 8, hipMemcpyDeviceToHost, H.s));
+    HIPCHK(hipStreamSynchronize(H.s));
+    const unsigned long long v = *(const unsigned long long*)H.L->pinned;
+    if (v < m) { *first_bad = lo + (size_t)v; return ZKHIP_OK; }
+  }
+  return ZKHIP_OK;
+}
+
 // ---- parity hooks ----------------------------------------------------------------------------------
 int zkhip_test_field_op(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
   if (field < 0 || field > 1 || op < 0 || op > 3 || (n && (!a || !b || !out))) { set_error("test_field_op: bad argument"); return ZKHIP_EINVAL; }

@@ -60,6 +60,47 @@ __global__ void __launch_bounds__(128) k_g1_op_quad(int op, const uint32_t* a, c
   if (q == 0) store_jacobian(r, out + i * 24);
 }
 
+// `G1Affine::read_raw` check of halo2curves [DEP] (what `SerdeFormat::RawBytes` readers run on every point of an SRS or key file):
+// both coordinates canonical Montgomery residues (< q) and (x, y) = (0, 0) or y^2 = x^3 + 3.  first_bad receives the smallest
+// index that fails (stays n when every point passes).
+__device__ __forceinline__ bool words_below_q(const uint32_t (&w)[8]) {
+  const fe v = fe_unpack<0>(w);                   // the raw 256-bit integer as limbs
+  bool lt = false, eq = true;
+#pragma unroll
+  for (int i = NL - 1; i >= 0; i--) {
+    lt = lt || (eq && v.l[i] < Fq::P[i]);
+    eq = eq && v.l[i] == Fq::P[i];
+  }
+  return lt;
+}
+
+__global__ void __launch_bounds__(256) k_g1_check(const uint32_t* __restrict__ pts, size_t n, unsigned long long* __restrict__ first_bad) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const affine_words p = load_affine(pts, i);
+  if (affine_is_identity(p)) return;
+  bool ok = words_below_q(p.x) && words_below_q(p.y);
+  if (ok) {
+    const fe one = fe_one<Fq>();
+    const fe x = fe_mul<Fq>(one, fe_from_ext_lazy(p.x)), y = fe_mul<Fq>(one, fe_from_ext_lazy(p.y));   // internal form, < 2p
+    const fe lhs = fe_sqr<Fq>(y);
+    const fe x3 = fe_mul<Fq>(fe_sqr<Fq>(x), x);
+    const fe three = fe_norm(fe_add(fe_add(one, one), one));                   // 3 in internal form, < 3p
+    const fe rhs = fe_norm(fe_add(x3, three));                                 // < 5p, N form
+    const fe diff = fe_mul<Fq>(one, fe_sub_red(lhs, rhs, Fq::P6_S1));          // same residue, < 2p
+    ok = fe_mulout_is_zero<Fq>(diff);
+  }
+  if (!ok) atomicMin(first_bad, (unsigned long long)i);
+}
+
+int g1_check_points_device(const uint32_t* d_points, size_t n, unsigned long long* d_first_bad, hipStream_t stream) {
+  const unsigned long long init = (unsigned long long)n;
+  if (hipMemcpyAsync(d_first_bad, &init, 8, hipMemcpyHostToDevice, stream) != hipSuccess) { set_error("g1_check: upload failed"); return ZKHIP_EHIP; }
+  if (hipStreamSynchronize(stream) != hipSuccess) return ZKHIP_EHIP;      // `init` is a stack variable
+  if (n) hipLaunchKernelGGL(k_g1_check, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_points, n, d_first_bad);
+  return hipGetLastError() == hipSuccess ? ZKHIP_OK : ZKHIP_EHIP;
+}
+
 int test_field_op(int field, int op, const uint32_t* d_a, const uint32_t* d_b, uint32_t* d_out, size_t n, hipStream_t stream) {
   if (n == 0) return ZKHIP_OK;
   dim3 grid((unsigned)((n + 255) / 256)), block(256);

@@ -71,6 +71,7 @@ int lookup_permute_device(const uint32_t* d_input, const uint32_t* d_table, size
 
 // selftest.hip
 int test_field_op(int field, int op, const uint32_t* d_a, const uint32_t* d_b, uint32_t* d_out, size_t n, hipStream_t stream);
+int g1_check_points_device(const uint32_t* d_points, size_t n, unsigned long long* d_first_bad, hipStream_t stream);
 int test_g1_op(int op, const uint32_t* d_a, const uint32_t* d_b, uint32_t* d_out, size_t n, hipStream_t stream);
 
 }  // namespace zkhip

@@ -1,0 +1,348 @@
+"""`keygen_vk` / `keygen_pk` and the `VerifyingKey` / `ProvingKey` file formats.
+
+Mirror of [DEP] halo2-axiom `plonk/keygen.rs`, `plonk/permutation/keygen.rs` and the `read` / `write` methods of `plonk.rs` /
+`plonk/permutation.rs`, as the reference reaches them:
+  * `keygen_vk` + `keygen_pk`                     /root/reference/aggregator/src/wrapper.rs:106-109, :236-242 (and inside the timed loop
+                                                   of the wrapper bench, /root/reference/aggregator/benches/wrapper_circuit.rs:123-141)
+  * `pk.write(&mut f, SerdeFormat::RawBytesUnchecked)`  /root/reference/aggregator/src/wrapper.rs:967-989 (`build/*_pk.bin`)
+  * `ProvingKey::read::<_, C>(.., RawBytesUnchecked, ..)` /root/reference/aggregator/src/wrapper.rs:1007-1034, :1073-1106
+
+The dependency is un-vendored and no key file exists in the reference tree, so the layout is the PUBLISHED one restated from the
+crate -- **unpinned** (DESIGN.md section 6): a key written by the Rust prover has never been read by this code.
+
+    VerifyingKey:  k (u32 BE) | #fixed_commitments (u32 BE) | fixed_commitments (G1Affine each) |
+                   permutation commitments (one G1Affine per permutation column, no count) |
+                   selectors: for every selector ceil(n / 8) bytes, 8 rows per byte, row j of a chunk in bit j
+    Polynomial:    #values (u32 BE) | values (Fr each)
+    ProvingKey:    VerifyingKey | l0 | l_last | l_active_row (extended-coset polynomials) |
+                   fixed_values | fixed_polys | fixed_cosets (each: count u32 BE, then polynomials) |
+                   permutation: permutations | polys | cosets (each: count u32 BE, then polynomials)
+    Fr / G1Affine under RawBytes / RawBytesUnchecked: the in-memory Montgomery limbs (4 x u64 LE per field element; a point is x || y),
+    i.e. exactly the arrays the C ABI takes.  RawBytes checks on read that every element is canonical and every point on the curve;
+    RawBytesUnchecked does not.  The compressed `Processed` form is not handled (as in srs.py).
+
+What keygen computes -- everything on the GPU through the batched device entry points:
+    fixed commitments / permutation commitments   `params.commit_lagrange(column)`                      prepared-table MSM
+    fixed_polys, permutation polys, l0 ...        `domain.lagrange_to_coeff`     zkhip_ifft_scaled_batch_device
+    fixed_cosets, permutation cosets, l0 ...      `domain.coeff_to_extended`     zkhip_coeff_to_extended_device
+    sigma columns                                 delta^col' * omega^row' from the copy-constraint cycles (`Assembly`), one row program
+"""
+from __future__ import annotations
+
+import ctypes as C
+import struct
+from dataclasses import dataclass, field
+from typing import BinaryIO, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib, evaluation as E
+from .domain import EvaluationDomain
+from .fields import Q_MOD, R_MOD, fr_encode
+
+RAW_BYTES, RAW_BYTES_UNCHECKED, PROCESSED = "RawBytes", "RawBytesUnchecked", "Processed"      # `SerdeFormat`
+
+
+# ---------------------------------------------------------------------------------------------------
+# permutation::keygen::Assembly
+# ---------------------------------------------------------------------------------------------------
+class Assembly:
+    """Copy-constraint cycles over the permutation columns: `mapping[col][row]` is the next cell of the cycle through (col, row).
+    `copy` merges two cycles exactly as the reference does (smaller into larger, then one swap of the two mapping entries), so the
+    resulting sigma polynomials are the reference's for the same sequence of `copy` calls."""
+
+    def __init__(self, n: int, n_columns: int):
+        self.n, self.n_columns = n, n_columns
+        self.map_col = np.repeat(np.arange(n_columns, dtype=np.int32)[:, None], n, axis=1)
+        self.map_row = np.repeat(np.arange(n, dtype=np.int32)[None, :], n_columns, axis=0)
+        self.aux_col, self.aux_row = self.map_col.copy(), self.map_row.copy()
+        self.sizes = np.ones((n_columns, n), dtype=np.int64)
+
+    def copy(self, left_column: int, left_row: int, right_column: int, right_row: int) -> None:
+        if not (0 <= left_column < self.n_columns and 0 <= right_column < self.n_columns):
+            raise ValueError("column is not part of the permutation argument")       # Error::ColumnNotInPermutation
+        if not (0 <= left_row < self.n and 0 <= right_row < self.n):
+            raise ValueError("row out of bounds")                                      # Error::BoundsFailure
+        lc, lr = int(self.aux_col[left_column, left_row]), int(self.aux_row[left_column, left_row])
+        rc, rr = int(self.aux_col[right_column, right_row]), int(self.aux_row[right_column, right_row])
+        if (lc, lr) == (rc, rr):
+            return                                                                     # already in one cycle
+        if self.sizes[lc, lr] < self.sizes[rc, rr]:
+            (lc, lr), (rc, rr) = (rc, rr), (lc, lr)
+        self.sizes[lc, lr] += self.sizes[rc, rr]
+        i = (rc, rr)
+        while True:                                                                    # the right cycle takes the left cycle's representative
+            self.aux_col[i], self.aux_row[i] = lc, lr
+            i = (int(self.map_col[i]), int(self.map_row[i]))
+            if i == (rc, rr):
+                break
+        a, b = (left_column, left_row), (right_column, right_row)
+        ac, ar, bc, br = self.map_col[a], self.map_row[a], self.map_col[b], self.map_row[b]
+        self.map_col[a], self.map_row[a], self.map_col[b], self.map_row[b] = bc, br, ac, ar
+
+    def sigma_columns(self, k: int) -> List[np.ndarray]:
+        """`build_pk`'s `permutations`: sigma_i[j] = delta^(mapping col) * omega^(mapping row), Lagrange basis, one (n, 4) array per
+        column.  omega^row comes from one row program; the products run as one more (two gathered columns multiplied)."""
+        n = 1 << k
+        assert n == self.n
+        omega = _omega(k)
+        powers = E.RowProgram(omega=omega)
+        powers.emit(E.OP_MOV, 0, E.RowProgram.ROWPOW)
+        omega_pow = powers.run([], k)                                                  # omega^j
+        deltas = fr_encode([pow(E.DELTA, c, R_MOD) for c in range(self.n_columns)])
+        mul = E.RowProgram()
+        mul.emit(E.OP_MUL, 0, mul.column(0), mul.column(1))
+        out = []
+        for c in range(self.n_columns):
+            out.append(mul.run([omega_pow[self.map_row[c]], deltas[self.map_col[c]]], k))
+        return out
+
+
+def _omega(k: int) -> int:
+    from .fields import omega_for
+
+    return omega_for(k)
+
+
+# ---------------------------------------------------------------------------------------------------
+# device helpers (no torch in the package: buffers come from the C ABI)
+# ---------------------------------------------------------------------------------------------------
+class _DeviceBuffer:
+    def __init__(self, nbytes: int):
+        self.lib = _lib.load()
+        self.ptr = C.c_void_p()
+        self.nbytes = nbytes
+        _lib.check(self.lib.zkhip_alloc(nbytes, C.byref(self.ptr)))
+
+    def upload(self, a: np.ndarray, offset: int = 0) -> None:
+        a = np.ascontiguousarray(a)
+        _lib.check(self.lib.zkhip_upload(C.c_void_p(self.ptr.value + offset), a.ctypes.data, a.nbytes))
+
+    def download(self, shape, offset: int = 0) -> np.ndarray:
+        out = np.empty(shape, dtype=np.uint64)
+        _lib.check(self.lib.zkhip_download(out.ctypes.data, C.c_void_p(self.ptr.value + offset), out.nbytes))
+        return out
+
+    def free(self) -> None:
+        if self.ptr:
+            self.lib.zkhip_free(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.free()
+
+
+def _transform_columns(dom: EvaluationDomain, lagrange: Sequence[np.ndarray], want_cosets: bool = True, max_bytes: int = 1 << 32):
+    """(polys, cosets) of Lagrange-basis columns: batched `lagrange_to_coeff` then batched `coeff_to_extended`, in groups of columns
+    that keep the device buffers under `max_bytes`."""
+    lib = _lib.load()
+    n, en = dom.n, dom.extended_len()
+    polys, cosets = [], []
+    per_col = n * 32 + (en * 32 if want_cosets else 0)
+    group = max(1, min(len(lagrange), max_bytes // per_col)) if lagrange else 1
+    for g0 in range(0, len(lagrange), group):
+        cols = lagrange[g0:g0 + group]
+        m = len(cols)
+        with _DeviceBuffer(m * n * 32) as d_c:
+            d_c.upload(np.stack([np.ascontiguousarray(c, dtype=np.uint64).reshape(n, 4) for c in cols]))
+            _lib.check(lib.zkhip_ifft_scaled_batch_device(d_c.ptr, dom.omega_inv.ctypes.data, dom.k, dom.ifft_divisor.ctypes.data, m, n, None))
+            pc = d_c.download((m, n, 4))
+            polys.extend(pc[i] for i in range(m))
+            if want_cosets:
+                with _DeviceBuffer(m * en * 32) as d_e:
+                    _lib.check(lib.zkhip_coeff_to_extended_device(d_c.ptr, n, dom.k, d_e.ptr, en, dom.extended_k, m, dom.extended_omega.ctypes.data,
+                                                                  dom.g_coset.ctypes.data, None))
+                    ec = d_e.download((m, en, 4))
+                    cosets.extend(ec[i] for i in range(m))
+    return polys, cosets
+
+
+# ---------------------------------------------------------------------------------------------------
+# keys
+# ---------------------------------------------------------------------------------------------------
+@dataclass
+class VerifyingKey:
+    k: int
+    fixed_commitments: np.ndarray                       # (num_fixed, 8) uint64, G1Affine
+    permutation_commitments: np.ndarray                 # (num permutation columns, 8) uint64
+    selectors: List[np.ndarray] = field(default_factory=list)      # bool arrays of n rows
+    cs: Optional[E.ConstraintSystem] = None             # re-derived from the circuit on read (not serialised), as in the reference
+
+    def write(self, w: BinaryIO, fmt: str = RAW_BYTES) -> None:
+        _check_format(fmt)
+        w.write(struct.pack(">I", self.k))
+        w.write(struct.pack(">I", self.fixed_commitments.shape[0]))
+        w.write(np.ascontiguousarray(self.fixed_commitments, dtype="<u8").tobytes())
+        w.write(np.ascontiguousarray(self.permutation_commitments, dtype="<u8").tobytes())
+        for sel in self.selectors:
+            w.write(np.packbits(np.asarray(sel, dtype=bool), bitorder="little").tobytes())
+
+    @classmethod
+    def read(cls, r: BinaryIO, fmt: str, cs: E.ConstraintSystem, num_selectors: int = 0) -> "VerifyingKey":
+        """`VerifyingKey::read::<_, ConcreteCircuit>`: the constraint system (column counts, selectors) comes from the circuit, the
+        commitments from the file"""
+        _check_format(fmt)
+        k, = struct.unpack(">I", _take(r, 4))
+        if k > 28:
+            raise ValueError(f"circuit size k = {k} out of range")
+        nf, = struct.unpack(">I", _take(r, 4))
+        if nf != cs.num_fixed:
+            raise ValueError(f"the key holds {nf} fixed commitments, the circuit has {cs.num_fixed} fixed columns")
+        fixed = _read_points(r, nf, fmt)
+        perm = _read_points(r, len(cs.permutation_columns), fmt)
+        n = 1 << k
+        sels = [np.unpackbits(np.frombuffer(_take(r, (n + 7) // 8), dtype=np.uint8), bitorder="little")[:n].astype(bool) for _ in range(num_selectors)]
+        return cls(k, fixed, perm, sels, cs)
+
+
+@dataclass
+class ProvingKey:
+    vk: VerifyingKey
+    l0: np.ndarray                                      # extended coset (2^extended_k, 4)
+    l_last: np.ndarray
+    l_active_row: np.ndarray
+    fixed_values: List[np.ndarray]                      # Lagrange basis (n, 4)
+    fixed_polys: List[np.ndarray]                       # coefficients (n, 4)
+    fixed_cosets: List[np.ndarray]                      # extended coset
+    permutations: List[np.ndarray]                      # sigma columns, Lagrange basis
+    permutation_polys: List[np.ndarray]
+    permutation_cosets: List[np.ndarray]
+
+    def write(self, w: BinaryIO, fmt: str = RAW_BYTES_UNCHECKED) -> None:
+        _check_format(fmt)
+        self.vk.write(w, fmt)
+        for p in (self.l0, self.l_last, self.l_active_row):
+            _write_poly(w, p)
+        for group in (self.fixed_values, self.fixed_polys, self.fixed_cosets, self.permutations, self.permutation_polys, self.permutation_cosets):
+            w.write(struct.pack(">I", len(group)))
+            for p in group:
+                _write_poly(w, p)
+
+    @classmethod
+    def read(cls, r: BinaryIO, fmt: str, cs: E.ConstraintSystem, num_selectors: int = 0) -> "ProvingKey":
+        vk = VerifyingKey.read(r, fmt, cs, num_selectors)
+        n = 1 << vk.k
+        dom = EvaluationDomain(cs.degree, vk.k)
+        en = dom.extended_len()
+        l0, l_last, l_active = (_read_poly(r, fmt, en) for _ in range(3))
+        groups = []
+        for want_len, want_count in ((n, cs.num_fixed), (n, cs.num_fixed), (en, cs.num_fixed), (n, len(cs.permutation_columns)),
+                                     (n, len(cs.permutation_columns)), (en, len(cs.permutation_columns))):
+            count, = struct.unpack(">I", _take(r, 4))
+            if count != want_count:
+                raise ValueError(f"the key holds {count} polynomials where the circuit has {want_count} columns")
+            groups.append([_read_poly(r, fmt, want_len) for _ in range(count)])
+        return cls(vk, l0, l_last, l_active, *groups)
+
+    # the column block `evaluate_h_program` reads from the proving key, in QuotientColumns order
+    def quotient_key_columns(self):
+        return {"fixed": self.fixed_cosets, "l0": self.l0, "l_last": self.l_last, "l_active_row": self.l_active_row, "sigma": self.permutation_cosets}
+
+
+def keygen_vk(params, cs: E.ConstraintSystem, fixed: Sequence[np.ndarray], assembly: Assembly, selectors: Sequence[np.ndarray] = ()) -> VerifyingKey:
+    """`keygen_vk(params, circuit)`: commitments to the fixed columns and to the sigma columns (Lagrange-basis MSMs against the
+    registered `g_lagrange`).  `fixed` already holds the selector-derived columns (the mirror has no floor planner)."""
+    n = 1 << params.k
+    if len(fixed) != cs.num_fixed or assembly.n_columns != len(cs.permutation_columns) or assembly.n != n:
+        raise ValueError("fixed columns / permutation assembly do not match the constraint system")
+    if n < cs.blinding_factors + 3:
+        raise ValueError("not enough rows available")                                  # Error::not_enough_rows_available
+    sigma = assembly.sigma_columns(params.k)
+    fc = _commit_lagrange_affine(params, fixed)
+    pc = _commit_lagrange_affine(params, sigma)
+    return VerifyingKey(params.k, fc, pc, [np.asarray(s, dtype=bool) for s in selectors], cs)
+
+
+def keygen_pk(params, vk: VerifyingKey, cs: E.ConstraintSystem, fixed: Sequence[np.ndarray], assembly: Assembly) -> ProvingKey:
+    """`keygen_pk(params, vk, circuit)`: fixed_polys / fixed_cosets, the permutation's polys / cosets, and the l0 / l_last /
+    l_active_row cosets.  l_active_row = 1 - (l_last + l_blind) on the extended coset equals the coset of the indicator of the
+    usable rows (both are the same polynomial of degree < n), which is how it is produced here."""
+    k, n = params.k, 1 << params.k
+    if vk.k != k:
+        raise ValueError("verifying key and params differ in k")
+    dom = EvaluationDomain(cs.degree, k)
+    u = n - (cs.blinding_factors + 1)
+    one = fr_encode([1])[0]
+    l0 = np.zeros((n, 4), dtype=np.uint64); l0[0] = one
+    l_last = np.zeros((n, 4), dtype=np.uint64); l_last[u] = one
+    l_active = np.zeros((n, 4), dtype=np.uint64); l_active[:u] = one
+    sigma = assembly.sigma_columns(k)
+    fixed = [np.ascontiguousarray(c, dtype=np.uint64).reshape(n, 4) for c in fixed]
+    polys, cosets = _transform_columns(dom, list(fixed) + sigma + [l0, l_last, l_active])
+    nf, ns = len(fixed), len(sigma)
+    return ProvingKey(vk, cosets[nf + ns], cosets[nf + ns + 1], cosets[nf + ns + 2], fixed, polys[:nf], cosets[:nf],
+                      sigma, polys[nf:nf + ns], cosets[nf:nf + ns])
+
+
+# ---------------------------------------------------------------------------------------------------
+# serialisation helpers
+# ---------------------------------------------------------------------------------------------------
+def _check_format(fmt: str) -> None:
+    if fmt == PROCESSED:
+        raise ValueError("SerdeFormat::Processed (compressed points, canonical scalars) is not handled: the reference writes RawBytesUnchecked")
+    if fmt not in (RAW_BYTES, RAW_BYTES_UNCHECKED):
+        raise ValueError(f"unknown SerdeFormat {fmt!r}")
+
+
+def _take(r: BinaryIO, nbytes: int) -> bytes:
+    b = r.read(nbytes)
+    if len(b) != nbytes:
+        raise EOFError(f"key file truncated: wanted {nbytes} bytes, got {len(b)}")
+    return b
+
+
+def _write_poly(w: BinaryIO, p: np.ndarray) -> None:
+    p = np.ascontiguousarray(p, dtype="<u8").reshape(-1, 4)
+    w.write(struct.pack(">I", p.shape[0]))
+    w.write(p.tobytes())
+
+
+_R_LIMBS = np.array([(R_MOD >> (64 * i)) & ((1 << 64) - 1) for i in range(4)], dtype=np.uint64)
+_Q_LIMBS = np.array([(Q_MOD >> (64 * i)) & ((1 << 64) - 1) for i in range(4)], dtype=np.uint64)
+
+
+def _all_below(a: np.ndarray, mod_limbs: np.ndarray) -> bool:
+    """every row of the (m, 4) little-endian limb array is < modulus"""
+    lt = np.zeros(a.shape[0], dtype=bool)
+    eq = np.ones(a.shape[0], dtype=bool)
+    for i in (3, 2, 1, 0):
+        lt |= eq & (a[:, i] < mod_limbs[i])
+        eq &= a[:, i] == mod_limbs[i]
+    return bool(lt.all())
+
+
+def _read_poly(r: BinaryIO, fmt: str, want_len: int) -> np.ndarray:
+    m, = struct.unpack(">I", _take(r, 4))
+    if m != want_len:
+        raise ValueError(f"polynomial of {m} values where {want_len} were expected")
+    a = np.frombuffer(_take(r, m * 32), dtype="<u8").reshape(m, 4).astype(np.uint64)
+    if fmt == RAW_BYTES and not _all_below(a, _R_LIMBS):
+        raise ValueError("non-canonical field element in key file")
+    return a
+
+
+def _read_points(r: BinaryIO, count: int, fmt: str) -> np.ndarray:
+    a = np.frombuffer(_take(r, count * 64), dtype="<u8").reshape(count, 8).astype(np.uint64)
+    if fmt == RAW_BYTES and count:
+        if not (_all_below(a[:, :4], _Q_LIMBS) and _all_below(a[:, 4:], _Q_LIMBS)):
+            raise ValueError("non-canonical coordinate in key file")
+        from .srs import g1_first_invalid
+
+        bad = g1_first_invalid(a)
+        if bad is not None:
+            raise ValueError(f"point {bad} of the key file is not a valid curve point")
+    return a
+
+
+def _commit_lagrange_affine(params, columns: Sequence[np.ndarray]) -> np.ndarray:
+    """commit_lagrange of every column -> affine points (the verifying key stores `to_affine()` of the commitments); the
+    normalisation is one inversion per point on the host (a handful of points)."""
+    from .fields import g1_decode_jacobian, g1_encode
+
+    pts = []
+    for col in columns:
+        pts.append(g1_decode_jacobian(params.commit_lagrange(np.ascontiguousarray(col, dtype=np.uint64))))
+    return g1_encode(pts) if pts else np.zeros((0, 8), dtype=np.uint64)

@@ -41,9 +41,25 @@ class ParamsKZG:
         self.g2 = None if g2 is None else np.ascontiguousarray(g2, dtype=np.uint64).reshape(16)
         self.s_g2 = None if s_g2 is None else np.ascontiguousarray(s_g2, dtype=np.uint64).reshape(16)
         lib = _lib.load()
-        _lib.check(lib.zkhip_register_bases(self.g.ctypes.data, self.n))
-        if self.g_lagrange is not None:
-            _lib.check(lib.zkhip_register_bases(self.g_lagrange.ctypes.data, self.n))
+        # The library recognises registered bases by host address (include/zkhip.h), so the registration must end before the arrays
+        # are freed: `close()` / the context manager do it explicitly, and a finalizer does it when the object is collected without
+        # either (the arrays are kept alive by the finalizer's own references until then).  The arrays are made read-only: the prepared
+        # tables are built from their contents at registration.
+        arrays = [self.g] + ([self.g_lagrange] if self.g_lagrange is not None else [])
+        registered = []
+        try:
+            for a in arrays:
+                _lib.check(lib.zkhip_register_bases(a.ctypes.data, self.n))
+                registered.append(a)
+        except Exception:
+            for a in registered:
+                lib.zkhip_unregister_bases(a.ctypes.data)
+            raise
+        for a in arrays:
+            a.flags.writeable = False
+        import weakref
+
+        self._finalizer = weakref.finalize(self, _unregister_arrays, arrays)
 
     @classmethod
     def setup(cls, k: int, s: int) -> "ParamsKZG":
@@ -107,8 +123,9 @@ class ParamsKZG:
         srs.write_params(f, self.k, self.g, self.g_lagrange, self.g2, self.s_g2)
 
     @classmethod
-    def read(cls, f, check_points: int = 64) -> "ParamsKZG":
-        """`ParamsKZG::read` [DEP]: parses the file and pins both tables in HBM"""
+    def read(cls, f, check_points=None) -> "ParamsKZG":
+        """`ParamsKZG::read` [DEP]: parses the file, verifies every point (one GPU pass per table: the RawBytes reader's check; pass a
+        number to sample on the host instead, 0 for RawBytesUnchecked) and pins both tables in HBM"""
         from . import srs
 
         k, g, g_lagrange, g2, s_g2 = srs.read_params(f, check_points)
@@ -145,7 +162,20 @@ class ParamsKZG:
         return out
 
     def close(self) -> None:
+        """end the residency of g / g_lagrange (idempotent); also runs when the object is garbage-collected"""
+        self._finalizer()
+
+    def __enter__(self) -> "ParamsKZG":
+        return self
+
+    def __exit__(self, *exc) -> None:
+        self.close()
+
+
+def _unregister_arrays(arrays) -> None:
+    try:
         lib = _lib.load()
-        lib.zkhip_unregister_bases(self.g.ctypes.data)
-        if self.g_lagrange is not None:
-            lib.zkhip_unregister_bases(self.g_lagrange.ctypes.data)
+    except Exception:   # noqa: BLE001  (interpreter shutdown)
+        return
+    for a in arrays:
+        lib.zkhip_unregister_bases(a.ctypes.data)

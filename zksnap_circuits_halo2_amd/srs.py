@@ -121,6 +121,19 @@ def _g1_sample_on_curve(points: np.ndarray, sample: int) -> None:
             raise ValueError(f"point {i} is not on the curve")
 
 
+def g1_first_invalid(points: np.ndarray) -> Optional[int]:
+    """index of the first point of an (n, 8) G1Affine array that is not a valid curve point (non-canonical limbs or off the curve), None
+    when all are valid: one GPU pass over the whole table (`zkhip_g1_check_points`), the check the reference's RawBytes reader runs"""
+    import ctypes as C
+
+    from . import _lib
+
+    pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 8)
+    bad = C.c_uint64(0)
+    _lib.check(_lib.load().zkhip_g1_check_points(pts.ctypes.data, pts.shape[0], C.byref(bad)))
+    return None if bad.value >= pts.shape[0] else int(bad.value)
+
+
 def write_params(f: BinaryIO, k: int, g: np.ndarray, g_lagrange: np.ndarray, g2: np.ndarray, s_g2: np.ndarray) -> None:
     n = 1 << k
     g = np.ascontiguousarray(g, dtype="<u8").reshape(-1, 8)
@@ -134,9 +147,10 @@ def write_params(f: BinaryIO, k: int, g: np.ndarray, g_lagrange: np.ndarray, g2:
     f.write(np.ascontiguousarray(s_g2, dtype="<u8").reshape(16).tobytes())
 
 
-def read_params(f: BinaryIO, check_points: int = 64, max_k: int = 28):
-    """-> (k, g, g_lagrange, g2, s_g2).  `check_points`: curve membership is verified on that many evenly spaced points of each table and
-    on both G2 points (the reference's RawBytes reader checks every point; 0 = its RawBytesUnchecked)."""
+def read_params(f: BinaryIO, check_points: Optional[int] = None, max_k: int = 28):
+    """-> (k, g, g_lagrange, g2, s_g2).  `check_points`: None (default) verifies EVERY point of both tables on the GPU and both G2 points
+    on the host, like the reference's SerdeFormat::RawBytes reader; a positive number samples that many evenly spaced points on the host
+    (no GPU needed); 0 checks nothing (the reference's RawBytesUnchecked)."""
     head = f.read(4)
     if len(head) != 4:
         raise ValueError("truncated SRS file: no header")
@@ -157,9 +171,15 @@ def read_params(f: BinaryIO, check_points: int = 64, max_k: int = 28):
         raise ValueError("truncated SRS file: g2 / s_g2 missing")
     g2 = np.frombuffer(tail[:128], dtype="<u8").astype(np.uint64)
     s_g2 = np.frombuffer(tail[128:], dtype="<u8").astype(np.uint64)
-    if check_points:
+    if check_points is None:
+        for name, tab in (("g", g), ("g_lagrange", g_lagrange)):
+            bad = g1_first_invalid(tab)
+            if bad is not None:
+                raise ValueError(f"{name}: point {bad} is not a valid curve point")
+    elif check_points:
         _g1_sample_on_curve(g, check_points)
         _g1_sample_on_curve(g_lagrange, check_points)
+    if check_points is None or check_points:
         for name, p in (("g2", g2), ("s_g2", s_g2)):
             if not g2_is_on_curve(g2_decode(p)):
                 raise ValueError(f"{name} is not on the twist curve")
