@@ -403,9 +403,9 @@ class ParamsKZG {
     out.write(reinterpret_cast<const char*>(s_g2_.data()), 128);
     if (!out) throw std::runtime_error("ParamsKZG::write: stream error");
   }
-  // `check` (default): every point of both tables is verified on the GPU (zkhip_g1_check_points), as the reference's
+  // `verify_points` (default): every point of both tables is verified on the GPU (zkhip_g1_check_points), as the reference's
   // SerdeFormat::RawBytes reader does; false = RawBytesUnchecked
-  static ParamsKZG read(std::istream& in, bool check = true) {
+  static ParamsKZG read(std::istream& in, bool verify_points = true) {
     uint32_t k = 0;
     in.read(reinterpret_cast<char*>(&k), 4);
     if (!in || k > 28) throw std::runtime_error("ParamsKZG::read: not a RawBytes KZG parameter file");
@@ -417,11 +417,11 @@ class ParamsKZG {
     in.read(reinterpret_cast<char*>(g2.data()), 128);
     in.read(reinterpret_cast<char*>(s_g2.data()), 128);
     if (!in) throw std::runtime_error("ParamsKZG::read: truncated file");
-    if (check) {
+    if (verify_points) {
       uint64_t bad = 0;
-      detail::check(zkhip_g1_check_points(reinterpret_cast<const uint64_t*>(g.data()), (size_t)n, &bad), "zkhip_g1_check_points");
+      halo2::check(zkhip_g1_check_points(reinterpret_cast<const uint64_t*>(g.data()), (size_t)n, &bad), "zkhip_g1_check_points");
       if (bad < n) throw std::runtime_error("ParamsKZG::read: g holds a point that is not on the curve");
-      detail::check(zkhip_g1_check_points(reinterpret_cast<const uint64_t*>(gl.data()), (size_t)n, &bad), "zkhip_g1_check_points");
+      halo2::check(zkhip_g1_check_points(reinterpret_cast<const uint64_t*>(gl.data()), (size_t)n, &bad), "zkhip_g1_check_points");
       if (bad < n) throw std::runtime_error("ParamsKZG::read: g_lagrange holds a point that is not on the curve");
     }
     ParamsKZG p(k, std::move(g), std::move(gl));
