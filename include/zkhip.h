@@ -68,6 +68,12 @@ int zkhip_msm_g1(const uint64_t *scalars, const uint64_t *bases, size_t n, uint6
  * a circuit; out_xyz: batch Jacobian points.  With registered bases this is one launch set (see the _device variant). */
 int zkhip_msm_g1_batch(const uint64_t *scalars, const uint64_t *bases, size_t n, size_t batch, uint64_t *out_xyz);
 
+/* The same over G2 (`best_multiexp::<G2Affine>`): bases n x 16 limbs (G2Affine = x.c0 || x.c1 || y.c0 || y.c1, Montgomery Fq, all-zero =
+ * identity), out 24 limbs (G2 Jacobian x || y || z, each an Fq2).  No call site in the reference prover multiplies in G2 (it reads
+ * params.g2() / params.s_g2(): /root/reference/aggregator/src/wrapper.rs:1142-1144); provided because the MSM is generic over the
+ * curve.  General path only (per-window bucket sets + window fold). */
+int zkhip_msm_g2(const uint64_t *scalars, const uint64_t *bases, size_t n, uint64_t out_xyz[24]);
+
 /* Residency for `ParamsKZG::{g, g_lagrange}` (static per params object): upload once and build the prepared table
  * (2^(c w) * P_i for every window w: W * 64 bytes per point of HBM, one-time ~25 ms per 2^20 points) on every shard's device;
  * zkhip_msm_g1 recognises `bases` pointers inside a registered range (any sub-range), skips the upload and runs the prepared
@@ -188,6 +194,7 @@ int zkhip_sync(void);
  * with the caller's other default-stream work -- e.g. what torch.cuda.current_stream().cuda_stream is when no stream was set) --- */
 /* Used by the pipeline / bench so that polynomials and scalars stay in HBM between calls. */
 int zkhip_msm_g1_device(const void *d_scalars, const void *d_bases, size_t n, void *d_out_xyz, void *stream);
+int zkhip_msm_g2_device(const void *d_scalars, const void *d_bases, size_t n, void *d_out_xyz, void *stream);
 /* prepared (fixed-base) path for device-resident bases: the handle owns the table until released */
 int zkhip_prepare_bases_device(const void *d_bases, size_t n, uint64_t *handle);
 /* same with an explicit window size (2..20; 0 = automatic) -- experiments and tests of the wide-window path */
@@ -257,6 +264,9 @@ int zkhip_test_field_op(int field, int op, const uint64_t *a, const uint64_t *b,
 /* op: 0 = affine a[i] + affine b[i], 1 = 2 * a[i], 2 = a[i] + (-b[i]); with the quad-cooperative formulas of the reduction tail:
  * 3 = 2 a[i] + 2 b[i], 4 = 4 a[i].  out: n Jacobian points. */
 int zkhip_test_g1_op(int op, const uint64_t *a, const uint64_t *b, uint64_t *out_xyz, size_t n);
+
+/* G2 (Fq2 + twist curve arithmetic): op 0 = a[i] + b[i], 1 = 2 a[i], 2 = a[i] - b[i]; a, b: n G2Affine points, out: n G2 Jacobian points */
+int zkhip_test_g2_op(int op, const uint64_t *a, const uint64_t *b, uint64_t *out_xyz, size_t n);
 
 #ifdef __cplusplus
 }

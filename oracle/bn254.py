@@ -63,6 +63,135 @@ def from_limbs(l: Sequence[int]) -> int:
 
 
 # ----------------------------------------------------------------------------------------------
+# G2: y^2 = x^3 + 3 / (9 + u) over Fq2 = Fq[u] / (u^2 + 1)  (halo2curves bn256::{Fq2, G2Affine, G2} [DEP]; the alt_bn128 twist of
+# EIP-197).  Fq2 elements are (c0, c1) tuples of canonical ints; affine points ((x0, x1), (y0, y1)), None = identity; Jacobian
+# points (X, Y, Z) of Fq2 elements.  Pinned to public values in tests/test_oracle.py: the generator of EIP-197, membership of the
+# twist curve, r * G2 = identity.
+# ----------------------------------------------------------------------------------------------
+F2 = Tuple[int, int]
+G2_GEN = ((10857046999023057135944570762232829481370756359578518086990519993285655852781,
+           11559732032986387107991004021392285783925812861821192530917403151452391805634),
+          (8495653923123431417604973247489272438418190587263600148770280649306958101930,
+           4082367875863433681332203403145435568316851327593401208105741076214120093531))
+
+
+def f2_add(a: F2, b: F2) -> F2: return ((a[0] + b[0]) % Q_MOD, (a[1] + b[1]) % Q_MOD)
+def f2_sub(a: F2, b: F2) -> F2: return ((a[0] - b[0]) % Q_MOD, (a[1] - b[1]) % Q_MOD)
+def f2_mul(a: F2, b: F2) -> F2: return ((a[0] * b[0] - a[1] * b[1]) % Q_MOD, (a[0] * b[1] + a[1] * b[0]) % Q_MOD)
+def f2_scale(a: F2, k: int) -> F2: return (a[0] * k % Q_MOD, a[1] * k % Q_MOD)
+
+
+def f2_inv(a: F2) -> F2:
+    d = pow(a[0] * a[0] + a[1] * a[1], -1, Q_MOD)
+    return (a[0] * d % Q_MOD, -a[1] * d % Q_MOD)
+
+
+G2_B = f2_mul((3, 0), f2_inv((9, 1)))
+G2_JAC_ID = ((0, 0), (1, 0), (0, 0))
+
+
+def g2_on_curve(P) -> bool:
+    if P is None:
+        return True
+    x, y = P
+    return f2_mul(y, y) == f2_add(f2_mul(f2_mul(x, x), x), G2_B)
+
+
+def g2_neg(P):
+    return None if P is None else (P[0], f2_sub((0, 0), P[1]))
+
+
+def g2_jac_double(P):
+    X, Y, Z = P
+    if Z == (0, 0) or Y == (0, 0):
+        return G2_JAC_ID
+    A, B = f2_mul(X, X), f2_mul(Y, Y)
+    Cc = f2_mul(B, B)
+    t = f2_add(X, B)
+    D = f2_scale(f2_sub(f2_sub(f2_mul(t, t), A), Cc), 2)
+    E = f2_scale(A, 3)
+    X3 = f2_sub(f2_mul(E, E), f2_scale(D, 2))
+    Y3 = f2_sub(f2_mul(E, f2_sub(D, X3)), f2_scale(Cc, 8))
+    return (X3, Y3, f2_scale(f2_mul(Y, Z), 2))
+
+
+def g2_jac_add(P, Q):
+    X1, Y1, Z1 = P
+    X2, Y2, Z2 = Q
+    if Z1 == (0, 0):
+        return Q
+    if Z2 == (0, 0):
+        return P
+    Z1Z1, Z2Z2 = f2_mul(Z1, Z1), f2_mul(Z2, Z2)
+    U1, U2 = f2_mul(X1, Z2Z2), f2_mul(X2, Z1Z1)
+    S1, S2 = f2_mul(f2_mul(Y1, Z2), Z2Z2), f2_mul(f2_mul(Y2, Z1), Z1Z1)
+    if U1 == U2:
+        return g2_jac_double(P) if S1 == S2 else G2_JAC_ID
+    H, Rr = f2_sub(U2, U1), f2_sub(S2, S1)
+    HH = f2_mul(H, H)
+    HHH, V = f2_mul(H, HH), f2_mul(U1, HH)
+    X3 = f2_sub(f2_sub(f2_mul(Rr, Rr), HHH), f2_scale(V, 2))
+    Y3 = f2_sub(f2_mul(Rr, f2_sub(V, X3)), f2_mul(S1, HHH))
+    return (X3, Y3, f2_mul(f2_mul(Z1, Z2), H))
+
+
+def g2_to_jac(P):
+    return G2_JAC_ID if P is None else (P[0], P[1], (1, 0))
+
+
+def g2_to_affine(P):
+    X, Y, Z = P
+    if Z == (0, 0):
+        return None
+    zi = f2_inv(Z)
+    zi2 = f2_mul(zi, zi)
+    return (f2_mul(X, zi2), f2_mul(Y, f2_mul(zi2, zi)))
+
+
+def g2_add(P, Q):
+    return g2_to_affine(g2_jac_add(g2_to_jac(P), g2_to_jac(Q)))
+
+
+def g2_scalar_mul(k: int, P):
+    k %= R_MOD
+    acc, base = G2_JAC_ID, g2_to_jac(P)
+    while k:
+        if k & 1:
+            acc = g2_jac_add(acc, base)
+        base = g2_jac_double(base)
+        k >>= 1
+    return g2_to_affine(acc)
+
+
+def g2_msm_naive(scalars: Sequence[int], bases) -> object:
+    acc = G2_JAC_ID
+    for k, P in zip(scalars, bases):
+        if P is not None and k % R_MOD:
+            acc = g2_jac_add(acc, g2_to_jac(g2_scalar_mul(k, P)))
+    return g2_to_affine(acc)
+
+
+def g2_affine_to_limbs(P) -> List[int]:
+    """G2Affine memory: x.c0 | x.c1 | y.c0 | y.c1, each 4 x u64 Montgomery limbs; identity = all zero"""
+    if P is None:
+        return [0] * 16
+    out: List[int] = []
+    for v in (P[0][0], P[0][1], P[1][0], P[1][1]):
+        out += limbs4(to_mont(v, Q_MOD))
+    return out
+
+
+def g2_jac_from_limbs(l: Sequence[int]):
+    """G2 memory (24 limbs: x, y, z as Fq2) -> affine point or None; asserts canonical limbs"""
+    v = []
+    for c in range(6):
+        m = from_limbs(l[4 * c:4 * c + 4])
+        assert m < Q_MOD, "non-canonical limbs"
+        v.append(from_mont(m, Q_MOD))
+    return g2_to_affine(((v[0], v[1]), (v[2], v[3]), (v[4], v[5])))
+
+
+# ----------------------------------------------------------------------------------------------
 # G1: y^2 = x^3 + 3 over Fq.  Affine points are (x, y) tuples of canonical ints; None = identity.
 # ----------------------------------------------------------------------------------------------
 Affine = Optional[Tuple[int, int]]

@@ -163,3 +163,29 @@ def test_row_a7_oracles_agree(cref):
         cref.batch_invert(W)
         inv = F.fr_decode(W)
         assert inv == O.batch_invert(v) and all((p * q_) % O.R_MOD == (1 if p else 0) for p, q_ in zip(v, inv))
+
+
+# ---------------------------------------------------------------- G2 (Fq2, twist curve): pinned to public values
+def test_g2_oracle_public_facts():
+    """the alt_bn128 G2 generator of EIP-197 lies on the twist y^2 = x^3 + 3/(9+u), has order r, and the Jacobian formulas agree with
+    an independent affine implementation (zksnap_circuits_halo2_amd/srs.py, written for ParamsKZG::setup's s_g2)"""
+    from zksnap_circuits_halo2_amd import srs
+
+    assert O.g2_on_curve(O.G2_GEN)
+    assert O.f2_mul(O.G2_B, (9, 1)) == (3, 0)
+    assert O.g2_scalar_mul(O.R_MOD - 1, O.G2_GEN) == O.g2_neg(O.G2_GEN)
+    assert O.g2_add(O.g2_scalar_mul(O.R_MOD - 1, O.G2_GEN), O.G2_GEN) is None
+    assert O.f2_mul((0, 1), (0, 1)) == (O.Q_MOD - 1, 0)                      # u^2 = -1
+    g = O.SplitMix64(222)
+    for _ in range(4):
+        k = g.fr()
+        P = O.g2_scalar_mul(k, O.G2_GEN)
+        assert O.g2_on_curve(P) and P == srs.g2_mul(k)
+        assert O.g2_add(P, P) == O.g2_scalar_mul(2 * k, O.G2_GEN)
+    a, b = g.fr(), g.fr()
+    lhs = O.g2_msm_naive([a, b, 0], [O.G2_GEN, O.g2_scalar_mul(5, O.G2_GEN), O.G2_GEN])
+    assert lhs == O.g2_scalar_mul((a + 5 * b) % O.R_MOD, O.G2_GEN)
+    enc = O.g2_affine_to_limbs(O.G2_GEN)
+    one = O.limbs4(O.to_mont(1, O.Q_MOD))
+    assert O.g2_jac_from_limbs(enc + one + [0, 0, 0, 0]) == O.G2_GEN
+    assert enc == [int(x) for x in srs.g2_encode(srs.G2_GENERATOR)]

@@ -18,6 +18,9 @@ _SIGS = {
     "zkhip_set_msm_shards": (C.c_int, [C.c_int]),
     "zkhip_msm_shards": (C.c_int, []),
     "zkhip_msm_g1": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "zkhip_msm_g2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "zkhip_msm_g2_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "zkhip_test_g2_op": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "zkhip_msm_g1_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
     "zkhip_ntt_fr_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]),
     "zkhip_register_bases": (C.c_int, [C.c_void_p, C.c_size_t]),

@@ -26,6 +26,16 @@ def best_multiexp(coeffs: np.ndarray, bases: np.ndarray) -> np.ndarray:
     return out
 
 
+def best_multiexp_g2(coeffs: np.ndarray, bases: np.ndarray) -> np.ndarray:
+    """`best_multiexp::<G2Affine>`: coeffs (n,4) uint64 Fr, bases (n,16) uint64 G2Affine -> (24,) uint64 G2 (Jacobian over Fq2)."""
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+    bases2 = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, 16)
+    assert coeffs.shape[0] == bases2.shape[0], "coeffs.len() != bases.len()"
+    out = np.zeros(24, dtype=np.uint64)
+    _lib.check(_lib.load().zkhip_msm_g2(_ptr(coeffs), _ptr(bases2), coeffs.shape[0], _ptr(out)))
+    return out
+
+
 def best_fft(a: np.ndarray, omega: np.ndarray, log_n: int) -> None:
     """In-place NTT of a ((2^log_n, 4) uint64 Fr) with the (4,) uint64 root `omega`."""
     assert a.dtype == np.uint64 and a.flags.c_contiguous

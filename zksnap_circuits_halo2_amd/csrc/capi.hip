@@ -1357,6 +1357,39 @@ int zkhip_g1_gen_walk_device(const uint64_t t0[4], const uint64_t d[4], size_t n
   return g1_gen_walk_device((const uint32_t*)t0, (const uint32_t*)d, n, (uint32_t*)d_out, sc->ws.p, sc->ws.cap, s);
 }
 
+// ---- G2 MSM: best_multiexp::<G2Affine> -------------------------------------------------------------------------------
+int zkhip_msm_g2_device(const void* d_scalars, const void* d_bases, size_t n, void* d_out_xyz, void* stream) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (!d_out_xyz || (n && (!d_scalars || !d_bases))) { set_error("msm_g2: null pointer"); return ZKHIP_EINVAL; }
+  hipStream_t s = caller_stream(stream);
+  scratch* sc = scratch_for(primary(), s);
+  if ((rc = sc->ws.reserve(msm_g2_workspace_bytes(n))) != ZKHIP_OK) return rc;
+  return msm_g2_device((const uint32_t*)d_scalars, (const uint32_t*)d_bases, n, (uint32_t*)d_out_xyz, sc->ws.p, sc->ws.cap, s);
+}
+
+int zkhip_msm_g2(const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t out_xyz[24]) {
+  if (!out_xyz || (n && (!scalars || !bases))) { set_error("msm_g2: null pointer"); return ZKHIP_EINVAL; }
+  lane_hold H;
+  if (H.rc != ZKHIP_OK) return H.rc;
+  int rc;
+  hipStream_t s = H.s;
+  if ((rc = H.sc->small.reserve(4096)) != ZKHIP_OK) return rc;
+  if (n) {
+    if ((rc = H.sc->scalars.reserve(n * 32)) != ZKHIP_OK) return rc;
+    if ((rc = H.sc->bases.reserve(n * 128)) != ZKHIP_OK) return rc;
+    if ((rc = H.sc->ws.reserve(msm_g2_workspace_bytes(n))) != ZKHIP_OK) return rc;
+    HIPCHK(hipMemcpyAsync(H.sc->scalars.p, scalars, n * 32, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(H.sc->bases.p, bases, n * 128, hipMemcpyHostToDevice, s));
+  }
+  if ((rc = msm_g2_device((const uint32_t*)H.sc->scalars.p, (const uint32_t*)H.sc->bases.p, n, (uint32_t*)H.sc->small.p, H.sc->ws.p, H.sc->ws.cap, s)) != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(H.L->pinned, H.sc->small.p, 192, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  memcpy(out_xyz, H.L->pinned, 192);
+  return ZKHIP_OK;
+}
+
 // ---- SRS / key-file validation: every point canonical and on the curve (RawBytes readers) ------------------------------
 int zkhip_g1_check_points_device(const void* d_points, size_t n, uint64_t* first_bad, void* stream) {
   guard_t g(g_mu);
@@ -1426,6 +1459,23 @@ int zkhip_test_g1_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out
   HIPCHK(hipMemcpyAsync(d + n * 64, b, n * 64, hipMemcpyHostToDevice, s));
   if ((rc = test_g1_op(op, (uint32_t*)d, (uint32_t*)(d + n * 64), (uint32_t*)(d + n * 128), n, s)) != ZKHIP_OK) return rc;
   HIPCHK(hipMemcpyAsync(out_xyz, d + n * 128, n * 96, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return ZKHIP_OK;
+}
+
+int zkhip_test_g2_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out_xyz, size_t n) {
+  if (op < 0 || op > 2 || (n && (!a || !b || !out_xyz))) { set_error("test_g2_op: bad argument"); return ZKHIP_EINVAL; }
+  if (n == 0) return ZKHIP_OK;
+  lane_hold H;
+  if (H.rc != ZKHIP_OK) return H.rc;
+  int rc;
+  hipStream_t s = H.s;
+  if ((rc = H.sc->poly.reserve(n * (128 + 128 + 192))) != ZKHIP_OK) return rc;
+  char* d = (char*)H.sc->poly.p;
+  HIPCHK(hipMemcpyAsync(d, a, n * 128, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d + n * 128, b, n * 128, hipMemcpyHostToDevice, s));
+  if ((rc = test_g2_op(op, (uint32_t*)d, (uint32_t*)(d + n * 128), (uint32_t*)(d + n * 256), n, s)) != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(out_xyz, d + n * 256, n * 192, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   return ZKHIP_OK;
 }

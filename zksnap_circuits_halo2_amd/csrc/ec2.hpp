@@ -1,0 +1,209 @@
+// BN254 G2: the quadratic extension Fq2 = Fq[u] / (u^2 + 1) over the lazy radix-2^29 field of fp29.hpp, and extended Jacobian
+// "XYZZ" point arithmetic on the sextic twist y^2 = x^3 + 3 / (9 + u) over it.
+//
+// Replaces halo2curves bn256::{Fq2, G2Affine, G2} [DEP] for `best_multiexp::<G2Affine>`.  No call site in the reference prover reaches an
+// MSM over G2 (it only reads `params.g2()` / `params.s_g2()`: /root/reference/aggregator/src/wrapper.rs:1142-1144); the north star names
+// "MSM on BN254 G1/G2", so the path exists, written for correctness first: unlike ec.hpp there is no bound tracking across operations.
+// Every Fq2 operation returns both components in STANDARD FORM -- N form (fp29.hpp), value < 2p + 2^233 -- by ending with the ~50
+// instruction quotient-estimate reduction (fe_reduce_soft), so the formulas below read like the textbook ones.
+//
+// Memory formats (the Rust in-memory layouts): Fq2 = c0 || c1 (2 x 4 u64 Montgomery limbs); G2Affine = x || y (128 B, identity all zero);
+// G2 = x || y || z Jacobian (192 B, identity z = 0).  The formulas never use the curve constant, as in ec.hpp.
+#pragma once
+#include "ec.hpp"
+
+namespace zkhip {
+
+struct fe2 {
+  fe c0, c1;
+};
+
+ZK_HD fe std_form(const fe& lazy) { return fe_reduce_soft<Fq>(fe_norm(lazy)); }   // any value < 2^261 with limbs < 2^32 -> standard form
+
+ZK_HD fe2 f2_zero() { return {fe_zero(), fe_zero()}; }
+ZK_HD fe2 f2_one() { return {fe_one<Fq>(), fe_zero()}; }
+ZK_HD bool f2_is_zero_limbs(const fe2& a) { return fe_is_zero_limbs(a.c0) && fe_is_zero_limbs(a.c1); }
+
+ZK_HD fe2 f2_add(const fe2& a, const fe2& b) { return {std_form(fe_add(a.c0, b.c0)), std_form(fe_add(a.c1, b.c1))}; }
+ZK_HD fe2 f2_dbl(const fe2& a) { return {std_form(fe_dbl(a.c0)), std_form(fe_dbl(a.c1))}; }
+// a - b: a + 4p - b limb-wise (P4_S1 is borrow-proof for a subtrahend in N form below 3p)
+ZK_HD fe2 f2_sub(const fe2& a, const fe2& b) { return {std_form(fe_sub_red(a.c0, b.c0, Fq::P4_S1)), std_form(fe_sub_red(a.c1, b.c1, Fq::P4_S1))}; }
+ZK_HD fe2 f2_neg(const fe2& a) { return {std_form(fe_neg_red(a.c0, Fq::P4_S1)), std_form(fe_neg_red(a.c1, Fq::P4_S1))}; }
+
+// Karatsuba: (a0 b0 - a1 b1) + (( a0 + a1)(b0 + b1) - a0 b0 - a1 b1) u.  Operands in standard form: the sums are < 4p + 2^234 with limbs
+// < 2^30, so every product is within fe_mul's limits and comes out N-form < 2p.
+ZK_HD fe2 f2_mul(const fe2& a, const fe2& b) {
+  const fe t0 = fe_mul<Fq>(a.c0, b.c0), t1 = fe_mul<Fq>(a.c1, b.c1);
+  const fe s = fe_mul<Fq>(fe_add(a.c0, a.c1), fe_add(b.c0, b.c1));
+  fe2 r;
+  r.c0 = std_form(fe_sub_red(t0, t1, Fq::P4_S1));                               // t0 - t1 + 4p
+  r.c1 = std_form(fe_sub_red(s, fe_norm(fe_add(t0, t1)), Fq::P6_S1));           // s - (t0 + t1) + 6p; t0 + t1 < 4p
+  return r;
+}
+
+// (a0 + a1)(a0 - a1) + 2 a0 a1 u
+ZK_HD fe2 f2_sqr(const fe2& a) {
+  const fe d = fe_norm(fe_sub_red(a.c0, a.c1, Fq::P4_S1));                      // a0 - a1 + 4p < 7p, N form
+  const fe s = fe_add(a.c0, a.c1);
+  fe2 r;
+  r.c0 = std_form(fe_mul<Fq>(s, d));
+  r.c1 = std_form(fe_dbl(fe_mul<Fq>(a.c0, a.c1)));
+  return r;
+}
+
+// is the value 0 mod p (both components)?  One multiplication by one brings a standard-form value below 2p, where zero is 0 or p.
+ZK_HD bool f2_is_zero(const fe2& a) {
+  const fe one = fe_one<Fq>();
+  return fe_mulout_is_zero<Fq>(fe_mul<Fq>(one, a.c0)) && fe_mulout_is_zero<Fq>(fe_mul<Fq>(one, a.c1));
+}
+
+// ---- points ------------------------------------------------------------------------------------------------------------
+struct xyzz2 {
+  fe2 X, Y, ZZ, ZZZ;        // x = X / ZZ, y = Y / ZZZ; identity <=> ZZ has all limbs zero
+};
+
+ZK_HD xyzz2 xyzz2_identity() { return {f2_zero(), f2_zero(), f2_zero(), f2_zero()}; }
+ZK_HD bool xyzz2_is_identity(const xyzz2& a) { return f2_is_zero_limbs(a.ZZ); }
+
+// 2A (dbl-2008-s-1, a = 0)
+ZK_HD xyzz2 xyzz2_dbl(const xyzz2& A) {
+  if (xyzz2_is_identity(A)) return A;
+  const fe2 U = f2_dbl(A.Y), V = f2_sqr(U), W = f2_mul(U, V), S = f2_mul(A.X, V);
+  const fe2 XX = f2_sqr(A.X), M = f2_add(f2_dbl(XX), XX);
+  xyzz2 r;
+  r.X = f2_sub(f2_sqr(M), f2_dbl(S));
+  r.Y = f2_sub(f2_mul(M, f2_sub(S, r.X)), f2_mul(W, A.Y));
+  r.ZZ = f2_mul(V, A.ZZ);
+  r.ZZZ = f2_mul(W, A.ZZZ);
+  return r;
+}
+
+// A + B (add-2008-s), with the doubling / opposite-point cases
+ZK_HD xyzz2 xyzz2_add(const xyzz2& A, const xyzz2& B) {
+  if (xyzz2_is_identity(A)) return B;
+  if (xyzz2_is_identity(B)) return A;
+  const fe2 U1 = f2_mul(A.X, B.ZZ), U2 = f2_mul(B.X, A.ZZ), S1 = f2_mul(A.Y, B.ZZZ), S2 = f2_mul(B.Y, A.ZZZ);
+  const fe2 P = f2_sub(U2, U1), R = f2_sub(S2, S1);
+  if (f2_is_zero(P)) {
+    if (f2_is_zero(R)) return xyzz2_dbl(A);
+    return xyzz2_identity();
+  }
+  const fe2 PP = f2_sqr(P), PPP = f2_mul(P, PP), Q = f2_mul(U1, PP);
+  xyzz2 r;
+  r.X = f2_sub(f2_sub(f2_sqr(R), PPP), f2_dbl(Q));
+  r.Y = f2_sub(f2_mul(R, f2_sub(Q, r.X)), f2_mul(S1, PPP));
+  r.ZZ = f2_mul(f2_mul(A.ZZ, B.ZZ), PP);
+  r.ZZZ = f2_mul(f2_mul(A.ZZZ, B.ZZZ), PPP);
+  return r;
+}
+
+// acc += (x2, y2) affine, not the identity (madd-2008-s); coordinates in standard form
+ZK_HD void xyzz2_madd(xyzz2& acc, const fe2& x2, const fe2& y2) {
+  if (xyzz2_is_identity(acc)) {
+    acc.X = x2; acc.Y = y2; acc.ZZ = f2_one(); acc.ZZZ = f2_one();
+    return;
+  }
+  const fe2 U2 = f2_mul(x2, acc.ZZ), S2 = f2_mul(y2, acc.ZZZ);
+  const fe2 P = f2_sub(U2, acc.X), R = f2_sub(S2, acc.Y);
+  if (f2_is_zero(P)) {
+    if (f2_is_zero(R)) {
+      xyzz2 t;
+      t.X = x2; t.Y = y2; t.ZZ = f2_one(); t.ZZZ = f2_one();
+      acc = xyzz2_dbl(t);
+    } else {
+      acc = xyzz2_identity();
+    }
+    return;
+  }
+  const fe2 PP = f2_sqr(P), PPP = f2_mul(P, PP), Q = f2_mul(acc.X, PP);
+  const fe2 X3 = f2_sub(f2_sub(f2_sqr(R), PPP), f2_dbl(Q));
+  acc.Y = f2_sub(f2_mul(R, f2_sub(Q, X3)), f2_mul(acc.Y, PPP));
+  acc.X = X3;
+  acc.ZZ = f2_mul(acc.ZZ, PP);
+  acc.ZZZ = f2_mul(acc.ZZZ, PPP);
+}
+
+#if defined(__HIPCC__)
+// external Montgomery-256 words -> standard-form internal value (x * 2^261 mod p): one multiplication by one
+ZK_D fe fq_from_ext(const uint32_t* w8) {
+  uint32_t w[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) w[i] = w8[i];
+  return fe_mul<Fq>(fe_one<Fq>(), fe_from_ext_lazy(w));
+}
+ZK_D void fq_to_ext(const fe& a, uint32_t* out8) {
+  uint32_t w[8];
+  fe_to_ext<Fq>(a, w);
+#pragma unroll
+  for (int i = 0; i < 8; i++) out8[i] = w[i];
+}
+
+struct affine2_words { uint32_t w[32]; };   // x.c0 | x.c1 | y.c0 | y.c1
+
+ZK_D affine2_words load_affine2(const uint32_t* base, size_t idx) {
+  affine2_words a;
+  const uint4* q = reinterpret_cast<const uint4*>(base + idx * 32);
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const uint4 v = q[i];
+    a.w[4 * i] = v.x; a.w[4 * i + 1] = v.y; a.w[4 * i + 2] = v.z; a.w[4 * i + 3] = v.w;
+  }
+  return a;
+}
+ZK_D bool affine2_is_identity(const affine2_words& a) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < 32; i++) o |= a.w[i];
+  return o == 0;
+}
+ZK_D void affine2_coords(const affine2_words& a, bool negate, fe2& x, fe2& y) {
+  x.c0 = fq_from_ext(a.w); x.c1 = fq_from_ext(a.w + 8);
+  y.c0 = fq_from_ext(a.w + 16); y.c1 = fq_from_ext(a.w + 24);
+  if (negate) y = f2_neg(y);
+}
+
+// XYZZ work format in global memory: 8 x 9 limbs (288 B)
+ZK_D xyzz2 load_xyzz2(const uint32_t* base, size_t idx) {
+  const uint4* q = reinterpret_cast<const uint4*>(base + idx * 72);
+  uint32_t w[72];
+#pragma unroll
+  for (int i = 0; i < 18; i++) {
+    const uint4 v = q[i];
+    w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+  }
+  xyzz2 r;
+  fe* f[8] = {&r.X.c0, &r.X.c1, &r.Y.c0, &r.Y.c1, &r.ZZ.c0, &r.ZZ.c1, &r.ZZZ.c0, &r.ZZZ.c1};
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+#pragma unroll
+    for (int i = 0; i < 9; i++) f[k]->l[i] = w[9 * k + i];
+  return r;
+}
+ZK_D void store_xyzz2(uint32_t* base, size_t idx, const xyzz2& a) {
+  uint32_t w[72];
+  const fe* f[8] = {&a.X.c0, &a.X.c1, &a.Y.c0, &a.Y.c1, &a.ZZ.c0, &a.ZZ.c1, &a.ZZZ.c0, &a.ZZZ.c1};
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+#pragma unroll
+    for (int i = 0; i < 9; i++) w[9 * k + i] = f[k]->l[i];
+  uint4* q = reinterpret_cast<uint4*>(base + idx * 72);
+#pragma unroll
+  for (int i = 0; i < 18; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+
+// XYZZ -> G2 Jacobian memory (x || y || z, 48 u32 words): (X ZZ^2, Y ZZZ^2, ZZZ); identity = (0, 1, 0) like halo2curves `G2::identity()`
+ZK_D void store_jacobian2(const xyzz2& a, uint32_t* out) {
+  if (xyzz2_is_identity(a)) {
+#pragma unroll
+    for (int i = 0; i < 48; i++) out[i] = 0;
+    fq_to_ext(fe_one<Fq>(), out + 16);
+    return;
+  }
+  const fe2 x = f2_mul(a.X, f2_sqr(a.ZZ)), y = f2_mul(a.Y, f2_sqr(a.ZZZ));
+  fq_to_ext(x.c0, out); fq_to_ext(x.c1, out + 8);
+  fq_to_ext(y.c0, out + 16); fq_to_ext(y.c1, out + 24);
+  fq_to_ext(a.ZZZ.c0, out + 32); fq_to_ext(a.ZZZ.c1, out + 40);
+}
+#endif
+
+}  // namespace zkhip

@@ -1101,7 +1101,7 @@ static uint32_t msm_task_shift(size_t entries /* W n K */, size_t NB) {
   return task_shift;
 }
 
-static msm_layout msm_lay_out(char* base, size_t n, size_t K, int c, bool prepared) {
+static msm_layout msm_lay_out(char* base, size_t n, size_t K, int c, bool prepared, size_t xyzz_bytes = 144) {
   msm_layout L;
   const size_t W = (256 + c - 1) / c, B = (size_t)1 << (c - 1), WB = prepared ? K : W, NB = WB * B;
   const bool wide = c > 16;
@@ -1128,71 +1128,52 @@ static msm_layout msm_lay_out(char* base, size_t n, size_t K, int c, bool prepar
   L.bsum2 = (uint32_t*)carve((NB / SCAN_TILE + 2) * sizeof(uint32_t));
   L.tasks = (task_t*)carve(L.max_tasks * sizeof(task_t));
   L.order = (uint4*)carve(L.max_tasks * sizeof(uint4));    // execution order: one record per task
-  L.partials = (uint32_t*)carve(L.max_tasks * 144);
-  L.pyrA = (uint32_t*)carve(WB * B * 144);                 // pyramid ping-pong: per bucket set N + (s-1) N/2 <= B elements at every step
-  L.pyrB = (uint32_t*)carve(WB * B * 144);
-  L.winsum = (uint32_t*)carve((W + K) * 144);              // window / bucket-set sums
+  L.partials = (uint32_t*)carve(L.max_tasks * xyzz_bytes);
+  L.pyrA = (uint32_t*)carve(WB * B * xyzz_bytes);          // pyramid ping-pong: per bucket set N + (s-1) N/2 <= B elements at every step
+  L.pyrB = (uint32_t*)carve(WB * B * xyzz_bytes);
+  L.winsum = (uint32_t*)carve((W + K) * xyzz_bytes);       // window / bucket-set sums
   L.total = (size_t)(p - base);
   return L;
 }
 
-size_t msm_workspace_bytes(size_t n_one, int c, bool prepared, size_t batch) {
+size_t msm_workspace_bytes(size_t n_one, int c, bool prepared, size_t batch, size_t xyzz_bytes) {
   if (n_one == 0 || batch == 0) return 0;
-  return msm_lay_out(nullptr, n_one, batch, c, prepared).total;
+  return msm_lay_out(nullptr, n_one, batch, c, prepared, xyzz_bytes).total;
 }
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s failed: %s", #x, hipGetErrorString(e_)); return ZKHIP_EHIP; } } while (0)
 
-// d_scalars: n x 8 words, d_bases: n x 16 words, d_out: 24 words (device).  ws: workspace of msm_workspace_bytes.
-// prepared != nullptr: d_bases is ignored, points come from the table (window w of point i at table[w * stride + off + i]).
-// batch > 1 (prepared path, c <= 16 only): `batch` scalar vectors of n elements, vector k at d_scalars + k * scalar_stride
-// elements, all against the same bases; d_out receives `batch` results (24 words each).
-int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, uint32_t* d_out, void* ws, size_t ws_bytes,
-                  int c_override, hipStream_t stream, const prepared_bases* prepared, size_t prepared_off, size_t batch,
-                  size_t scalar_stride) {
-  if (batch == 0) return ZKHIP_OK;
-  if (n == 0) {
-    for (size_t k = 0; k < batch; k++) hipLaunchKernelGGL(k_sum_jacobian, dim3(1), dim3(64), 0, stream, (const uint32_t*)nullptr, 0, d_out + k * 24);
-    HIPCHK(hipGetLastError());
-    return ZKHIP_OK;
-  }
-  if (batch > 1 && (!prepared || prepared->c > 16 || batch > 65535)) { set_error("msm: batch needs prepared bases with a window <= 16 bits"); return ZKHIP_EINVAL; }
+// Steps 1 - 5 (digits, bucket sort, tasks, execution order): everything that depends on the scalars only, shared by the curves.
+// `shared_buckets`: one bucket set per MSM of the batch for all windows (prepared G1 tables) instead of one per window.
+// ref_base / ref_stride: point reference of entry i of window w = ref_base + w * ref_stride + i.
+int msm_build_tasks(const uint32_t* d_scalars, size_t n, size_t batch, size_t scalar_stride, int c, bool shared_buckets, uint32_t ref_base, uint32_t ref_stride,
+                    size_t xyzz_bytes, void* ws, size_t ws_bytes, hipStream_t stream, msm_tasks_view* out) {
   const uint32_t K = (uint32_t)batch;
-  if (n >= (1ull << 31)) { set_error("msm: n = %zu too large", n); return ZKHIP_EINVAL; }
-  const int c = prepared ? prepared->c : (c_override > 0 ? c_override : msm_pick_window(n));
-  const bool wide = c > 16;                         // two-level bucket sort, int32 digits: prepared path only
-  if (c < 2 || c > (prepared ? MAX_WINDOW_PREPARED : 16)) { set_error("msm: window bits %d out of range", c); return ZKHIP_EINVAL; }
+  const bool wide = c > 16;                         // two-level bucket sort, int32 digits
   const int W = (256 + c - 1) / c;
   const uint32_t B = 1u << (c - 1);
-  const int WB = prepared ? (int)K : W;            // number of bucket sets
+  const int WB = shared_buckets ? (int)K : W;      // number of bucket sets
   const uint32_t NB = (uint32_t)WB * B;
-  if (prepared) {
-    if (prepared_off + n > prepared->n) { set_error("msm: range exceeds the prepared bases"); return ZKHIP_EINVAL; }
-    if ((size_t)W * prepared->n >= (1ull << 31)) { set_error("msm: prepared table too large for 31-bit point references"); return ZKHIP_EINVAL; }
-    d_bases = prepared->table;
-  }
   if ((size_t)W * n * K >= (1ull << 32) || (size_t)WB * B >= (1ull << 31)) { set_error("msm: W*n*batch overflows 32-bit slot index"); return ZKHIP_EINVAL; }
-  const size_t nk = n * K;                          // scalars in the whole batch
-  const msm_layout lay = msm_lay_out((char*)ws, n, K, c, prepared != nullptr);
+  if (wide && (!shared_buckets || K != 1)) { set_error("msm: windows above 16 bits need one shared bucket set"); return ZKHIP_EINVAL; }
+  const msm_layout lay = msm_lay_out((char*)ws, n, K, c, shared_buckets, xyzz_bytes);
   if (ws_bytes < lay.total) { set_error("msm: workspace too small (%zu < %zu bytes)", ws_bytes, lay.total); return ZKHIP_EINVAL; }
   const uint32_t task_shift = lay.task_shift;
-  const size_t max_tasks = lay.max_tasks;
   const uint32_t n_pad = (uint32_t)((n + 7) & ~(size_t)7);
   void* const digits = lay.digits;
   uint32_t* const stage_ref = lay.stage_ref;
   uint16_t* const stage_fine = lay.stage_fine;
-  char* const zero_lo = lay.zero_lo;
-  const size_t zero_bytes = lay.zero_bytes;
   uint32_t *const gcounters = lay.gcounters, *const counters = lay.counters, *const count = lay.count, *const sorted = lay.sorted,
            *const offset = lay.offset, *const cursor = lay.cursor, *const task_off = lay.task_off, *const bsum1 = lay.bsum1, *const bsum2 = lay.bsum2;
   task_t* const tasks = lay.tasks;
   uint4* const order = lay.order;
-  uint32_t *const partials = lay.partials, *const pyrA = lay.pyrA, *const pyrB = lay.pyrB, *const winsum = lay.winsum;
 
   prof_begin(stream);
-  HIPCHK(hipMemsetAsync(zero_lo, 0, zero_bytes, stream));
+  HIPCHK(hipMemsetAsync(lay.zero_lo, 0, lay.zero_bytes, stream));
   // 1. digits
   const size_t sstride = K > 1 ? scalar_stride : n;
+  const size_t nk = n * K, max_tasks = lay.max_tasks;
+  (void)nk; (void)max_tasks;
   const unsigned dblocks = (unsigned)(((size_t)K * n_pad + 255) / 256);
   if (wide) hipLaunchKernelGGL(k_digits<int32_t>, dim3(dblocks), dim3(256), 0, stream, d_scalars, (int32_t*)digits, (uint32_t)n, n_pad, c, W, K, sstride);
   else hipLaunchKernelGGL(k_digits<int16_t>, dim3(dblocks), dim3(256), 0, stream, d_scalars, (int16_t*)digits, (uint32_t)n, n_pad, c, W, K, sstride);
@@ -1220,8 +1201,7 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   const bool sort_ids = (size_t)W * n < ((size_t)G << 17);           // fewer than 2^17 staged entries per group on average
   const uint32_t sort_chunk = sort_ids ? SORT_CHUNK_IDS : SORT_CHUNK;
   const uint32_t sort_chunks = (uint32_t)(((size_t)W * n + sort_chunk - 1) / sort_chunk) + (uint32_t)G;     // upper bound of the fine passes' chunks; surplus workgroups return at once
-  const uint32_t wb_stride = prepared ? 0u : B;
-  const uint32_t ref_base = prepared ? (uint32_t)prepared_off : 0u, ref_stride = prepared ? (uint32_t)prepared->n : 0u;
+  const uint32_t wb_stride = shared_buckets ? 0u : B;
   if (wide) {
     hipLaunchKernelGGL(k_coarse_pass<false>, dim3(chunks, W), dim3(1024), 0, stream, (const int32_t*)digits, n_pad, chunk, gcounters, (uint32_t*)nullptr,
                        (uint16_t*)nullptr, ref_base, ref_stride);
@@ -1269,6 +1249,48 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   }
   hipLaunchKernelGGL(k_make_order, dim3(task_blocks), dim3(256), 0, stream, offset, task_off, NB, task_shift, counters + 192, sorted, order);
   prof_mark(stream, "tasks");
+  out->c = c; out->W = W; out->WB = WB; out->B = B; out->NB = NB; out->task_shift = task_shift; out->max_tasks = lay.max_tasks; out->nk = n * K;
+  out->tasks = tasks; out->ntasks = counters + 1; out->max_parts = counters + 2; out->order = order; out->sorted = sorted; out->task_off = task_off;
+  out->partials = lay.partials; out->pyrA = lay.pyrA; out->pyrB = lay.pyrB; out->winsum = lay.winsum;
+  HIPCHK(hipGetLastError());
+  return ZKHIP_OK;
+}
+
+// d_scalars: n x 8 words, d_bases: n x 16 words, d_out: 24 words (device).  ws: workspace of msm_workspace_bytes.
+// prepared != nullptr: d_bases is ignored, points come from the table (window w of point i at table[w * stride + off + i]).
+// batch > 1 (prepared path, c <= 16 only): `batch` scalar vectors of n elements, vector k at d_scalars + k * scalar_stride
+// elements, all against the same bases; d_out receives `batch` results (24 words each).
+int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, uint32_t* d_out, void* ws, size_t ws_bytes,
+                  int c_override, hipStream_t stream, const prepared_bases* prepared, size_t prepared_off, size_t batch,
+                  size_t scalar_stride) {
+  if (batch == 0) return ZKHIP_OK;
+  if (n == 0) {
+    for (size_t k = 0; k < batch; k++) hipLaunchKernelGGL(k_sum_jacobian, dim3(1), dim3(64), 0, stream, (const uint32_t*)nullptr, 0, d_out + k * 24);
+    HIPCHK(hipGetLastError());
+    return ZKHIP_OK;
+  }
+  if (batch > 1 && (!prepared || prepared->c > 16 || batch > 65535)) { set_error("msm: batch needs prepared bases with a window <= 16 bits"); return ZKHIP_EINVAL; }
+  const uint32_t K = (uint32_t)batch;
+  if (n >= (1ull << 31)) { set_error("msm: n = %zu too large", n); return ZKHIP_EINVAL; }
+  const int c = prepared ? prepared->c : (c_override > 0 ? c_override : msm_pick_window(n));
+  if (c < 2 || c > (prepared ? MAX_WINDOW_PREPARED : 16)) { set_error("msm: window bits %d out of range", c); return ZKHIP_EINVAL; }
+  if (prepared) {
+    if (prepared_off + n > prepared->n) { set_error("msm: range exceeds the prepared bases"); return ZKHIP_EINVAL; }
+    if ((size_t)((256 + c - 1) / c) * prepared->n >= (1ull << 31)) { set_error("msm: prepared table too large for 31-bit point references"); return ZKHIP_EINVAL; }
+    d_bases = prepared->table;
+  }
+  msm_tasks_view tv;
+  int rc = msm_build_tasks(d_scalars, n, batch, scalar_stride, c, prepared != nullptr, prepared ? (uint32_t)prepared_off : 0u, prepared ? (uint32_t)prepared->n : 0u,
+                           144, ws, ws_bytes, stream, &tv);
+  if (rc != ZKHIP_OK) return rc;
+  const int W = tv.W, WB = tv.WB;
+  const uint32_t B = tv.B, NB = tv.NB, task_shift = tv.task_shift;
+  const size_t max_tasks = tv.max_tasks, nk = tv.nk;
+  const task_t* const tasks = (const task_t*)tv.tasks;
+  uint32_t* const counters = tv.ntasks - 1;
+  const uint4* const order = tv.order;
+  const uint32_t *const sorted = tv.sorted, *const task_off = tv.task_off;
+  uint32_t *const partials = tv.partials, *const pyrA = tv.pyrA, *const pyrB = tv.pyrB, *const winsum = tv.winsum;
   // 6. accumulate (grid-stride over the device-side task count)
   {
     uint32_t blocks = (uint32_t)((max_tasks + 127) / 128);

@@ -1,0 +1,204 @@
+// BN254 G2 multi-scalar multiplication: `best_multiexp::<G2Affine>` [DEP halo2-axiom arithmetic.rs is generic over the curve].
+//
+// The north star names "Pippenger-bucketed MSM on BN254 G1/G2"; the reference prover itself never multiplies in G2 (it reads
+// `params.g2()` / `params.s_g2()`: /root/reference/aggregator/src/wrapper.rs:1142-1144), so this path is built for correctness and
+// shares everything that depends on the scalars only with the G1 path (msm.hip `msm_build_tasks`: signed digits, LDS counting sorts,
+// tasks in longest-first order).  Curve-specific, here: bucket accumulation (one thread per task, XYZZ over Fq2 in registers),
+// per-bucket combination of the task partials, the log-depth bucket pyramid (same index algebra as k_pyramid_step in msm.hip), the
+// per-window weighted sum and the window fold.  One bucket set per window (no prepared tables: there is no fixed-base caller).
+// Work points are 288 bytes (8 x 9 limbs).
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "ec2.hpp"
+#include "zkhip_internal.hpp"
+
+namespace zkhip {
+
+struct task_t {
+  uint32_t bucket, start, len;
+};
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s failed: %s", #x, hipGetErrorString(e_)); return ZKHIP_EHIP; } } while (0)
+
+__global__ void __launch_bounds__(64) k2_accumulate(const uint32_t* __restrict__ ntasks_p, const uint4* __restrict__ order, const uint32_t* __restrict__ sorted,
+                                                    const uint32_t* __restrict__ bases, uint32_t* __restrict__ partials, uint32_t* __restrict__ buckets) {
+  const uint32_t ntasks = *ntasks_p;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ntasks; i += gridDim.x * blockDim.x) {
+    const uint4 rec = order[i];
+    const uint32_t t = rec.x, start = rec.y, len = rec.z;
+    xyzz2 acc = xyzz2_identity();
+#pragma unroll 1
+    for (uint32_t j = 0; j < len; j++) {
+      const uint32_t ref = sorted[start + j];
+      const affine2_words pt = load_affine2(bases, ref & 0x7fffffffu);
+      if (affine2_is_identity(pt)) continue;
+      fe2 x, y;
+      affine2_coords(pt, (ref >> 31) != 0, x, y);
+      xyzz2_madd(acc, x, y);
+    }
+    if (t >> 31) store_xyzz2(buckets, t & 0x7fffffffu, acc);      // the bucket's only task writes the bucket itself
+    else store_xyzz2(partials, t, acc);
+  }
+}
+
+// one thread per bucket: sum of its task partials (a bucket with a single task was written by k2_accumulate)
+__global__ void __launch_bounds__(64) k2_combine(const uint32_t* __restrict__ task_off, uint32_t nbuckets, const uint32_t* __restrict__ partials,
+                                                 uint32_t* __restrict__ buckets) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nbuckets) return;
+  const uint32_t t = task_off[k], m = task_off[k + 1] - t;
+  if (m == 1) return;
+  xyzz2 acc = xyzz2_identity();
+#pragma unroll 1
+  for (uint32_t j = 0; j < m; j++) acc = xyzz2_add(acc, load_xyzz2(partials, t + j));
+  store_xyzz2(buckets, k, acc);
+}
+
+// pyramid step (see msm.hip section 8 for the state layout): sum_k (k + 1) B_k = Tot + sum_l 2^l T_l
+__global__ void __launch_bounds__(64) k2_pyramid_step(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t N, int s, uint32_t in_stride,
+                                                      uint32_t out_stride) {
+  const uint32_t per_win = N / 2 + (uint32_t)s * (N / 4);
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= per_win) return;
+  const int win = blockIdx.y;
+  const uint32_t* wi = in + (size_t)win * in_stride * 72;
+  uint32_t* wo = out + (size_t)win * out_stride * 72;
+  uint32_t ia, ib;
+  if (tid < N / 2) {
+    ia = 2 * tid; ib = 2 * tid + 1;
+  } else {
+    const uint32_t r = tid - N / 2, l = r / (N / 4), u = r % (N / 4);
+    if ((int)l == s - 1) { ia = 4 * u + 1; ib = 4 * u + 3; }
+    else { ia = N + l * (N / 2) + 2 * u; ib = ia + 1; }
+  }
+  store_xyzz2(wo, tid, xyzz2_add(load_xyzz2(wi, ia), load_xyzz2(wi, ib)));
+}
+
+// window sum = X0 + X1 + sum_l 2^l Z^l + 2^nz X1 (state after the last pyramid step: X has 2 elements, Z^0 .. Z^(nz-1) one each).
+// One 32-lane group per window, a shuffle tree over the terms (nz + 2 <= 32).
+__device__ __forceinline__ xyzz2 xyzz2_shfl_xor(const xyzz2& a, int mask) {
+  xyzz2 r;
+  const fe* src[8] = {&a.X.c0, &a.X.c1, &a.Y.c0, &a.Y.c1, &a.ZZ.c0, &a.ZZ.c1, &a.ZZZ.c0, &a.ZZZ.c1};
+  fe* dst[8] = {&r.X.c0, &r.X.c1, &r.Y.c0, &r.Y.c1, &r.ZZ.c0, &r.ZZ.c1, &r.ZZZ.c0, &r.ZZZ.c1};
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+#pragma unroll
+    for (int i = 0; i < NL; i++) dst[k]->l[i] = (uint32_t)__shfl_xor((int)src[k]->l[i], mask, 64);
+  return r;
+}
+
+__global__ void __launch_bounds__(64) k2_window_sum(const uint32_t* __restrict__ in, uint32_t in_stride, int nz, uint32_t* __restrict__ winsum, int W) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int win = gid >> 5, lane = gid & 31;
+  xyzz2 acc = xyzz2_identity();
+  if (win < W) {
+    const uint32_t* wi = in + (size_t)win * in_stride * 72;
+    int dbl = 0;
+    if (lane < nz) { acc = load_xyzz2(wi, 2 + lane); dbl = lane; }
+    else if (lane == nz) { acc = load_xyzz2(wi, 1); dbl = nz; }
+    else if (lane == nz + 1) acc = xyzz2_add(load_xyzz2(wi, 0), load_xyzz2(wi, 1));
+#pragma unroll 1
+    for (int i = 0; i < dbl; i++) acc = xyzz2_dbl(acc);
+  }
+#pragma unroll 1
+  for (int mask = 1; mask < 32; mask <<= 1) acc = xyzz2_add(acc, xyzz2_shfl_xor(acc, mask));
+  if (win < W && lane == 0) store_xyzz2(winsum, win, acc);
+}
+
+// result = sum_w 2^(c w) winsum[w], written as a Jacobian G2 point (48 words)
+__global__ void __launch_bounds__(64) k2_fold(const uint32_t* __restrict__ winsum, int W, int c, uint32_t* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  xyzz2 acc = load_xyzz2(winsum, W - 1);
+  for (int w = W - 2; w >= 0; w--) {
+#pragma unroll 1
+    for (int i = 0; i < c; i++) acc = xyzz2_dbl(acc);
+    acc = xyzz2_add(acc, load_xyzz2(winsum, w));
+  }
+  store_jacobian2(acc, out);
+}
+
+__global__ void __launch_bounds__(64) k2_store_identity(uint32_t* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) store_jacobian2(xyzz2_identity(), out);
+}
+
+// parity hook: out[i] = a[i] + b[i] (op 0), 2 a[i] (op 1), a[i] - b[i] (op 2) as Jacobian G2 points
+__global__ void __launch_bounds__(64) k2_test_op(int op, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint32_t* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const affine2_words pa = load_affine2(a, i), pb = load_affine2(b, i);
+  xyzz2 acc = xyzz2_identity();
+  fe2 x, y;
+  if (!affine2_is_identity(pa)) { affine2_coords(pa, false, x, y); xyzz2_madd(acc, x, y); }
+  if (op == 1) acc = xyzz2_dbl(acc);
+  else if (!affine2_is_identity(pb)) {
+    affine2_coords(pb, op == 2, x, y);
+    // through the general addition as well as the mixed one: even rows use xyzz2_add on a lifted point
+    if (i & 1) xyzz2_madd(acc, x, y);
+    else { xyzz2 t = xyzz2_identity(); xyzz2_madd(t, x, y); acc = xyzz2_add(acc, t); }
+  }
+  store_jacobian2(acc, out + i * 48);
+}
+
+static int pick_window_g2(size_t n) {
+  // additions cost ~3.5x the G1 ones, the tail is single-lane: the model of msm_pick_window with a heavier bucket term
+  int best = 2;
+  double best_cost = 1e300;
+  for (int c = 2; c <= 16; c++) {
+    const int W = (256 + c - 1) / c, top_bits = 254 - (W - 1) * c;
+    if (top_bits > 0 && top_bits < 6) continue;
+    const double cost = (double)W * ((double)n + 6.0 * (double)(1u << (c - 1)));
+    if (cost < best_cost) { best_cost = cost; best = c; }
+  }
+  return best;
+}
+
+size_t msm_g2_workspace_bytes(size_t n) { return n ? msm_workspace_bytes(n, pick_window_g2(n), false, 1, 288) : 0; }
+
+// d_scalars: n x 8 words (Fr, Montgomery), d_bases: n x 32 words (G2Affine), d_out: 48 words (G2 Jacobian)
+int msm_g2_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, uint32_t* d_out, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (n == 0) {
+    hipLaunchKernelGGL(k2_store_identity, dim3(1), dim3(64), 0, stream, d_out);
+    HIPCHK(hipGetLastError());
+    return ZKHIP_OK;
+  }
+  if (n >= (1ull << 31)) { set_error("msm_g2: n = %zu too large", n); return ZKHIP_EINVAL; }
+  const int c = pick_window_g2(n);
+  msm_tasks_view tv;
+  int rc = msm_build_tasks(d_scalars, n, 1, n, c, false, 0u, 0u, 288, ws, ws_bytes, stream, &tv);
+  if (rc != ZKHIP_OK) return rc;
+  {
+    uint32_t blocks = (uint32_t)((tv.max_tasks + 63) / 64);
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(k2_accumulate, dim3(blocks), dim3(64), 0, stream, tv.ntasks, tv.order, tv.sorted, d_bases, tv.partials, tv.pyrA);
+  }
+  prof_mark(stream, "accumulate_g2");
+  hipLaunchKernelGGL(k2_combine, dim3((tv.NB + 63) / 64), dim3(64), 0, stream, tv.task_off, tv.NB, tv.partials, tv.pyrA);
+  prof_mark(stream, "combine_g2");
+  uint32_t* cur = tv.pyrA;
+  uint32_t* nxt = tv.pyrB;
+  uint32_t in_stride = tv.B, N = tv.B;
+  int s = 1;
+  while (N > 2) {
+    const uint32_t per_win = N / 2 + (uint32_t)s * (N / 4);
+    hipLaunchKernelGGL(k2_pyramid_step, dim3((per_win + 63) / 64, tv.WB), dim3(64), 0, stream, cur, nxt, N, s, in_stride, per_win);
+    uint32_t* t = cur; cur = nxt; nxt = t;
+    in_stride = per_win;
+    N >>= 1;
+    s++;
+  }
+  const int nz = s - 1;
+  prof_mark(stream, "pyramid_g2");
+  hipLaunchKernelGGL(k2_window_sum, dim3((tv.WB * 32 + 63) / 64), dim3(64), 0, stream, cur, in_stride, nz, tv.winsum, tv.WB);
+  hipLaunchKernelGGL(k2_fold, dim3(1), dim3(64), 0, stream, tv.winsum, tv.WB, c, d_out);
+  prof_mark(stream, "fold_g2");
+  HIPCHK(hipGetLastError());
+  return ZKHIP_OK;
+}
+
+int test_g2_op(int op, const uint32_t* d_a, const uint32_t* d_b, uint32_t* d_out, size_t n, hipStream_t stream) {
+  if (n == 0) return ZKHIP_OK;
+  hipLaunchKernelGGL(k2_test_op, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, op, d_a, d_b, d_out, n);
+  return hipGetLastError() == hipSuccess ? ZKHIP_OK : ZKHIP_EHIP;
+}
+
+}  // namespace zkhip

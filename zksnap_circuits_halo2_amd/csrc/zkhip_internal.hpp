@@ -21,7 +21,26 @@ size_t g1_fixed_base_workspace(size_t n);
 int g1_fixed_base_table_build(uint32_t* d_table, void* ws, size_t ws_bytes, hipStream_t stream);
 int g1_fixed_base_mul_device(const uint32_t* d_scalars, size_t n, const uint32_t* d_table, uint32_t* d_out, void* ws, size_t ws_bytes, hipStream_t stream);
 int msm_pick_window(size_t n);
-size_t msm_workspace_bytes(size_t n, int c, bool prepared = false, size_t batch = 1);
+size_t msm_workspace_bytes(size_t n, int c, bool prepared = false, size_t batch = 1, size_t xyzz_bytes = 144);
+// what the curve-specific kernels (accumulate, combine, bucket reduction) need once the scalars are sorted into tasks
+struct msm_tasks_view {
+  int c, W, WB;                    // window bits, windows, bucket sets
+  uint32_t B, NB, task_shift;      // buckets per set, buckets in all, log2 task length
+  size_t max_tasks, nk;
+  const void* tasks;               // task_t {bucket, start, len}
+  uint32_t* ntasks;                // device: number of tasks
+  uint32_t* max_parts;             // device: largest task count of one bucket
+  const uint4* order;              // execution order records (task | 0x80000000 + bucket, start, len, first reference)
+  const uint32_t* sorted;          // point references (bit 31 = negate), bucket by bucket
+  const uint32_t* task_off;        // first task of every bucket (NB + 1)
+  uint32_t *partials, *pyrA, *pyrB, *winsum;   // work arrays of xyzz_bytes-sized points
+};
+int msm_build_tasks(const uint32_t* d_scalars, size_t n, size_t batch, size_t scalar_stride, int c, bool shared_buckets, uint32_t ref_base, uint32_t ref_stride,
+                    size_t xyzz_bytes, void* ws, size_t ws_bytes, hipStream_t stream, msm_tasks_view* out);
+// msm_g2.hip
+size_t msm_g2_workspace_bytes(size_t n);
+int msm_g2_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, uint32_t* d_out, void* ws, size_t ws_bytes, hipStream_t stream);
+int test_g2_op(int op, const uint32_t* d_a, const uint32_t* d_b, uint32_t* d_out, size_t n, hipStream_t stream);
 struct prepared_bases {   // table[w * n + i] = 2^(c w) * P_i, affine external format
   uint32_t* table;
   size_t n;
