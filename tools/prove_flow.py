@@ -80,8 +80,8 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk
     clock[0] = time.perf_counter()
     # ---- SRS -------------------------------------------------------------------------------------------------------------
     params = Z.ParamsKZG.setup(k, s)
-    d_g = torch.from_numpy(params.g.view(np.int64)).to(dev)
-    d_gl = torch.from_numpy(params.g_lagrange.view(np.int64)).to(dev)
+    d_g = torch.from_numpy(np.array(params.g).view(np.int64)).to(dev)            # (the params' arrays are read-only while registered)
+    d_gl = torch.from_numpy(np.array(params.g_lagrange).view(np.int64)).to(dev)
     h_g, h_gl = C.c_uint64(0), C.c_uint64(0)
     _lib.check(lib.zkhip_prepare_bases_device(d_g.data_ptr(), n, C.byref(h_g)))
     _lib.check(lib.zkhip_prepare_bases_device(d_gl.data_ptr(), n, C.byref(h_gl)))

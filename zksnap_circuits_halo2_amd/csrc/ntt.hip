@@ -22,6 +22,7 @@
 //     x*2^-5, and the NTT is linear, so no format conversion multiply is needed on either side.
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -106,7 +107,13 @@ __device__ __forceinline__ fe scale_pick(const scale_arg& s, uint32_t idx) {
   return fr_ext_to_internal(w);
 }
 
-__global__ void __launch_bounds__(256, 2) k_ntt_pass(pass_args a) {
+// E = elements a thread holds in a round (log2 E radix-2 stages per LDS round trip).  E = 8: 256 threads per 2048-element tile, 3 stages
+// per round, 202 VGPRs -> 2 waves per SIMD.  E = 4 (default): 512 threads per tile, 2 stages per round, 123 VGPRs -> 4 waves per SIMD at
+// the price of one more LDS round trip per 8-bit pass (+5.6 % VALU instructions).  Measured equal within noise at 2^22 .. 2^26 (the
+// kernel runs at the VALU issue rate of its instruction mix either way: DESIGN.md section 4), E = 4 ahead on small transforms.
+template <int E>
+__global__ void __launch_bounds__(2048 / E, E == 8 ? 2 : 4) k_ntt_pass(pass_args a) {
+  constexpr int VM = E == 8 ? 3 : 2;
   extern __shared__ uint32_t lds[];
   const uint32_t B = a.B, R = 1u << B, L = a.L;
   const uint32_t N = 1u << L;
@@ -158,29 +165,28 @@ __global__ void __launch_bounds__(256, 2) k_ntt_pass(pass_args a) {
     const uint32_t jj = threadIdx.x & (J - 1), m = threadIdx.x >> logJ;
     uint32_t s = 0;
     while (s < B) {
-      const uint32_t v = (B - s) < 3 ? (B - s) : 3;
-      fe x[8];
-      uint32_t pos[8];
+      const uint32_t v = (B - s) < (uint32_t)VM ? (B - s) : (uint32_t)VM;
+      fe x[E];
+      uint32_t pos[E];
 #pragma unroll
-      for (int e = 0; e < 8; e++) {
-        const uint32_t rest = (m << (3 - v)) | ((uint32_t)e >> v);
+      for (int e = 0; e < E; e++) {
+        const uint32_t rest = (m << (VM - v)) | ((uint32_t)e >> v);
         const uint32_t lo = rest & ((1u << s) - 1), hi = rest >> s;
         pos[e] = (hi << (s + v)) | (((uint32_t)e & ((1u << v) - 1)) << s) | lo;
         x[e] = load_lds9(lds, pos[e] * J + jj);
       }
       if (s == 0) {
-        // First round (v == 3, lo == 0): twiddles depend only on the register index and 7 of the 12 are w^0 = 1, so
+        // First round (v == VM, lo == 0): twiddles depend only on the register index and 7 of the 12 (E = 4: 3 of the 4) are w^0 = 1, so
         // those butterflies need no multiply.  Inputs are N-form < 2p.  Bounds (value / limb) are noted per stage.
-        const fe w4 = load_fe9(a.tw_local, 1u << (B - 2)), w8 = load_fe9(a.tw_local, 1u << (B - 3)),
-                 w83 = load_fe9(a.tw_local, 3u << (B - 3));
+        const fe w4 = load_fe9(a.tw_local, 1u << (B - 2));
 #pragma unroll
-        for (int e = 0; e < 8; e += 2) {                    // stage 0: all trivial.  x' < 4p / 2^30, y' < 5p / 1.5*2^30
+        for (int e = 0; e < E; e += 2) {                    // stage 0: all trivial.  x' < 4p / 2^30, y' < 5p / 1.5*2^30
           fe t = x[e + 1];
           x[e + 1] = fe_sub_red(x[e], t, Fr::P3_S1);
           x[e] = fe_add(x[e], t);
         }
 #pragma unroll
-        for (int e = 0; e < 8; e += 4) {                    // stage 1
+        for (int e = 0; e < E; e += 4) {                    // stage 1
           fe t = fe_norm(x[e + 2]);                         // trivial pair (e, e+2): t < 4p, N
           x[e + 2] = fe_sub_red(x[e], t, Fr::P6_S1);        // < 10p / 2^31
           x[e] = fe_add(x[e], t);                           // < 8p / 1.5*2^30
@@ -188,7 +194,8 @@ __global__ void __launch_bounds__(256, 2) k_ntt_pass(pass_args a) {
           x[e + 3] = fe_sub_red(x[e + 1], u1, Fr::P3_S1);   // < 8p / 2.5*2^30
           x[e + 1] = fe_add(x[e + 1], u1);                  // < 7p / 2^31
         }
-        {                                                   // stage 2
+        if constexpr (E == 8) {                             // stage 2
+          const fe w8 = load_fe9(a.tw_local, 1u << (B - 3)), w83 = load_fe9(a.tw_local, 3u << (B - 3));
           fe t = fe_norm(x[4]);                             // trivial pair (0, 4): t < 8p, N
           x[4] = fe_sub_red(x[0], t, Fr::P10_S1);           // < 18p / 2.5*2^30
           x[0] = fe_add(x[0], t);                           // < 16p / 2^31
@@ -204,11 +211,11 @@ __global__ void __launch_bounds__(256, 2) k_ntt_pass(pass_args a) {
         }
       } else {
 #pragma unroll
-        for (int u = 0; u < 3; u++) {
+        for (int u = 0; u < VM; u++) {
           if ((uint32_t)u < v) {
             const uint32_t st = s + u;
   #pragma unroll
-            for (int e = 0; e < 8; e++) {
+            for (int e = 0; e < E; e++) {
               if ((e >> u) & 1) continue;          // e is the upper element of a pair
               const int f = e | (1 << u);
               const uint32_t lo_i = pos[e] & ((1u << st) - 1);
@@ -220,7 +227,7 @@ __global__ void __launch_bounds__(256, 2) k_ntt_pass(pass_args a) {
         }
       }
 #pragma unroll
-      for (int e = 0; e < 8; e++) store_lds9(lds, pos[e] * J + jj, fe_norm(x[e]));
+      for (int e = 0; e < E; e++) store_lds9(lds, pos[e] * J + jj, fe_norm(x[e]));
       __syncthreads();
       s += v;
     }
@@ -467,7 +474,8 @@ int ntt_transform(const uint32_t* d_in, uint32_t in_len, uint32_t in_stride, uin
     HIPCHK(hipGetDevice(&cur_dev));
     std::lock_guard<std::mutex> ag(attr_mu);
     if (!attr_set_dev[cur_dev & 63]) {
-      HIPCHK(hipFuncSetAttribute((const void*)k_ntt_pass, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_LDS_WORDS * 4));
+      HIPCHK(hipFuncSetAttribute((const void*)k_ntt_pass<8>, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_LDS_WORDS * 4));
+      HIPCHK(hipFuncSetAttribute((const void*)k_ntt_pass<4>, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_LDS_WORDS * 4));
       attr_set_dev[cur_dev & 63] = true;
     }
   }
@@ -488,7 +496,9 @@ int ntt_transform(const uint32_t* d_in, uint32_t in_len, uint32_t in_stride, uin
     a.dst = a.last ? d_out : tmp[i & 1];
     a.src_stride = i == 0 ? in_stride : N;
     a.dst_stride = a.last ? out_stride : N;
-    hipLaunchKernelGGL(k_ntt_pass, dim3(N / tile, batch), dim3(tile / 8), (size_t)(lds_word_host(tile) + 16) * 4, stream, a);
+    static const int elems = [] { const char* e = getenv("ZKHIP_NTT_ELEMS"); return e && atoi(e) == 8 ? 8 : 4; }();      // A/B knob
+    if (elems == 4 && tile >= 8) hipLaunchKernelGGL(k_ntt_pass<4>, dim3(N / tile, batch), dim3(tile / 4), (size_t)(lds_word_host(tile) + 16) * 4, stream, a);
+    else hipLaunchKernelGGL(k_ntt_pass<8>, dim3(N / tile, batch), dim3(tile / 8), (size_t)(lds_word_host(tile) + 16) * 4, stream, a);
     prof_mark(stream, i == 0 ? "ntt_pass0" : (i == 1 ? "ntt_pass1" : (i == 2 ? "ntt_pass2" : "ntt_pass3")));
   }
   HIPCHK(hipGetLastError());
