@@ -335,17 +335,24 @@ constexpr uint32_t SORT_CHUNK_IDS = 20480;
 
 // goff[g] = start of group g in the staging array (exclusive scan of the group counts), gcursor = copy; cstart[g] = index of the
 // group's first SORT_CHUNK-sized chunk in the numbering of k_fine_sorted's workgroups
-__global__ void k_group_offsets(const uint32_t* __restrict__ gcount, int G, uint32_t* __restrict__ goff, uint32_t* __restrict__ gcursor,
-                                uint32_t* __restrict__ cstart, uint32_t chunk) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  uint32_t run = 0, crun = 0;
-  for (int g = 0; g < G; g++) {
-    goff[g] = run; gcursor[g] = run; cstart[g] = crun;
-    run += gcount[g];
-    crun += (gcount[g] + chunk - 1) / chunk;
+__global__ void __launch_bounds__(64) k_group_offsets(const uint32_t* __restrict__ gcount, int G, uint32_t* __restrict__ goff, uint32_t* __restrict__ gcursor,
+                                                       uint32_t* __restrict__ cstart, uint32_t chunk) {
+  // one wavefront, groups 2 lane and 2 lane + 1 per lane (G <= MAX_GROUPS = 128): two exclusive scans by shuffles (the serial loop
+  // this replaces took 12 us: 128 dependent global loads)
+  if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+  const int lane = threadIdx.x;
+  const uint32_t c0 = 2 * lane < G ? gcount[2 * lane] : 0u, c1 = 2 * lane + 1 < G ? gcount[2 * lane + 1] : 0u;
+  const uint32_t k0 = (c0 + chunk - 1) / chunk, k1 = (c1 + chunk - 1) / chunk;
+  uint32_t x = c0 + c1, y = k0 + k1;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t xs = __shfl_up(x, off, 64), ys = __shfl_up(y, off, 64);
+    if (lane >= off) { x += xs; y += ys; }
   }
-  goff[G] = run;
-  cstart[G] = crun;
+  const uint32_t ex = x - (c0 + c1), ey = y - (k0 + k1);
+  if (2 * lane < G) { goff[2 * lane] = ex; gcursor[2 * lane] = ex; cstart[2 * lane] = ey; }
+  if (2 * lane + 1 < G) { goff[2 * lane + 1] = ex + c0; gcursor[2 * lane + 1] = ex + c0; cstart[2 * lane + 1] = ey + k0; }
+  if (lane == 63) { goff[G] = x; cstart[G] = y; }
 }
 
 // Fine scatter with the chunk sorted in LDS first.  A plain placement (as in k_sort_pass<true>) stores every reference with its own
@@ -963,7 +970,7 @@ __global__ void __launch_bounds__(64) k_window_horner(const uint32_t* __restrict
 // The same with one quad per term: a 128-thread workgroup per window, term t = threadIdx / 4 (t < 32), doubling chains and the
 // 5-step addition tree on the quad formulas; the two wavefronts meet through LDS for the last addition.
 __global__ void __launch_bounds__(128) k_window_horner_quad(const uint32_t* __restrict__ in, uint32_t in_stride, int nz,
-                                                            uint32_t* __restrict__ winsum) {
+                                                            uint32_t* __restrict__ winsum, uint32_t* __restrict__ jac_out) {
   __shared__ __attribute__((aligned(16))) uint32_t xch[36];
   const int win = blockIdx.x, term = threadIdx.x >> 2;
   const uint32_t q = threadIdx.x & 3;
@@ -981,7 +988,10 @@ __global__ void __launch_bounds__(128) k_window_horner_quad(const uint32_t* __re
   __syncthreads();
   if (threadIdx.x < 4) {
     acc = xyzz_add_quad(acc, load_xyzz(xch, 0), q);
-    if (q == 0) store_xyzz(winsum, win, acc);
+    if (q == 0) {
+      if (jac_out) store_jacobian(acc, jac_out + (size_t)win * 24);     // prepared path: a bucket set's weighted sum is a final result
+      else store_xyzz(winsum, win, acc);
+    }
   }
 }
 
@@ -1360,10 +1370,11 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
     set_error("msm: internal: B == 1");
     return ZKHIP_EINVAL;
   }
-  if (WB <= 2048) hipLaunchKernelGGL(k_window_horner_quad, dim3(WB), dim3(128), 0, stream, cur, in_stride, nz, winsum);
+  const bool direct = prepared && WB <= 2048;     // the weighted-sum kernel writes the results itself (one launch less)
+  if (WB <= 2048) hipLaunchKernelGGL(k_window_horner_quad, dim3(WB), dim3(128), 0, stream, cur, in_stride, nz, winsum, direct ? d_out : (uint32_t*)nullptr);
   else hipLaunchKernelGGL(k_window_horner, dim3((WB * 32 + 63) / 64), dim3(64), 0, stream, cur, in_stride, nz, winsum, WB);
   prof_mark(stream, "horner");
-  if (prepared) hipLaunchKernelGGL(k_store_results, dim3((K + 63) / 64), dim3(64), 0, stream, winsum, K, d_out);   // one result per bucket set
+  if (prepared) { if (!direct) hipLaunchKernelGGL(k_store_results, dim3((K + 63) / 64), dim3(64), 0, stream, winsum, K, d_out); }   // one result per bucket set
   else hipLaunchKernelGGL(k_fold, dim3(1), dim3(64), 0, stream, winsum, WB, c, d_out);
   prof_mark(stream, "fold");
   HIPCHK(hipGetLastError());
