@@ -4,7 +4,7 @@
 # rocprofv3 passes: kernel stats of the bench command, kernel stats of the full bench, FETCH_SIZE / WRITE_SIZE (separate passes),
 # SQ issue/wait counters of the MSM + NTT workload (separate passes, --kernel-trace only).
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
