@@ -160,7 +160,44 @@ def fuzz_batched(seed):
     finally:
         lib.zkhip_release_bases(h)
 
-fns = [fuzz_msm] if LARGE else [fuzz_msm, fuzz_ntt, fuzz_poly, fuzz_rows, fuzz_lookup, fuzz_batched]
+def fuzz_sharded(seed):
+    """the host-buffer MSM over registered bases cut into a random number of shards (the multi-GPU path on one card), random sub-ranges"""
+    n = rng.choice([rng.randint(1, 500), rng.randint(500, 60000)])
+    bases = torch.empty(n * 8, dtype=torch.int64, device="cuda")
+    _lib.check(lib.zkhip_g1_gen_walk_device(t0m.ctypes.data, dm.ctypes.data, n, bases.data_ptr(), None))
+    torch.cuda.synchronize()
+    hb = np.ascontiguousarray(bases.cpu().numpy().view(np.uint64).reshape(n, 8))
+    sc = scalars(n, seed)
+    S = rng.choice([1, 2, 3, 5, 8, 13])
+    _lib.check(lib.zkhip_set_msm_shards(S))
+    _lib.check(lib.zkhip_register_bases(hb.ctypes.data, n))
+    try:
+        for _ in range(3):
+            off = rng.randrange(0, n); m = rng.randint(1, n - off)
+            sub = np.ascontiguousarray(sc[off:off + m])
+            out = np.zeros(12, dtype=np.uint64)
+            _lib.check(lib.zkhip_msm_g1(sub.ctypes.data, hb[off:].ctypes.data, m, out.ctypes.data))
+            exp = aff(Cr.scalar_mul(Cr.expected_scalar(sub, (T0 + off * D) % R, D), Cr.generator()))
+            assert np.array_equal(aff(out), exp), f"sharded msm n={n} S={S} off={off} m={m}"
+    finally:
+        lib.zkhip_unregister_bases(hb.ctypes.data)
+        lib.zkhip_set_msm_shards(0)
+
+_g2_walk = {}
+def fuzz_g2(seed):
+    """G2 MSM on a prefix of a fixed walk of G2 points (the oracle builds the walk once: big-integer Fq2 arithmetic)"""
+    if not _g2_walk:
+        P, Dp = O.g2_to_jac(O.g2_scalar_mul(T0, O.G2_GEN)), O.g2_to_jac(O.g2_scalar_mul(D, O.G2_GEN))
+        pts = []
+        for _ in range(1500):
+            pts.append(P); P = O.g2_jac_add(P, Dp)
+        _g2_walk["enc"] = np.array([O.g2_affine_to_limbs(O.g2_to_affine(J)) for J in pts], dtype=np.uint64).reshape(-1, 16)
+    n = rng.randint(1, 1500)
+    sc = scalars(n, seed)
+    got = O.g2_jac_from_limbs([int(x) for x in A.best_multiexp_g2(sc, _g2_walk["enc"][:n])])
+    assert got == O.g2_scalar_mul(Cr.expected_scalar(sc, T0, D), O.G2_GEN), f"g2 msm n={n}"
+
+fns = [fuzz_msm] if LARGE else [fuzz_msm, fuzz_ntt, fuzz_poly, fuzz_rows, fuzz_lookup, fuzz_batched, fuzz_sharded, fuzz_g2]
 t_end = time.time() + budget
 it = 0
 while time.time() < t_end:
