@@ -246,6 +246,11 @@ int zkhip_g1_fft_device(void *d_points_xyz, const uint64_t omega[4], uint32_t lo
 /* `g_to_lagrange(g, k)` [DEP poly/kzg/commitment.rs, used by ParamsKZG::setup / from_parts for an SRS whose trapdoor is not known]:
  * d_g_lagrange[i] = (1/n) sum_j omega_k^(-i j) d_g[j], both arrays 2^k G1Affine points (64 B); may not alias. */
 int zkhip_g_to_lagrange_device(const void *d_g, uint32_t k, void *d_g_lagrange, void *stream);
+/* `Curve::batch_normalize` [DEP group / halo2curves; create_proof normalises its commitments before they enter the transcript, and
+ * keygen stores `to_affine()` of the fixed / permutation commitments in the verifying key]: n Jacobian points (12 limbs each) -> n
+ * affine points (8 limbs each, canonical Montgomery limbs; the identity becomes (0, 0)). */
+int zkhip_g1_batch_normalize(const uint64_t *points_xyz, size_t n, uint64_t *out_affine);
+int zkhip_g1_batch_normalize_device(const void *d_points_xyz, size_t n, void *d_out_affine, void *stream);
 /* `G1Affine::read_raw`'s validity check [DEP halo2curves; run on every point by the SerdeFormat::RawBytes readers of SRS and key files:
  * ParamsKZG::read, VerifyingKey::read]: coordinates canonical Montgomery residues and (x, y) = (0, 0) or y^2 = x^3 + 3.  *first_bad =
  * index of the first point that fails, n when all pass (the XYZZ formulas never use b, so an off-curve point would otherwise give

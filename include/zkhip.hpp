@@ -144,6 +144,31 @@ inline G1 best_multiexp(const std::vector<Fr>& coeffs, const std::vector<G1Affin
   static const G1Affine dummy_b{};
   return best_multiexp(coeffs.empty() ? &dummy_s : coeffs.data(), coeffs.size(), bases.empty() ? &dummy_b : bases.data(), bases.size());
 }
+// `best_multiexp::<G2Affine>`: the same function over the twist group (halo2curves bn256::{G2Affine, G2} memory: Fq2 = c0 || c1)
+struct G2Affine {
+  uint64_t x[8], y[8];   // identity = all zero
+};
+struct G2 {
+  uint64_t x[8], y[8], z[8];   // Jacobian, identity z = 0
+};
+static_assert(sizeof(G2Affine) == 128 && sizeof(G2) == 192, "layouts must match the Rust types");
+inline G2 best_multiexp(const std::vector<Fr>& coeffs, const std::vector<G2Affine>& bases) {
+  if (coeffs.size() != bases.size()) throw std::invalid_argument("best_multiexp: coeffs.len() != bases.len()");
+  static const Fr dummy_s{};
+  static const G2Affine dummy_b{};
+  G2 out;
+  check(zkhip_msm_g2(coeffs.empty() ? dummy_s.l : coeffs.data()->l, bases.empty() ? dummy_b.x : bases.data()->x, coeffs.size(), out.x), "best_multiexp::<G2Affine>");
+  return out;
+}
+
+// The devices this process drives (one `create_proof` process, several GPUs: /root/reference/aggregator/src/wrapper.rs:129).  devices[0]
+// is the primary device; an SRS registered afterwards (ParamsKZG below) is cut into one point range per device and every commit is
+// fanned out, gathered and folded by the library.  `set_msm_shards` cuts into more ranges than devices (round robin).
+inline void init(const std::vector<int>& devices) { check(zkhip_init(devices.empty() ? nullptr : devices.data(), (int)devices.size()), "zkhip_init"); }
+inline int device_count() { return zkhip_device_count(); }
+inline void set_msm_shards(int shards) { check(zkhip_set_msm_shards(shards), "zkhip_set_msm_shards"); }
+inline int msm_shards() { return zkhip_msm_shards(); }
+
 inline void best_fft(std::vector<Fr>& a, const Fr& omega, uint32_t log_n) {
   if (a.size() != ((size_t)1 << log_n)) throw std::invalid_argument("best_fft: a.len() != 1 << log_n");
   check(zkhip_ntt_fr(a.data()->l, omega.l, log_n), "best_fft");
@@ -465,6 +490,281 @@ class ParamsKZG {
   std::vector<G1Affine> g_, g_lagrange_;
   G2Bytes g2_{}, s_g2_{};
 };
+
+// ---- plonk::keygen, plonk::permutation::keygen, key files -----------------------------------------
+// `keygen_vk` / `keygen_pk` and `VerifyingKey` / `ProvingKey::{write, read}` [DEP halo2-axiom plonk/keygen.rs, plonk/permutation/keygen.rs,
+// plonk.rs], as the reference uses them: /root/reference/aggregator/src/wrapper.rs:106-109 (keygen), :967-989 (`pk.write(..,
+// SerdeFormat::RawBytesUnchecked)` into build/*_pk.bin), :1007-1034 (`ProvingKey::read`).  The file layout is restated from the
+// published crate and NOT pinned by a file written by the Rust prover (none exists in the reference tree):
+//   VerifyingKey: k u32 BE | #fixed u32 BE | fixed commitments (G1Affine raw) | permutation commitments (one per permutation column)
+//                 | selectors, ceil(n / 8) bytes each, row j of a group of eight in bit j
+//   Polynomial:   #values u32 BE | values (Fr raw);     slices of polynomials: count u32 BE, then the polynomials
+//   ProvingKey:   VerifyingKey | l0 | l_last | l_active_row | fixed_values | fixed_polys | fixed_cosets | permutations | polys | cosets
+// "raw" = the in-memory Montgomery limbs (RawBytes and RawBytesUnchecked; the former checks every element / point on read).
+enum class SerdeFormat { Processed, RawBytes, RawBytesUnchecked };
+
+// the part of `ConstraintSystem` keygen and the key readers need (the mirror has no circuit synthesis: the host supplies the assigned
+// fixed columns and the copy constraints)
+struct CircuitShape {
+  uint32_t num_fixed = 0, num_permutation_columns = 0, num_selectors = 0;
+  uint32_t degree = 4;             // cs.degree(): the extended domain is 2^k * (degree - 1) rounded up
+  uint32_t blinding_factors = 5;   // cs.blinding_factors()
+};
+
+// `permutation::keygen::Assembly`: mapping[col][row] = next cell of the copy-constraint cycle through (col, row)
+class Assembly {
+ public:
+  Assembly(size_t n, size_t columns) : n_(n), cols_(columns), mapping_(columns * n), aux_(columns * n), sizes_(columns * n, 1) {
+    for (size_t c = 0; c < columns; c++)
+      for (size_t r = 0; r < n; r++) mapping_[c * n + r] = aux_[c * n + r] = {(uint32_t)c, (uint32_t)r};
+  }
+  // merge the cycles of the two cells exactly as the reference does: the smaller cycle takes the larger one's representative, then the
+  // two mapping entries are swapped
+  void copy(size_t left_column, size_t left_row, size_t right_column, size_t right_row) {
+    if (left_column >= cols_ || right_column >= cols_) throw std::invalid_argument("Assembly::copy: column not in the permutation");
+    if (left_row >= n_ || right_row >= n_) throw std::invalid_argument("Assembly::copy: row out of bounds");
+    cell l = aux_[left_column * n_ + left_row], r = aux_[right_column * n_ + right_row];
+    if (l == r) return;
+    if (sizes_[idx(l)] < sizes_[idx(r)]) std::swap(l, r);
+    sizes_[idx(l)] += sizes_[idx(r)];
+    cell i = r;
+    do {
+      aux_[idx(i)] = l;
+      i = mapping_[idx(i)];
+    } while (!(i == r));
+    std::swap(mapping_[left_column * n_ + left_row], mapping_[right_column * n_ + right_row]);
+  }
+  size_t columns() const { return cols_; }
+  size_t rows() const { return n_; }
+  // `build_pk`'s permutations: sigma_c[row] = delta^(mapping column) * omega^(mapping row), Lagrange basis.  omega^row is one row
+  // program on the device (the running power), the products another.
+  std::vector<std::vector<Fr>> sigma_columns(uint32_t k) const;
+
+ private:
+  struct cell {
+    uint32_t c, r;
+    bool operator==(const cell& o) const { return c == o.c && r == o.r; }
+  };
+  size_t idx(const cell& x) const { return (size_t)x.c * n_ + x.r; }
+  size_t n_, cols_;
+  std::vector<cell> mapping_, aux_;
+  std::vector<uint64_t> sizes_;
+};
+
+// `Fr::DELTA` = 7^(2^28): generator of the cosets the permutation argument labels its columns with
+inline Fr fr_delta() {
+  Fr d = detail::from_u64(7);
+  for (uint32_t i = 0; i < FR_S; i++) d = detail::mul(d, d);
+  return d;
+}
+
+inline std::vector<std::vector<Fr>> Assembly::sigma_columns(uint32_t k) const {
+  if (((size_t)1 << k) != n_) throw std::invalid_argument("Assembly::sigma_columns: n != 2^k");
+  Fr omega = fr_root_of_unity();
+  for (uint32_t i = k; i < FR_S; i++) omega = detail::mul(omega, omega);
+  RowProgram powers;
+  powers.uses_omega = true;
+  powers.omega = omega;
+  powers.emit(ZKHIP_OP_MOV, 0, zkhip_vm_operand{ZKHIP_SRC_ROWPOW, 0, 0});
+  DeviceVec d_pow(n_);
+  powers.run({}, k, d_pow);
+  const std::vector<Fr> omega_pow = d_pow.to_host();
+  std::vector<Fr> delta_pow(cols_);
+  Fr dp = detail::one();
+  const Fr delta = fr_delta();
+  for (size_t c = 0; c < cols_; c++) { delta_pow[c] = dp; dp = detail::mul(dp, delta); }
+  RowProgram mul;
+  mul.rotations = {0};
+  mul.emit(ZKHIP_OP_MUL, 0, RowProgram::column(0, 0), RowProgram::column(1, 0));
+  std::vector<std::vector<Fr>> out;
+  std::vector<Fr> a(n_), b(n_);
+  for (size_t c = 0; c < cols_; c++) {
+    for (size_t r = 0; r < n_; r++) {
+      const cell m = mapping_[c * n_ + r];
+      a[r] = omega_pow[m.r];
+      b[r] = delta_pow[m.c];
+    }
+    DeviceVec da(a), db(b), dout(n_);
+    mul.run({&da, &db}, k, dout);
+    out.push_back(dout.to_host());
+  }
+  return out;
+}
+
+namespace detail {
+inline void put_u32_be(std::ostream& out, uint32_t v) {
+  const unsigned char b[4] = {(unsigned char)(v >> 24), (unsigned char)(v >> 16), (unsigned char)(v >> 8), (unsigned char)v};
+  out.write(reinterpret_cast<const char*>(b), 4);
+}
+inline uint32_t get_u32_be(std::istream& in) {
+  unsigned char b[4];
+  in.read(reinterpret_cast<char*>(b), 4);
+  if (!in) throw std::runtime_error("key file truncated");
+  return ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | b[3];
+}
+inline void check_format(SerdeFormat f) {
+  if (f == SerdeFormat::Processed) throw std::invalid_argument("SerdeFormat::Processed is not handled (the reference writes RawBytesUnchecked)");
+}
+inline void put_poly(std::ostream& out, const std::vector<Fr>& p) {
+  put_u32_be(out, (uint32_t)p.size());
+  out.write(reinterpret_cast<const char*>(p.data()), (std::streamsize)(p.size() * sizeof(Fr)));
+}
+inline std::vector<Fr> get_poly(std::istream& in, SerdeFormat f, size_t want) {
+  const uint32_t m = get_u32_be(in);
+  if (m != want) throw std::runtime_error("key file: polynomial of unexpected length");
+  std::vector<Fr> p(m);
+  in.read(reinterpret_cast<char*>(p.data()), (std::streamsize)(m * sizeof(Fr)));
+  if (!in) throw std::runtime_error("key file truncated");
+  if (f == SerdeFormat::RawBytes)
+    for (const Fr& v : p) if (geq(v.l, R_MOD)) throw std::runtime_error("key file: non-canonical field element");
+  return p;
+}
+inline void put_slice(std::ostream& out, const std::vector<std::vector<Fr>>& s) {
+  put_u32_be(out, (uint32_t)s.size());
+  for (const auto& p : s) put_poly(out, p);
+}
+inline std::vector<std::vector<Fr>> get_slice(std::istream& in, SerdeFormat f, size_t want_count, size_t want_len) {
+  if (get_u32_be(in) != want_count) throw std::runtime_error("key file: unexpected number of polynomials");
+  std::vector<std::vector<Fr>> s;
+  for (size_t i = 0; i < want_count; i++) s.push_back(get_poly(in, f, want_len));
+  return s;
+}
+inline std::vector<G1Affine> get_points(std::istream& in, SerdeFormat f, size_t count) {
+  std::vector<G1Affine> p(count);
+  in.read(reinterpret_cast<char*>(p.data()), (std::streamsize)(count * sizeof(G1Affine)));
+  if (!in) throw std::runtime_error("key file truncated");
+  if (f == SerdeFormat::RawBytes && count) {
+    uint64_t bad = 0;
+    check(zkhip_g1_check_points(p.data()->x, count, &bad), "zkhip_g1_check_points");
+    if (bad < count) throw std::runtime_error("key file: point is not on the curve");
+  }
+  return p;
+}
+}  // namespace detail
+
+struct VerifyingKey {
+  uint32_t k = 0;
+  std::vector<G1Affine> fixed_commitments, permutation_commitments;
+  std::vector<std::vector<bool>> selectors;
+
+  void write(std::ostream& out, SerdeFormat f = SerdeFormat::RawBytes) const {
+    detail::check_format(f);
+    detail::put_u32_be(out, k);
+    detail::put_u32_be(out, (uint32_t)fixed_commitments.size());
+    out.write(reinterpret_cast<const char*>(fixed_commitments.data()), (std::streamsize)(fixed_commitments.size() * sizeof(G1Affine)));
+    out.write(reinterpret_cast<const char*>(permutation_commitments.data()), (std::streamsize)(permutation_commitments.size() * sizeof(G1Affine)));
+    for (const auto& sel : selectors)
+      for (size_t i = 0; i < sel.size(); i += 8) {
+        unsigned char byte = 0;
+        for (size_t j = 0; j < 8 && i + j < sel.size(); j++) byte |= (unsigned char)(sel[i + j] ? 1u << j : 0u);
+        out.put((char)byte);
+      }
+  }
+  // `VerifyingKey::read::<_, ConcreteCircuit>`: the shape comes from the circuit, the commitments from the file
+  static VerifyingKey read(std::istream& in, SerdeFormat f, const CircuitShape& cs) {
+    detail::check_format(f);
+    VerifyingKey vk;
+    vk.k = detail::get_u32_be(in);
+    if (vk.k > 28) throw std::runtime_error("key file: k out of range");
+    if (detail::get_u32_be(in) != cs.num_fixed) throw std::runtime_error("key file: number of fixed commitments does not match the circuit");
+    vk.fixed_commitments = detail::get_points(in, f, cs.num_fixed);
+    vk.permutation_commitments = detail::get_points(in, f, cs.num_permutation_columns);
+    const size_t n = (size_t)1 << vk.k;
+    for (uint32_t s_i = 0; s_i < cs.num_selectors; s_i++) {
+      std::vector<bool> sel(n);
+      for (size_t i = 0; i < n; i += 8) {
+        const int byte = in.get();
+        if (byte < 0) throw std::runtime_error("key file truncated");
+        for (size_t j = 0; j < 8 && i + j < n; j++) sel[i + j] = (byte >> j) & 1;
+      }
+      vk.selectors.push_back(std::move(sel));
+    }
+    return vk;
+  }
+};
+
+struct ProvingKey {
+  VerifyingKey vk;
+  std::vector<Fr> l0, l_last, l_active_row;                                            // extended coset
+  std::vector<std::vector<Fr>> fixed_values, fixed_polys, fixed_cosets;                // Lagrange, coefficient, extended coset
+  std::vector<std::vector<Fr>> permutations, permutation_polys, permutation_cosets;    // the sigma columns, likewise
+
+  void write(std::ostream& out, SerdeFormat f = SerdeFormat::RawBytesUnchecked) const {
+    vk.write(out, f);
+    detail::put_poly(out, l0); detail::put_poly(out, l_last); detail::put_poly(out, l_active_row);
+    detail::put_slice(out, fixed_values); detail::put_slice(out, fixed_polys); detail::put_slice(out, fixed_cosets);
+    detail::put_slice(out, permutations); detail::put_slice(out, permutation_polys); detail::put_slice(out, permutation_cosets);
+    if (!out) throw std::runtime_error("ProvingKey::write: stream error");
+  }
+  static ProvingKey read(std::istream& in, SerdeFormat f, const CircuitShape& cs) {
+    ProvingKey pk;
+    pk.vk = VerifyingKey::read(in, f, cs);
+    const EvaluationDomain dom(cs.degree, pk.vk.k);
+    const size_t n = (size_t)1 << pk.vk.k, en = dom.extended_len();
+    pk.l0 = detail::get_poly(in, f, en); pk.l_last = detail::get_poly(in, f, en); pk.l_active_row = detail::get_poly(in, f, en);
+    pk.fixed_values = detail::get_slice(in, f, cs.num_fixed, n);
+    pk.fixed_polys = detail::get_slice(in, f, cs.num_fixed, n);
+    pk.fixed_cosets = detail::get_slice(in, f, cs.num_fixed, en);
+    pk.permutations = detail::get_slice(in, f, cs.num_permutation_columns, n);
+    pk.permutation_polys = detail::get_slice(in, f, cs.num_permutation_columns, n);
+    pk.permutation_cosets = detail::get_slice(in, f, cs.num_permutation_columns, en);
+    return pk;
+  }
+};
+
+namespace detail {
+inline std::vector<G1Affine> commit_lagrange_affine(const ParamsKZG& params, const std::vector<std::vector<Fr>>& columns) {
+  std::vector<G1> jac;
+  for (const auto& c : columns) jac.push_back(params.commit_lagrange(c));
+  std::vector<G1Affine> out(jac.size());
+  if (!jac.empty()) check(zkhip_g1_batch_normalize(jac.data()->x, jac.size(), out.data()->x), "batch_normalize");   // `Curve::batch_normalize`
+  return out;
+}
+}  // namespace detail
+
+// `keygen_vk(params, circuit)`: commitments to the fixed columns and the sigma columns (Lagrange-basis MSMs against g_lagrange)
+inline VerifyingKey keygen_vk(const ParamsKZG& params, const CircuitShape& cs, const std::vector<std::vector<Fr>>& fixed, const Assembly& assembly,
+                              std::vector<std::vector<bool>> selectors = {}) {
+  if (fixed.size() != cs.num_fixed || assembly.columns() != cs.num_permutation_columns || assembly.rows() != params.n())
+    throw std::invalid_argument("keygen_vk: fixed columns / permutation assembly do not match the circuit shape");
+  if (params.n() < cs.blinding_factors + 3) throw std::invalid_argument("keygen_vk: not enough rows available");
+  VerifyingKey vk;
+  vk.k = params.k();
+  vk.fixed_commitments = detail::commit_lagrange_affine(params, fixed);
+  vk.permutation_commitments = detail::commit_lagrange_affine(params, assembly.sigma_columns(params.k()));
+  vk.selectors = std::move(selectors);
+  return vk;
+}
+
+// `keygen_pk(params, vk, circuit)`: polys by lagrange_to_coeff, cosets by coeff_to_extended; l_active_row = 1 - (l_last + l_blind) on the
+// extended coset is the coset of the indicator of the usable rows (the same polynomial of degree < n)
+inline ProvingKey keygen_pk(const ParamsKZG& params, const VerifyingKey& vk, const CircuitShape& cs, const std::vector<std::vector<Fr>>& fixed,
+                            const Assembly& assembly) {
+  if (vk.k != params.k()) throw std::invalid_argument("keygen_pk: verifying key and params differ in k");
+  const EvaluationDomain dom(cs.degree, params.k());
+  const size_t n = (size_t)params.n(), u = n - (cs.blinding_factors + 1);
+  ProvingKey pk;
+  pk.vk = vk;
+  auto transform = [&](const std::vector<Fr>& lagrange, std::vector<Fr>* poly, std::vector<Fr>* coset) {
+    std::vector<Fr> c = dom.lagrange_to_coeff(lagrange);
+    if (coset) *coset = dom.coeff_to_extended(c);
+    if (poly) *poly = std::move(c);
+  };
+  std::vector<Fr> ind(n, Fr{});
+  ind[0] = detail::one();
+  transform(ind, nullptr, &pk.l0);
+  ind[0] = Fr{}; ind[u] = detail::one();
+  transform(ind, nullptr, &pk.l_last);
+  for (size_t i = 0; i < n; i++) ind[i] = i < u ? detail::one() : Fr{};
+  transform(ind, nullptr, &pk.l_active_row);
+  pk.fixed_values = fixed;
+  pk.fixed_polys.resize(fixed.size()); pk.fixed_cosets.resize(fixed.size());
+  for (size_t i = 0; i < fixed.size(); i++) transform(fixed[i], &pk.fixed_polys[i], &pk.fixed_cosets[i]);
+  pk.permutations = assembly.sigma_columns(params.k());
+  pk.permutation_polys.resize(pk.permutations.size()); pk.permutation_cosets.resize(pk.permutations.size());
+  for (size_t i = 0; i < pk.permutations.size(); i++) transform(pk.permutations[i], &pk.permutation_polys[i], &pk.permutation_cosets[i]);
+  return pk;
+}
 
 }  // namespace halo2
 }  // namespace zkhip

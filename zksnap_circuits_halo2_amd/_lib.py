@@ -72,6 +72,8 @@ _SIGS = {
     "zkhip_msm_window_bits": (C.c_int, [C.c_size_t]),
     "zkhip_g1_fixed_base_mul_device": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "zkhip_g1_gen_walk_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "zkhip_g1_batch_normalize": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "zkhip_g1_batch_normalize_device": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "zkhip_g1_check_points": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]),
     "zkhip_g1_check_points_device": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64), C.c_void_p]),
     "zkhip_profile_enable": (C.c_int, [C.c_int]),

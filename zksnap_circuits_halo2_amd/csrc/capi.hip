@@ -1357,6 +1357,36 @@ int zkhip_g1_gen_walk_device(const uint64_t t0[4], const uint64_t d[4], size_t n
   return g1_gen_walk_device((const uint32_t*)t0, (const uint32_t*)d, n, (uint32_t*)d_out, sc->ws.p, sc->ws.cap, s);
 }
 
+// ---- Curve::batch_normalize: Jacobian commitments -> affine (what create_proof writes into the transcript) ------------------------
+int zkhip_g1_batch_normalize_device(const void* d_points_xyz, size_t n, void* d_out_affine, void* stream) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (n && (!d_points_xyz || !d_out_affine)) { set_error("batch_normalize: null pointer"); return ZKHIP_EINVAL; }
+  if (n == 0) return ZKHIP_OK;
+  hipStream_t s = caller_stream(stream);
+  scratch* sc = scratch_for(primary(), s);
+  if ((rc = sc->ws.reserve(g1_batch_normalize_workspace(n))) != ZKHIP_OK) return rc;
+  return g1_batch_normalize_device((const uint32_t*)d_points_xyz, n, (uint32_t*)d_out_affine, sc->ws.p, sc->ws.cap, s);
+}
+
+int zkhip_g1_batch_normalize(const uint64_t* points_xyz, size_t n, uint64_t* out_affine) {
+  if (n && (!points_xyz || !out_affine)) { set_error("batch_normalize: null pointer"); return ZKHIP_EINVAL; }
+  if (n == 0) return ZKHIP_OK;
+  lane_hold H;
+  if (H.rc != ZKHIP_OK) return H.rc;
+  int rc;
+  hipStream_t s = H.s;
+  if ((rc = H.sc->poly.reserve(n * (96 + 64))) != ZKHIP_OK) return rc;
+  if ((rc = H.sc->ws.reserve(g1_batch_normalize_workspace(n))) != ZKHIP_OK) return rc;
+  char* d = (char*)H.sc->poly.p;
+  HIPCHK(hipMemcpyAsync(d, points_xyz, n * 96, hipMemcpyHostToDevice, s));
+  if ((rc = g1_batch_normalize_device((const uint32_t*)d, n, (uint32_t*)(d + n * 96), H.sc->ws.p, H.sc->ws.cap, s)) != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(out_affine, d + n * 96, n * 64, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return ZKHIP_OK;
+}
+
 // ---- G2 MSM: best_multiexp::<G2Affine> -------------------------------------------------------------------------------
 int zkhip_msm_g2_device(const void* d_scalars, const void* d_bases, size_t n, void* d_out_xyz, void* stream) {
   guard_t g(g_mu);

@@ -1829,6 +1829,27 @@ __global__ void __launch_bounds__(64) k_xyzz_to_affine(const uint32_t* __restric
   }
 }
 
+// `Curve::batch_normalize` [DEP group / halo2curves; create_proof normalises its commitments before they enter the transcript]:
+// n Jacobian points (96 B) -> n affine points (64 B), identity -> (0, 0); one inversion per chunk of 32 points
+__global__ void __launch_bounds__(64) k_jacobian_to_xyzz(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ work) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) store_xyzz(work, i, load_jacobian(in + (size_t)i * 24));
+}
+
+size_t g1_batch_normalize_workspace(size_t n) { return align_up(n * 144, 256) + align_up(n * 36, 256) + 256; }
+
+int g1_batch_normalize_device(const uint32_t* d_in, size_t n, uint32_t* d_out, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (n == 0) return ZKHIP_OK;
+  if (n >= (1ull << 31)) { set_error("batch_normalize: n too large"); return ZKHIP_EINVAL; }
+  if (ws_bytes < g1_batch_normalize_workspace(n)) { set_error("batch_normalize: workspace too small"); return ZKHIP_EINVAL; }
+  uint32_t* work = (uint32_t*)ws;
+  uint32_t* pref = (uint32_t*)((char*)ws + align_up(n * 144, 256));
+  hipLaunchKernelGGL(k_jacobian_to_xyzz, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_in, (uint32_t)n, work);
+  hipLaunchKernelGGL(k_xyzz_to_affine, dim3((unsigned)(((n + AFFINE_CHUNK - 1) / AFFINE_CHUNK + 63) / 64)), dim3(64), 0, stream, work, (uint32_t)n, d_out, pref);
+  HIPCHK(hipGetLastError());
+  return ZKHIP_OK;
+}
+
 size_t g1_fft_workspace(size_t n) { return align_up(n * 144, 256) + align_up(n * 36, 256) + 256; }
 
 // in_format / out_format: 0 = affine (64 B), 1 = Jacobian (96 B).  scale_ext: optional factor applied to every input point.

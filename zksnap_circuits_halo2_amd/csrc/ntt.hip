@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <vector>
 #include <array>
@@ -343,23 +344,31 @@ struct ntt_plan {
   uint32_t* tw_lo[4] = {nullptr, nullptr, nullptr, nullptr};
   uint32_t* tw_hi[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<void*> allocs;
+  size_t bytes = 0;          // device memory held by the tables
+  uint64_t last_use = 0;
+  ~ntt_plan() {              // a transform queued on some stream may still read the tables
+    if (!allocs.empty()) (void)hipDeviceSynchronize();
+    for (void* d : allocs) (void)hipFree(d);
+  }
 };
 
 static std::mutex g_plan_mu;
-static std::map<std::array<uint32_t, 9>, ntt_plan*> g_plans;
+static std::map<std::array<uint32_t, 9>, std::shared_ptr<ntt_plan>> g_plans;   // a transform in flight keeps its plan alive past an eviction
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s failed: %s", #x, hipGetErrorString(e_)); return ZKHIP_EHIP; } } while (0)
 
 static int plan_alloc(ntt_plan* p, uint32_t** out, size_t bytes) {
   void* d = nullptr;
-  if (hipMalloc(&d, bytes) != hipSuccess) { set_error("ntt: hipMalloc(%zu) failed", bytes); return ZKHIP_ENOMEM; }
+  if (hipMalloc(&d, bytes) != hipSuccess) { (void)hipGetLastError(); set_error("ntt: hipMalloc(%zu) failed", bytes); return ZKHIP_ENOMEM; }
   p->allocs.push_back(d);
+  p->bytes += bytes;
   *out = (uint32_t*)d;
   return ZKHIP_OK;
 }
 
 static int build_plan(const uint32_t omega_ext[8], uint32_t L, hipStream_t stream, ntt_plan** out) {
   ntt_plan* p = new ntt_plan();
+  *out = p;                  // the caller frees a partly built plan on any error return below
   p->L = L;
   int rc;
   uint32_t* d_omega = nullptr;
@@ -400,23 +409,36 @@ static int build_plan(const uint32_t omega_ext[8], uint32_t L, hipStream_t strea
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(stream));   // tables are shared by later calls on any stream
-  *out = p;
   return ZKHIP_OK;
 }
 
-static int get_plan(const uint32_t omega_ext[8], uint32_t L, hipStream_t stream, ntt_plan** out) {
+static int get_plan(const uint32_t omega_ext[8], uint32_t L, hipStream_t stream, std::shared_ptr<ntt_plan>* out) {
   std::array<uint32_t, 9> key;
   for (int i = 0; i < 8; i++) key[i] = omega_ext[i];
   key[8] = L;
   std::lock_guard<std::mutex> g(g_plan_mu);
+  static uint64_t clock = 0;
   auto it = g_plans.find(key);
-  if (it != g_plans.end()) { *out = it->second; return ZKHIP_OK; }
-  ntt_plan* p = nullptr;
-  int rc = build_plan(omega_ext, L, stream, &p);
-  if (rc != ZKHIP_OK) {
-    if (p) { for (void* d : p->allocs) (void)hipFree(d); delete p; }
-    return rc;
+  if (it != g_plans.end()) { it->second->last_use = ++clock; *out = it->second; return ZKHIP_OK; }
+  // The cache is bounded: a 2^24 plan holds 1.2 GB of twiddles (36 B per entry of two direct tables), and a host that walks through many
+  // (omega, log n) pairs must not accumulate them.  Beyond the cap the least recently used plans leave the cache (their memory is
+  // freed when the last transform holding them has been enqueued, after a device synchronisation: ~ntt_plan).
+  constexpr size_t PLAN_CACHE_BYTES = (size_t)12 << 30;
+  constexpr size_t PLAN_CACHE_ENTRIES = 48;
+  size_t held = 0;
+  for (auto& kv : g_plans) held += kv.second->bytes;
+  const size_t incoming = (size_t)36 << (L > 2 ? L : 2);
+  while (!g_plans.empty() && (g_plans.size() >= PLAN_CACHE_ENTRIES || held + incoming > PLAN_CACHE_BYTES)) {
+    auto victim = g_plans.begin();
+    for (auto jt = g_plans.begin(); jt != g_plans.end(); ++jt) if (jt->second->last_use < victim->second->last_use) victim = jt;
+    held -= victim->second->bytes;
+    g_plans.erase(victim);
   }
+  ntt_plan* raw = nullptr;
+  int rc = build_plan(omega_ext, L, stream, &raw);
+  std::shared_ptr<ntt_plan> p(raw);          // a partly built plan is freed here on an error return
+  if (rc != ZKHIP_OK) return rc;
+  p->last_use = ++clock;
   g_plans[key] = p;
   *out = p;
   return ZKHIP_OK;
@@ -424,10 +446,6 @@ static int get_plan(const uint32_t omega_ext[8], uint32_t L, hipStream_t stream,
 
 void ntt_clear_cache() {
   std::lock_guard<std::mutex> g(g_plan_mu);
-  for (auto& kv : g_plans) {
-    for (void* d : kv.second->allocs) (void)hipFree(d);
-    delete kv.second;
-  }
   g_plans.clear();
 }
 
@@ -455,7 +473,7 @@ int ntt_transform(const uint32_t* d_in, uint32_t in_len, uint32_t in_stride, uin
     set_error("ntt: scale period must be 0, 1 or 3");
     return ZKHIP_EINVAL;
   }
-  ntt_plan* p = nullptr;
+  std::shared_ptr<ntt_plan> p;
   int rc = get_plan(omega_ext, L, stream, &p);
   if (rc != ZKHIP_OK) return rc;
   const uint32_t N = 1u << L;

@@ -338,11 +338,11 @@ def _read_points(r: BinaryIO, count: int, fmt: str) -> np.ndarray:
 
 
 def _commit_lagrange_affine(params, columns: Sequence[np.ndarray]) -> np.ndarray:
-    """commit_lagrange of every column -> affine points (the verifying key stores `to_affine()` of the commitments); the
-    normalisation is one inversion per point on the host (a handful of points)."""
-    from .fields import g1_decode_jacobian, g1_encode
-
-    pts = []
-    for col in columns:
-        pts.append(g1_decode_jacobian(params.commit_lagrange(np.ascontiguousarray(col, dtype=np.uint64))))
-    return g1_encode(pts) if pts else np.zeros((0, 8), dtype=np.uint64)
+    """commit_lagrange of every column -> affine points (the verifying key stores `to_affine()` of the commitments): the commitments
+    are normalised together on the GPU (`Curve::batch_normalize`, zkhip_g1_batch_normalize)"""
+    if not len(columns):
+        return np.zeros((0, 8), dtype=np.uint64)
+    jac = np.ascontiguousarray(np.stack([params.commit_lagrange(np.ascontiguousarray(col, dtype=np.uint64)) for col in columns]))
+    out = np.zeros((jac.shape[0], 8), dtype=np.uint64)
+    _lib.check(_lib.load().zkhip_g1_batch_normalize(jac.ctypes.data, jac.shape[0], out.ctypes.data))
+    return out
