@@ -474,6 +474,21 @@ def extras(lib, _lib, F, torch, dev, stream) -> dict:
     del g, ext, sc
     bufs.clear()
     torch.cuda.empty_cache()
+    # G2 MSM (best_multiexp::<G2Affine>; no prover call site, correctness-first kernels): 2^16 points = 64 distinct multiples of the
+    # generator (host big-integer arithmetic of the package's srs module) repeated, uniform scalars
+    try:
+        from zksnap_circuits_halo2_amd import srs as _srs
+
+        base = np.stack([_srs.g2_encode(_srs.g2_mul(1000003 * (i + 1))) for i in range(64)])
+        n2 = 1 << 16
+        d_b2 = torch.from_numpy(np.ascontiguousarray(np.tile(base, (n2 // 64, 1))).view(np.int64)).to(dev)
+        d_s2 = torch.from_numpy(synth_scalars(n2, 4242).view(np.int64)).to(dev)
+        d_o2 = torch.zeros(24, dtype=torch.int64, device=dev)
+        ms_g2 = timed(lambda: _lib.check(lib.zkhip_msm_g2_device(d_s2.data_ptr(), d_b2.data_ptr(), n2, d_o2.data_ptr(), stream)), 3)
+        out["msm_g2_2^16"] = {"ms": round(ms_g2, 3), "Mpoints_per_s": round(n2 / ms_g2 / 1e3, 2), "note": "general path, single-lane Fq2 arithmetic; not on the prover's path"}
+        del d_b2, d_s2
+    except Exception as exc:   # an extra: never fail the bench line
+        out["msm_g2_2^16"] = {"error": repr(exc)}
     out["small_circuit_replays"] = small_replays(lib, _lib, F, torch, dev, stream, timed)
     out["prover_phases_k22"] = prover_phases(lib, _lib, F, torch, dev, stream, timed)
     out["wrapper_replay"] = {"workload": "k=22: 18 MSM 2^22 + 13 iNTT 2^22 + 13 NTT 2^24 + 1 iNTT 2^24, device-resident",

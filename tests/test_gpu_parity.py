@@ -1058,3 +1058,31 @@ def test_shutdown_and_lazy_reinit(lib, cref):
     assert np.array_equal(params.g, g_before)
     params.close()
     assert np.array_equal(before, structured_expect(cref, sc, t0, d))
+
+
+def test_ntt_eight_elements_per_thread_variant(cref, tmp_path):
+    """the NTT kernel has two instances (4 elements per thread: default; 8: ZKHIP_NTT_ELEMS=8, read once per process): run the second one
+    in a child process over one-, two- and three-pass sizes with input / output scales and compare with the oracle"""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "ntt8.py"
+    script.write_text(
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "import zksnap_circuits_halo2_amd as Z\n"
+        "from oracle import cpu_ref as Cr\n"
+        "from zksnap_circuits_halo2_amd import fields as F\n"
+        "for L in (3, 6, 9, 10, 13, 17, 19):\n"
+        "    a = Cr.gen_scalars(900 + L, 1 << L, L % 2); om = F.fr_encode([F.omega_for(L)])[0]\n"
+        "    ref = a.copy(); Cr.best_fft(ref, om, L, 4); Z.best_fft(a, om, L)\n"
+        "    assert np.array_equal(a, ref), L\n"
+        "dom = Z.EvaluationDomain(4, 11)\n"
+        "p = Cr.gen_scalars(77, dom.n, 0)\n"
+        "back = dom.extended_to_coeff(dom.coeff_to_extended(p))\n"
+        "assert np.array_equal(back[:dom.n], p) and not back[dom.n:].any()\n"
+        "print('ok')\n")
+    env = dict(os.environ, ZKHIP_NTT_ELEMS="8")
+    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
