@@ -77,5 +77,5 @@ else:
     out = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, --kernel-trace), python3 bench.py --steps 3 --warmup 1 --no-extras --no-cpu-baseline --no-general-path",
            "workload": "prepared MSM 2^20 (bench headline configuration)",
            "correction": "FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported; counters are KiB",
-           "k_accumulate": entry("zkhip::k_accumulate"), "k_coarse_sorted": entry("zkhip::k_coarse_sorted"), "k_fine_sorted": entry("zkhip::k_fine_sorted_ids")}
+           "k_accumulate": entry("zkhip::k_accumulate"), "k_coarse_sorted": entry("zkhip::k_coarse_sorted"), "k_fine_sorted": entry("zkhip::k_fine_sorted")}
     json.dump(out, open(sys.argv[5], "w"), indent=1)

@@ -360,11 +360,15 @@ __global__ void __launch_bounds__(64) k_group_offsets(const uint32_t* __restrict
 // owns SORT_CHUNK staged entries of one group of 2^FINE_BITS buckets, counting-sorts their references by bucket inside LDS, and
 // writes bucket runs: neighbouring lanes store neighbouring words (~7 entries per bucket and chunk).
 //   LDS: cur[FB] (histogram -> run starts -> run ends) | delta[FB] (global slot of a run minus its LDS position) | refs[SORT_CHUNK]
+// IDS: the second shape for small groups (SORT_CHUNK_IDS above): every sorted entry's 16-bit bucket id stays in LDS next to its
+// reference, so the way out is one lookup instead of a 12-step search over the run ends.
+template <bool IDS>
 __global__ void __launch_bounds__(1024) k_fine_sorted(const uint16_t* __restrict__ stage_fine, const uint32_t* __restrict__ stage_ref,
                                                       const uint32_t* __restrict__ goff, const uint32_t* __restrict__ cstart, int G,
                                                       uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
   extern __shared__ uint32_t hist[];
   constexpr uint32_t FB = 1u << FINE_BITS;
+  constexpr uint32_t CHUNK = IDS ? SORT_CHUNK_IDS : SORT_CHUNK;
   static_assert(FB == 4096, "one thread owns four buckets in the scan");
   __shared__ uint32_t wsum[16];
   uint32_t* cur = hist;
@@ -375,7 +379,7 @@ __global__ void __launch_bounds__(1024) k_fine_sorted(const uint16_t* __restrict
   uint32_t glo = 0, ghi = (uint32_t)G;                      // group of chunk w: last g with cstart[g] <= w
   while (ghi - glo > 1) { const uint32_t mid = (glo + ghi) >> 1; if (cstart[mid] <= w) glo = mid; else ghi = mid; }
   const uint32_t g = glo;
-  const uint32_t start = goff[g] + (w - cstart[g]) * SORT_CHUNK, end = min(goff[g + 1], start + SORT_CHUNK), cnt_n = end - start;
+  const uint32_t start = goff[g] + (w - cstart[g]) * CHUNK, end = min(goff[g + 1], start + CHUNK), cnt_n = end - start;
   for (uint32_t b = threadIdx.x; b < FB; b += blockDim.x) cur[b] = 0;
   __syncthreads();
   for (uint32_t p = start + threadIdx.x; p < end; p += blockDim.x) atomicAdd(&cur[stage_fine[p]], 1u);
@@ -406,71 +410,25 @@ __global__ void __launch_bounds__(1024) k_fine_sorted(const uint16_t* __restrict
 #pragma unroll
   for (int k = 0; k < 4; k++) { cur[4 * threadIdx.x + k] = l[k]; delta[4 * threadIdx.x + k] = gb[k] - l[k]; }
   __syncthreads();
-  for (uint32_t p = start + threadIdx.x; p < end; p += blockDim.x) refs[atomicAdd(&cur[stage_fine[p]], 1u)] = stage_ref[p];
-  __syncthreads();
-  // cur[b] is now the end of bucket b's run; entry i belongs to the first bucket whose run ends after i
-  for (uint32_t i = threadIdx.x; i < cnt_n; i += blockDim.x) {
-    uint32_t lo = 0, hi = FB - 1;                             // invariant: answer in [lo, hi]; 12 LDS reads (a proportional first guess
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (cur[mid] > i) hi = mid; else lo = mid + 1; }   // with linear probing measured slower)
-    sorted[delta[lo] + i] = refs[i];
+  if constexpr (IDS) {
+    uint16_t* ids = reinterpret_cast<uint16_t*>(refs + CHUNK);
+    for (uint32_t p = start + threadIdx.x; p < end; p += blockDim.x) {
+      const uint32_t f = stage_fine[p], pos = atomicAdd(&cur[f], 1u);
+      refs[pos] = stage_ref[p];
+      ids[pos] = (uint16_t)f;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < cnt_n; i += blockDim.x) sorted[delta[ids[i]] + i] = refs[i];
+  } else {
+    for (uint32_t p = start + threadIdx.x; p < end; p += blockDim.x) refs[atomicAdd(&cur[stage_fine[p]], 1u)] = stage_ref[p];
+    __syncthreads();
+    // cur[b] is now the end of bucket b's run; entry i belongs to the first bucket whose run ends after i
+    for (uint32_t i = threadIdx.x; i < cnt_n; i += blockDim.x) {
+      uint32_t lo = 0, hi = FB - 1;                             // invariant: answer in [lo, hi]; 12 LDS reads (a proportional first guess
+      while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (cur[mid] > i) hi = mid; else lo = mid + 1; }   // with linear probing measured slower)
+      sorted[delta[lo] + i] = refs[i];
+    }
   }
-}
-
-// the same with the bucket id of every sorted entry kept in LDS (SORT_CHUNK_IDS above)
-__global__ void __launch_bounds__(1024) k_fine_sorted_ids(const uint16_t* __restrict__ stage_fine, const uint32_t* __restrict__ stage_ref,
-                                                      const uint32_t* __restrict__ goff, const uint32_t* __restrict__ cstart, int G,
-                                                      uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
-  extern __shared__ uint32_t hist[];
-  constexpr uint32_t FB = 1u << FINE_BITS;
-  static_assert(FB == 4096, "one thread owns four buckets in the scan");
-  __shared__ uint32_t wsum[16];
-  uint32_t* cur = hist;
-  uint32_t* delta = hist + FB;
-  uint32_t* refs = hist + 2 * FB;
-  const uint32_t w = blockIdx.x;
-  if (w >= cstart[G]) return;
-  uint32_t glo = 0, ghi = (uint32_t)G;                      // group of chunk w: last g with cstart[g] <= w
-  while (ghi - glo > 1) { const uint32_t mid = (glo + ghi) >> 1; if (cstart[mid] <= w) glo = mid; else ghi = mid; }
-  const uint32_t g = glo;
-  const uint32_t start = goff[g] + (w - cstart[g]) * SORT_CHUNK_IDS, end = min(goff[g + 1], start + SORT_CHUNK_IDS), cnt_n = end - start;
-  for (uint32_t b = threadIdx.x; b < FB; b += blockDim.x) cur[b] = 0;
-  __syncthreads();
-  for (uint32_t p = start + threadIdx.x; p < end; p += blockDim.x) atomicAdd(&cur[stage_fine[p]], 1u);
-  __syncthreads();
-  // exclusive scan over the 4096 counts: thread t owns buckets 4t .. 4t + 3
-  uint32_t c[4], l[4], s = 0;
-#pragma unroll
-  for (int k = 0; k < 4; k++) { c[k] = cur[4 * threadIdx.x + k]; s += c[k]; }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t x = s;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t y = __shfl_up(x, off, 64);
-    if (lane >= off) x += y;
-  }
-  if (lane == 63) wsum[wave] = x;
-  __syncthreads();
-  uint32_t before = 0;
-#pragma unroll
-  for (int i = 0; i < 16; i++) if (i < wave) before += wsum[i];
-  uint32_t run = before + x - s;
-  uint32_t* gl = cursor + (size_t)g * FB;
-  uint32_t gb[4];
-#pragma unroll
-  for (int k = 0; k < 4; k++) { l[k] = run; run += c[k]; }
-#pragma unroll
-  for (int k = 0; k < 4; k++) gb[k] = c[k] ? atomicAdd(&gl[4 * threadIdx.x + k], c[k]) : 0u;      // reserve the runs' slots
-#pragma unroll
-  for (int k = 0; k < 4; k++) { cur[4 * threadIdx.x + k] = l[k]; delta[4 * threadIdx.x + k] = gb[k] - l[k]; }
-  __syncthreads();
-  uint16_t* ids = reinterpret_cast<uint16_t*>(refs + SORT_CHUNK_IDS);
-  for (uint32_t p = start + threadIdx.x; p < end; p += blockDim.x) {
-    const uint32_t f = stage_fine[p], pos = atomicAdd(&cur[f], 1u);
-    refs[pos] = stage_ref[p];
-    ids[pos] = (uint16_t)f;
-  }
-  __syncthreads();
-  for (uint32_t i = threadIdx.x; i < cnt_n; i += blockDim.x) sorted[delta[ids[i]] + i] = refs[i];
 }
 
 // count pass of the same tiling (one workgroup per SORT_CHUNK entries of a group): LDS histogram, non-empty counts merged into the
@@ -1203,8 +1161,8 @@ int msm_build_tasks(const uint32_t* d_scalars, size_t n, size_t batch, size_t sc
   if (!attr_set) {
     HIPCHK(hipFuncSetAttribute((const void*)k_sort_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)k_sort_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void*)k_fine_sorted, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * (1 << FINE_BITS) + SORT_CHUNK) * 4));
-    HIPCHK(hipFuncSetAttribute((const void*)k_fine_sorted_ids, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * (1 << FINE_BITS) + SORT_CHUNK_IDS) * 4 + SORT_CHUNK_IDS * 2));
+    HIPCHK(hipFuncSetAttribute((const void*)k_fine_sorted<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * (1 << FINE_BITS) + SORT_CHUNK) * 4));
+    HIPCHK(hipFuncSetAttribute((const void*)k_fine_sorted<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * (1 << FINE_BITS) + SORT_CHUNK_IDS) * 4 + SORT_CHUNK_IDS * 2));
     attr_set = true;
   }
   const int G = wide ? (int)(B >> FINE_BITS) : 1;                      // coarse groups
@@ -1238,9 +1196,9 @@ int msm_build_tasks(const uint32_t* d_scalars, size_t n, size_t batch, size_t sc
   prof_mark(stream, "scan");
   // 4. scatter
   if (wide) {
-    if (sort_ids) hipLaunchKernelGGL(k_fine_sorted_ids, dim3(sort_chunks), dim3(1024), (size_t)(2u * (1u << FINE_BITS) + SORT_CHUNK_IDS) * 4 + SORT_CHUNK_IDS * 2, stream,
+    if (sort_ids) hipLaunchKernelGGL(k_fine_sorted<true>, dim3(sort_chunks), dim3(1024), (size_t)(2u * (1u << FINE_BITS) + SORT_CHUNK_IDS) * 4 + SORT_CHUNK_IDS * 2, stream,
                                      stage_fine, stage_ref, gcounters + 128, gcounters + 512, G, cursor, sorted);
-    else hipLaunchKernelGGL(k_fine_sorted, dim3(sort_chunks), dim3(1024), (size_t)(2u * (1u << FINE_BITS) + SORT_CHUNK) * 4, stream, stage_fine, stage_ref,
+    else hipLaunchKernelGGL(k_fine_sorted<false>, dim3(sort_chunks), dim3(1024), (size_t)(2u * (1u << FINE_BITS) + SORT_CHUNK) * 4, stream, stage_fine, stage_ref,
                             gcounters + 128, gcounters + 512, G, cursor, sorted);
   }
   else hipLaunchKernelGGL(k_sort_pass<true>, dim3(chunks, W, K), dim3(1024), lds, stream, (const int16_t*)digits, n_pad, chunk, c, cursor, sorted, wb_stride, ref_base, ref_stride);
