@@ -720,11 +720,31 @@ def cpu_baseline(log_n, d_scalars, d_bases, d_out, n) -> dict:
         d_, _ = msm_s(np.ascontiguousarray(sc22[r * m:(r + 1) * m]), bs, usable)
         dt22 += d_
     mix = 18 * dt22 + 13 * ntt["2^22"]["s"] + 14 * ntt["2^24"]["s"]
+    # the small circuits' op mixes (BASELINE configs[0] / [2]; op counts as in small_replays), one op of each kind timed (best of 3) and multiplied
+    small = {}
+    for name, k_, n_msm, n_ext in (("voter_k13", 13, 350, 345), ("state_transition_k15", 15, 16, 11)):
+        nn = 1 << k_
+        s_ = np.ascontiguousarray(sc[:nn]); b_ = np.ascontiguousarray(bs[:nn])
+        t_msm = min(msm_s(s_, b_, usable)[0] for _ in range(3))
+        def fft_s(L_):
+            a_ = synth_scalars(1 << L_, 4200 + L_)
+            om_ = F.fr_encode([F.omega_for(L_)])[0]
+            best = 1e9
+            for _ in range(3):
+                c_ = a_.copy()
+                t_ = time.perf_counter()
+                Cr.best_fft(c_, om_, L_, usable)
+                best = min(best, time.perf_counter() - t_)
+            return best
+        t_n, t_e = fft_s(k_), fft_s(k_ + 2)
+        tot = n_msm * (t_msm + t_n) + (n_ext + 1) * t_e
+        small[name] = {"s": round(tot, 3), "proofs_per_s_msm_ntt_portion": round(1.0 / tot, 2), "msm_ms": round(t_msm * 1e3, 3), "ntt_ms": round(t_n * 1e3, 3),
+                       "ext_ntt_ms": round(t_e * 1e3, 3), "how": f"{n_msm} x (MSM 2^{k_} + iNTT 2^{k_}) + {n_ext + 1} x NTT 2^{k_ + 2}"}
     return {"value": round(m / dt / 1e6, 4), "unit": "Mpoints/s", "cores": usable, "kind": "port",
             "sample": f"one 2^{log_s}-point MSM (the GPU run's inputs), oracle/cpu_ref.c best_multiexp with {usable} threads, {dt:.2f} s wall",
             "cores_usable": usable, "sched_affinity": affinity, "cgroup_cpu_max": quota, "os_cpu_count": os.cpu_count(),
             "gpu_result_matches": agree, "thread_sweep_msm_2^20": sweep, "ntt_best_fft": ntt,
-            "msm_2^22_s": round(dt22, 3),
+            "msm_2^22_s": round(dt22, 3), "small_circuit_mixes": small,
             "wrapper_shape_mix": {"s": round(mix, 2), "proofs_per_s_msm_ntt_portion": round(1.0 / mix, 4),
                                   "how": "18 x (2^22 MSM, timed as 4 x 2^20) + 13 x (2^22 best_fft) + 14 x (2^24 best_fft), one op of each kind timed and multiplied",
                                   "note": "restatement of the reference's CPU algorithms, not `cargo bench`: no witness generation, no transcript, and the 4x64 field multiply here is plain C (halo2curves uses assembly, roughly 2x faster per multiply)"},
