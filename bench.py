@@ -232,7 +232,10 @@ def main() -> None:
         dist.destroy_process_group()
 
 
-def config4_leg(lib, _lib, F, torch, dist, dev, stream, rank, world, gather_fold_device) -> dict:
+CONFIG4_T0, CONFIG4_D = 0x5A4B534E41500002 + 424242, 0x9E3779B97F4A7C15F39CC0605CEDC835
+
+
+def config4_leg(lib, _lib, F, torch, dist, dev, stream, rank, world, gather_fold_device, debug: dict = None) -> dict:
     """BASELINE configs[4] (wrapper_circuit at bench-k + 2: one 2^24-point MSM over the node's GPUs, partial sums exchanged and folded).
     world > 1: strong-scaling leg -- rank g holds points [g n / N, (g + 1) n / N) of the 2^24 (device-resident, prepared), the step is its
     MSM + the all_gather(96 B) + fold, timed like the headline (barrier + synchronize on both sides, max over ranks).
@@ -241,7 +244,7 @@ def config4_leg(lib, _lib, F, torch, dist, dev, stream, rank, world, gather_fold
     kernel-side number, the eight shard MSMs + fold device-resident."""
     total = 1 << 24
     per = total // world
-    T0, D = 0x5A4B534E41500002 + 424242, 0x9E3779B97F4A7C15F39CC0605CEDC835
+    T0, D = CONFIG4_T0, CONFIG4_D
     dd = F.fr_encode([D])[0]
     steps = 5
     if world > 1:
@@ -251,7 +254,8 @@ def config4_leg(lib, _lib, F, torch, dist, dev, stream, rank, world, gather_fold
         torch.cuda.synchronize()
         h = C.c_uint64(0)
         _lib.check(lib.zkhip_prepare_bases_device(g.data_ptr(), per, C.byref(h)))
-        sc = torch.from_numpy(synth_scalars(per, 0x5A4B534E41500103 + rank).view(np.int64)).to(dev)
+        h_sc = synth_scalars(per, 0x5A4B534E41500103 + rank)
+        sc = torch.from_numpy(h_sc.view(np.int64)).to(dev)
         part = torch.zeros(12, dtype=torch.int64, device=dev)
         gat = torch.zeros(12 * world, dtype=torch.int64, device=dev)
         fin = torch.zeros(12, dtype=torch.int64, device=dev)
@@ -270,10 +274,12 @@ def config4_leg(lib, _lib, F, torch, dist, dev, stream, rank, world, gather_fold
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
-        el = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device=dev)
+        el = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         ms = float(el.item()) / steps * 1e3
         lib.zkhip_release_bases(h)
+        if debug is not None:       # the rehearsal test checks the folded point against the structured identity
+            debug.update(final=fin.cpu().numpy().view(np.uint64)[:12].copy(), scalars=h_sc, t0=(T0 + rank * per * D) % F.R_MOD, d=D)
         return {"workload": f"BASELINE configs[4]: 2^24-point MSM, 2^{per.bit_length() - 1} points per GPU x {world} GPUs, all_gather(96 B) + fold, device-resident",
                 "scaling": "strong", "ms_per_msm": round(ms, 4), "Mpoints_per_s": round(total / ms / 1e3, 1), "steps": steps}
     # one card: 8 virtual shards through the C ABI

@@ -235,3 +235,61 @@ def test_multi_device_path_on_duplicate_contexts(lib, cref):
         lib.zkhip_shutdown()
         del os.environ["ZKHIP_TEST_DUPLICATE_DEVICES"]
         _lib.check(lib.zkhip_init(None, 0))
+
+
+def _config4_worker(rank, world, port, q):
+    """one rank of bench.py's configs[4] leg (world > 1 branch), gloo in place of RCCL, all ranks on the one card of the test box"""
+    import os
+    import sys
+
+    import torch
+    import torch.distributed as dist
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    from oracle import cpu_ref as Cr
+    from zksnap_circuits_halo2_amd import _lib as L, fields as FF
+    from zksnap_circuits_halo2_amd.multi_gpu import gather_fold_device
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    lib = L.load()
+    dev = torch.device("cuda", 0)
+    dbg = {}
+    res = bench.config4_leg(lib, L, FF, torch, dist, dev, torch.cuda.current_stream().cuda_stream, rank, world, gather_fold_device, debug=dbg)
+    # every rank's share of the expected scalar, summed over the ranks: MSM = [sum_r sum_i a_{r,i} (t0_r + i d)] G
+    mine = Cr.expected_scalar(dbg["scalars"], dbg["t0"], dbg["d"])
+    parts = [None] * world
+    dist.all_gather_object(parts, mine)
+    exp = Cr.jac_to_affine(Cr.scalar_mul(sum(parts) % FF.R_MOD, Cr.generator()))
+    got = Cr.jac_to_affine(np.ascontiguousarray(dbg["final"]))
+    q.put((rank, bool(np.array_equal(got, exp)), res["Mpoints_per_s"], res["workload"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_config4_leg_four_ranks_on_one_gpu():
+    """bench.py's configs[4] leg as `--gpus N` runs it (2^24 points split over the ranks, prepared MSM per rank, all_gather of the 96-byte
+    partials, fold), with 4 processes of 2^22 points each on this box's one GPU (the pool allows at most 6 processes on the card, so the
+    8 x 2^21 split runs as 8 shards inside one process instead: test_config4_rehearsal_8_shards_of_2p21); every rank's folded result must
+    be the structured-SRS point of the whole 2^24-point MSM"""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 4
+    procs = [ctx.Process(target=_config4_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(r[:2] for r in res) == [(r, True) for r in range(world)]
+    assert "2^22 points per GPU x 4" in res[0][3]
