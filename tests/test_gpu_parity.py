@@ -1086,3 +1086,30 @@ def test_ntt_eight_elements_per_thread_variant(cref, tmp_path):
     env = dict(os.environ, ZKHIP_NTT_ELEMS="8")
     out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("prepared", [False, True])
+def test_msm_opposite_points_cancel_inside_buckets(lib, cref, prepared):
+    """P and -P with the same scalar meet in the same bucket of every window: the accumulator passes through the identity in the middle of a
+    task (XYZZ: ZZ = 0) and must pick up the next point as a fresh start; the MSM of the cancelling pairs is the identity, and with one
+    extra (scalar, point) it is that single product"""
+    n = 4096
+    bases, t0, d = cref.gen_bases(51, n // 2)
+    neg = bases.copy()
+    neg[:, 4:8] = cref.field_op(0, 2, np.zeros((n // 2, 4), dtype=np.uint64), np.ascontiguousarray(bases[:, 4:8]))      # y -> -y
+    pts = np.ascontiguousarray(np.stack([bases, neg], axis=1).reshape(n, 8))                                                # P0, -P0, P1, -P1, ...
+    sc_half = cref.gen_scalars(52, n // 2, 0)
+    sc_half[: n // 4] = sc_half[0]                                                                                          # a quarter of the pairs share one scalar: long tasks
+    sc = np.ascontiguousarray(np.repeat(sc_half, 2, axis=0))
+    if prepared:
+        _lib.check(lib.zkhip_register_bases(pts.ctypes.data, n))
+    try:
+        assert F.g1_decode_jacobian(Z.best_multiexp(sc, pts)) is None
+        sc2 = sc.copy()
+        sc2[-1] = 0                                       # the last -P drops out: what is left is s * P_last
+        got = aff(cref, Z.best_multiexp(sc2, pts))
+        k = F.fr_decode(sc[-2:-1])[0]
+        assert np.array_equal(got, cref.jac_to_affine(cref.scalar_mul(k, pts[-2])))
+    finally:
+        if prepared:
+            _lib.check(lib.zkhip_unregister_bases(pts.ctypes.data))
