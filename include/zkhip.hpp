@@ -463,6 +463,15 @@ class ParamsKZG {
     std::vector<G1Affine> gl = g_to_lagrange(g, k);
     return ParamsKZG(k, std::move(g), std::move(gl));
   }
+  // `ParamsKZG::downsize(k)`: the first 2^k points of g, Lagrange basis re-derived on the device
+  ParamsKZG downsize(uint32_t new_k) const {
+    if (new_k > k_) throw std::invalid_argument("downsize: new_k > k");
+    std::vector<G1Affine> g(g_.begin(), g_.begin() + ((size_t)1 << new_k));
+    std::vector<G1Affine> gl = g_to_lagrange(g, new_k);
+    ParamsKZG p(new_k, std::move(g), std::move(gl));
+    p.set_g2(g2_, s_g2_);
+    return p;
+  }
   // commit(poly) = best_multiexp(poly.coeffs, g[..len]); blinding is ignored for KZG, as in the reference
   G1 commit(const std::vector<Fr>& poly) const {
     if (poly.size() > n_) throw std::invalid_argument("commit: polynomial longer than the SRS");

@@ -133,3 +133,25 @@ def test_generated_mac_blocks_header_is_current(tmp_path):
     spec.loader.exec_module(importlib.util.module_from_spec(spec))
     assert (csrc / "mac_blocks.hpp").read_text() == committed
     assert committed.count("v_mad_u64_u32") >= 2 * sum(range(1, 10))
+
+
+def test_domain_scalar_helpers():
+    """rotate_omega / l_i_range of the EvaluationDomain mirror against their definitions (host big-int arithmetic only)"""
+    d = EvaluationDomain(4, 5)
+    n, w = d.n, O.omega_for(5)
+    g = O.SplitMix64(5)
+    x = g.fr()
+    assert d.rotate_omega(x, 3) == x * pow(w, 3, O.R_MOD) % O.R_MOD
+    assert d.rotate_omega(x, -2) == x * pow(w, -2, O.R_MOD) % O.R_MOD
+    xn = pow(x, n, O.R_MOD)
+    rots = list(range(-3, 4))
+    got = d.l_i_range(x, xn, rots)
+    for r, v in zip(rots, got):      # l_i(x) = prod_{j != i} (x - w^j) / (w^i - w^j)
+        i = r % n
+        num = den = 1
+        for j in range(n):
+            if j != i:
+                num = num * (x - pow(w, j, O.R_MOD)) % O.R_MOD
+                den = den * (pow(w, i, O.R_MOD) - pow(w, j, O.R_MOD)) % O.R_MOD
+        assert v == num * pow(den, -1, O.R_MOD) % O.R_MOD, r
+    assert d.l_i_range(pow(w, 2, O.R_MOD), 1, [2, 3]) == [1, 0]

@@ -1113,3 +1113,14 @@ def test_msm_opposite_points_cancel_inside_buckets(lib, cref, prepared):
     finally:
         if prepared:
             _lib.check(lib.zkhip_unregister_bases(pts.ctypes.data))
+
+
+def test_params_downsize_equals_smaller_setup(lib):
+    """`ParamsKZG::downsize(k)`: the first 2^k points of g and the Lagrange basis re-derived from them (g_to_lagrange on the GPU) are
+    exactly what setup produces for the smaller k with the same trapdoor"""
+    with Z.ParamsKZG.setup(8, 4242) as big, Z.ParamsKZG.setup(6, 4242) as small:
+        with big.downsize(6) as down:
+            assert down.k == 6 and np.array_equal(down.g, small.g) and np.array_equal(down.g_lagrange, small.g_lagrange)
+            assert np.array_equal(down.s_g2, small.s_g2)
+        with pytest.raises(ValueError):
+            big.downsize(9)

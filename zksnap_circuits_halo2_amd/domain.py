@@ -43,6 +43,25 @@ class EvaluationDomain:
     def extended_len(self) -> int:
         return 1 << self.extended_k
 
+    # ---- scalar helpers of `EvaluationDomain` the prover / verifier use next to the transforms (host big-int arithmetic, as the
+    # reference computes them on the host) -------------------------------------------------------------------------------------------
+    def rotate_omega(self, value: int, rotation: int) -> int:
+        """`rotate_omega(value, Rotation(r))` = value * omega^r (r may be negative)"""
+        w = self._omega if rotation >= 0 else pow(self._omega, -1, R_MOD)
+        return value * pow(w, abs(rotation), R_MOD) % R_MOD
+
+    def l_i_range(self, x: int, xn: int, rotations) -> list:
+        """`l_i_range(x, x^n, rotations)`: the Lagrange basis polynomials l_i(X) = (X^n - 1) / (n (X omega^-i - 1)) evaluated at x for every
+        rotation i of the range; a rotation whose omega^i equals x gives 1 (the reference's special case through batch inversion of zero)"""
+        rotations = list(rotations)
+        common = (xn - 1) * pow(self.n, -1, R_MOD) % R_MOD
+        out = []
+        for rot in rotations:
+            wi = self.rotate_omega(1, rot)
+            den = (x - wi) % R_MOD
+            out.append(1 if den == 0 else common * wi % R_MOD * pow(den, -1, R_MOD) % R_MOD)
+        return out
+
     @staticmethod
     def _p(a):
         return a.ctypes.data

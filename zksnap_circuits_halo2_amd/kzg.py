@@ -114,6 +114,14 @@ class ParamsKZG:
         """`ParamsKZG::from_parts` [DEP]: the Lagrange basis is derived from g when it is not supplied"""
         return cls(k, g, g_to_lagrange(g, k) if g_lagrange is None else g_lagrange, g2, s_g2)
 
+    def downsize(self, new_k: int) -> "ParamsKZG":
+        """`ParamsKZG::downsize(k)` [DEP]: the first 2^k monomial-basis points, and their Lagrange basis re-derived with `g_to_lagrange`
+        (the inverse FFT over G1 points on the GPU); returns a new object, as the mirror's arrays are pinned by address"""
+        if new_k > self.k:
+            raise ValueError("downsize: new_k > k")                                  # the reference asserts `new_k <= self.k`
+        g = np.array(self.g[: 1 << new_k])
+        return ParamsKZG(new_k, g, g_to_lagrange(g, new_k), self.g2, self.s_g2)
+
     def write(self, f) -> None:
         """`ParamsKZG::write` (SerdeFormat::RawBytes) [DEP]; layout in srs.py"""
         from . import srs
