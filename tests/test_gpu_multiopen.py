@@ -82,3 +82,84 @@ def test_gwc_create_proof_on_a_known_trapdoor_srs(lib, cref):
             _lib.check(lib.zkhip_release_bases(h))
             for ptr in d_polys + [d_g, d_out]:
                 lib.zkhip_free(ptr)
+
+
+def test_shplonk_create_proof_on_a_known_trapdoor_srs(lib, cref):
+    """`ProverSHPLONK::create_proof` (the bench path's multi-open): rotation sets as the reference builds them, and the two commitments
+    satisfy the SHPLONK opening equation in the exponent on an SRS whose trapdoor is known:
+        Z_{T\\S_0}(u) (s - u) H' = sum_i v^i Z_{T\\S_i}(u) sum_j y^j (C_ij - R_ij(u) G) - Z_T(u) H
+    together with h(s) Z-divisibility: for every set, sum_j y^j (P_ij - R_ij)(s) = Q_i(s) Z_i(s) is implied by H = [sum_i v^i Q_i(s)] G,
+    which is checked directly against big-integer arithmetic."""
+    k, s = 8, 0x0F1E2D3C4B5A6978
+    n = 1 << k
+    with Z.ParamsKZG.setup(k, s) as params:
+        g = params.g.copy()
+    polys = [cref.gen_scalars(3300 + i, n, 0) for i in range(5)]
+    d_polys = []
+    for p in polys:
+        ptr = C.c_void_p()
+        _lib.check(lib.zkhip_alloc(n * 32, C.byref(ptr)))
+        _lib.check(lib.zkhip_upload(ptr, p.ctypes.data, n * 32))
+        d_polys.append(ptr)
+    d_g = C.c_void_p()
+    _lib.check(lib.zkhip_alloc(n * 64, C.byref(d_g)))
+    _lib.check(lib.zkhip_upload(d_g, g.ctypes.data, n * 64))
+    h = C.c_uint64(0)
+    _lib.check(lib.zkhip_prepare_bases_device(d_g, n, C.byref(h)))
+    d_out = C.c_void_p()
+    _lib.check(lib.zkhip_alloc(96, C.byref(d_out)))
+
+    def commit(d_coeffs):
+        _lib.check(lib.zkhip_msm_g1_prepared_device(h, 0, C.c_void_p(d_coeffs), n, d_out, None))
+        out = np.zeros(12, dtype=np.uint64)
+        _lib.check(lib.zkhip_download(out.ctypes.data, d_out, 96))
+        return out
+
+    try:
+        gen = O.SplitMix64(33)
+        x = gen.fr()
+        w = F.omega_for(k)
+        px, pn, pp = x, x * w % R, x * pow(w, -1, R) % R
+        # polys 0, 3: {x};  1: {x, wx};  2, 4: {x, wx, w^-1 x}: three rotation sets, in this order of first appearance
+        plan = [(0, px), (1, px), (1, pn), (2, px), (2, pn), (2, pp), (3, px), (4, pp), (4, px), (4, pn)]
+        queries = [M.ProverQuery(pt, d_polys[pi].value) for pi, pt in plan]
+        y, v, u = gen.fr(), gen.fr(), gen.fr()
+        H, Hp = M.ProverSHPLONK(k, commit).create_proof(queries, y, v, u)
+        sets, T = M.construct_rotation_sets(queries)
+        ptr_to_idx = {d.value: i for i, d in enumerate(d_polys)}
+        assert [[ptr_to_idx[p] for p in rs.polys] for rs in sets] == [[0, 3], [1], [2, 4]]
+        assert [rs.points for rs in sets] == [[px], sorted([px, pn]), sorted([px, pn, pp])] and T == sorted([px, pn, pp])
+        ints = [F.fr_decode(p) for p in polys]
+        at_s = [O.eval_polynomial(c, s) for c in ints]
+        Gp = cref.generator()
+        # H = [h(s)] G with h(s) = sum_i v^i (sum_j y^j (P_ij(s) - R_ij(s))) / Z_i(s)
+        hs = 0
+        for i, rs in enumerate(sets):
+            num = 0
+            for j, p in enumerate(rs.polys):
+                r_s = M._eval_small(M._interpolate(rs.points, rs.evals[j]), s)
+                num = (num + pow(y, j, R) * (at_s[ptr_to_idx[p]] - r_s)) % R
+            hs = (hs + pow(v, i, R) * num % R * pow(M._vanishing_at(rs.points, s), -1, R)) % R
+        assert np.array_equal(cref.jac_to_affine(H), cref.jac_to_affine(cref.scalar_mul(hs, Gp)))
+        # the opening equation, everything as multiples of G (the commitments C_ij = [P_ij(s)] G on this SRS)
+        rhs = 0
+        for i, rs in enumerate(sets):
+            zi = M._vanishing_at([p for p in T if p not in rs.points], u)
+            inner = 0
+            for j, p in enumerate(rs.polys):
+                r_u = M._eval_small(M._interpolate(rs.points, rs.evals[j]), u)
+                inner = (inner + pow(y, j, R) * (at_s[ptr_to_idx[p]] - r_u)) % R
+            rhs = (rhs + pow(v, i, R) * zi % R * inner) % R
+        rhs = (rhs - M._vanishing_at(T, u) * hs) % R
+        z0 = M._vanishing_at([p for p in T if p not in sets[0].points], u)
+        lhs_point = cref.scalar_mul(z0 * (s - u) % R, cref.jac_to_affine(Hp))
+        assert np.array_equal(cref.jac_to_affine(lhs_point), cref.jac_to_affine(cref.scalar_mul(rhs, Gp)))
+        # an evaluation that does not belong to its polynomial is caught by the prover's own L(u) = 0 assertion
+        bad = [M.ProverQuery(q.point, q.poly, q.eval) for q in queries]
+        bad[4].eval = (bad[4].eval + 1) % R
+        with pytest.raises(ArithmeticError):
+            M.ProverSHPLONK(k, commit).create_proof(bad, y, v, u)
+    finally:
+        _lib.check(lib.zkhip_release_bases(h))
+        for ptr in d_polys + [d_g, d_out]:
+            lib.zkhip_free(ptr)

@@ -1,4 +1,5 @@
-"""`ProverGWC::create_proof` — the KZG multi-open argument of the reference's `gen_snark` path.
+"""The KZG multi-open arguments of the reference: `ProverGWC::create_proof` (the `gen_snark` path) and, below,
+`ProverSHPLONK::create_proof` (the bench path).
 
 Mirror of [DEP] halo2-axiom `poly/kzg/multiopen/gwc.rs` + `gwc/prover.rs` as the reference reaches it:
 `gen_snark::<.., ProverGWC<_>, ..>` (/root/reference/aggregator/src/wrapper.rs:59-60, 127-137; accumulation scheme `KzgAs<Bn256, Gwc19>`,
@@ -10,8 +11,7 @@ wrapper.rs:55).  For every distinct opening point z, in the order the points fir
 Everything runs on device-resident polynomials: the combination is one fused row program (`linear_combination_program`), the
 quotient is `zkhip_fr_kate_division_device`, the commitment the prepared MSM.  The transcript is the host's business: the challenge v is
 an argument and the witness commitments are returned (the reference writes each to the transcript as it is produced).
-The bench path of the reference uses SHPLONK instead (halo2-base `gen_proof`); its building blocks are the same three kernels plus
-`zkhip_fr_eval_polynomial_batch_device`, but its composition (rotation sets, interpolated evaluations) is not mirrored here.
+The bench path of the reference uses SHPLONK instead (halo2-base `gen_proof`): `ProverSHPLONK` in the second half of this file.
 """
 from __future__ import annotations
 
@@ -103,3 +103,181 @@ class ProverGWC:
             if quot:
                 lib.zkhip_free(quot)
         return witnesses
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# SHPLONK: `ProverSHPLONK::create_proof` [DEP poly/kzg/multiopen/shplonk.rs + shplonk/prover.rs] -- the multi-open of the reference's
+# bench path (halo2-base `gen_proof`: /root/reference/aggregator/benches/wrapper_circuit.rs:140, state_transition_circuit.rs:84,
+# /root/reference/voter/benches/voter_circuit.rs:80).  Restated from the published algorithm (unpinned, as everything at this boundary):
+#
+#   rotation sets      polynomials grouped by the SET of points they are opened at (sets in order of first appearance of their first
+#                      polynomial, polynomials in order of first appearance, the points of a set ascending as canonical integers: a BTreeSet)
+#   R_ij               the interpolation of P_ij's evaluations over its set's points ("low degree equivalent")
+#   h(X)  = sum_i v^i ( sum_j y^j (P_ij - R_ij) ) / Z_i(X),   Z_i = prod over the set's points (X - z)                    -> commit: H
+#   L(X)  = sum_i v^i Z_{T \ S_i}(u) sum_j y^j (P_ij(X) - R_ij(u))  -  Z_T(u) h(X),     T = all points;   L(u) = 0
+#   h'(X) = L(X) / (X - u) / Z_{T \ S_0}(u)                                                                              -> commit: H'
+#
+# Device work: the y- and v-combinations are fused row programs over the device-resident polynomials, the divisions
+# `zkhip_fr_kate_division_device`, the two commitments prepared MSMs; the interpolations are host arithmetic on a handful of points.
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _interpolate(points: Sequence[int], evals: Sequence[int]) -> List[int]:
+    """`lagrange_interpolate`: coefficients (low to high) of the polynomial of degree < len(points) through (points[i], evals[i])"""
+    m = len(points)
+    coeffs = [0] * m
+    for i in range(m):
+        num = [1]
+        den = 1
+        for j in range(m):
+            if j == i:
+                continue
+            num = [(a - points[j] * b) % R_MOD for a, b in zip([0] + num, num + [0])]      # num * (X - points[j])
+            den = den * (points[i] - points[j]) % R_MOD
+        scale = evals[i] * pow(den, -1, R_MOD) % R_MOD
+        for t in range(m):
+            coeffs[t] = (coeffs[t] + scale * num[t]) % R_MOD
+    return coeffs
+
+
+def _eval_small(coeffs: Sequence[int], x: int) -> int:
+    acc = 0
+    for c in reversed(coeffs):
+        acc = (acc * x + c) % R_MOD
+    return acc
+
+
+def _vanishing_at(points: Sequence[int], x: int) -> int:
+    acc = 1
+    for p in points:
+        acc = acc * (x - p) % R_MOD
+    return acc
+
+
+@dataclass
+class RotationSet:
+    points: List[int]                      # ascending canonical integers
+    polys: List[int]                       # device addresses, in order of first appearance
+    evals: List[List[int]]                 # evals[j][t] = P_j(points[t])
+
+
+def construct_rotation_sets(queries: Sequence[ProverQuery]) -> Tuple[List[RotationSet], List[int]]:
+    """`construct_intermediate_sets` of shplonk.rs -> (rotation sets, super point set ascending)"""
+    by_poly: List[Tuple[int, set]] = []
+    for q in queries:
+        for poly, pts in by_poly:
+            if poly == q.poly:
+                pts.add(q.point % R_MOD)
+                break
+        else:
+            by_poly.append((q.poly, {q.point % R_MOD}))
+    sets: List[Tuple[frozenset, List[int]]] = []
+    for poly, pts in by_poly:
+        key = frozenset(pts)
+        for k2, polys in sets:
+            if k2 == key:
+                polys.append(poly)
+                break
+        else:
+            sets.append((key, [poly]))
+
+    def get_eval(poly, point):
+        return next(q.eval for q in queries if q.poly == poly and q.point % R_MOD == point)
+
+    out = []
+    for key, polys in sets:
+        pts = sorted(key)
+        out.append(RotationSet(pts, polys, [[get_eval(p, z) for z in pts] for p in polys]))
+    return out, sorted({q.point % R_MOD for q in queries})
+
+
+class ProverSHPLONK:
+    def __init__(self, k: int, commit):
+        self.k, self.n, self.commit = k, 1 << k, commit
+
+    def _patch_low(self, d_poly: int, low: Sequence[int]) -> None:
+        """d_poly[t] -= low[t] for the first len(low) coefficients (the low degree equivalent has as many coefficients as the set has points)"""
+        lib = _lib.load()
+        m = len(low)
+        host = np.zeros((m, 4), dtype=np.uint64)
+        _lib.check(lib.zkhip_sync())
+        _lib.check(lib.zkhip_download(host.ctypes.data, C.c_void_p(d_poly), m * 32))
+        new = fr_encode([(a - b) % R_MOD for a, b in zip(fr_decode(host), low)])
+        _lib.check(lib.zkhip_upload(C.c_void_p(d_poly), new.ctypes.data, m * 32))
+
+    def _divide(self, d_poly: int, d_tmp: int, roots: Sequence[int], stream: int) -> int:
+        """`div_by_vanishing`: successive `kate_division`s, the quotient kept at n coefficients (zero-padded); returns the buffer that holds it"""
+        lib = _lib.load()
+        zero = np.zeros(4, dtype=np.uint64)
+        src, dst = d_poly, d_tmp
+        for z in roots:
+            zw = fr_encode([z])[0]
+            _lib.check(lib.zkhip_fr_kate_division_device(C.c_void_p(src), self.n, zw.ctypes.data, C.c_void_p(dst), stream))
+            _lib.check(lib.zkhip_sync())
+            _lib.check(lib.zkhip_upload(C.c_void_p(dst + (self.n - 1) * 32), zero.ctypes.data, 32))
+            src, dst = dst, src
+        return src
+
+    def create_proof(self, queries: Sequence[ProverQuery], y: int, v: int, u: int, stream: int = 0):
+        """-> (H, H') as 12-limb Jacobian commitments.  In the reference y and v are squeezed before h is committed and u after h has been
+        written to the transcript; here all three are arguments."""
+        lib = _lib.load()
+        n = self.n
+        evaluate_queries(queries, self.k, stream)
+        sets, super_points = construct_rotation_sets(queries)
+        bufs = []
+
+        def alloc():
+            p = C.c_void_p()
+            _lib.check(lib.zkhip_alloc(n * 32, C.byref(p)))
+            bufs.append(p)
+            return p.value
+
+        try:
+            # ---- h(X): per set the y-combination of P - R, divided by the set's vanishing polynomial; then the v-combination -------------
+            quotients = []
+            for rs in sets:
+                ypow = [pow(y, j, R_MOD) for j in range(len(rs.polys))]
+                low = [_interpolate(rs.points, ev) for ev in rs.evals]                         # R_ij, len(points) coefficients each
+                acc, tmp = alloc(), alloc()
+                E.linear_combination_program(ypow).run_device(rs.polys, self.k, acc, stream=stream)
+                self._patch_low(acc, [sum(yp * lo[t] for yp, lo in zip(ypow, low)) % R_MOD for t in range(len(rs.points))])
+                quotients.append(self._divide(acc, tmp, rs.points, stream))
+            vpow = [pow(v, i, R_MOD) for i in range(len(sets))]
+            h_x = alloc()
+            E.linear_combination_program(vpow).run_device(quotients, self.k, h_x, stream=stream)
+            _lib.check(lib.zkhip_sync())
+            H = np.array(self.commit(h_x), dtype=np.uint64).reshape(12)
+            # ---- L(X) and the final quotient ----------------------------------------------------------------------------------------------
+            z_diffs = [_vanishing_at([p for p in super_points if p not in rs.points], u) for rs in sets]
+            zt_eval = _vanishing_at(super_points, u)
+            norm = pow(z_diffs[0], -1, R_MOD)                                                  # "normalize by the coefficient of the first polynomial"
+            cols, coeffs, const = [], [], 0
+            for i, rs in enumerate(sets):
+                for j, poly in enumerate(rs.polys):
+                    c = vpow[i] * z_diffs[i] % R_MOD * pow(y, j, R_MOD) % R_MOD * norm % R_MOD
+                    cols.append(poly)
+                    coeffs.append(c)
+                    r_eval = _eval_small(_interpolate(rs.points, rs.evals[j]), u)               # R_ij(u)
+                    const = (const + c * r_eval) % R_MOD
+            cols.append(h_x)
+            coeffs.append((-zt_eval * norm) % R_MOD)
+            l_x, tmp = alloc(), alloc()
+            E.linear_combination_program(coeffs).run_device(cols, self.k, l_x, stream=stream)
+            self._patch_low(l_x, [const])
+            # the reference's debug assertion: L(u) = 0
+            chk = C.c_void_p()
+            _lib.check(lib.zkhip_alloc(32, C.byref(chk)))
+            bufs.append(chk)
+            uw = fr_encode([u])[0]
+            _lib.check(lib.zkhip_fr_eval_polynomial_device(C.c_void_p(l_x), n, uw.ctypes.data, chk, stream))
+            res = np.zeros(4, dtype=np.uint64)
+            _lib.check(lib.zkhip_download(res.ctypes.data, chk, 32))
+            if res.any():
+                raise ArithmeticError("SHPLONK: L(u) != 0 -- inconsistent queries (an evaluation does not match its polynomial)")
+            final = self._divide(l_x, tmp, [u], stream)
+            _lib.check(lib.zkhip_sync())
+            Hp = np.array(self.commit(final), dtype=np.uint64).reshape(12)
+            return H, Hp
+        finally:
+            _lib.check(lib.zkhip_sync())
+            for p in bufs:
+                lib.zkhip_free(p)
