@@ -261,12 +261,50 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk
         _lib.check(lib.zkhip_fr_eval_polynomial_batch_device(ptrs, ncol + 3, n, F.fr_encode([x])[0].ctypes.data, evals.data_ptr(), None))
         lap("evaluations")
 
+        # ---- multiopen (SHPLONK, the benches' `gen_proof` path): every opened (polynomial, rotation) of the halo2 prover's query plan -----
+        from zksnap_circuits_halo2_amd import multiopen as MO
+
+        w_ = F.omega_for(k)
+        rot = lambda r: x * pow(w_, r, R) % R
+        queries = []
+        for i in range(qc.fixed, qc.advice):                       # fixed columns (selectors, constants, table): at x
+            queries.append(MO.ProverQuery(rot(0), coeff[i].data_ptr()))
+        for i in range(G):                                         # gate advice columns: the vertical gate reads rows 0 .. 3
+            for r in range(4):
+                queries.append(MO.ProverQuery(rot(r), coeff[qc.advice + i].data_ptr()))
+        queries.append(MO.ProverQuery(rot(0), coeff[qc.advice + G].data_ptr()))     # lookup advice
+        for i in range(qc.sigma, qc.sigma + len(perm_cols)):       # permutation polynomials (proving key)
+            queries.append(MO.ProverQuery(rot(0), coeff[i].data_ptr()))
+        for si in range(cs.num_permutation_sets):                  # permutation products: x, omega x, and the last usable row for chaining
+            zi = coeff[qc.perm_product + si].data_ptr()
+            queries += [MO.ProverQuery(rot(0), zi), MO.ProverQuery(rot(1), zi)]
+            if si + 1 < cs.num_permutation_sets:
+                queries.append(MO.ProverQuery(rot(u), zi))
+        zl_i, pa_i, ps_i = (coeff[qc.lookup + t].data_ptr() for t in range(3))
+        queries += [MO.ProverQuery(rot(0), zl_i), MO.ProverQuery(rot(1), zl_i), MO.ProverQuery(rot(0), pa_i), MO.ProverQuery(rot(-1), pa_i),
+                    MO.ProverQuery(rot(0), ps_i)]
+        for i in range(3):                                         # the quotient's pieces
+            queries.append(MO.ProverQuery(rot(0), h_coeff[i * n:].data_ptr()))
+
+        def commit_ptr(ptr):
+            out = torch.zeros(12, dtype=torch.int64, device=dev)
+            _lib.check(lib.zkhip_msm_g1_prepared_device(h_g, 0, C.c_void_p(ptr), n, out.data_ptr(), None))
+            return out.cpu().numpy().view(np.uint64)
+
+        y_mo, v_mo, u_mo = (rng.randrange(1, R) for _ in range(3))
+        mo_ok = True
+        try:
+            MO.ProverSHPLONK(k, commit_ptr).create_proof(queries, y_mo, v_mo, u_mo)      # raises if L(u) != 0: an evaluation that does not belong to its polynomial
+        except ArithmeticError:
+            mo_ok = False
+        lap("multiopen_shplonk")
+
         top_is_zero = not bool(h_coeff[3 * n:].any().item())
         low_nonzero = bool(h_coeff[:3 * n].any().item())
         commit_agrees = affine(adv_commit[0]) == affine(a0_coeff_commit)
         checks = {"permutation_product_closes": perm_closes, "lookup_product_closes": lookup_closes, "quotient_is_a_polynomial": top_is_zero and low_nonzero,
-                  "commit_lagrange_equals_commit_coeff": commit_agrees}
-        n_msm = len(adv_commit) + len(prod_commit) + 1 + len(h_commit)
+                  "commit_lagrange_equals_commit_coeff": commit_agrees, "multiopen_linearisation_vanishes": mo_ok}
+        n_msm = len(adv_commit) + len(prod_commit) + 1 + len(h_commit) + 2
         prove_ms = sum(v for kk, v in t.items() if kk not in ("setup_srs", "witness_columns", "stack_columns", "pk_file_round_trip") and not kk.startswith("keygen_"))
         n_proof_cols = sum(hi - lo for lo, hi in proof_ranges)
         if verbose:
