@@ -52,6 +52,9 @@ def test_gwc_create_proof_on_a_known_trapdoor_srs(lib, cref):
             v = gen.fr()
             prover = M.ProverGWC(k, commit)
             W = prover.create_proof(queries, v)
+            W2 = prover.create_proof(queries, v)                     # a second proof reuses the prover's buffers
+            assert all(np.array_equal(cref.jac_to_affine(a), cref.jac_to_affine(b)) for a, b in zip(W, W2))      # (Jacobian representatives differ run to run)
+            prover.close()
             sets = M.construct_intermediate_sets(queries)
             assert [z for z, _ in sets] == points and [len(qs) for _, qs in sets] == [4, 2, 2] and len(W) == 3
             # evaluations filled in by the prover = the oracle's eval_polynomial
@@ -124,7 +127,11 @@ def test_shplonk_create_proof_on_a_known_trapdoor_srs(lib, cref):
         plan = [(0, px), (1, px), (1, pn), (2, px), (2, pn), (2, pp), (3, px), (4, pp), (4, px), (4, pn)]
         queries = [M.ProverQuery(pt, d_polys[pi].value) for pi, pt in plan]
         y, v, u = gen.fr(), gen.fr(), gen.fr()
-        H, Hp = M.ProverSHPLONK(k, commit).create_proof(queries, y, v, u)
+        sh = M.ProverSHPLONK(k, commit)
+        H, Hp = sh.create_proof(queries, y, v, u)
+        H2, Hp2 = sh.create_proof(queries, y, v, u)                  # buffers reused
+        assert np.array_equal(cref.jac_to_affine(H), cref.jac_to_affine(H2)) and np.array_equal(cref.jac_to_affine(Hp), cref.jac_to_affine(Hp2))
+        sh.close()
         sets, T = M.construct_rotation_sets(queries)
         ptr_to_idx = {d.value: i for i, d in enumerate(d_polys)}
         assert [[ptr_to_idx[p] for p in rs.polys] for rs in sets] == [[0, 3], [1], [2, 4]]
@@ -157,8 +164,10 @@ def test_shplonk_create_proof_on_a_known_trapdoor_srs(lib, cref):
         # an evaluation that does not belong to its polynomial is caught by the prover's own L(u) = 0 assertion
         bad = [M.ProverQuery(q.point, q.poly, q.eval) for q in queries]
         bad[4].eval = (bad[4].eval + 1) % R
+        sh = M.ProverSHPLONK(k, commit)
         with pytest.raises(ArithmeticError):
-            M.ProverSHPLONK(k, commit).create_proof(bad, y, v, u)
+            sh.create_proof(bad, y, v, u)
+        sh.close()
     finally:
         _lib.check(lib.zkhip_release_bases(h))
         for ptr in d_polys + [d_g, d_out]:

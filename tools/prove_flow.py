@@ -293,11 +293,13 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk
 
         y_mo, v_mo, u_mo = (rng.randrange(1, R) for _ in range(3))
         mo_ok = True
+        mo_prover = MO.ProverSHPLONK(k, commit_ptr)
         try:
-            MO.ProverSHPLONK(k, commit_ptr).create_proof(queries, y_mo, v_mo, u_mo)      # raises if L(u) != 0: an evaluation that does not belong to its polynomial
+            mo_prover.create_proof(queries, y_mo, v_mo, u_mo)      # raises if L(u) != 0: an evaluation that does not belong to its polynomial
         except ArithmeticError:
             mo_ok = False
         lap("multiopen_shplonk")
+        mo_prover.close()
 
         top_is_zero = not bool(h_coeff[3 * n:].any().item())
         low_nonzero = bool(h_coeff[:3 * n].any().item())

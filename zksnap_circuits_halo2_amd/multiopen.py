@@ -66,42 +66,74 @@ def evaluate_queries(queries: Sequence[ProverQuery], k: int, stream: int = 0) ->
             q.eval = e
 
 
+def _sub_const_at(d_poly: int, index: int, value: int, stream: int = 0) -> None:
+    """d_poly[index] -= value, enqueued on the stream (a one-row program: no host round trip)"""
+    prog = E.RowProgram()
+    prog.emit(E.OP_SUB, 0, prog.column(0), prog.constant(value))
+    prog.run_device([d_poly + index * 32], 0, d_poly + index * 32, stream=stream)
+
+
+def _zero_at(d_poly: int, index: int, stream: int = 0) -> None:
+    prog = E.RowProgram()
+    prog.emit(E.OP_MOV, 0, prog.constant(0))
+    prog.run_device([], 0, d_poly + index * 32, stream=stream)
+
+
+class _BufferPool:
+    """n-coefficient device buffers kept between proofs (a prover object lives as long as its proving key)"""
+
+    def __init__(self, n: int):
+        self.n, self.free, self.all = n, [], []
+
+    def take(self) -> int:
+        if self.free:
+            return self.free.pop()
+        p = C.c_void_p()
+        _lib.check(_lib.load().zkhip_alloc(self.n * 32, C.byref(p)))
+        self.all.append(p)
+        return p.value
+
+    def give_back(self, taken: List[int]) -> None:
+        self.free.extend(taken)
+
+    def close(self) -> None:
+        lib = _lib.load()
+        for p in self.all:
+            lib.zkhip_free(p)
+        self.all, self.free = [], []
+
+
 class ProverGWC:
     """`ProverGWC::new(params)` / `create_proof(transcript, queries)`; `commit` is a callable taking the device address of 2^k
     coefficients and returning the commitment (12 uint64 limbs, Jacobian) -- e.g. a prepared-table MSM over `params.g`"""
 
     def __init__(self, k: int, commit):
         self.k, self.n, self.commit = k, 1 << k, commit
+        self.pool = _BufferPool(self.n)
+
+    def close(self) -> None:
+        self.pool.close()
 
     def create_proof(self, queries: Sequence[ProverQuery], v: int, stream: int = 0) -> List[np.ndarray]:
         lib = _lib.load()
         n = self.n
         evaluate_queries(queries, self.k, stream)
-        batch, quot = C.c_void_p(), C.c_void_p()
-        _lib.check(lib.zkhip_alloc(n * 32, C.byref(batch)))
+        batch, quot = self.pool.take(), self.pool.take()
         witnesses = []
         try:
-            _lib.check(lib.zkhip_alloc(n * 32, C.byref(quot)))
             for z, qs in construct_intermediate_sets(queries):
                 powers = [pow(v, i, R_MOD) for i in range(len(qs))]
                 eval_batch = sum(p * q.eval for p, q in zip(powers, qs)) % R_MOD
-                # poly_batch - eval_batch: the combination over all n rows, then the constant term alone (a 1-row program on the same buffer)
-                E.linear_combination_program(powers).run_device([q.poly for q in qs], self.k, batch.value, stream=stream)
-                fix = E.RowProgram()
-                fix.emit(E.OP_SUB, 0, fix.column(0), fix.constant(eval_batch))
-                fix.run_device([batch.value], 0, batch.value, stream=stream)
+                # poly_batch - eval_batch: the combination over all n rows, then the constant term alone (a one-row program on the same buffer)
+                E.linear_combination_program(powers).run_device([q.poly for q in qs], self.k, batch, stream=stream)
+                _sub_const_at(batch, 0, eval_batch, stream)
                 zw = fr_encode([z])[0]
-                _lib.check(lib.zkhip_fr_kate_division_device(batch, n, zw.ctypes.data, quot, stream))
-                # the quotient has n - 1 coefficients; the commitment takes n scalars: clear the last one
-                zero = np.zeros(4, dtype=np.uint64)
-                _lib.check(lib.zkhip_sync())
-                _lib.check(lib.zkhip_upload(C.c_void_p(quot.value + (n - 1) * 32), zero.ctypes.data, 32))
-                witnesses.append(np.array(self.commit(quot.value), dtype=np.uint64).reshape(12))
+                _lib.check(lib.zkhip_fr_kate_division_device(C.c_void_p(batch), n, zw.ctypes.data, C.c_void_p(quot), stream))
+                _zero_at(quot, n - 1, stream)           # the quotient has n - 1 coefficients; the commitment takes n scalars
+                witnesses.append(np.array(self.commit(quot), dtype=np.uint64).reshape(12))
         finally:
             _lib.check(lib.zkhip_sync())
-            lib.zkhip_free(batch)
-            if quot:
-                lib.zkhip_free(quot)
+            self.pool.give_back([batch, quot])
         return witnesses
 
 
@@ -192,27 +224,25 @@ def construct_rotation_sets(queries: Sequence[ProverQuery]) -> Tuple[List[Rotati
 class ProverSHPLONK:
     def __init__(self, k: int, commit):
         self.k, self.n, self.commit = k, 1 << k, commit
+        self.pool = _BufferPool(self.n)
 
-    def _patch_low(self, d_poly: int, low: Sequence[int]) -> None:
+    def close(self) -> None:
+        self.pool.close()
+
+    def _patch_low(self, d_poly: int, low: Sequence[int], stream: int = 0) -> None:
         """d_poly[t] -= low[t] for the first len(low) coefficients (the low degree equivalent has as many coefficients as the set has points)"""
-        lib = _lib.load()
-        m = len(low)
-        host = np.zeros((m, 4), dtype=np.uint64)
-        _lib.check(lib.zkhip_sync())
-        _lib.check(lib.zkhip_download(host.ctypes.data, C.c_void_p(d_poly), m * 32))
-        new = fr_encode([(a - b) % R_MOD for a, b in zip(fr_decode(host), low)])
-        _lib.check(lib.zkhip_upload(C.c_void_p(d_poly), new.ctypes.data, m * 32))
+        for t, val in enumerate(low):
+            if val % R_MOD:
+                _sub_const_at(d_poly, t, val, stream)
 
     def _divide(self, d_poly: int, d_tmp: int, roots: Sequence[int], stream: int) -> int:
         """`div_by_vanishing`: successive `kate_division`s, the quotient kept at n coefficients (zero-padded); returns the buffer that holds it"""
         lib = _lib.load()
-        zero = np.zeros(4, dtype=np.uint64)
         src, dst = d_poly, d_tmp
         for z in roots:
             zw = fr_encode([z])[0]
             _lib.check(lib.zkhip_fr_kate_division_device(C.c_void_p(src), self.n, zw.ctypes.data, C.c_void_p(dst), stream))
-            _lib.check(lib.zkhip_sync())
-            _lib.check(lib.zkhip_upload(C.c_void_p(dst + (self.n - 1) * 32), zero.ctypes.data, 32))
+            _zero_at(dst, self.n - 1, stream)
             src, dst = dst, src
         return src
 
@@ -226,10 +256,8 @@ class ProverSHPLONK:
         bufs = []
 
         def alloc():
-            p = C.c_void_p()
-            _lib.check(lib.zkhip_alloc(n * 32, C.byref(p)))
-            bufs.append(p)
-            return p.value
+            bufs.append(self.pool.take())
+            return bufs[-1]
 
         try:
             # ---- h(X): per set the y-combination of P - R, divided by the set's vanishing polynomial; then the v-combination -------------
@@ -239,12 +267,11 @@ class ProverSHPLONK:
                 low = [_interpolate(rs.points, ev) for ev in rs.evals]                         # R_ij, len(points) coefficients each
                 acc, tmp = alloc(), alloc()
                 E.linear_combination_program(ypow).run_device(rs.polys, self.k, acc, stream=stream)
-                self._patch_low(acc, [sum(yp * lo[t] for yp, lo in zip(ypow, low)) % R_MOD for t in range(len(rs.points))])
+                self._patch_low(acc, [sum(yp * lo[t] for yp, lo in zip(ypow, low)) % R_MOD for t in range(len(rs.points))], stream)
                 quotients.append(self._divide(acc, tmp, rs.points, stream))
             vpow = [pow(v, i, R_MOD) for i in range(len(sets))]
             h_x = alloc()
             E.linear_combination_program(vpow).run_device(quotients, self.k, h_x, stream=stream)
-            _lib.check(lib.zkhip_sync())
             H = np.array(self.commit(h_x), dtype=np.uint64).reshape(12)
             # ---- L(X) and the final quotient ----------------------------------------------------------------------------------------------
             z_diffs = [_vanishing_at([p for p in super_points if p not in rs.points], u) for rs in sets]
@@ -262,22 +289,19 @@ class ProverSHPLONK:
             coeffs.append((-zt_eval * norm) % R_MOD)
             l_x, tmp = alloc(), alloc()
             E.linear_combination_program(coeffs).run_device(cols, self.k, l_x, stream=stream)
-            self._patch_low(l_x, [const])
-            # the reference's debug assertion: L(u) = 0
-            chk = C.c_void_p()
-            _lib.check(lib.zkhip_alloc(32, C.byref(chk)))
-            bufs.append(chk)
+            self._patch_low(l_x, [const], stream)
+            # the reference's debug assertion: L(u) = 0 (the result lands in the top coefficient slot of the scratch buffer, which the
+            # division below overwrites)
             uw = fr_encode([u])[0]
-            _lib.check(lib.zkhip_fr_eval_polynomial_device(C.c_void_p(l_x), n, uw.ctypes.data, chk, stream))
+            chk = tmp + (n - 1) * 32
+            _lib.check(lib.zkhip_fr_eval_polynomial_device(C.c_void_p(l_x), n, uw.ctypes.data, C.c_void_p(chk), stream))
             res = np.zeros(4, dtype=np.uint64)
-            _lib.check(lib.zkhip_download(res.ctypes.data, chk, 32))
+            _lib.check(lib.zkhip_download(res.ctypes.data, C.c_void_p(chk), 32))
             if res.any():
                 raise ArithmeticError("SHPLONK: L(u) != 0 -- inconsistent queries (an evaluation does not match its polynomial)")
             final = self._divide(l_x, tmp, [u], stream)
-            _lib.check(lib.zkhip_sync())
             Hp = np.array(self.commit(final), dtype=np.uint64).reshape(12)
             return H, Hp
         finally:
             _lib.check(lib.zkhip_sync())
-            for p in bufs:
-                lib.zkhip_free(p)
+            self.pool.give_back(bufs)
