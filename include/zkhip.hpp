@@ -19,6 +19,7 @@
 #include <cstdint>
 #include <cstring>
 #include <istream>
+#include <memory>
 #include <ostream>
 #include <stdexcept>
 #include <string>
@@ -104,6 +105,18 @@ inline Fr sub_fr(const Fr& a, const Fr& b) {
   else { uint64_t t[4]; sub(t, b.l, a.l); sub(r.l, R_MOD, t); }
   return r;
 }
+inline Fr add_fr(const Fr& a, const Fr& b) {
+  Fr r;
+  uint64_t carry = 0, t[4];
+  for (int i = 0; i < 4; i++) {
+    const u128 sum = (u128)a.l[i] + b.l[i] + carry;
+    t[i] = (uint64_t)sum;
+    carry = (uint64_t)(sum >> 64);
+  }
+  if (carry || geq(t, R_MOD)) sub(r.l, t, R_MOD); else std::memcpy(r.l, t, 32);
+  return r;
+}
+inline Fr neg_fr(const Fr& a) { return sub_fr(Fr{}, a); }
 inline Fr pow(Fr base, const uint64_t e[4]) {
   Fr acc = one();
   for (int i = 0; i < 256; i++) {
@@ -773,6 +786,269 @@ inline ProvingKey keygen_pk(const ParamsKZG& params, const VerifyingKey& vk, con
   pk.permutation_polys.resize(pk.permutations.size()); pk.permutation_cosets.resize(pk.permutations.size());
   for (size_t i = 0; i < pk.permutations.size(); i++) transform(pk.permutations[i], &pk.permutation_polys[i], &pk.permutation_cosets[i]);
   return pk;
+}
+
+// ---- poly::kzg::multiopen: ProverGWC (the gen_snark path) and ProverSHPLONK (the benches' gen_proof path) -------------------------
+// [DEP halo2-axiom poly/kzg/multiopen/{gwc.rs, gwc/prover.rs, shplonk.rs, shplonk/prover.rs]; reached from
+// /root/reference/aggregator/src/wrapper.rs:59-60, 127-137 (GWC) and /root/reference/aggregator/benches/wrapper_circuit.rs:140 (SHPLONK).
+// Polynomials stay on the device: combinations are fused row programs, quotients zkhip_fr_kate_division_device, commitments a prepared MSM.
+// The transcript is the host's: challenges come in as arguments, commitments go out.  Restated from the published algorithms (unpinned).
+
+// the SRS pinned for device-resident commits (`params.commit(&poly)` on a polynomial that lives in HBM)
+class DeviceCommitter {
+ public:
+  explicit DeviceCommitter(const std::vector<G1Affine>& g) : n_(g.size()) {
+    check(zkhip_alloc(n_ * sizeof(G1Affine), &d_g_), "DeviceCommitter alloc");
+    int rc = zkhip_upload(d_g_, g.data(), n_ * sizeof(G1Affine));
+    if (rc == ZKHIP_OK) rc = zkhip_prepare_bases_device(d_g_, n_, &handle_);
+    if (rc == ZKHIP_OK) rc = zkhip_alloc(sizeof(G1), &d_out_);
+    if (rc != ZKHIP_OK) { (void)zkhip_free(d_g_); check(rc, "DeviceCommitter"); }
+  }
+  ~DeviceCommitter() {
+    if (handle_) (void)zkhip_release_bases(handle_);
+    (void)zkhip_free(d_g_);
+    (void)zkhip_free(d_out_);
+  }
+  DeviceCommitter(const DeviceCommitter&) = delete;
+  DeviceCommitter& operator=(const DeviceCommitter&) = delete;
+  G1 commit(const void* d_coeffs) const {          // n coefficients
+    G1 out;
+    check(zkhip_msm_g1_prepared_device(handle_, 0, d_coeffs, n_, d_out_, nullptr), "commit");
+    check(zkhip_download(&out, d_out_, sizeof(G1)), "commit download");
+    return out;
+  }
+  size_t n() const { return n_; }
+
+ private:
+  size_t n_;
+  void *d_g_ = nullptr, *d_out_ = nullptr;
+  uint64_t handle_ = 0;
+};
+
+struct ProverQuery {
+  Fr point;
+  const DeviceVec* poly;   // 2^k coefficients
+  Fr eval{};
+  bool has_eval = false;
+};
+
+namespace detail {
+// out[row] = sum_k coeffs[k] * column_k[row]: a chain of multiply-adds in one register (plonk::evaluation's Horner shape)
+inline void linear_combination(const std::vector<Fr>& coeffs, const std::vector<const DeviceVec*>& cols, uint32_t k, DeviceVec& out) {
+  RowProgram p;
+  p.rotations = {0};
+  p.constants = coeffs;
+  p.emit(ZKHIP_OP_MUL, 0, RowProgram::column(0, 0), RowProgram::constant(0));
+  for (size_t i = 1; i < coeffs.size(); i++) p.emit(ZKHIP_OP_MAD, 0, RowProgram::column((uint16_t)i, 0), RowProgram::constant((uint16_t)i), RowProgram::reg(0));
+  p.run(cols, k, out);
+}
+// d_poly[index] -= value / d_poly[index] = 0: one-row programs on the element itself (no host round trip)
+inline void sub_const_at(DeviceVec& poly, size_t index, const Fr& value) {
+  zkhip_vm_insn insn{ZKHIP_OP_SUB, 0, 0, RowProgram::column(0, 0), RowProgram::constant(0), zkhip_vm_operand{}};
+  const int32_t rot0 = 0;
+  zkhip_vm_program p{};
+  p.insns = &insn; p.n_insns = 1; p.constants = value.l; p.n_constants = 1; p.rotations = &rot0; p.n_rotations = 1; p.rot_scale = 1;
+  const void* col = static_cast<const char*>(poly.data()) + index * sizeof(Fr);
+  check(zkhip_fr_eval_rows_device(&p, &col, 1, 0, 0, const_cast<void*>(col), nullptr), "sub_const_at");
+}
+inline void zero_at(DeviceVec& poly, size_t index) {
+  const Fr zero{};
+  zkhip_vm_insn insn{ZKHIP_OP_MOV, 0, 0, RowProgram::constant(0), zkhip_vm_operand{}, zkhip_vm_operand{}};
+  zkhip_vm_program p{};
+  p.insns = &insn; p.n_insns = 1; p.constants = zero.l; p.n_constants = 1; p.rot_scale = 1;
+  check(zkhip_fr_eval_rows_device(&p, nullptr, 0, 0, 0, static_cast<char*>(poly.data()) + index * sizeof(Fr), nullptr), "zero_at");
+}
+// `kate_division` keeping n coefficients (the top one zero): out = in / (X - root)
+inline void divide_by_root(const DeviceVec& in, const Fr& root, DeviceVec& out) {
+  check(zkhip_fr_kate_division_device(in.data(), in.size(), root.l, out.data(), nullptr), "kate_division");
+  zero_at(out, in.size() - 1);
+}
+// evaluations the queries lack: one batched eval_polynomial per distinct point
+inline void evaluate_queries(std::vector<ProverQuery>& queries, size_t n) {
+  std::vector<char> done(queries.size(), 0);
+  for (size_t i = 0; i < queries.size(); i++) {
+    if (queries[i].has_eval || done[i]) continue;
+    std::vector<size_t> idx;
+    std::vector<const void*> ptrs;
+    for (size_t j = i; j < queries.size(); j++)
+      if (!queries[j].has_eval && !done[j] && queries[j].point == queries[i].point) { idx.push_back(j); ptrs.push_back(queries[j].poly->data()); done[j] = 1; }
+    DeviceVec d_out(idx.size());
+    check(zkhip_fr_eval_polynomial_batch_device(ptrs.data(), ptrs.size(), n, queries[i].point.l, d_out.data(), nullptr), "eval_polynomial_batch");
+    const std::vector<Fr> ev = d_out.to_host();
+    for (size_t t = 0; t < idx.size(); t++) { queries[idx[t]].eval = ev[t]; queries[idx[t]].has_eval = true; }
+  }
+}
+inline bool less_fr(const Fr& a, const Fr& b) {          // `Ord` of the canonical integers (a BTreeSet<Fr> iterates in this order)
+  const Fr one_raw{{1, 0, 0, 0}};
+  const Fr ca = mul(a, one_raw), cb = mul(b, one_raw);   // out of Montgomery form
+  for (int i = 3; i >= 0; i--) if (ca.l[i] != cb.l[i]) return ca.l[i] < cb.l[i];
+  return false;
+}
+// coefficients (low to high) of the polynomial of degree < m through (points[i], evals[i])
+inline std::vector<Fr> lagrange_interpolate(const std::vector<Fr>& points, const std::vector<Fr>& evals) {
+  const size_t m = points.size();
+  std::vector<Fr> coeffs(m, Fr{});
+  for (size_t i = 0; i < m; i++) {
+    std::vector<Fr> num{one()};
+    Fr den = one();
+    for (size_t j = 0; j < m; j++) {
+      if (j == i) continue;
+      std::vector<Fr> next(num.size() + 1, Fr{});
+      for (size_t t = 0; t < num.size(); t++) {
+        next[t + 1] = add_fr(next[t + 1], num[t]);
+        next[t] = sub_fr(next[t], mul(points[j], num[t]));
+      }
+      num = std::move(next);
+      den = mul(den, sub_fr(points[i], points[j]));
+    }
+    const Fr scale = mul(evals[i], invert(den));
+    for (size_t t = 0; t < m; t++) coeffs[t] = add_fr(coeffs[t], mul(scale, num[t]));
+  }
+  return coeffs;
+}
+inline Fr eval_small(const std::vector<Fr>& coeffs, const Fr& x) {
+  Fr acc{};
+  for (size_t i = coeffs.size(); i-- > 0;) acc = add_fr(mul(acc, x), coeffs[i]);
+  return acc;
+}
+inline Fr vanishing_at(const std::vector<Fr>& points, const Fr& x) {
+  Fr acc = one();
+  for (const Fr& p : points) acc = mul(acc, sub_fr(x, p));
+  return acc;
+}
+}  // namespace detail
+
+// `ProverGWC::create_proof`: for every distinct point z (order of first appearance): W_z = commit((sum_i v^i p_i - sum_i v^i e_i) / (X - z))
+inline std::vector<G1> gwc_create_proof(const DeviceCommitter& params, uint32_t k, std::vector<ProverQuery> queries, const Fr& v) {
+  const size_t n = (size_t)1 << k;
+  detail::evaluate_queries(queries, n);
+  std::vector<Fr> points;
+  for (const auto& q : queries) {
+    bool seen = false;
+    for (const Fr& p : points) seen = seen || p == q.point;
+    if (!seen) points.push_back(q.point);
+  }
+  DeviceVec batch(n), quot(n);
+  std::vector<G1> out;
+  for (const Fr& z : points) {
+    std::vector<Fr> powers;
+    std::vector<const DeviceVec*> cols;
+    Fr pw = detail::one(), eval_batch{};
+    for (const auto& q : queries) {
+      if (!(q.point == z)) continue;
+      powers.push_back(pw);
+      cols.push_back(q.poly);
+      eval_batch = detail::add_fr(eval_batch, detail::mul(pw, q.eval));
+      pw = detail::mul(pw, v);
+    }
+    detail::linear_combination(powers, cols, k, batch);
+    detail::sub_const_at(batch, 0, eval_batch);
+    detail::divide_by_root(batch, z, quot);
+    out.push_back(params.commit(quot.data()));
+  }
+  return out;
+}
+
+// `ProverSHPLONK::create_proof` -> (H, H'): see zksnap_circuits_halo2_amd/multiopen.py for the formulas; the same steps in the same order
+inline std::pair<G1, G1> shplonk_create_proof(const DeviceCommitter& params, uint32_t k, std::vector<ProverQuery> queries, const Fr& y, const Fr& v, const Fr& u) {
+  const size_t n = (size_t)1 << k;
+  detail::evaluate_queries(queries, n);
+  // polynomial -> its set of points (order of first appearance), then sets of points -> their polynomials (order of first appearance)
+  struct poly_pts { const DeviceVec* poly; std::vector<Fr> pts; };
+  std::vector<poly_pts> by_poly;
+  std::vector<Fr> super;
+  auto insert_sorted = [](std::vector<Fr>& vset, const Fr& p) {
+    for (const Fr& e : vset) if (e == p) return;
+    auto it = vset.begin();
+    while (it != vset.end() && detail::less_fr(*it, p)) ++it;
+    vset.insert(it, p);
+  };
+  for (const auto& q : queries) {
+    insert_sorted(super, q.point);
+    bool found = false;
+    for (auto& pp : by_poly) if (pp.poly == q.poly) { insert_sorted(pp.pts, q.point); found = true; break; }
+    if (!found) by_poly.push_back({q.poly, {q.point}});
+  }
+  struct rotation_set { std::vector<Fr> points; std::vector<const DeviceVec*> polys; std::vector<std::vector<Fr>> evals; };
+  std::vector<rotation_set> sets;
+  auto same = [](const std::vector<Fr>& a, const std::vector<Fr>& b) {
+    if (a.size() != b.size()) return false;
+    for (size_t i = 0; i < a.size(); i++) if (!(a[i] == b[i])) return false;
+    return true;
+  };
+  for (const auto& pp : by_poly) {
+    rotation_set* rs = nullptr;
+    for (auto& s_ : sets) if (same(s_.points, pp.pts)) rs = &s_;
+    if (!rs) { sets.push_back({pp.pts, {}, {}}); rs = &sets.back(); }
+    std::vector<Fr> ev;
+    for (const Fr& z : pp.pts)
+      for (const auto& q : queries) if (q.poly == pp.poly && q.point == z) { ev.push_back(q.eval); break; }
+    rs->polys.push_back(pp.poly);
+    rs->evals.push_back(std::move(ev));
+  }
+  // h(X)
+  std::vector<std::unique_ptr<DeviceVec>> keep;
+  auto fresh = [&]() { keep.emplace_back(new DeviceVec(n)); return keep.back().get(); };
+  std::vector<const DeviceVec*> quotients;
+  for (const auto& rs : sets) {
+    std::vector<Fr> ypow;
+    Fr yp = detail::one();
+    for (size_t j = 0; j < rs.polys.size(); j++) { ypow.push_back(yp); yp = detail::mul(yp, y); }
+    DeviceVec* acc = fresh();
+    DeviceVec* tmp = fresh();
+    detail::linear_combination(ypow, rs.polys, k, *acc);
+    std::vector<Fr> low(rs.points.size(), Fr{});
+    for (size_t j = 0; j < rs.polys.size(); j++) {
+      const std::vector<Fr> r = detail::lagrange_interpolate(rs.points, rs.evals[j]);
+      for (size_t t = 0; t < low.size(); t++) low[t] = detail::add_fr(low[t], detail::mul(ypow[j], r[t]));
+    }
+    for (size_t t = 0; t < low.size(); t++) detail::sub_const_at(*acc, t, low[t]);
+    DeviceVec *src = acc, *dst = tmp;
+    for (const Fr& z : rs.points) { detail::divide_by_root(*src, z, *dst); std::swap(src, dst); }
+    quotients.push_back(src);
+  }
+  std::vector<Fr> vpow;
+  Fr vp = detail::one();
+  for (size_t i = 0; i < sets.size(); i++) { vpow.push_back(vp); vp = detail::mul(vp, v); }
+  DeviceVec* h_x = fresh();
+  detail::linear_combination(vpow, quotients, k, *h_x);
+  const G1 H = params.commit(h_x->data());
+  // L(X) and the final quotient
+  std::vector<Fr> z_diffs;
+  for (const auto& rs : sets) {
+    std::vector<Fr> diff;
+    for (const Fr& p : super) { bool in = false; for (const Fr& q : rs.points) in = in || q == p; if (!in) diff.push_back(p); }
+    z_diffs.push_back(detail::vanishing_at(diff, u));
+  }
+  const Fr zt_eval = detail::vanishing_at(super, u), norm = detail::invert(z_diffs[0]);
+  std::vector<Fr> coeffs;
+  std::vector<const DeviceVec*> cols;
+  Fr constant{};
+  for (size_t i = 0; i < sets.size(); i++) {
+    Fr yp = detail::one();
+    for (size_t j = 0; j < sets[i].polys.size(); j++) {
+      const Fr c = detail::mul(detail::mul(detail::mul(vpow[i], z_diffs[i]), yp), norm);
+      cols.push_back(sets[i].polys[j]);
+      coeffs.push_back(c);
+      constant = detail::add_fr(constant, detail::mul(c, detail::eval_small(detail::lagrange_interpolate(sets[i].points, sets[i].evals[j]), u)));
+      yp = detail::mul(yp, y);
+    }
+  }
+  cols.push_back(h_x);
+  coeffs.push_back(detail::neg_fr(detail::mul(zt_eval, norm)));
+  DeviceVec* l_x = fresh();
+  DeviceVec* tmp = fresh();
+  detail::linear_combination(coeffs, cols, k, *l_x);
+  detail::sub_const_at(*l_x, 0, constant);
+  {
+    DeviceVec chk(1);
+    check(zkhip_fr_eval_polynomial_device(l_x->data(), n, u.l, chk.data(), nullptr), "eval_polynomial");
+    const Fr r = chk.to_host()[0];
+    if (!(r == Fr{})) throw std::runtime_error("SHPLONK: L(u) != 0 -- an evaluation does not belong to its polynomial");
+  }
+  detail::divide_by_root(*l_x, u, *tmp);
+  const G1 Hp = params.commit(tmp->data());
+  return {H, Hp};
 }
 
 }  // namespace halo2

@@ -172,3 +172,74 @@ def test_shplonk_create_proof_on_a_known_trapdoor_srs(lib, cref):
         _lib.check(lib.zkhip_release_bases(h))
         for ptr in d_polys + [d_g, d_out]:
             lib.zkhip_free(ptr)
+
+
+def test_cpp_multiopen_mirror_matches_python(lib, cref, tmp_path):
+    """The compiled-host mirror (include/zkhip.hpp: DeviceCommitter, gwc_create_proof, shplonk_create_proof) against the Python mirror on
+    the same polynomials, queries and challenges: the same commitments (compared in affine form), and the L(u) = 0 assertion fires."""
+    import os
+    import struct
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    drv = os.path.join(root, "tests", "cpp", "multiopen_driver")
+    assert os.path.exists(drv), "build it with __graft_entry__.build()"
+    k, s = 10, 0x5A5A1234F00D
+    n = 1 << k
+    polys = [cref.gen_scalars(3500 + i, n, i % 2) for i in range(6)]
+    gen = O.SplitMix64(35)
+    x = gen.fr()
+    w = F.omega_for(k)
+    px, pn, pp, p2 = x, x * w % R, x * pow(w, -1, R) % R, x * w * w % R
+    plan = [(0, px), (1, px), (1, pn), (2, pp), (2, px), (2, pn), (3, px), (4, pp), (4, px), (4, pn), (5, p2), (5, px)]
+    y, v, u = gen.fr(), gen.fr(), gen.fr()
+    fin, report = tmp_path / "in.bin", tmp_path / "report.bin"
+    with open(fin, "wb") as f:
+        f.write(struct.pack("<IIIQ", k, len(polys), len(plan), s))
+        for p in polys:
+            f.write(p.tobytes())
+        for pi, pt in plan:
+            f.write(struct.pack("<I", pi))
+            f.write(F.fr_encode([pt]).tobytes())
+        f.write(F.fr_encode([y, v, u]).tobytes())
+    subprocess.check_call([drv, str(fin), str(report)], timeout=300)
+    rep = report.read_bytes()
+    count, = struct.unpack("<I", rep[:4])
+    pts = np.frombuffer(rep[4:4 + 64 * (count + 2)], dtype=np.uint64).reshape(count + 2, 8)
+    flags, = struct.unpack("<Q", rep[4 + 64 * (count + 2):])
+    assert flags == 1
+    # the Python mirror on the same inputs
+    with Z.ParamsKZG.setup(k, s) as params:
+        g = params.g.copy()
+    d_polys = []
+    for p in polys:
+        ptr = C.c_void_p()
+        _lib.check(lib.zkhip_alloc(n * 32, C.byref(ptr)))
+        _lib.check(lib.zkhip_upload(ptr, p.ctypes.data, n * 32))
+        d_polys.append(ptr)
+    d_g, d_out, h = C.c_void_p(), C.c_void_p(), C.c_uint64(0)
+    _lib.check(lib.zkhip_alloc(n * 64, C.byref(d_g)))
+    _lib.check(lib.zkhip_upload(d_g, g.ctypes.data, n * 64))
+    _lib.check(lib.zkhip_prepare_bases_device(d_g, n, C.byref(h)))
+    _lib.check(lib.zkhip_alloc(96, C.byref(d_out)))
+
+    def commit(d_coeffs):
+        _lib.check(lib.zkhip_msm_g1_prepared_device(h, 0, C.c_void_p(d_coeffs), n, d_out, None))
+        out = np.zeros(12, dtype=np.uint64)
+        _lib.check(lib.zkhip_download(out.ctypes.data, d_out, 96))
+        return out
+
+    try:
+        gwc = M.ProverGWC(k, commit)
+        W = gwc.create_proof([M.ProverQuery(pt, d_polys[pi].value) for pi, pt in plan], v)
+        gwc.close()
+        sh = M.ProverSHPLONK(k, commit)
+        H, Hp = sh.create_proof([M.ProverQuery(pt, d_polys[pi].value) for pi, pt in plan], y, v, u)
+        sh.close()
+        assert count == len(W) == 4
+        for a, b in zip(list(W) + [H, Hp], pts):
+            assert np.array_equal(cref.jac_to_affine(a), b)
+    finally:
+        _lib.check(lib.zkhip_release_bases(h))
+        for ptr in d_polys + [d_g, d_out]:
+            lib.zkhip_free(ptr)
