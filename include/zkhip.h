@@ -257,6 +257,17 @@ int zkhip_g1_batch_normalize_device(const void *d_points_xyz, size_t n, void *d_
  * garbage commitments without any error). */
 int zkhip_g1_check_points(const uint64_t *points, size_t n, uint64_t *first_bad);
 int zkhip_g1_check_points_device(const void *d_points, size_t n, uint64_t *first_bad, void *stream);
+/* `GroupEncoding::{to_bytes, from_bytes}` of G1Affine [DEP halo2curves derive/curve.rs], one call per point in the reference's
+ * `SerdeFormat::Processed` writers / readers (ParamsKZG::{write_custom, read_custom}, VerifyingKey / ProvingKey::{write, read}); the
+ * reference itself writes RawBytesUnchecked (/root/reference/aggregator/src/wrapper.rs:971-988).  32 bytes per point: x canonical
+ * little-endian plus flags in the last byte.  flag_layout 0 (halo2curves >= 0.3.2): bit 6 = lsb of canonical y, bit 7 = identity;
+ * flag_layout 1 (earlier releases): bit 7 = lsb of canonical y, identity = 32 zero bytes.  Decompression is y = (x^3 + 3)^((q+1)/4)
+ * per point, strict: *first_bad = index of the first encoding that is not canonical / not on the curve (its output point is (0, 0)),
+ * n when all decode. */
+int zkhip_g1_compress(const uint64_t *points, size_t n, uint8_t *out32, int flag_layout);
+int zkhip_g1_compress_device(const void *d_points, size_t n, void *d_out32, int flag_layout, void *stream);
+int zkhip_g1_decompress(const uint8_t *in32, size_t n, uint64_t *points, int flag_layout, uint64_t *first_bad);
+int zkhip_g1_decompress_device(const void *d_in32, size_t n, void *d_points, int flag_layout, uint64_t *first_bad, void *stream);
 /* Per-phase timing with HIP events on the stream the kernels run on.  enable(1), run one call, then
  * zkhip_profile_read synchronises and returns the number of phases of the last profiled call, writing up to
  * `max` durations (milliseconds) and names (63 chars + NUL each). */

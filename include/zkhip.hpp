@@ -68,23 +68,24 @@ inline void sub(uint64_t r[4], const uint64_t a[4], const uint64_t b[4]) {
     borrow = (uint64_t)(d >> 64) & 1;
   }
 }
-inline Fr mul(const Fr& a, const Fr& b) {
+// Montgomery product a b 2^-256 mod `mod` (CIOS, 4 x 64), for either BN254 field
+inline void mont_mul(uint64_t r[4], const uint64_t a[4], const uint64_t b[4], const uint64_t mod[4], uint64_t inv) {
   uint64_t t[6] = {0, 0, 0, 0, 0, 0};
   for (int i = 0; i < 4; i++) {
     uint64_t carry = 0;
     for (int j = 0; j < 4; j++) {
-      u128 s = (u128)a.l[j] * b.l[i] + t[j] + carry;
+      u128 s = (u128)a[j] * b[i] + t[j] + carry;
       t[j] = (uint64_t)s;
       carry = (uint64_t)(s >> 64);
     }
     u128 s = (u128)t[4] + carry;
     t[4] = (uint64_t)s;
     t[5] = (uint64_t)(s >> 64);
-    const uint64_t m = t[0] * R_INV;
-    s = (u128)m * R_MOD[0] + t[0];
+    const uint64_t m = t[0] * inv;
+    s = (u128)m * mod[0] + t[0];
     carry = (uint64_t)(s >> 64);
     for (int j = 1; j < 4; j++) {
-      s = (u128)m * R_MOD[j] + t[j] + carry;
+      s = (u128)m * mod[j] + t[j] + carry;
       t[j - 1] = (uint64_t)s;
       carry = (uint64_t)(s >> 64);
     }
@@ -92,8 +93,11 @@ inline Fr mul(const Fr& a, const Fr& b) {
     t[3] = (uint64_t)s;
     t[4] = t[5] + (uint64_t)(s >> 64);
   }
+  if (t[4] || geq(t, mod)) sub(r, t, mod); else std::memcpy(r, t, 32);
+}
+inline Fr mul(const Fr& a, const Fr& b) {
   Fr r;
-  if (t[4] || geq(t, R_MOD)) sub(r.l, t, R_MOD); else std::memcpy(r.l, t, 32);
+  mont_mul(r.l, a.l, b.l, R_MOD, R_INV);
   return r;
 }
 inline Fr one() { Fr r; std::memcpy(r.l, R_ONE, 32); return r; }
@@ -144,6 +148,123 @@ inline Fr fr_zeta() {
   const uint64_t raw[4] = {0xb8ca0b2d36636f23ULL, 0xcc37a73fec2bc5e9ULL, 0x048b6e193fd84104ULL, 0x30644e72e131a029ULL};
   return detail::from_raw(raw);
 }
+
+// ---- base field Fq and Fq2 on the host: only for the two G2 points of a `SerdeFormat::Processed` parameter file ----------------------
+namespace detail {
+constexpr uint64_t Q_MOD[4] = {0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+constexpr uint64_t Q_INV = 0x87d20782e4866389ULL;  // -q^-1 mod 2^64
+constexpr uint64_t Q_ONE[4] = {0xd35d438dc58f0d9dULL, 0x0a78eb28f5c70b3dULL, 0x666ea36f7879462cULL, 0x0e0a77c19a07df2fULL};
+constexpr uint64_t Q_R2[4] = {0xf32cfc5b538afa89ULL, 0xb5e71911d44501fbULL, 0x47ab1eff0a417ff6ULL, 0x06d89f71cab8351fULL};
+struct Fq {
+  uint64_t l[4];   // Montgomery form
+  bool operator==(const Fq& o) const { return std::memcmp(l, o.l, 32) == 0; }
+  bool is_zero() const { return !(l[0] | l[1] | l[2] | l[3]); }
+};
+inline Fq fq_mul(const Fq& a, const Fq& b) { Fq r; mont_mul(r.l, a.l, b.l, Q_MOD, Q_INV); return r; }
+inline Fq fq_add(const Fq& a, const Fq& b) {
+  Fq r;
+  uint64_t carry = 0, t[4];
+  for (int i = 0; i < 4; i++) { const u128 sum = (u128)a.l[i] + b.l[i] + carry; t[i] = (uint64_t)sum; carry = (uint64_t)(sum >> 64); }
+  if (carry || geq(t, Q_MOD)) sub(r.l, t, Q_MOD); else std::memcpy(r.l, t, 32);
+  return r;
+}
+inline Fq fq_sub(const Fq& a, const Fq& b) {
+  Fq r;
+  if (geq(a.l, b.l)) sub(r.l, a.l, b.l);
+  else { uint64_t t[4]; sub(t, b.l, a.l); sub(r.l, Q_MOD, t); }
+  return r;
+}
+inline Fq fq_neg(const Fq& a) { return fq_sub(Fq{}, a); }
+inline Fq fq_one() { Fq r; std::memcpy(r.l, Q_ONE, 32); return r; }
+inline Fq fq_from_canonical(const uint64_t v[4]) { Fq raw, r2; std::memcpy(raw.l, v, 32); std::memcpy(r2.l, Q_R2, 32); return fq_mul(raw, r2); }
+inline void fq_to_canonical(const Fq& a, uint64_t out[4]) { const Fq one_raw{{1, 0, 0, 0}}; const Fq c = fq_mul(a, one_raw); std::memcpy(out, c.l, 32); }
+inline Fq fq_from_u64(uint64_t v) { const uint64_t raw[4] = {v, 0, 0, 0}; return fq_from_canonical(raw); }
+inline Fq fq_pow(Fq base, const uint64_t e[4]) {
+  Fq acc = fq_one();
+  for (int i = 0; i < 256; i++) {
+    if ((e[i >> 6] >> (i & 63)) & 1) acc = fq_mul(acc, base);
+    base = fq_mul(base, base);
+  }
+  return acc;
+}
+inline Fq fq_invert(const Fq& a) { uint64_t e[4]; const uint64_t two[4] = {2, 0, 0, 0}; sub(e, Q_MOD, two); return fq_pow(a, e); }
+// a root of a (q = 3 mod 4: a^((q+1)/4)); false when a is not a square
+inline bool fq_sqrt(const Fq& a, Fq* root) {
+  const uint64_t e[4] = {0x4f082305b61f3f52ULL, 0x65e05aa45a1c72a3ULL, 0x6e14116da0605617ULL, 0x0c19139cb84c680aULL};   // (q + 1) / 4
+  *root = fq_pow(a, e);
+  return fq_mul(*root, *root) == a;
+}
+struct Fq2 { Fq c0, c1; bool operator==(const Fq2& o) const { return c0 == o.c0 && c1 == o.c1; } };   // c0 + c1 u, u^2 = -1
+inline Fq2 f2_mul(const Fq2& a, const Fq2& b) { return {fq_sub(fq_mul(a.c0, b.c0), fq_mul(a.c1, b.c1)), fq_add(fq_mul(a.c0, b.c1), fq_mul(a.c1, b.c0))}; }
+inline Fq2 f2_add(const Fq2& a, const Fq2& b) { return {fq_add(a.c0, b.c0), fq_add(a.c1, b.c1)}; }
+inline Fq2 f2_invert(const Fq2& a) {
+  const Fq d = fq_invert(fq_add(fq_mul(a.c0, a.c0), fq_mul(a.c1, a.c1)));
+  return {fq_mul(a.c0, d), fq_neg(fq_mul(a.c1, d))};
+}
+// with s^2 = a0^2 + a1^2: x0^2 = (a0 +- s) / 2, x1 = a1 / (2 x0)
+inline bool f2_sqrt(const Fq2& a, Fq2* root) {
+  Fq r;
+  if (a.c1.is_zero()) {
+    if (fq_sqrt(a.c0, &r)) { *root = {r, Fq{}}; return true; }
+    if (fq_sqrt(fq_neg(a.c0), &r)) { *root = {Fq{}, r}; return true; }     // a0 = -(r^2) = (r u)^2
+    return false;
+  }
+  Fq s;
+  if (!fq_sqrt(fq_add(fq_mul(a.c0, a.c0), fq_mul(a.c1, a.c1)), &s)) return false;
+  const Fq half = fq_invert(fq_from_u64(2));
+  const Fq cand[2] = {fq_mul(fq_add(a.c0, s), half), fq_mul(fq_sub(a.c0, s), half)};
+  for (const Fq& t : cand) {
+    Fq x0;
+    if (!fq_sqrt(t, &x0) || x0.is_zero()) continue;
+    const Fq2 x{x0, fq_mul(a.c1, fq_invert(fq_add(x0, x0)))};
+    if (f2_mul(x, x) == a) { *root = x; return true; }
+  }
+  return false;
+}
+// `G2Affine::{to_bytes, from_bytes}`: 64 bytes, x.c0 || x.c1 canonical little-endian, flags in the last byte; the sign is the lsb of the
+// first byte of y's encoding, i.e. of canonical y.c0.  `g2` = the memory of a G2Affine (16 Montgomery limbs); flag layouts as in zkhip.h
+inline std::array<unsigned char, 64> g2_compress(const std::array<uint64_t, 16>& g2, int flag_layout) {
+  std::array<unsigned char, 64> out{};
+  bool zero = true;
+  for (uint64_t w : g2) zero = zero && w == 0;
+  if (zero) { if (flag_layout == 0) out[63] = 0x80; return out; }
+  Fq c[3];
+  for (int i = 0; i < 3; i++) std::memcpy(c[i].l, g2.data() + 4 * i, 32);
+  uint64_t x0[4], x1[4], y0[4];
+  fq_to_canonical(c[0], x0); fq_to_canonical(c[1], x1); fq_to_canonical(c[2], y0);
+  std::memcpy(out.data(), x0, 32);
+  std::memcpy(out.data() + 32, x1, 32);
+  out[63] |= (unsigned char)((y0[0] & 1) << (flag_layout == 0 ? 6 : 7));
+  return out;
+}
+inline std::array<uint64_t, 16> g2_decompress(const unsigned char in[64], int flag_layout) {
+  unsigned char b[64];
+  std::memcpy(b, in, 64);
+  bool is_inf, sign;
+  if (flag_layout == 0) { is_inf = (b[63] >> 7) != 0; sign = ((b[63] >> 6) & 1) != 0; b[63] &= 0x3f; }
+  else { sign = (b[63] >> 7) != 0; b[63] &= 0x7f; is_inf = !sign; for (int i = 0; i < 64; i++) is_inf = is_inf && b[i] == 0; }
+  std::array<uint64_t, 16> out{};
+  bool any = false;
+  for (int i = 0; i < 64; i++) any = any || b[i] != 0;
+  if (is_inf) {
+    if (any || sign) throw std::runtime_error("G2: identity flag on a non-zero encoding");
+    return out;
+  }
+  uint64_t x0[4], x1[4];
+  std::memcpy(x0, b, 32); std::memcpy(x1, b + 32, 32);
+  if (geq(x0, Q_MOD) || geq(x1, Q_MOD)) throw std::runtime_error("G2: x is not canonical");
+  const Fq2 x{fq_from_canonical(x0), fq_from_canonical(x1)};
+  const Fq2 twist_b = f2_mul(Fq2{fq_from_u64(3), Fq{}}, f2_invert(Fq2{fq_from_u64(9), fq_one()}));     // 3 / (9 + u)
+  Fq2 y;
+  if (!f2_sqrt(f2_add(f2_mul(f2_mul(x, x), x), twist_b), &y)) throw std::runtime_error("G2: x is not the abscissa of a point of the twist");
+  uint64_t y0[4];
+  fq_to_canonical(y.c0, y0);
+  if (((y0[0] & 1) != 0) != sign) y = {fq_neg(y.c0), fq_neg(y.c1)};
+  std::memcpy(out.data(), x.c0.l, 32); std::memcpy(out.data() + 4, x.c1.l, 32);
+  std::memcpy(out.data() + 8, y.c0.l, 32); std::memcpy(out.data() + 12, y.c1.l, 32);
+  return out;
+}
+}  // namespace detail
 
 // ---- halo2_proofs::arithmetic ----------------------------------------------------------------------------------
 inline G1 best_multiexp(const Fr* coeffs, size_t coeffs_len, const G1Affine* bases, size_t bases_len) {
@@ -365,6 +486,10 @@ inline std::vector<G1Affine> g_to_lagrange(const std::vector<G1Affine>& g, uint3
   return out;
 }
 
+// `SerdeFormat` [DEP halo2-axiom helpers.rs]: Processed = compressed points and canonical scalars; RawBytes = the in-memory Montgomery
+// limbs, checked on read; RawBytesUnchecked = the same without the checks (what the reference writes its proving keys with)
+enum class SerdeFormat { Processed, RawBytes, RawBytesUnchecked };
+
 class ParamsKZG {
  public:
   // takes ownership of the SRS arrays and pins them in HBM (prepared fixed-base tables)
@@ -467,6 +592,46 @@ class ParamsKZG {
     return p;
   }
 
+  // `ParamsKZG::{write_custom, read_custom}`: Processed = k u32 LE | g: 2^k x 32 B | g_lagrange: 2^k x 32 B | g2 64 B | s_g2 64 B, every
+  // point compressed (the two tables on the GPU: zkhip_g1_compress / zkhip_g1_decompress, the G2 points on the host)
+  void write_custom(std::ostream& out, SerdeFormat f, int flag_layout = 0) const {
+    if (f != SerdeFormat::Processed) { write(out); return; }
+    if (g_lagrange_.size() != n_) throw std::invalid_argument("ParamsKZG::write: no Lagrange basis");
+    out.write(reinterpret_cast<const char*>(&k_), 4);
+    std::vector<unsigned char> buf(n_ * 32);
+    for (const std::vector<G1Affine>* tab : {&g_, &g_lagrange_}) {
+      halo2::check(zkhip_g1_compress(tab->data()->x, (size_t)n_, buf.data(), flag_layout), "zkhip_g1_compress");
+      out.write(reinterpret_cast<const char*>(buf.data()), (std::streamsize)buf.size());
+    }
+    for (const G2Bytes* pt : {&g2_, &s_g2_}) {
+      const std::array<unsigned char, 64> c = detail::g2_compress(*pt, flag_layout);
+      out.write(reinterpret_cast<const char*>(c.data()), 64);
+    }
+    if (!out) throw std::runtime_error("ParamsKZG::write: stream error");
+  }
+  static ParamsKZG read_custom(std::istream& in, SerdeFormat f, int flag_layout = 0) {
+    if (f != SerdeFormat::Processed) return read(in, f == SerdeFormat::RawBytes);
+    uint32_t k = 0;
+    in.read(reinterpret_cast<char*>(&k), 4);
+    if (!in || k > 28) throw std::runtime_error("ParamsKZG::read: not a KZG parameter file");
+    const uint64_t n = (uint64_t)1 << k;
+    std::vector<G1Affine> tabs[2] = {std::vector<G1Affine>(n), std::vector<G1Affine>(n)};
+    std::vector<unsigned char> buf(n * 32);
+    for (auto& tab : tabs) {
+      in.read(reinterpret_cast<char*>(buf.data()), (std::streamsize)buf.size());
+      if (!in) throw std::runtime_error("ParamsKZG::read: truncated file");
+      uint64_t bad = 0;
+      halo2::check(zkhip_g1_decompress(buf.data(), (size_t)n, tab.data()->x, flag_layout, &bad), "zkhip_g1_decompress");
+      if (bad < n) throw std::runtime_error("ParamsKZG::read: a point does not decode to a curve point");
+    }
+    unsigned char tail[128];
+    in.read(reinterpret_cast<char*>(tail), 128);
+    if (!in) throw std::runtime_error("ParamsKZG::read: truncated file");
+    ParamsKZG p(k, std::move(tabs[0]), std::move(tabs[1]));
+    p.set_g2(detail::g2_decompress(tail, flag_layout), detail::g2_decompress(tail + 64, flag_layout));
+    return p;
+  }
+
   uint32_t k() const { return k_; }
   uint64_t n() const { return n_; }
   const std::vector<G1Affine>& get_g() const { return g_; }
@@ -522,8 +687,8 @@ class ParamsKZG {
 //                 | selectors, ceil(n / 8) bytes each, row j of a group of eight in bit j
 //   Polynomial:   #values u32 BE | values (Fr raw);     slices of polynomials: count u32 BE, then the polynomials
 //   ProvingKey:   VerifyingKey | l0 | l_last | l_active_row | fixed_values | fixed_polys | fixed_cosets | permutations | polys | cosets
-// "raw" = the in-memory Montgomery limbs (RawBytes and RawBytesUnchecked; the former checks every element / point on read).
-enum class SerdeFormat { Processed, RawBytes, RawBytesUnchecked };
+// "raw" = the in-memory Montgomery limbs (RawBytes and RawBytesUnchecked; the former checks every element / point on read).  Processed:
+// the same sequence with commitments compressed (32 B) and scalars as canonical integers (`to_repr`), both converted on the GPU.
 
 // the part of `ConstraintSystem` keygen and the key readers need (the mirror has no circuit synthesis: the host supplies the assigned
 // fixed columns and the copy constraints)
@@ -624,12 +789,35 @@ inline uint32_t get_u32_be(std::istream& in) {
   if (!in) throw std::runtime_error("key file truncated");
   return ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | b[3];
 }
-inline void check_format(SerdeFormat f) {
-  if (f == SerdeFormat::Processed) throw std::invalid_argument("SerdeFormat::Processed is not handled (the reference writes RawBytesUnchecked)");
+inline void check_format(SerdeFormat) {}
+// Montgomery words <-> canonical integers (`to_repr` / `from_repr`) as one row program: a Montgomery product with the constant whose
+// words are 1 strips the factor R, one with the constant whose words are R^2 puts it back
+inline std::vector<Fr> convert_repr(const std::vector<Fr>& p, bool to_repr) {
+  if (p.empty()) return p;
+  uint32_t log = 0;
+  while (((size_t)1 << log) < p.size()) log++;
+  std::vector<Fr> padded(p);
+  padded.resize((size_t)1 << log, Fr{});
+  Fr c{{1, 0, 0, 0}};
+  if (!to_repr) std::memcpy(c.l, R_R2, 32);
+  RowProgram prog;
+  prog.rotations = {0};
+  prog.constants = {c};
+  prog.emit(ZKHIP_OP_MUL, 0, RowProgram::column(0, 0), RowProgram::constant(0));
+  DeviceVec in(padded), out(padded.size());
+  prog.run({&in}, log, out);
+  std::vector<Fr> r = out.to_host();
+  r.resize(p.size());
+  return r;
 }
-inline void put_poly(std::ostream& out, const std::vector<Fr>& p) {
+inline void put_poly(std::ostream& out, const std::vector<Fr>& p, SerdeFormat f = SerdeFormat::RawBytes) {
   put_u32_be(out, (uint32_t)p.size());
-  out.write(reinterpret_cast<const char*>(p.data()), (std::streamsize)(p.size() * sizeof(Fr)));
+  if (f == SerdeFormat::Processed) {
+    const std::vector<Fr> repr = convert_repr(p, true);
+    out.write(reinterpret_cast<const char*>(repr.data()), (std::streamsize)(repr.size() * sizeof(Fr)));
+  } else {
+    out.write(reinterpret_cast<const char*>(p.data()), (std::streamsize)(p.size() * sizeof(Fr)));
+  }
 }
 inline std::vector<Fr> get_poly(std::istream& in, SerdeFormat f, size_t want) {
   const uint32_t m = get_u32_be(in);
@@ -637,13 +825,20 @@ inline std::vector<Fr> get_poly(std::istream& in, SerdeFormat f, size_t want) {
   std::vector<Fr> p(m);
   in.read(reinterpret_cast<char*>(p.data()), (std::streamsize)(m * sizeof(Fr)));
   if (!in) throw std::runtime_error("key file truncated");
-  if (f == SerdeFormat::RawBytes)
+  if (f != SerdeFormat::RawBytesUnchecked)
     for (const Fr& v : p) if (geq(v.l, R_MOD)) throw std::runtime_error("key file: non-canonical field element");
-  return p;
+  return f == SerdeFormat::Processed ? convert_repr(p, false) : p;
 }
-inline void put_slice(std::ostream& out, const std::vector<std::vector<Fr>>& s) {
+inline void put_slice(std::ostream& out, const std::vector<std::vector<Fr>>& s, SerdeFormat f = SerdeFormat::RawBytes) {
   put_u32_be(out, (uint32_t)s.size());
-  for (const auto& p : s) put_poly(out, p);
+  for (const auto& p : s) put_poly(out, p, f);
+}
+inline void put_points(std::ostream& out, const std::vector<G1Affine>& pts, SerdeFormat f) {
+  if (f != SerdeFormat::Processed) { out.write(reinterpret_cast<const char*>(pts.data()), (std::streamsize)(pts.size() * sizeof(G1Affine))); return; }
+  if (pts.empty()) return;
+  std::vector<unsigned char> buf(pts.size() * 32);
+  check(zkhip_g1_compress(pts.data()->x, pts.size(), buf.data(), 0), "zkhip_g1_compress");
+  out.write(reinterpret_cast<const char*>(buf.data()), (std::streamsize)buf.size());
 }
 inline std::vector<std::vector<Fr>> get_slice(std::istream& in, SerdeFormat f, size_t want_count, size_t want_len) {
   if (get_u32_be(in) != want_count) throw std::runtime_error("key file: unexpected number of polynomials");
@@ -653,6 +848,16 @@ inline std::vector<std::vector<Fr>> get_slice(std::istream& in, SerdeFormat f, s
 }
 inline std::vector<G1Affine> get_points(std::istream& in, SerdeFormat f, size_t count) {
   std::vector<G1Affine> p(count);
+  if (f == SerdeFormat::Processed) {
+    if (!count) return p;
+    std::vector<unsigned char> buf(count * 32);
+    in.read(reinterpret_cast<char*>(buf.data()), (std::streamsize)buf.size());
+    if (!in) throw std::runtime_error("key file truncated");
+    uint64_t bad = 0;
+    check(zkhip_g1_decompress(buf.data(), count, p.data()->x, 0, &bad), "zkhip_g1_decompress");
+    if (bad < count) throw std::runtime_error("key file: a commitment does not decode to a curve point");
+    return p;
+  }
   in.read(reinterpret_cast<char*>(p.data()), (std::streamsize)(count * sizeof(G1Affine)));
   if (!in) throw std::runtime_error("key file truncated");
   if (f == SerdeFormat::RawBytes && count) {
@@ -673,8 +878,8 @@ struct VerifyingKey {
     detail::check_format(f);
     detail::put_u32_be(out, k);
     detail::put_u32_be(out, (uint32_t)fixed_commitments.size());
-    out.write(reinterpret_cast<const char*>(fixed_commitments.data()), (std::streamsize)(fixed_commitments.size() * sizeof(G1Affine)));
-    out.write(reinterpret_cast<const char*>(permutation_commitments.data()), (std::streamsize)(permutation_commitments.size() * sizeof(G1Affine)));
+    detail::put_points(out, fixed_commitments, f);
+    detail::put_points(out, permutation_commitments, f);
     for (const auto& sel : selectors)
       for (size_t i = 0; i < sel.size(); i += 8) {
         unsigned char byte = 0;
@@ -713,9 +918,9 @@ struct ProvingKey {
 
   void write(std::ostream& out, SerdeFormat f = SerdeFormat::RawBytesUnchecked) const {
     vk.write(out, f);
-    detail::put_poly(out, l0); detail::put_poly(out, l_last); detail::put_poly(out, l_active_row);
-    detail::put_slice(out, fixed_values); detail::put_slice(out, fixed_polys); detail::put_slice(out, fixed_cosets);
-    detail::put_slice(out, permutations); detail::put_slice(out, permutation_polys); detail::put_slice(out, permutation_cosets);
+    detail::put_poly(out, l0, f); detail::put_poly(out, l_last, f); detail::put_poly(out, l_active_row, f);
+    detail::put_slice(out, fixed_values, f); detail::put_slice(out, fixed_polys, f); detail::put_slice(out, fixed_cosets, f);
+    detail::put_slice(out, permutations, f); detail::put_slice(out, permutation_polys, f); detail::put_slice(out, permutation_cosets, f);
     if (!out) throw std::runtime_error("ProvingKey::write: stream error");
   }
   static ProvingKey read(std::istream& in, SerdeFormat f, const CircuitShape& cs) {

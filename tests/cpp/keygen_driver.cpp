@@ -1,11 +1,13 @@
 // Drives the C++ mirror of keygen / key files / G2 / sharded commits (include/zkhip.hpp) the way a compiled host of the reference would;
 // run by tests/test_gpu_prover_flow.py::test_cpp_keygen_mirror_matches_python, which builds the same circuit through the Python mirror and
 // compares the two proving-key files byte for byte.
-//   usage: keygen_driver <in.bin> <pk_out.bin> <report.bin> [pk_to_read.bin]
+//   usage: keygen_driver <in.bin> <pk_out.bin> <report.bin> [pk_to_read.bin [pk_processed_out.bin params_raw_in.bin params_processed_out.bin]]
 //   in : u32 k, u32 F (fixed columns), u32 P (permutation columns), u64 trapdoor, F x 2^k Fr, u32 copies, copies x (u32 lc, lr, rc, rr),
 //        u32 m (G2 points), m x G2Affine, m x Fr
 //   report: u64 flags (bit 0: ProvingKey::read(write(pk)) == pk, bit 1: the key file given as argv[4] reads back equal, bit 2: a truncated file
-//           is refused, bit 3: commits agree for 1 and 5 MSM shards), then the G2 MSM result (G2, 192 bytes)
+//           is refused, bit 3: commits agree for 1 and 5 MSM shards, bit 4: the key written with SerdeFormat::Processed reads back equal,
+//           bit 5: the RawBytes parameter file given as argv[6], rewritten as Processed, reads back with the same points), then the G2 MSM
+//           result (G2, 192 bytes)
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -97,6 +99,27 @@ int main(int argc, char** argv) {
       }
       set_msm_shards(0);
       if (!std::memcmp(&one, &five, sizeof(G1Affine)) && !std::memcmp(&one, &vk.fixed_commitments[0], sizeof(G1Affine))) flags |= 8;
+    }
+    if (argc > 7) {
+      {
+        std::ofstream f(argv[5], std::ios::binary);
+        pk.write(f, SerdeFormat::Processed);
+      }
+      {
+        std::ifstream f(argv[5], std::ios::binary);
+        if (same_key(ProvingKey::read(f, SerdeFormat::Processed, cs), pk)) flags |= 16;
+      }
+      std::ifstream pf(argv[6], std::ios::binary);
+      ParamsKZG raw = ParamsKZG::read(pf);
+      {
+        std::ofstream f(argv[7], std::ios::binary);
+        raw.write_custom(f, SerdeFormat::Processed);
+      }
+      std::ifstream f(argv[7], std::ios::binary);
+      ParamsKZG back = ParamsKZG::read_custom(f, SerdeFormat::Processed);
+      if (back.k() == raw.k() && !std::memcmp(back.get_g().data(), raw.get_g().data(), raw.n() * sizeof(G1Affine)) &&
+          !std::memcmp(back.get_g_lagrange().data(), raw.get_g_lagrange().data(), raw.n() * sizeof(G1Affine)) && back.g2() == raw.g2() && back.s_g2() == raw.s_g2())
+        flags |= 32;
     }
     const G2 g2 = best_multiexp(g2sc, g2pts);
     FILE* rep = fopen(argv[3], "wb");

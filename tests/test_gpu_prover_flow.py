@@ -302,12 +302,25 @@ def test_cpp_keygen_mirror_matches_python(lib, cref, tmp_path):
     py_file = tmp_path / "py_pk.bin"
     py_file.write_bytes(buf.getvalue())
     cpp_file, report = tmp_path / "cpp_pk.bin", tmp_path / "report.bin"
-    subprocess.check_call([drv, str(fin), str(cpp_file), str(report), str(py_file)], timeout=300)
+    # SerdeFormat::Processed on both sides: the key and the parameter file (compressed points, canonical scalars)
+    pbuf = io.BytesIO()
+    pk.write(pbuf, KG.PROCESSED)
+    with Z.ParamsKZG.setup(k, trapdoor) as params:
+        raw_params, proc_params = io.BytesIO(), io.BytesIO()
+        params.write(raw_params)
+        params.write_custom(proc_params, KG.PROCESSED)
+    py_params = tmp_path / "py_params.bin"
+    py_params.write_bytes(raw_params.getvalue())
+    cpp_pk_proc, cpp_params_proc = tmp_path / "cpp_pk_processed.bin", tmp_path / "cpp_params_processed.bin"
+    subprocess.check_call([drv, str(fin), str(cpp_file), str(report), str(py_file), str(cpp_pk_proc), str(py_params), str(cpp_params_proc)], timeout=300)
     assert cpp_file.read_bytes() == buf.getvalue(), "the C++ and Python mirrors write different proving-key files"
+    assert cpp_pk_proc.read_bytes() == pbuf.getvalue(), "the two mirrors write different SerdeFormat::Processed key files"
+    assert cpp_params_proc.read_bytes() == proc_params.getvalue(), "the two mirrors write different SerdeFormat::Processed parameter files"
+    assert len(pbuf.getvalue()) < len(buf.getvalue()) and len(proc_params.getvalue()) == 4 + 2 * N * 32 + 128
     back = KG.ProvingKey.read(io.BytesIO(cpp_file.read_bytes()), KG.RAW_BYTES, cs)      # checked reader on the C++ file
     assert np.array_equal(back.vk.fixed_commitments, vk.fixed_commitments) and np.array_equal(back.permutation_cosets[2], pk.permutation_cosets[2])
     rep = report.read_bytes()
     flags, = struct.unpack("<Q", rep[:8])
-    assert flags == 0b1111, bin(flags)
+    assert flags == 0b111111, bin(flags)
     g2 = np.frombuffer(rep[8:8 + 192], dtype=np.uint64)
     assert g2_dec(g2) == O.g2_scalar_mul(cref.expected_scalar(sc, 31337, 4242), O.G2_GEN)

@@ -71,7 +71,7 @@ def test_key_reader_rejects_bad_files():
     with pytest.raises(EOFError):
         KG.ProvingKey.read(io.BytesIO(bytes(raw[:-5])), KG.RAW_BYTES_UNCHECKED, cs)
     with pytest.raises(ValueError):
-        KG.ProvingKey.read(io.BytesIO(bytes(raw)), KG.PROCESSED, cs)
+        KG.ProvingKey.read(io.BytesIO(bytes(raw)), "Compressed", cs)                  # not a SerdeFormat (Processed needs the GPU: tests/test_gpu_serde.py)
     other = E.ConstraintSystem(num_fixed=4, num_advice=2, permutation_columns=cs.permutation_columns, degree=4)
     with pytest.raises(ValueError):
         KG.ProvingKey.read(io.BytesIO(bytes(raw)), KG.RAW_BYTES_UNCHECKED, other)     # the circuit has another number of fixed columns

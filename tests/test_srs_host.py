@@ -89,3 +89,50 @@ def test_identity_points_are_accepted():
     g[1] = 0                                                                 # (0, 0) = the identity in G1Affine memory
     out = srs.read_params(io.BytesIO(srs.params_to_bytes(k, g, gl, g2, s_g2)), check_points=64)
     assert not out[1][1].any()
+
+
+def test_g2_compression_round_trip_and_flags():
+    """`G2Affine::{to_bytes, from_bytes}` on the host (the two G2 points of a SerdeFormat::Processed parameter file): both flag layouts,
+    identity, the sign bit selects between y and -y, non-canonical / off-curve / mis-flagged encodings are refused"""
+    rng = random.Random(9)
+    pts = [srs.G2_GENERATOR, srs.g2_mul(0xABCDEF), srs.g2_mul(rng.randrange(O.R_MOD)), srs.g2_mul(O.R_MOD - 1), None]
+    for lay in (0, 1):
+        for P in pts:
+            b = srs.g2_compress(P, lay)
+            assert len(b) == 64 and srs.g2_decompress(b, lay) == P
+        P = pts[1]
+        b = bytearray(srs.g2_compress(P, lay))
+        b[63] ^= 0x40 if lay == 0 else 0x80                                         # flip the sign flag: the other root
+        Q = srs.g2_decompress(bytes(b), lay)
+        assert Q == (P[0], ((-P[1][0]) % F.Q_MOD, (-P[1][1]) % F.Q_MOD))
+    # x and the sign as the encoding defines them: little-endian canonical c0 || c1, sign = lsb of y.c0
+    P = pts[2]
+    b = srs.g2_compress(P, 0)
+    assert int.from_bytes(b[:32], "little") == P[0][0] and int.from_bytes(bytes(b[32:63]) + bytes([b[63] & 0x3F]), "little") == P[0][1]
+    assert (b[63] >> 6) & 1 == P[1][0] & 1 and b[63] >> 7 == 0
+    assert srs.g2_compress(None, 0)[63] == 0x80 and srs.g2_compress(None, 1) == bytes(64)
+    with pytest.raises(ValueError):                                                  # x.c0 = q: not canonical
+        srs.g2_decompress(F.Q_MOD.to_bytes(32, "little") + bytes(32), 0)
+    with pytest.raises(ValueError):                                                  # identity flag on a non-zero x
+        srs.g2_decompress(bytes([1]) + bytes(62) + bytes([0x80]), 0)
+    bad = next(x for x in range(1, 50) if srs._f2sqrt(tuple((c + d) % F.Q_MOD for c, d in zip(srs._f2mul(srs._f2mul((x, 0), (x, 0)), (x, 0)), srs.G2_B))) is None)
+    with pytest.raises(ValueError):                                                  # x^3 + b' is not a square in Fq2
+        srs.g2_decompress(bad.to_bytes(32, "little") + bytes(32), 0)
+
+
+def test_fq2_square_roots():
+    rng = random.Random(10)
+    squares = 0
+    for _ in range(60):
+        a = (rng.randrange(F.Q_MOD), rng.randrange(F.Q_MOD))
+        s2 = srs._f2mul(a, a)
+        r = srs._f2sqrt(s2)
+        assert r is not None and srs._f2mul(r, r) == s2
+        r = srs._f2sqrt(a)
+        if r is not None:
+            squares += 1
+            assert srs._f2mul(r, r) == a
+    assert 10 < squares < 50                                                        # about half of Fq2 are squares
+    for a0 in (4, F.Q_MOD - 4, 0, 3, F.Q_MOD - 3):                                  # c1 = 0: the root is real or purely imaginary
+        r = srs._f2sqrt((a0, 0))
+        assert r is not None and srs._f2mul(r, r) == (a0 % F.Q_MOD, 0)

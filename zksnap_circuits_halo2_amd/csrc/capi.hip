@@ -646,6 +646,10 @@ int zkhip_register_bases(const uint64_t* bases, size_t n) {
   int S, ndev;
   { guard_t g(g_mu); S = g_ctx.shards; ndev = (int)g_ctx.devs.size(); }
   if ((size_t)S > n) S = (int)n;
+  // shards on the other devices are uploaded through those devices' single lane, which a multi-device MSM of another thread drives
+  // through its workers: the two take turns
+  std::unique_lock<std::mutex> fan(g_fanout_mu, std::defer_lock);
+  if (ndev > 1 && S > 1) fan.lock();
   auto reg = std::make_shared<registered_t>();
   reg->host = bases;
   reg->n = n;
@@ -1450,6 +1454,78 @@ int zkhip_g1_check_points(const uint64_t* points, size_t n, uint64_t* first_bad)
     const size_t m = std::min(chunk, n - lo);
     HIPCHK(hipMemcpyAsync(H.sc->bases.p, points + lo * 8, m * 64, hipMemcpyHostToDevice, H.s));
     if ((rc = g1_check_points_device((const uint32_t*)H.sc->bases.p, m, (unsigned long long*)H.sc->small.p, H.s)) != ZKHIP_OK) return rc;
+    HIPCHK(hipMemcpyAsync(H.L->pinned, H.sc->small.p, 8, hipMemcpyDeviceToHost, H.s));
+    HIPCHK(hipStreamSynchronize(H.s));
+    const unsigned long long v = *(const unsigned long long*)H.L->pinned;
+    if (v < m) { *first_bad = lo + (size_t)v; return ZKHIP_OK; }
+  }
+  return ZKHIP_OK;
+}
+
+// ---- SerdeFormat::Processed: compressed G1 points (serde.hip) -------------------------------------------------------------
+int zkhip_g1_compress_device(const void* d_points, size_t n, void* d_out32, int flag_layout, void* stream) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if ((n && (!d_points || !d_out32)) || flag_layout < 0 || flag_layout > 1) { set_error("g1_compress: bad argument"); return ZKHIP_EINVAL; }
+  return g1_compress_device((const uint32_t*)d_points, n, (uint32_t*)d_out32, flag_layout, caller_stream(stream));
+}
+
+int zkhip_g1_decompress_device(const void* d_in32, size_t n, void* d_points, int flag_layout, uint64_t* first_bad, void* stream) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (!first_bad || (n && (!d_in32 || !d_points)) || flag_layout < 0 || flag_layout > 1) { set_error("g1_decompress: bad argument"); return ZKHIP_EINVAL; }
+  hipStream_t s = caller_stream(stream);
+  scratch* sc = scratch_for(primary(), s);
+  if ((rc = sc->small.reserve(4096)) != ZKHIP_OK) return rc;
+  unsigned long long v = (unsigned long long)n;
+  HIPCHK(hipMemcpyAsync(sc->small.p, &v, 8, hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));                     // `v` is a stack variable
+  if ((rc = g1_decompress_device((const uint32_t*)d_in32, n, (uint32_t*)d_points, flag_layout, (unsigned long long*)sc->small.p, s)) != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(&v, sc->small.p, 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  *first_bad = (uint64_t)v;
+  return ZKHIP_OK;
+}
+
+int zkhip_g1_compress(const uint64_t* points, size_t n, uint8_t* out32, int flag_layout) {
+  if ((n && (!points || !out32)) || flag_layout < 0 || flag_layout > 1) { set_error("g1_compress: bad argument"); return ZKHIP_EINVAL; }
+  if (n == 0) return ZKHIP_OK;
+  lane_hold H;
+  if (H.rc != ZKHIP_OK) return H.rc;
+  int rc;
+  const size_t chunk = (size_t)1 << 23;                // 512 MiB of points per upload
+  if ((rc = H.sc->bases.reserve(std::min(n, chunk) * 64)) != ZKHIP_OK) return rc;
+  if ((rc = H.sc->poly.reserve(std::min(n, chunk) * 32)) != ZKHIP_OK) return rc;
+  for (size_t lo = 0; lo < n; lo += chunk) {
+    const size_t m = std::min(chunk, n - lo);
+    HIPCHK(hipMemcpyAsync(H.sc->bases.p, points + lo * 8, m * 64, hipMemcpyHostToDevice, H.s));
+    if ((rc = g1_compress_device((const uint32_t*)H.sc->bases.p, m, (uint32_t*)H.sc->poly.p, flag_layout, H.s)) != ZKHIP_OK) return rc;
+    HIPCHK(hipMemcpyAsync(out32 + lo * 32, H.sc->poly.p, m * 32, hipMemcpyDeviceToHost, H.s));
+    HIPCHK(hipStreamSynchronize(H.s));
+  }
+  return ZKHIP_OK;
+}
+
+int zkhip_g1_decompress(const uint8_t* in32, size_t n, uint64_t* points, int flag_layout, uint64_t* first_bad) {
+  if (!first_bad || (n && (!in32 || !points)) || flag_layout < 0 || flag_layout > 1) { set_error("g1_decompress: bad argument"); return ZKHIP_EINVAL; }
+  *first_bad = n;
+  if (n == 0) return ZKHIP_OK;
+  lane_hold H;
+  if (H.rc != ZKHIP_OK) return H.rc;
+  int rc;
+  const size_t chunk = (size_t)1 << 23;
+  if ((rc = H.sc->bases.reserve(std::min(n, chunk) * 64)) != ZKHIP_OK) return rc;
+  if ((rc = H.sc->poly.reserve(std::min(n, chunk) * 32)) != ZKHIP_OK) return rc;
+  if ((rc = H.sc->small.reserve(4096)) != ZKHIP_OK) return rc;
+  for (size_t lo = 0; lo < n; lo += chunk) {
+    const size_t m = std::min(chunk, n - lo);
+    *(unsigned long long*)H.L->pinned = (unsigned long long)m;
+    HIPCHK(hipMemcpyAsync(H.sc->small.p, H.L->pinned, 8, hipMemcpyHostToDevice, H.s));
+    HIPCHK(hipMemcpyAsync(H.sc->poly.p, in32 + lo * 32, m * 32, hipMemcpyHostToDevice, H.s));
+    if ((rc = g1_decompress_device((const uint32_t*)H.sc->poly.p, m, (uint32_t*)H.sc->bases.p, flag_layout, (unsigned long long*)H.sc->small.p, H.s)) != ZKHIP_OK) return rc;
+    HIPCHK(hipMemcpyAsync(points + lo * 8, H.sc->bases.p, m * 64, hipMemcpyDeviceToHost, H.s));
     HIPCHK(hipMemcpyAsync(H.L->pinned, H.sc->small.p, 8, hipMemcpyDeviceToHost, H.s));
     HIPCHK(hipStreamSynchronize(H.s));
     const unsigned long long v = *(const unsigned long long*)H.L->pinned;

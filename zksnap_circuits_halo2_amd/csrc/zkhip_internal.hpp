@@ -90,6 +90,10 @@ size_t lookup_permute_workspace_bytes(size_t usable_rows);
 int lookup_permute_device(const uint32_t* d_input, const uint32_t* d_table, size_t usable_rows, uint32_t* d_out_input, uint32_t* d_out_table,
                           void* ws, size_t ws_bytes, hipStream_t stream);
 
+// serde.hip
+int g1_compress_device(const uint32_t* d_points, size_t n, uint32_t* d_out, int layout, hipStream_t stream);
+int g1_decompress_device(const uint32_t* d_in, size_t n, uint32_t* d_points, int layout, unsigned long long* d_first_bad, hipStream_t stream);
+
 // selftest.hip
 int test_field_op(int field, int op, const uint32_t* d_a, const uint32_t* d_b, uint32_t* d_out, size_t n, hipStream_t stream);
 int g1_check_points_device(const uint32_t* d_points, size_t n, unsigned long long* d_first_bad, hipStream_t stream);

@@ -19,7 +19,8 @@ crate -- **unpinned** (DESIGN.md section 6): a key written by the Rust prover ha
                    permutation: permutations | polys | cosets (each: count u32 BE, then polynomials)
     Fr / G1Affine under RawBytes / RawBytesUnchecked: the in-memory Montgomery limbs (4 x u64 LE per field element; a point is x || y),
     i.e. exactly the arrays the C ABI takes.  RawBytes checks on read that every element is canonical and every point on the curve;
-    RawBytesUnchecked does not.  The compressed `Processed` form is not handled (as in srs.py).
+    RawBytesUnchecked does not.  `Processed` stores commitments compressed (32 B, srs.py) and scalars as their canonical integers
+    (`to_repr`, 32 B little-endian): both conversions run on the GPU.
 
 What keygen computes -- everything on the GPU through the batched device entry points:
     fixed commitments / permutation commitments   `params.commit_lagrange(column)`                      prepared-table MSM
@@ -175,8 +176,8 @@ class VerifyingKey:
         _check_format(fmt)
         w.write(struct.pack(">I", self.k))
         w.write(struct.pack(">I", self.fixed_commitments.shape[0]))
-        w.write(np.ascontiguousarray(self.fixed_commitments, dtype="<u8").tobytes())
-        w.write(np.ascontiguousarray(self.permutation_commitments, dtype="<u8").tobytes())
+        _write_points(w, self.fixed_commitments, fmt)
+        _write_points(w, self.permutation_commitments, fmt)
         for sel in self.selectors:
             w.write(np.packbits(np.asarray(sel, dtype=bool), bitorder="little").tobytes())
 
@@ -215,11 +216,11 @@ class ProvingKey:
         _check_format(fmt)
         self.vk.write(w, fmt)
         for p in (self.l0, self.l_last, self.l_active_row):
-            _write_poly(w, p)
+            _write_poly(w, p, fmt)
         for group in (self.fixed_values, self.fixed_polys, self.fixed_cosets, self.permutations, self.permutation_polys, self.permutation_cosets):
             w.write(struct.pack(">I", len(group)))
             for p in group:
-                _write_poly(w, p)
+                _write_poly(w, p, fmt)
 
     @classmethod
     def read(cls, r: BinaryIO, fmt: str, cs: E.ConstraintSystem, num_selectors: int = 0) -> "ProvingKey":
@@ -281,10 +282,29 @@ def keygen_pk(params, vk: VerifyingKey, cs: E.ConstraintSystem, fixed: Sequence[
 # serialisation helpers
 # ---------------------------------------------------------------------------------------------------
 def _check_format(fmt: str) -> None:
-    if fmt == PROCESSED:
-        raise ValueError("SerdeFormat::Processed (compressed points, canonical scalars) is not handled: the reference writes RawBytesUnchecked")
-    if fmt not in (RAW_BYTES, RAW_BYTES_UNCHECKED):
+    if fmt not in (RAW_BYTES, RAW_BYTES_UNCHECKED, PROCESSED):
         raise ValueError(f"unknown SerdeFormat {fmt!r}")
+
+
+# Montgomery words <-> canonical integers as one row program each: a Montgomery product with the constant whose WORDS are 1 (the value
+# R^-1) strips the factor R, one with the constant whose words are R^2 (the value R) puts it back
+_R_INV = pow(1 << 256, -1, R_MOD)
+_R = (1 << 256) % R_MOD
+
+
+def _convert_repr(p: np.ndarray, constant: int) -> np.ndarray:
+    p = np.ascontiguousarray(p, dtype=np.uint64).reshape(-1, 4)
+    m = p.shape[0]
+    if m == 0:
+        return p
+    log = (m - 1).bit_length()
+    if (1 << log) != m:                                    # row programs run over 2^log rows
+        pad = np.zeros(((1 << log), 4), dtype=np.uint64)
+        pad[:m] = p
+        p = pad
+    prog = E.RowProgram()
+    prog.emit(E.OP_MUL, 0, prog.column(0), prog.constant(constant))
+    return prog.run([p], log)[:m]
 
 
 def _take(r: BinaryIO, nbytes: int) -> bytes:
@@ -294,10 +314,19 @@ def _take(r: BinaryIO, nbytes: int) -> bytes:
     return b
 
 
-def _write_poly(w: BinaryIO, p: np.ndarray) -> None:
+def _write_poly(w: BinaryIO, p: np.ndarray, fmt: str = RAW_BYTES) -> None:
     p = np.ascontiguousarray(p, dtype="<u8").reshape(-1, 4)
     w.write(struct.pack(">I", p.shape[0]))
-    w.write(p.tobytes())
+    w.write((_convert_repr(p, _R_INV) if fmt == PROCESSED else p).tobytes())
+
+
+def _write_points(w: BinaryIO, pts: np.ndarray, fmt: str) -> None:
+    if fmt == PROCESSED:
+        from .srs import g1_compress
+
+        w.write(g1_compress(pts))
+    else:
+        w.write(np.ascontiguousarray(pts, dtype="<u8").tobytes())
 
 
 _R_LIMBS = np.array([(R_MOD >> (64 * i)) & ((1 << 64) - 1) for i in range(4)], dtype=np.uint64)
@@ -319,12 +348,16 @@ def _read_poly(r: BinaryIO, fmt: str, want_len: int) -> np.ndarray:
     if m != want_len:
         raise ValueError(f"polynomial of {m} values where {want_len} were expected")
     a = np.frombuffer(_take(r, m * 32), dtype="<u8").reshape(m, 4).astype(np.uint64)
-    if fmt == RAW_BYTES and not _all_below(a, _R_LIMBS):
+    if fmt in (RAW_BYTES, PROCESSED) and not _all_below(a, _R_LIMBS):
         raise ValueError("non-canonical field element in key file")
-    return a
+    return _convert_repr(a, _R) if fmt == PROCESSED else a
 
 
 def _read_points(r: BinaryIO, count: int, fmt: str) -> np.ndarray:
+    if fmt == PROCESSED:
+        from .srs import g1_decompress
+
+        return g1_decompress(_take(r, count * 32), count, what="key file") if count else np.zeros((0, 8), dtype=np.uint64)
     a = np.frombuffer(_take(r, count * 64), dtype="<u8").reshape(count, 8).astype(np.uint64)
     if fmt == RAW_BYTES and count:
         if not (_all_below(a[:, :4], _Q_LIMBS) and _all_below(a[:, 4:], _Q_LIMBS)):

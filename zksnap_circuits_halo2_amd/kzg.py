@@ -124,11 +124,16 @@ class ParamsKZG:
 
     def write(self, f) -> None:
         """`ParamsKZG::write` (SerdeFormat::RawBytes) [DEP]; layout in srs.py"""
+        self.write_custom(f, "RawBytes")
+
+    def write_custom(self, f, fmt: str, flag_layout: int = 0) -> None:
+        """`ParamsKZG::write_custom(writer, format)` [DEP]: RawBytes / RawBytesUnchecked (the memory of the points) or Processed (every
+        point compressed: the two tables on the GPU)"""
         from . import srs
 
         if self.g_lagrange is None or self.g2 is None or self.s_g2 is None:
             raise ValueError("write needs g_lagrange, g2 and s_g2")
-        srs.write_params(f, self.k, self.g, self.g_lagrange, self.g2, self.s_g2)
+        srs.write_params(f, self.k, self.g, self.g_lagrange, self.g2, self.s_g2, fmt, flag_layout)
 
     @classmethod
     def read(cls, f, check_points=None) -> "ParamsKZG":
@@ -137,6 +142,14 @@ class ParamsKZG:
         from . import srs
 
         k, g, g_lagrange, g2, s_g2 = srs.read_params(f, check_points)
+        return cls(k, g, g_lagrange, g2, s_g2)
+
+    @classmethod
+    def read_custom(cls, f, fmt: str, flag_layout: int = 0) -> "ParamsKZG":
+        """`ParamsKZG::read_custom(reader, format)` [DEP]"""
+        from . import srs
+
+        k, g, g_lagrange, g2, s_g2 = srs.read_params(f, None, fmt=fmt, flag_layout=flag_layout)
         return cls(k, g, g_lagrange, g2, s_g2)
 
     def get_g2(self) -> np.ndarray:
