@@ -36,7 +36,6 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 constexpr int MAX_TASK_LEN = 128;       // tasks are 2^task_shift entries, task_shift <= 7 (length histograms hold MAX_TASK_LEN + 1 counters)
 constexpr int TASK_SHIFT = 6;           // 64 entries per accumulate task: short tasks keep the tail of the launch balanced
                                         // (measured at 2^22: 5.9 ms with 64-entry tasks, 6.9 ms with 256, 8.1 ms with 512)
-constexpr int COMBINE_LEVELS = 10;      // radix-4 tree levels above the final step: covers 16 * 4^10 partials per bucket
 
 struct task_t {
   uint32_t bucket, start, len;
@@ -599,35 +598,66 @@ __global__ void __launch_bounds__(1024) k_scan_single(const uint32_t* __restrict
   }
 }
 
+constexpr uint32_t HEAVY_SLICE = 2048;   // partials of a heavy bucket one workgroup of the combine step sums (16 per thread)
 // ------------------------------------------------------------------------------------------------
 // 5. tasks: bucket k with cnt entries -> ceil(cnt / 2^task_shift) tasks; max_parts = largest task count of any bucket
 // ------------------------------------------------------------------------------------------------
-// One thread per bucket.  (A thread-per-task variant with a binary search for the bucket is robust against a bucket that
-// holds a large share of all entries, but measured 2-5x slower in the common case: 0.28 vs 0.05 ms at 2^22; a degenerate
-// input -- every scalar equal -- costs this version ~1-2 ms of serial task records, which is acceptable.)
+// One thread per bucket; a bucket with more than COOP_TASKS tasks is written by the whole wavefront instead (its owner's values
+// are broadcast, lane l writes records l, l + 64, ...).  A column of selector bits or of many equal witness values puts a large share
+// of all entries into one bucket: with the owner writing alone, 5 % equal scalars cost 0.9 ms at 2^22 and an all-ones column 11 ms
+// (65536 records from one thread, here and again in k_make_order).  (A thread-per-task variant with a binary search for the bucket was
+// measured 2-5x slower in the common case: 0.28 vs 0.05 ms at 2^22.)
+constexpr uint32_t COOP_TASKS = 32;
 __global__ void __launch_bounds__(256) k_make_tasks(const uint32_t* __restrict__ offset, const uint32_t* __restrict__ task_off,
                                                     uint32_t nbuckets, task_t* __restrict__ tasks, uint32_t task_shift,
-                                                    uint32_t* __restrict__ max_parts, uint32_t* __restrict__ len_count) {
+                                                    uint32_t* __restrict__ max_parts, uint32_t* __restrict__ len_count, uint32_t seq_parts,
+                                                    uint32_t* __restrict__ heavy_count, uint2* __restrict__ heavy, uint32_t heavy_cap) {
   __shared__ uint32_t lh[MAX_TASK_LEN + 1];
   if (threadIdx.x <= MAX_TASK_LEN) lh[threadIdx.x] = 0;
   __syncthreads();
   // a capped grid walks the buckets: the length histogram costs one global atomic per (workgroup, length) on the same 65 words,
   // and with one workgroup per 256 buckets those were 2048 x 65 contended atomics at 2^19 buckets (99 us of a 6 ms MSM)
   uint32_t nt = 0;
-  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nbuckets; k += gridDim.x * blockDim.x) {
-    const uint32_t s = offset[k], e = offset[k + 1], t = task_off[k], m = task_off[k + 1] - t;
-    for (uint32_t j = 0; j < m; j++) {
-      task_t tk;
-      tk.bucket = k;
-      tk.start = s + (j << task_shift);
-      tk.len = min(1u << task_shift, e - tk.start);
-      tasks[t + j] = tk;
+  const uint32_t lane = threadIdx.x & 63u;
+  for (uint32_t base = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base < nbuckets; base += gridDim.x * blockDim.x) {   // uniform per wavefront
+    const uint32_t k = base + lane;
+    uint32_t s = 0, e = 0, t = 0, m = 0;
+    if (k < nbuckets) { s = offset[k]; e = offset[k + 1]; t = task_off[k]; m = task_off[k + 1] - t; }
+    const bool coop = m > COOP_TASKS;
+    if (!coop) {
+      for (uint32_t j = 0; j < m; j++) {
+        task_t tk;
+        tk.bucket = k;
+        tk.start = s + (j << task_shift);
+        tk.len = min(1u << task_shift, e - tk.start);
+        tasks[t + j] = tk;
+      }
     }
     if (m) {   // m - 1 full tasks and one of the remaining length
       if (m > 1) atomicAdd(&lh[1u << task_shift], m - 1);
       atomicAdd(&lh[(e - s) - ((m - 1) << task_shift)], 1u);
     }
+    if (m > seq_parts) {      // more partials than the per-bucket step of the combine kernel sums: listed for its heavy-bucket workgroups,
+      const uint32_t P = (m + HEAVY_SLICE - 1) / HEAVY_SLICE;     // one entry (bucket, slice) per HEAVY_SLICE partials, consecutive in the list
+      const uint32_t idx = atomicAdd(heavy_count, P);
+      for (uint32_t i = 0; i < P; i++)
+        if (idx + i < heavy_cap) heavy[idx + i] = make_uint2(k, i);   // (the cap cannot be exceeded: msm_lay_out)
+    }
     nt = max(nt, m);
+    unsigned long long big = __ballot(coop);
+    while (big) {
+      const int src = __ffsll((long long)big) - 1;
+      big &= big - 1;
+      const uint32_t bk = (uint32_t)__shfl((int)k, src, 64), bs = (uint32_t)__shfl((int)s, src, 64), be = (uint32_t)__shfl((int)e, src, 64),
+                     bt = (uint32_t)__shfl((int)t, src, 64), bm = (uint32_t)__shfl((int)m, src, 64);
+      for (uint32_t j = lane; j < bm; j += 64) {
+        task_t tk;
+        tk.bucket = bk;
+        tk.start = bs + (j << task_shift);
+        tk.len = min(1u << task_shift, be - tk.start);
+        tasks[bt + j] = tk;
+      }
+    }
   }
   __syncthreads();
   if (len_count && threadIdx.x <= MAX_TASK_LEN && lh[threadIdx.x]) atomicAdd(&len_count[threadIdx.x], lh[threadIdx.x]);   // nullptr: k_scan_single<1> made the histogram
@@ -681,27 +711,46 @@ __global__ void __launch_bounds__(256) k_make_order(const uint32_t* __restrict__
   __syncthreads();
   if (threadIdx.x == 0 && lh[full]) lh[full] = atomicAdd(&len_cursor[full], lh[full]);     // remainder tasks of full length, after the depth classes
   __syncthreads();
-  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nbuckets; k += step) {
-    const uint32_t t = task_off[k], nt = task_off[k + 1] - t;
-    if (!nt) continue;
-    // the record a task starts from, in execution order: (task, first entry, length, first point reference) -- one coalesced
-    // 16-byte load in k_accumulate instead of the chain order -> task -> sorted before the first point can be fetched
-    const uint32_t s0 = offset[k], rem = (offset[k + 1] - s0) - ((nt - 1) << task_shift);
-    const uint32_t nfull = nt - 1, head = min(nfull, (uint32_t)ORDER_JMAX);
-    for (uint32_t j = 0; j < head; j++) {
-      const uint32_t st = s0 + (j << task_shift);
-      order[atomicAdd(&joff[j], 1u)] = make_uint4(t + j, st, full, sorted[st]);
+  const uint32_t lane = threadIdx.x & 63u;
+  for (uint32_t base = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base < nbuckets; base += step) {     // uniform per wavefront
+    const uint32_t k = base + lane;
+    uint32_t t = 0, nt = 0, s0 = 0, pos = 0, nfull = 0, head = 0;
+    if (k < nbuckets) { t = task_off[k]; nt = task_off[k + 1] - t; }
+    if (nt) {
+      // the record a task starts from, in execution order: (task, first entry, length, first point reference) -- one coalesced
+      // 16-byte load in k_accumulate instead of the chain order -> task -> sorted before the first point can be fetched
+      s0 = offset[k];
+      const uint32_t rem = (offset[k + 1] - s0) - ((nt - 1) << task_shift);
+      nfull = nt - 1;
+      head = min(nfull, (uint32_t)ORDER_JMAX);
+      for (uint32_t j = 0; j < head; j++) {
+        const uint32_t st = s0 + (j << task_shift);
+        order[atomicAdd(&joff[j], 1u)] = make_uint4(t + j, st, full, sorted[st]);
+      }
+      if (nfull > head) pos = atomicAdd(&joff[ORDER_JMAX], nfull - head);
+      const uint32_t st = s0 + ((nt - 1) << task_shift);
+      // a bucket that is a single task needs no combining: its sum goes straight to the bucket array (bit 31 = "x is the bucket")
+      order[atomicAdd(&lh[rem], 1u)] = make_uint4(nt == 1 ? (0x80000000u | k) : t + nt - 1, st, rem, sorted[st]);
     }
-    if (nfull > head) {
-      const uint32_t pos = atomicAdd(&joff[ORDER_JMAX], nfull - head);
+    // full tasks beyond depth ORDER_JMAX: a short run is written by its owner, a long one by the wavefront (see k_make_tasks)
+    const bool coop = nfull - head > COOP_TASKS;
+    if (!coop) {
       for (uint32_t j = head; j < nfull; j++) {
         const uint32_t st = s0 + (j << task_shift);
         order[pos + j - head] = make_uint4(t + j, st, full, sorted[st]);
       }
     }
-    const uint32_t st = s0 + ((nt - 1) << task_shift);
-    // a bucket that is a single task needs no combining: its sum goes straight to the bucket array (bit 31 = "x is the bucket")
-    order[atomicAdd(&lh[rem], 1u)] = make_uint4(nt == 1 ? (0x80000000u | k) : t + nt - 1, st, rem, sorted[st]);
+    unsigned long long big = __ballot(coop);
+    while (big) {
+      const int src = __ffsll((long long)big) - 1;
+      big &= big - 1;
+      const uint32_t bt = (uint32_t)__shfl((int)t, src, 64), bs0 = (uint32_t)__shfl((int)s0, src, 64), bpos = (uint32_t)__shfl((int)pos, src, 64),
+                     bnfull = (uint32_t)__shfl((int)nfull, src, 64), bhead = (uint32_t)__shfl((int)head, src, 64);
+      for (uint32_t j = bhead + lane; j < bnfull; j += 64) {
+        const uint32_t st = bs0 + (j << task_shift);
+        order[bpos + j - bhead] = make_uint4(bt + j, st, full, sorted[st]);
+      }
+    }
   }
 }
 
@@ -766,46 +815,75 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))
 
 // ------------------------------------------------------------------------------------------------
 // 7. combine task partials per bucket.  A bucket with m partials needs m - 1 additions; total work is ~1/64 of the
-//    accumulation, so what matters is robustness to skew and few launches:
-//      - tree levels (in place, radix 4) run only for buckets that still have more than SEQ_PARTS partials left:
-//        level l turns partial j, j % 4^(l+1) == 0, into the sum of j, j + 4^l, j + 2 4^l, j + 3 4^l.  With uniform
-//        scalars no bucket qualifies and every level exits on one scalar load.
-//      - k_combine_seq: 8 lanes per bucket sum the <= SEQ_PARTS partials that are left (stride 4^levels), shuffle-reduce,
-//        and write the dense bucket array the pyramid reads.
+//    accumulation, so what matters is robustness to skew and few launches.  ONE launch:
+//      - workgroups [0, blocks): LANES adjacent lanes per bucket sum its m <= seq_parts partials (lane q takes q, q + LANES, ...),
+//        log2(LANES) xor-shuffle steps add the lane sums, and the dense bucket array the pyramid reads is written.  The host
+//        picks LANES from the expected partials per bucket (1 lane when buckets hold ~1-2 partials: the general path).
+//      - the last HEAVY_WGS workgroups walk the list of heavy buckets (m > seq_parts, collected by k_make_tasks: a selector column
+//        puts half of all points into the bucket of digit 1), one entry per HEAVY_SLICE partials: the 128 threads sum the slice's
+//        partials 128 apart, an LDS tree adds the 128 sums, and for a bucket of several slices the workgroup that finishes last adds the
+//        slice sums.  Depth <= 16 + 7 (+ slices / 128 + 7) additions; with uniform scalars the list is empty and these workgroups exit at once.
+//        (Until round 2 the heavy buckets were pre-reduced by up to eight radix-4 tree launches over all tasks, each of which cost
+//        ~4.7 us even when no bucket needed it.)
 // ------------------------------------------------------------------------------------------------
-// seq_parts: how many partials the final step may sum per bucket (16 per lane of k_combine_seq)
-__device__ __forceinline__ uint32_t tree_levels_for(uint32_t m, uint32_t seq_parts) {   // smallest L with ceil(m / 4^L) <= seq_parts
-  uint32_t L = 0;
-  while (((m + (1u << (2 * L)) - 1) >> (2 * L)) > seq_parts) L++;
-  return L;
+constexpr uint32_t HEAVY_WGS = 64;
+
+// sum of the 128 threads' points: LDS tree, result in thread 0 (xch: 64 x 36 words)
+__device__ __forceinline__ xyzz workgroup_sum_128(xyzz acc, uint32_t* __restrict__ xch) {
+#pragma unroll 1
+  for (uint32_t half = 64; half >= 1; half >>= 1) {
+    __syncthreads();
+    if (threadIdx.x >= half && threadIdx.x < 2 * half) store_xyzz(xch, threadIdx.x - half, acc);
+    __syncthreads();
+    if (threadIdx.x < half) acc = xyzz_add(acc, load_xyzz(xch, threadIdx.x));
+  }
+  return acc;
 }
 
-__global__ void __launch_bounds__(128) k_combine_tree(const task_t* __restrict__ tasks, const uint32_t* __restrict__ ntasks_p,
-                                                      const uint32_t* __restrict__ task_off, const uint32_t* __restrict__ max_parts,
-                                                      uint32_t* __restrict__ partials, int level, uint32_t seq_parts) {
-  const uint32_t stride = 1u << (2 * level);
-  if (((*max_parts + stride - 1) >> (2 * level)) <= seq_parts) return;   // no bucket needs this level
-  const uint32_t ntasks = *ntasks_p;
-  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < ntasks; t += gridDim.x * blockDim.x) {
-    const uint32_t b = tasks[t].bucket;
-    const uint32_t first = task_off[b], m = task_off[b + 1] - first, j = t - first;
-    if ((j & (4 * stride - 1)) != 0 || (uint32_t)level >= tree_levels_for(m, seq_parts)) continue;
-    xyzz acc = load_xyzz(partials, t);
+// One list entry = HEAVY_SLICE partials of one heavy bucket.  A bucket of one slice is finished by its workgroup.  Otherwise the
+// slice sum replaces the slice's first partial, and the workgroup that finishes LAST (a per-bucket counter; release / acquire through
+// __threadfence, the usual last-block reduction) adds the slice sums: no workgroup ever waits for another.
+__device__ __forceinline__ void combine_heavy_buckets(uint32_t wg, const uint32_t* __restrict__ task_off, uint32_t* __restrict__ partials,
+                                                      uint32_t* __restrict__ buckets, const uint32_t* __restrict__ heavy_count,
+                                                      const uint2* __restrict__ heavy, uint32_t heavy_cap, uint32_t* __restrict__ heavy_done,
+                                                      uint32_t* __restrict__ xch /* 64 x 36 words of LDS */) {
+  __shared__ uint32_t is_last;
+  const uint32_t nh = min(*heavy_count, heavy_cap);
+  for (uint32_t i = wg; i < nh; i += HEAVY_WGS) {          // uniform over the workgroup
+    const uint2 e = heavy[i];
+    const uint32_t k = e.x, sl = e.y, t = task_off[k], m = task_off[k + 1] - t;
+    const uint32_t P = (m + HEAVY_SLICE - 1) / HEAVY_SLICE, lo = sl * HEAVY_SLICE, hi = min(m, lo + HEAVY_SLICE);
+    xyzz acc = xyzz_identity();
 #pragma unroll 1
-    for (uint32_t q = 1; q < 4; q++) {
-      if (j + q * stride < m) acc = xyzz_add(acc, load_xyzz(partials, t + q * stride));
+    for (uint32_t j = lo + threadIdx.x; j < hi; j += 128) acc = xyzz_add(acc, load_xyzz(partials, t + j));
+    acc = workgroup_sum_128(acc, xch);
+    if (P == 1) {
+      if (threadIdx.x == 0) store_xyzz(buckets, k, acc);
+      continue;
     }
-    store_xyzz(partials, t, acc);
+    if (threadIdx.x == 0) {
+      store_xyzz(partials, t + lo, acc);
+      __threadfence();                                     // the slice sum is visible device-wide before the count moves
+      is_last = atomicAdd(&heavy_done[i - sl], 1u) == P - 1;
+    }
+    __syncthreads();
+    if (!is_last) continue;                                // (uniform: is_last is shared)
+    __threadfence();                                       // the other slices' sums, written by other workgroups
+    acc = xyzz_identity();
+#pragma unroll 1
+    for (uint32_t j = threadIdx.x; j < P; j += 128) acc = xyzz_add(acc, load_xyzz(partials, t + j * HEAVY_SLICE));
+    acc = workgroup_sum_128(acc, xch);
+    if (threadIdx.x == 0) store_xyzz(buckets, k, acc);
   }
 }
 
-// LANES adjacent lanes per bucket: lane q sums the remaining partials q, q + LANES, ... (stride 4^levels apart), then
-// log2(LANES) xor-shuffle steps add the lane sums.  Depth m/LANES + log2(LANES) additions instead of m - 1.  The host
-// picks LANES from the expected partials per bucket (1 lane when buckets hold ~1-2 partials: the general path).
 template <int COMBINE_LANES>
 __global__ void __launch_bounds__(128) k_combine_seq(const uint32_t* __restrict__ task_off, uint32_t nbuckets,
-                                                     const uint32_t* __restrict__ partials, uint32_t* __restrict__ buckets,
-                                                     uint32_t seq_parts) {
+                                                     uint32_t* __restrict__ partials, uint32_t* __restrict__ buckets,
+                                                     uint32_t seq_parts, uint32_t blocks, const uint32_t* __restrict__ heavy_count,
+                                                     const uint2* __restrict__ heavy, uint32_t heavy_cap, uint32_t* __restrict__ heavy_done) {
+  __shared__ __attribute__((aligned(16))) uint32_t xch[64 * 36];
+  if (blockIdx.x >= blocks) { combine_heavy_buckets(blockIdx.x - blocks, task_off, partials, buckets, heavy_count, heavy, heavy_cap, heavy_done, xch); return; }
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t k = gid / COMBINE_LANES, q = gid % COMBINE_LANES;
   const bool live = k < nbuckets;                  // whole lane groups are live or dead together (128 % 8 == 0)
@@ -814,22 +892,24 @@ __global__ void __launch_bounds__(128) k_combine_seq(const uint32_t* __restrict_
   if (live) {
     const uint32_t t = task_off[k];
     m = task_off[k + 1] - t;
-    const uint32_t stride = 1u << (2 * tree_levels_for(m, seq_parts));
-    const uint32_t left = m == 1 ? 0u : (m + stride - 1) / stride;   // partials still to be summed; a single task wrote its bucket itself
+    const uint32_t left = (m == 1 || m > seq_parts) ? 0u : m;   // a single task wrote its bucket itself; a heavy bucket has its own workgroup
 #pragma unroll 1
-    for (uint32_t j = q; j < left; j += COMBINE_LANES) acc = xyzz_add(acc, load_xyzz(partials, t + j * stride));
+    for (uint32_t j = q; j < left; j += COMBINE_LANES) acc = xyzz_add(acc, load_xyzz(partials, t + j));
   }
 #pragma unroll 1
   for (int mask = 1; mask < COMBINE_LANES; mask <<= 1) acc = xyzz_add(acc, xyzz_shfl_xor(acc, mask));
-  if (live && q == 0 && m != 1) store_xyzz(buckets, k, acc);
+  if (live && q == 0 && m != 1 && m <= seq_parts) store_xyzz(buckets, k, acc);
 }
 
 // the same with a quad per lane of the above (small MSMs: the bucket count is far below the chip's lane count and the step is
 // the latency of its additions)
 template <int COMBINE_LANES>
 __global__ void __launch_bounds__(128) k_combine_seq_quad(const uint32_t* __restrict__ task_off, uint32_t nbuckets,
-                                                          const uint32_t* __restrict__ partials, uint32_t* __restrict__ buckets,
-                                                          uint32_t seq_parts) {
+                                                          uint32_t* __restrict__ partials, uint32_t* __restrict__ buckets,
+                                                          uint32_t seq_parts, uint32_t blocks, const uint32_t* __restrict__ heavy_count,
+                                                          const uint2* __restrict__ heavy, uint32_t heavy_cap, uint32_t* __restrict__ heavy_done) {
+  __shared__ __attribute__((aligned(16))) uint32_t xch[64 * 36];
+  if (blockIdx.x >= blocks) { combine_heavy_buckets(blockIdx.x - blocks, task_off, partials, buckets, heavy_count, heavy, heavy_cap, heavy_done, xch); return; }
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t q = gid & 3, lane = (gid >> 2) % COMBINE_LANES, k = (gid >> 2) / COMBINE_LANES;
   const bool live = k < nbuckets;                  // whole groups of 4 * COMBINE_LANES lanes are live or dead together
@@ -838,14 +918,13 @@ __global__ void __launch_bounds__(128) k_combine_seq_quad(const uint32_t* __rest
   if (live) {
     const uint32_t t = task_off[k];
     m = task_off[k + 1] - t;
-    const uint32_t stride = 1u << (2 * tree_levels_for(m, seq_parts));
-    const uint32_t left = m == 1 ? 0u : (m + stride - 1) / stride;   // a single task wrote its bucket itself
+    const uint32_t left = (m == 1 || m > seq_parts) ? 0u : m;
 #pragma unroll 1
-    for (uint32_t j = lane; j < left; j += COMBINE_LANES) acc = xyzz_add_quad(acc, load_xyzz(partials, t + j * stride), q);
+    for (uint32_t j = lane; j < left; j += COMBINE_LANES) acc = xyzz_add_quad(acc, load_xyzz(partials, t + j), q);
   }
 #pragma unroll 1
   for (int mask = 1; mask < COMBINE_LANES; mask <<= 1) acc = xyzz_add_quad(acc, xyzz_shfl_xor(acc, 4 * mask), q);
-  if (live && lane == 0 && q == 0 && m != 1) store_xyzz(buckets, k, acc);
+  if (live && lane == 0 && q == 0 && m != 1 && m <= seq_parts) store_xyzz(buckets, k, acc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1044,6 +1123,10 @@ struct msm_layout {
   uint32_t *gcounters, *counters, *count, *sorted, *offset, *cursor, *task_off, *bsum1, *bsum2;
   task_t* tasks; uint4* order;
   uint32_t *partials, *pyrA, *pyrB, *winsum;
+  int combine_lanes;            // lanes that sum one bucket's partials in the combine step
+  uint32_t seq_parts;           // partials per bucket that step sums; buckets with more are "heavy"
+  uint2* heavy; uint32_t heavy_cap;      // list of (heavy bucket, slice) entries (count: counters[3])
+  uint32_t* heavy_done;                  // per list index of a bucket's first entry: slices finished
   size_t total;                 // bytes from the base to the end of the last region
 };
 
@@ -1077,6 +1160,12 @@ static msm_layout msm_lay_out(char* base, size_t n, size_t K, int c, bool prepar
   const size_t n_pad = (n + 7) & ~(size_t)7;
   L.task_shift = msm_task_shift(entries, NB);
   L.max_tasks = (entries >> L.task_shift) + NB + 1;        // every bucket adds at most one task that is not full
+  // expected partials per bucket decide how many lanes sum a bucket in the combine step; a bucket with more than 16 partials per lane
+  // is handled by a workgroup of its own, so a skewed bucket (a selector column, a short top window) never becomes a long chain
+  const double parts_avg = (double)entries / (double)NB / (double)(1u << L.task_shift);
+  L.combine_lanes = parts_avg <= 2.0 ? 1 : (parts_avg <= 4.0 ? 2 : (parts_avg <= 12.0 ? 4 : 8));
+  L.seq_parts = 16u * (uint32_t)L.combine_lanes;
+  L.heavy_cap = (uint32_t)(std::min<size_t>(L.max_tasks / (L.seq_parts + 1) + 1, NB) + L.max_tasks / HEAVY_SLICE + 1);   // heavy buckets + full slices
   char* p = base;
   auto carve = [&](size_t bytes) { void* r = p; p += align_up(bytes, 256); return r; };
   L.digits = carve(W * K * n_pad * (wide ? sizeof(int32_t) : sizeof(int16_t)));
@@ -1084,14 +1173,16 @@ static msm_layout msm_lay_out(char* base, size_t n, size_t K, int c, bool prepar
   L.stage_fine = wide ? (uint16_t*)carve(entries * sizeof(uint16_t)) : nullptr;
   L.zero_lo = p;
   L.gcounters = wide ? (uint32_t*)carve(4096) : nullptr;   // [0..128) group counts, [128..257) group offsets, [384..512) group cursors, [512..641) chunk starts
-  L.counters = (uint32_t*)carve(2048);                     // [0] total entries, [1] total tasks, [2] max task partials of one bucket,
+  L.counters = (uint32_t*)carve(2048);                     // [0] total entries, [1] total tasks, [2] max task partials of one bucket, [3] heavy buckets,
                                                            // [32..161) task-length histogram (MAX_TASK_LEN + 1), [192..321) its cursors
   L.count = (uint32_t*)carve((NB + 1) * sizeof(uint32_t));
+  L.heavy_done = (uint32_t*)carve((size_t)L.heavy_cap * sizeof(uint32_t));
   L.zero_bytes = (size_t)(p - L.zero_lo);
   L.sorted = (uint32_t*)carve(entries * sizeof(uint32_t));
   L.offset = (uint32_t*)carve((NB + 1) * sizeof(uint32_t));
   L.cursor = (uint32_t*)carve((NB + 1) * sizeof(uint32_t));
   L.task_off = (uint32_t*)carve((NB + 1) * sizeof(uint32_t));
+  L.heavy = (uint2*)carve((size_t)L.heavy_cap * sizeof(uint2));
   L.bsum1 = (uint32_t*)carve((NB / SCAN_TILE + 2) * sizeof(uint32_t));
   L.bsum2 = (uint32_t*)carve((NB / SCAN_TILE + 2) * sizeof(uint32_t));
   L.tasks = (task_t*)carve(L.max_tasks * sizeof(task_t));
@@ -1207,12 +1298,14 @@ int msm_build_tasks(const uint32_t* d_scalars, size_t n, size_t batch, size_t sc
   const unsigned task_blocks = (unsigned)std::min<size_t>((NB + 255) / 256, 256);
   if (scan_single) {
     hipLaunchKernelGGL(k_scan_single<1>, dim3(1), dim3(1024), 0, stream, count, (uint32_t)NB, counters + 1, task_off, (uint32_t*)nullptr, task_shift, counters + 192);
-    hipLaunchKernelGGL(k_make_tasks, dim3(task_blocks), dim3(256), 0, stream, offset, task_off, NB, tasks, task_shift, counters + 2, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_make_tasks, dim3(task_blocks), dim3(256), 0, stream, offset, task_off, NB, tasks, task_shift, counters + 2, (uint32_t*)nullptr, lay.seq_parts,
+                       counters + 3, lay.heavy, lay.heavy_cap);
   } else {
     hipLaunchKernelGGL(k_scan_sums<1>, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, count, NB, bsum2, task_shift);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_BLOCK), 0, stream, bsum2, nblk, counters + 1);
     hipLaunchKernelGGL(k_scan_apply<1>, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, count, NB, bsum2, counters + 1, task_off, (uint32_t*)nullptr, task_shift);
-    hipLaunchKernelGGL(k_make_tasks, dim3(task_blocks), dim3(256), 0, stream, offset, task_off, NB, tasks, task_shift, counters + 2, counters + 32);
+    hipLaunchKernelGGL(k_make_tasks, dim3(task_blocks), dim3(256), 0, stream, offset, task_off, NB, tasks, task_shift, counters + 2, counters + 32, lay.seq_parts,
+                       counters + 3, lay.heavy, lay.heavy_cap);
     hipLaunchKernelGGL(k_order_offsets, dim3(1), dim3(64), 0, stream, counters + 32, counters + 192);
   }
   hipLaunchKernelGGL(k_make_order, dim3(task_blocks), dim3(256), 0, stream, offset, task_off, NB, task_shift, counters + 192, sorted, order);
@@ -1220,6 +1313,7 @@ int msm_build_tasks(const uint32_t* d_scalars, size_t n, size_t batch, size_t sc
   out->c = c; out->W = W; out->WB = WB; out->B = B; out->NB = NB; out->task_shift = task_shift; out->max_tasks = lay.max_tasks; out->nk = n * K;
   out->tasks = tasks; out->ntasks = counters + 1; out->max_parts = counters + 2; out->order = order; out->sorted = sorted; out->task_off = task_off;
   out->partials = lay.partials; out->pyrA = lay.pyrA; out->pyrB = lay.pyrB; out->winsum = lay.winsum;
+  out->combine_lanes = lay.combine_lanes; out->seq_parts = lay.seq_parts; out->heavy_count = counters + 3; out->heavy = lay.heavy; out->heavy_cap = lay.heavy_cap; out->heavy_done = lay.heavy_done;
   HIPCHK(hipGetLastError());
   return ZKHIP_OK;
 }
@@ -1251,9 +1345,9 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   int rc = msm_build_tasks(d_scalars, n, batch, scalar_stride, c, prepared != nullptr, prepared ? (uint32_t)prepared_off : 0u, prepared ? (uint32_t)prepared->n : 0u,
                            144, ws, ws_bytes, stream, &tv);
   if (rc != ZKHIP_OK) return rc;
-  const int W = tv.W, WB = tv.WB;
-  const uint32_t B = tv.B, NB = tv.NB, task_shift = tv.task_shift;
-  const size_t max_tasks = tv.max_tasks, nk = tv.nk;
+  const int WB = tv.WB;
+  const uint32_t B = tv.B, NB = tv.NB;
+  const size_t max_tasks = tv.max_tasks;
   const task_t* const tasks = (const task_t*)tv.tasks;
   uint32_t* const counters = tv.ntasks - 1;
   const uint4* const order = tv.order;
@@ -1267,31 +1361,19 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
     else hipLaunchKernelGGL(k_accumulate<false>, dim3(blocks), dim3(128), 0, stream, tasks, counters + 1, order, sorted, d_bases, partials, pyrA);
   }
   prof_mark(stream, "accumulate");
-  // 7. combine
-  // expected partials per bucket decide how many lanes sum a bucket in the final step; the tree handles any bucket with more
-  // than 16 partials per lane, so a skewed bucket (e.g. from a short top window) never becomes a long sequential chain
-  const double parts_avg = (double)W * (double)nk / (double)NB / (double)(1u << task_shift);
-  const int combine_lanes = parts_avg <= 2.0 ? 1 : (parts_avg <= 4.0 ? 2 : (parts_avg <= 12.0 ? 4 : 8));
-  const uint32_t seq_parts = 16u * (uint32_t)combine_lanes;
+  // 7. combine: one launch (per-bucket sums + the heavy-bucket workgroups)
   {
-    uint32_t blocks = (uint32_t)((max_tasks + 127) / 128);
-    if (blocks > 256) blocks = 256;                 // grid-stride kernels; usually no bucket needs a level, and an idle launch costs by its wave count
-    // a bucket holds at most all W n entries of one MSM, i.e. (W n >> task_shift) + 1 partials: levels beyond ceil(log4(that / seq_parts))
-    // can never be needed (every level that is launched and not needed still costs ~3 us)
-    const uint64_t max_parts_bound = (((uint64_t)W * n) >> task_shift) + 1;
-    int levels = 0;
-    while (levels < COMBINE_LEVELS && ((max_parts_bound + ((uint64_t)1 << (2 * levels)) - 1) >> (2 * levels)) > seq_parts) levels++;
-    for (int level = 0; level < levels; level++)
-      hipLaunchKernelGGL(k_combine_tree, dim3(blocks), dim3(128), 0, stream, tasks, counters + 1, task_off, counters + 2, partials, level, seq_parts);
-  }
-  {
+    const int combine_lanes = tv.combine_lanes;
+    const uint32_t seq_parts = tv.seq_parts;
     const size_t lanes_total = (size_t)NB * combine_lanes;
     const bool quad = lanes_total * 4 <= 131072;        // far below the chip's lane count: the additions' latency is the step time
     const unsigned blocks = (unsigned)((lanes_total * (quad ? 4 : 1) + 127) / 128);
 #define ZK_LAUNCH_COMBINE(L)                                                                                                                        \
     do {                                                                                                                                              \
-      if (quad) hipLaunchKernelGGL(k_combine_seq_quad<L>, dim3(blocks), dim3(128), 0, stream, task_off, NB, partials, pyrA, seq_parts);             \
-      else hipLaunchKernelGGL(k_combine_seq<L>, dim3(blocks), dim3(128), 0, stream, task_off, NB, partials, pyrA, seq_parts);                       \
+      if (quad) hipLaunchKernelGGL(k_combine_seq_quad<L>, dim3(blocks + HEAVY_WGS), dim3(128), 0, stream, task_off, NB, partials, pyrA, seq_parts, blocks,   \
+                                   tv.heavy_count, (const uint2*)tv.heavy, tv.heavy_cap, tv.heavy_done);                                              \
+      else hipLaunchKernelGGL(k_combine_seq<L>, dim3(blocks + HEAVY_WGS), dim3(128), 0, stream, task_off, NB, partials, pyrA, seq_parts, blocks,             \
+                              tv.heavy_count, (const uint2*)tv.heavy, tv.heavy_cap, tv.heavy_done);                                                   \
     } while (0)
     if (combine_lanes == 1) ZK_LAUNCH_COMBINE(1);
     else if (combine_lanes == 2) ZK_LAUNCH_COMBINE(2);

@@ -34,6 +34,12 @@ struct msm_tasks_view {
   const uint32_t* sorted;          // point references (bit 31 = negate), bucket by bucket
   const uint32_t* task_off;        // first task of every bucket (NB + 1)
   uint32_t *partials, *pyrA, *pyrB, *winsum;   // work arrays of xyzz_bytes-sized points
+  int combine_lanes;               // G1 combine step: lanes per bucket, partials it sums per bucket, and the list of buckets with more
+  uint32_t seq_parts;
+  const uint32_t* heavy_count;
+  const void* heavy;               // uint2 (bucket, slice) entries
+  uint32_t heavy_cap;
+  uint32_t* heavy_done;
 };
 int msm_build_tasks(const uint32_t* d_scalars, size_t n, size_t batch, size_t scalar_stride, int c, bool shared_buckets, uint32_t ref_base, uint32_t ref_stride,
                     size_t xyzz_bytes, void* ws, size_t ws_bytes, hipStream_t stream, msm_tasks_view* out);
