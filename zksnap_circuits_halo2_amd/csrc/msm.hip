@@ -826,7 +826,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))
 //        (Until round 2 the heavy buckets were pre-reduced by up to eight radix-4 tree launches over all tasks, each of which cost
 //        ~4.7 us even when no bucket needed it.)
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t HEAVY_WGS = 64;
+constexpr uint32_t HEAVY_WGS = 256;
 
 // sum of the 128 threads' points: LDS tree, result in thread 0 (xch: 64 x 36 words)
 __device__ __forceinline__ xyzz workgroup_sum_128(xyzz acc, uint32_t* __restrict__ xch) {
