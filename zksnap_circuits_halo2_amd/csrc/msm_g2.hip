@@ -41,17 +41,38 @@ __global__ void __launch_bounds__(64) k2_accumulate(const uint32_t* __restrict__
   }
 }
 
-// one thread per bucket: sum of its task partials (a bucket with a single task was written by k2_accumulate)
+__device__ __forceinline__ xyzz2 xyzz2_shfl_xor(const xyzz2& a, int mask) {
+  xyzz2 r;
+  const fe* src[8] = {&a.X.c0, &a.X.c1, &a.Y.c0, &a.Y.c1, &a.ZZ.c0, &a.ZZ.c1, &a.ZZZ.c0, &a.ZZZ.c1};
+  fe* dst[8] = {&r.X.c0, &r.X.c1, &r.Y.c0, &r.Y.c1, &r.ZZ.c0, &r.ZZ.c1, &r.ZZZ.c0, &r.ZZZ.c1};
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+#pragma unroll
+    for (int i = 0; i < NL; i++) dst[k]->l[i] = (uint32_t)__shfl_xor((int)src[k]->l[i], mask, 64);
+  return r;
+}
+
+// 8 adjacent lanes per bucket: lane q sums the task partials q, q + 8, ..., three xor-shuffle steps add the lane sums (a bucket with a
+// single task was written by k2_accumulate).  A short top window puts thousands of entries into a handful of buckets: with one thread
+// per bucket their partials were a chain of 256 dependent additions (5 ms of a 19 ms MSM at 2^16).
 __global__ void __launch_bounds__(64) k2_combine(const uint32_t* __restrict__ task_off, uint32_t nbuckets, const uint32_t* __restrict__ partials,
                                                  uint32_t* __restrict__ buckets) {
-  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= nbuckets) return;
-  const uint32_t t = task_off[k], m = task_off[k + 1] - t;
-  if (m == 1) return;
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t k = gid >> 3, q = gid & 7;
+  const bool live = k < nbuckets;                 // whole groups of 8 lanes are live or dead together
   xyzz2 acc = xyzz2_identity();
+  uint32_t m = 0;
+  if (live) {
+    const uint32_t t = task_off[k];
+    m = task_off[k + 1] - t;
+    if (m != 1) {
 #pragma unroll 1
-  for (uint32_t j = 0; j < m; j++) acc = xyzz2_add(acc, load_xyzz2(partials, t + j));
-  store_xyzz2(buckets, k, acc);
+      for (uint32_t j = q; j < m; j += 8) acc = xyzz2_add(acc, load_xyzz2(partials, t + j));
+    }
+  }
+#pragma unroll 1
+  for (int mask = 1; mask < 8; mask <<= 1) acc = xyzz2_add(acc, xyzz2_shfl_xor(acc, mask));
+  if (live && q == 0 && m != 1) store_xyzz2(buckets, k, acc);
 }
 
 // pyramid step (see msm.hip section 8 for the state layout): sum_k (k + 1) B_k = Tot + sum_l 2^l T_l
@@ -76,17 +97,6 @@ __global__ void __launch_bounds__(64) k2_pyramid_step(const uint32_t* __restrict
 
 // window sum = X0 + X1 + sum_l 2^l Z^l + 2^nz X1 (state after the last pyramid step: X has 2 elements, Z^0 .. Z^(nz-1) one each).
 // One 32-lane group per window, a shuffle tree over the terms (nz + 2 <= 32).
-__device__ __forceinline__ xyzz2 xyzz2_shfl_xor(const xyzz2& a, int mask) {
-  xyzz2 r;
-  const fe* src[8] = {&a.X.c0, &a.X.c1, &a.Y.c0, &a.Y.c1, &a.ZZ.c0, &a.ZZ.c1, &a.ZZZ.c0, &a.ZZZ.c1};
-  fe* dst[8] = {&r.X.c0, &r.X.c1, &r.Y.c0, &r.Y.c1, &r.ZZ.c0, &r.ZZ.c1, &r.ZZZ.c0, &r.ZZZ.c1};
-#pragma unroll
-  for (int k = 0; k < 8; k++)
-#pragma unroll
-    for (int i = 0; i < NL; i++) dst[k]->l[i] = (uint32_t)__shfl_xor((int)src[k]->l[i], mask, 64);
-  return r;
-}
-
 __global__ void __launch_bounds__(64) k2_window_sum(const uint32_t* __restrict__ in, uint32_t in_stride, int nz, uint32_t* __restrict__ winsum, int W) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int win = gid >> 5, lane = gid & 31;
@@ -108,11 +118,17 @@ __global__ void __launch_bounds__(64) k2_window_sum(const uint32_t* __restrict__
 // result = sum_w 2^(c w) winsum[w], written as a Jacobian G2 point (48 words)
 __global__ void __launch_bounds__(64) k2_fold(const uint32_t* __restrict__ winsum, int W, int c, uint32_t* __restrict__ out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  xyzz2 acc = load_xyzz2(winsum, W - 1);
+  // One thread's work is uniform, and left to itself the compiler moves ALL of it to the scalar unit (no 32 x 32 -> 64 multiply-add
+  // there: a doubling then takes ~48 us and this fold 12 ms of a 19 ms MSM).  An opaque zero in a vector register keeps the addresses,
+  // and with them the arithmetic, on the vector unit.
+  uint32_t vz;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+  const uint32_t* ws = winsum + vz;
+  xyzz2 acc = load_xyzz2(ws, W - 1);
   for (int w = W - 2; w >= 0; w--) {
 #pragma unroll 1
     for (int i = 0; i < c; i++) acc = xyzz2_dbl(acc);
-    acc = xyzz2_add(acc, load_xyzz2(winsum, w));
+    acc = xyzz2_add(acc, load_xyzz2(ws, w));
   }
   store_jacobian2(acc, out);
 }
@@ -172,7 +188,7 @@ int msm_g2_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
     hipLaunchKernelGGL(k2_accumulate, dim3(blocks), dim3(64), 0, stream, tv.ntasks, tv.order, tv.sorted, d_bases, tv.partials, tv.pyrA);
   }
   prof_mark(stream, "accumulate_g2");
-  hipLaunchKernelGGL(k2_combine, dim3((tv.NB + 63) / 64), dim3(64), 0, stream, tv.task_off, tv.NB, tv.partials, tv.pyrA);
+  hipLaunchKernelGGL(k2_combine, dim3((unsigned)(((size_t)tv.NB * 8 + 63) / 64)), dim3(64), 0, stream, tv.task_off, tv.NB, tv.partials, tv.pyrA);
   prof_mark(stream, "combine_g2");
   uint32_t* cur = tv.pyrA;
   uint32_t* nxt = tv.pyrB;
