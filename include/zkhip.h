@@ -163,6 +163,12 @@ int zkhip_fr_eval_rows(const zkhip_vm_program *prog, const uint64_t *const *colu
  * only if that column is read at rotation 0 exclusively) */
 int zkhip_fr_eval_rows_device(const zkhip_vm_program *prog, const void *const *d_columns, uint32_t n_columns, uint32_t log_rows,
                               int accumulate, void *d_out, void *stream);
+/* out[j] = a[index_a[j]] * b[index_b[j]] (u32 indices, device-resident): the inner loop of `permutation::keygen::Assembly::build_pk`
+ * [DEP halo2-axiom plonk/permutation/keygen.rs; keygen_pk at /root/reference/aggregator/src/wrapper.rs:108] -- sigma_i[j] =
+ * delta^(column the cell (i, j) maps to) * omega^(its row) -- so that the sigma columns of a proving key are built in HBM.  Indices
+ * must be below the table lengths (they are reduced modulo the length rather than trusted: no fault on a bad index). */
+int zkhip_fr_gather_mul_device(const void *d_a, size_t a_len, const void *d_index_a, const void *d_b, size_t b_len, const void *d_index_b, size_t n,
+                               void *d_out, void *stream);
 /* grand product of the permutation / lookup arguments [DEP plonk/permutation/prover.rs, plonk/lookup/prover.rs]:
  * z[0] = 1, z[i+1] = z[i] * num[i] / den[i] for i < n - 1  (zero denominators count as zero, like BatchInvert).
  * num is preserved, den is overwritten (inverted in place), z may alias num. */
@@ -203,6 +209,11 @@ int zkhip_release_bases(uint64_t handle);
 /* window size (bits) the handle's table was built for; <= 0 for an unknown handle */
 int zkhip_prepared_window_bits(uint64_t handle);
 int zkhip_msm_g1_prepared_device(uint64_t handle, size_t offset, const void *d_scalars, size_t n, void *d_out_xyz, void *stream);
+/* Device-resident scalars against an array pinned with zkhip_register_bases: `bases` is the HOST pointer the caller would pass to
+ * zkhip_msm_g1 (any sub-range of a registered array), the scalars and the result live in HBM.  This is `params.commit(&poly)` for a
+ * polynomial that never left the device, against the same tables the host-buffer calls use.  ZKHIP_EINVAL when the range is not
+ * registered or spans several shards. */
+int zkhip_msm_g1_registered_device(const uint64_t *bases, const void *d_scalars, size_t n, void *d_out_xyz, void *stream);
 /* `batch` scalar vectors (vector k at d_scalars + k * scalar_stride elements) against the same prepared bases in one launch
  * set -- e.g. all advice columns of a circuit: small MSMs (k = 13..17) then run at large-MSM throughput.  d_out_xyz: batch
  * Jacobian results, 96 bytes each. */

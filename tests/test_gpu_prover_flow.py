@@ -324,3 +324,81 @@ def test_cpp_keygen_mirror_matches_python(lib, cref, tmp_path):
     assert flags == 0b111111, bin(flags)
     g2 = np.frombuffer(rep[8:8 + 192], dtype=np.uint64)
     assert g2_dec(g2) == O.g2_scalar_mul(cref.expected_scalar(sc, 31337, 4242), O.G2_GEN)
+
+
+def test_device_resident_keygen_equals_host_keygen(lib, cref):
+    """`keygen_device` (sigma columns by gather in HBM, commitments against the registered g_lagrange through
+    `zkhip_msm_g1_registered_device`, transforms in place) produces the key of `keygen_vk` + `keygen_pk` element for element; the
+    uploaded form of a key that was read from a file is the same memory"""
+    import ctypes as C
+    import io
+
+    from zksnap_circuits_halo2_amd import keygen as KG
+
+    rng = random.Random(91)
+    circ = toy_circuit(rng)
+    fixed = [enc(c) for c in circ["fixed"]]
+    cs = E.ConstraintSystem(num_fixed=3, num_advice=2, permutation_columns=PERM_COLUMNS, blinding_factors=BLIND, degree=4)
+    asm = KG.Assembly(N, 3)
+    for c in [(0, 1, 2, 2), (1, 10, 1, 20), (0, 13, 1, 30), (0, 17, 0, 21), (0, 21, 2, 5), (2, 40, 0, 41)]:
+        asm.copy(*c)
+    with Z.ParamsKZG.setup(K, 0xD15C0) as params:
+        vk = KG.keygen_vk(params, cs, fixed, asm)
+        pk = KG.keygen_pk(params, vk, cs, fixed, asm)
+        with KG.keygen_device(params, cs, fixed, asm) as dpk:
+            host = dpk.to_host()
+            # the accessors address what to_host() downloads
+            one = np.zeros((N, 4), dtype=np.uint64)
+            _lib.check(lib.zkhip_download(one.ctypes.data, C.c_void_p(dpk.permutation_poly(2)), N * 32))
+            assert np.array_equal(one, pk.permutation_polys[2])
+        # the registered-bases device entry point on its own: device scalars, host pointer of the registered table, any sub-range
+        sc = cref.gen_scalars(4411, N, 0)
+        d = C.c_void_p()
+        _lib.check(lib.zkhip_alloc(N * 32 + 96, C.byref(d)))
+        try:
+            _lib.check(lib.zkhip_upload(d, sc.ctypes.data, N * 32))
+            d_out = C.c_void_p(d.value + N * 32)
+            for lo, m in ((0, N), (5, 37), (N - 1, 1), (3, 0)):
+                _lib.check(lib.zkhip_msm_g1_registered_device(params.g_lagrange[lo:].ctypes.data, C.c_void_p(d.value + lo * 32), m, d_out, None))
+                got = np.zeros(12, dtype=np.uint64)
+                _lib.check(lib.zkhip_download(got.ctypes.data, d_out, 96))
+                exp = cref.best_multiexp(np.ascontiguousarray(sc[lo:lo + m]), np.ascontiguousarray(params.g_lagrange[lo:lo + m]), 2)
+                assert np.array_equal(cref.jac_to_affine(got), cref.jac_to_affine(exp))
+            other = np.zeros((N, 8), dtype=np.uint64)
+            assert lib.zkhip_msm_g1_registered_device(other.ctypes.data, d, N, d_out, None) == -1      # not a registered array
+        finally:
+            lib.zkhip_free(d)
+    a, b = io.BytesIO(), io.BytesIO()
+    pk.write(a)
+    host.write(b)
+    assert a.getvalue() == b.getvalue()
+    with KG.DeviceProvingKey.from_host(pk, cs) as up:
+        c = io.BytesIO()
+        up.to_host().write(c)
+        assert c.getvalue() == a.getvalue()
+
+
+def test_gather_mul_vs_big_integers(lib):
+    import ctypes as C
+
+    rng = random.Random(17)
+    na, nb, n = 37, 5, 1000
+    a = [rng.randrange(R) for _ in range(na)]
+    b = [rng.randrange(R) for _ in range(nb)]
+    ia = np.array([rng.randrange(na) for _ in range(n)], dtype=np.uint32)
+    ib = np.array([rng.randrange(nb) for _ in range(n)], dtype=np.uint32)
+    ia[0], ib[0] = na + 3, nb                                                       # out of range: reduced modulo the table length
+    bufs = [C.c_void_p() for _ in range(5)]
+    data = [enc(a), ia, enc(b), ib, np.zeros((n, 4), dtype=np.uint64)]
+    try:
+        for p, arr in zip(bufs, data):
+            _lib.check(lib.zkhip_alloc(arr.nbytes, C.byref(p)))
+            _lib.check(lib.zkhip_upload(p, arr.ctypes.data, arr.nbytes))
+        _lib.check(lib.zkhip_fr_gather_mul_device(bufs[0], na, bufs[1], bufs[2], nb, bufs[3], n, bufs[4], None))
+        out = np.zeros((n, 4), dtype=np.uint64)
+        _lib.check(lib.zkhip_download(out.ctypes.data, bufs[4], out.nbytes))
+        assert F.fr_decode(out) == [a[int(i) % na] * b[int(j) % nb] % R for i, j in zip(ia, ib)]
+        assert lib.zkhip_fr_gather_mul_device(bufs[0], 0, bufs[1], bufs[2], nb, bufs[3], n, bufs[4], None) == -1
+    finally:
+        for p in bufs:
+            lib.zkhip_free(p)

@@ -57,6 +57,7 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk
 
     ONE = words([1])[0]
 
+    dpk = None
     def rand_fr(m):                      # uniformly random canonical word patterns = random field elements
         a = torch.randint(-(1 << 63), (1 << 63) - 1, (m, 4), dtype=torch.int64, device=dev)
         a[:, 3] = torch.randint(0, 1 << 61, (m,), dtype=torch.int64, device=dev)
@@ -141,11 +142,18 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk
                 assembly.copy(c1, r1, c2, r2)
         host = lambda tns: tns.cpu().numpy().view(np.uint64).reshape(-1, 4)
         lap("witness_columns")
-        vk = KG.keygen_vk(params, cs, [host(f) for f in fixed], assembly)
-        lap("keygen_vk")
-        pk = KG.keygen_pk(params, vk, cs, [host(f) for f in fixed], assembly)
-        lap("keygen_pk")
         pk_bytes = None
+        if pk_file is None:
+            # the key is produced in HBM and stays there (keygen.keygen_device): sigma columns by gather, commitments against the
+            # registered g_lagrange, transforms in place
+            dpk = KG.keygen_device(params, cs, [host(f) for f in fixed], assembly)
+            vk = dpk.vk
+            lap("keygen_device")
+        else:
+            vk = KG.keygen_vk(params, cs, [host(f) for f in fixed], assembly)
+            lap("keygen_vk")
+            pk = KG.keygen_pk(params, vk, cs, [host(f) for f in fixed], assembly)
+            lap("keygen_pk")
         if pk_file is not None:
             with open(pk_file, "wb") as fh:
                 pk.write(fh, KG.RAW_BYTES_UNCHECKED)
@@ -158,9 +166,17 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk
             assert same, "ProvingKey::read(ProvingKey::write(pk)) differs from pk"
             pk = pk2
             lap("pk_file_round_trip")
+            dpk = KG.DeviceProvingKey.from_host(pk, cs)
+            del pk, pk2
+            lap("pk_upload")
         params.close()
-        dev_t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(dev)
-        sigma = [dev_t(p_) for p_ in pk.permutations]
+
+        def from_key(ptr, log_rows):                                               # a working copy of one of the key's columns
+            t_ = torch.empty((1 << log_rows, 4), dtype=torch.int64, device=dev)
+            KG._copy_device(t_.data_ptr(), ptr, log_rows)
+            return t_
+
+        sigma = [from_key(dpk.permutation_values(i), k) for i in range(len(perm_cols))]
         z_sets, last_z = [], 1
         for si in range(cs.num_permutation_sets):
             lo, hi = si * cs.chunk_len, min((si + 1) * cs.chunk_len, len(perm_cols))
@@ -199,8 +215,9 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk
         ncol = len(lagrange)
         coeff = torch.stack(lagrange).contiguous()                                  # [ncol][n][4]
         # the proving key's columns arrive transformed: coefficients (for the evaluations at x) and extended cosets (for the quotient)
-        key_polys = pk.fixed_polys + [None] * (qc.l0 - qc.advice) + [None, None, None] + pk.permutation_polys
-        key_cosets = pk.fixed_cosets + [None] * (qc.l0 - qc.advice) + [pk.l0, pk.l_last, pk.l_active_row] + pk.permutation_cosets
+        key_polys = [dpk.fixed_poly(i) for i in range(cs.num_fixed)] + [None] * (qc.l0 - qc.advice) + [None, None, None] + [dpk.permutation_poly(i) for i in range(len(perm_cols))]
+        key_cosets = ([dpk.fixed_coset(i) for i in range(cs.num_fixed)] + [None] * (qc.l0 - qc.advice) + [dpk.l0(), dpk.l_last(), dpk.l_active_row()]
+                      + [dpk.permutation_coset(i) for i in range(len(perm_cols))])
         lap("stack_columns")
         # Columns of the proving key (fixed, l_0 / l_last / l_active, the permutation's sigma polynomials) are transformed once per
         # circuit by keygen and their extended cosets are kept (pk.fixed_cosets, pk.permutation.cosets [DEP]); only the witness-dependent
@@ -216,7 +233,7 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk
         for lo, hi in pk_ranges:                 # l0 / l_last / l_active_row have no stored coefficient form in the key: transformed here, outside the proof time
             for i in range(lo, hi):
                 if key_polys[i] is not None:
-                    coeff[i] = dev_t(key_polys[i])
+                    KG._copy_device(coeff[i].data_ptr(), key_polys[i], k)
                 else:
                     ifft_range(i, i + 1)
         lap("keygen_lagrange_to_coeff")
@@ -236,7 +253,7 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk
 
         for lo, hi in pk_ranges:
             for i in range(lo, hi):
-                ext[i] = dev_t(key_cosets[i])
+                KG._copy_device(ext[i].data_ptr(), key_cosets[i], ek)
         lap("keygen_coeff_to_extended")
         for lo, hi in proof_ranges:
             extend_range(lo, hi)
@@ -307,7 +324,7 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk
         checks = {"permutation_product_closes": perm_closes, "lookup_product_closes": lookup_closes, "quotient_is_a_polynomial": top_is_zero and low_nonzero,
                   "commit_lagrange_equals_commit_coeff": commit_agrees, "multiopen_linearisation_vanishes": mo_ok}
         n_msm = len(adv_commit) + len(prod_commit) + 1 + len(h_commit) + 2
-        prove_ms = sum(v for kk, v in t.items() if kk not in ("setup_srs", "witness_columns", "stack_columns", "pk_file_round_trip") and not kk.startswith("keygen_"))
+        prove_ms = sum(v for kk, v in t.items() if kk not in ("setup_srs", "witness_columns", "stack_columns", "pk_file_round_trip", "pk_upload") and not kk.startswith("keygen_"))
         n_proof_cols = sum(hi - lo for lo, hi in proof_ranges)
         if verbose:
             print(f"k={k} gate_cols={G}: {ncol} columns ({n_proof_cols} witness-dependent, {ncol - n_proof_cols} of the proving key), {n_msm} MSMs of 2^{k}, "
@@ -317,9 +334,11 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk
             print(f"  {'prover steps (no setup/witness)':28s} {prove_ms:9.3f} ms")
             print("  checks:", checks)
         return {"timings_ms": t, "prove_ms": prove_ms, "checks": checks, "columns": ncol, "proof_columns": n_proof_cols, "msms": n_msm,
-                "keygen_ms": t.get("keygen_vk", 0.0) + t.get("keygen_pk", 0.0), "pk_file_bytes": pk_bytes}
+                "keygen_ms": t.get("keygen_vk", 0.0) + t.get("keygen_pk", 0.0) + t.get("keygen_device", 0.0), "pk_file_bytes": pk_bytes}
     finally:
         torch.cuda.synchronize()
+        if dpk is not None:
+            dpk.free()
         lib.zkhip_release_bases(h_g)
         lib.zkhip_release_bases(h_gl)
 

@@ -76,6 +76,8 @@ _SIGS = {
     "zkhip_g1_batch_normalize_device": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "zkhip_g1_check_points": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]),
     "zkhip_g1_check_points_device": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64), C.c_void_p]),
+    "zkhip_msm_g1_registered_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "zkhip_fr_gather_mul_device": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "zkhip_g1_compress": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]),
     "zkhip_g1_compress_device": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),
     "zkhip_g1_decompress": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]),

@@ -745,6 +745,27 @@ int zkhip_msm_g1_prepared_device(uint64_t handle, size_t offset, const void* d_s
   return msm_g1_device((const uint32_t*)d_scalars, nullptr, n, (uint32_t*)d_out_xyz, sc->ws.p, sc->ws.cap, 0, s, pb, offset);
 }
 
+// device-resident scalars against bases pinned with zkhip_register_bases (`bases` = a host pointer into a registered array): the commit
+// of a polynomial that lives in HBM against the SRS the host registered, without a second table (zkhip_prepare_bases_device)
+int zkhip_msm_g1_registered_device(const uint64_t* bases, const void* d_scalars, size_t n, void* d_out_xyz, void* stream) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (!d_out_xyz || (n && (!d_scalars || !bases))) { set_error("msm_registered: null pointer"); return ZKHIP_EINVAL; }
+  hipStream_t s = caller_stream(stream);
+  scratch* sc = scratch_for(primary(), s);
+  if (n == 0) return msm_g1_device(nullptr, nullptr, 0, (uint32_t*)d_out_xyz, nullptr, 0, 0, s);
+  size_t off = 0;
+  std::shared_ptr<registered_t> reg = find_registered(bases, n, &off);
+  if (!reg) { set_error("msm_registered: the range is not inside a registered array"); return ZKHIP_EINVAL; }
+  const shard_t* one = nullptr;
+  for (auto& sh : reg->shards) if (sh.dev == 0 && off >= sh.lo && off + n <= sh.lo + sh.n) one = &sh;
+  if (!one) { set_error("msm_registered: the range spans several shards (use the host-buffer entry point, which fans out)"); return ZKHIP_EINVAL; }
+  if ((rc = sc->ws.reserve(msm_workspace_bytes(n, one->pb->c, true))) != ZKHIP_OK) return rc;
+  // the table outlives the enqueued work: zkhip_unregister_bases synchronises every device before the last reference goes
+  return msm_g1_device((const uint32_t*)d_scalars, nullptr, n, (uint32_t*)d_out_xyz, sc->ws.p, sc->ws.cap, 0, s, one->pb, off - one->lo);
+}
+
 int zkhip_msm_g1_prepared_batch_device(uint64_t handle, size_t offset, const void* d_scalars, size_t n, size_t batch, size_t scalar_stride,
                                        void* d_out_xyz, void* stream) {
   guard_t g(g_mu);
@@ -1249,6 +1270,19 @@ int zkhip_fr_eval_rows(const zkhip_vm_program* prog, const uint64_t* const* colu
   HIPCHK(hipMemcpyAsync(out, H.sc->poly2.p, bytes, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   return ZKHIP_OK;
+}
+
+int zkhip_fr_gather_mul_device(const void* d_a, size_t a_len, const void* d_index_a, const void* d_b, size_t b_len, const void* d_index_b, size_t n,
+                               void* d_out, void* stream) {
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (n && (!d_a || !d_b || !d_index_a || !d_index_b || !d_out || a_len == 0 || b_len == 0 || a_len >= ((size_t)1 << 32) || b_len >= ((size_t)1 << 32))) {
+    set_error("gather_mul: bad argument");
+    return ZKHIP_EINVAL;
+  }
+  return fr_gather_mul_device((const uint32_t*)d_a, (uint32_t)a_len, (const uint32_t*)d_index_a, (const uint32_t*)d_b, (uint32_t)b_len, (const uint32_t*)d_index_b, n,
+                              (uint32_t*)d_out, caller_stream(stream));
 }
 
 int zkhip_fr_grand_product_device(const void* d_num, void* d_den, size_t n, void* d_z, void* stream) {

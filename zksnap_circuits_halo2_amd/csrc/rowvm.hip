@@ -205,6 +205,21 @@ __global__ void __launch_bounds__(256) k_fr_pointwise_mul(const uint32_t* __rest
   store_words(out + i * 8, w);
 }
 
+// out[j] = a[ia[j]] * b[ib[j]]: the inner loop of `permutation::keygen::Assembly::build_pk` [DEP] -- sigma_i[j] = delta^(column of the
+// cell (i, j) maps to) * omega^(its row) -- as a gather.  Indices are reduced modulo the table lengths, so a bad index cannot fault.
+__global__ void __launch_bounds__(256) k_fr_gather_mul(const uint32_t* __restrict__ a, uint32_t a_len, const uint32_t* __restrict__ ia,
+                                                       const uint32_t* __restrict__ b, uint32_t b_len, const uint32_t* __restrict__ ib, size_t n,
+                                                       uint32_t* __restrict__ out) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  uint32_t wb[8];
+  load_words(b + (size_t)(ib[j] % b_len) * 8, wb);
+  const fe p = fe_mul<Fr>(load_ext(a, ia[j] % a_len), fe_unpack<5>(wb));
+  uint32_t w[8];
+  fe_pack(fe_canon_lt2p<Fr>(p), w);
+  store_words(out + j * 8, w);
+}
+
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s failed: %s", #x, hipGetErrorString(e_)); return ZKHIP_EHIP; } } while (0)
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -335,6 +350,14 @@ int row_vm_device(const zkhip_vm_program* p, const void* const* d_columns, uint3
 int fr_pointwise_mul_device(const uint32_t* d_a, const uint32_t* d_b, size_t n, uint32_t* d_out, hipStream_t stream) {
   if (n == 0) return ZKHIP_OK;
   hipLaunchKernelGGL(k_fr_pointwise_mul, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_a, d_b, n, d_out);
+  HIPCHK(hipGetLastError());
+  return ZKHIP_OK;
+}
+
+int fr_gather_mul_device(const uint32_t* d_a, uint32_t a_len, const uint32_t* d_ia, const uint32_t* d_b, uint32_t b_len, const uint32_t* d_ib, size_t n,
+                         uint32_t* d_out, hipStream_t stream) {
+  if (n == 0) return ZKHIP_OK;
+  hipLaunchKernelGGL(k_fr_gather_mul, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_a, a_len, d_ia, d_b, b_len, d_ib, n, d_out);
   HIPCHK(hipGetLastError());
   return ZKHIP_OK;
 }

@@ -90,6 +90,8 @@ size_t row_vm_workspace_bytes(const zkhip_vm_program* p, uint32_t n_columns, uin
 int row_vm_device(const zkhip_vm_program* p, const void* const* d_columns, uint32_t n_columns, uint32_t log_rows, int accumulate,
                   uint32_t* d_out, void* ws, size_t ws_bytes, hipStream_t stream);
 int fr_pointwise_mul_device(const uint32_t* d_a, const uint32_t* d_b, size_t n, uint32_t* d_out, hipStream_t stream);
+int fr_gather_mul_device(const uint32_t* d_a, uint32_t a_len, const uint32_t* d_ia, const uint32_t* d_b, uint32_t b_len, const uint32_t* d_ib, size_t n,
+                         uint32_t* d_out, hipStream_t stream);
 
 // lookup.hip
 size_t lookup_permute_workspace_bytes(size_t usable_rows);

@@ -370,6 +370,170 @@ def _read_points(r: BinaryIO, count: int, fmt: str) -> np.ndarray:
     return a
 
 
+# ---------------------------------------------------------------------------------------------------
+# device-resident keygen: the key is produced in HBM and stays there (a k = 22 wrapper key is 10.5 GiB of 288)
+# ---------------------------------------------------------------------------------------------------
+class DeviceProvingKey:
+    """`ProvingKey` whose polynomials live in HBM, as the prover's device-resident pipeline wants them: two
+    allocations -- extended cosets [l0 | l_last | l_active_row | fixed... | sigma...] and n-element columns
+    [fixed values | sigma values | fixed polys | sigma polys] -- addressed through the accessors.  `to_host()` downloads a `ProvingKey`
+    (for `write`), `from_host(pk)` uploads one (after `ProvingKey.read`)."""
+
+    def __init__(self, vk: VerifyingKey, cs: E.ConstraintSystem, ext: _DeviceBuffer, base: _DeviceBuffer):
+        self.vk, self.cs, self.k, self.n = vk, cs, vk.k, 1 << vk.k
+        self.en = EvaluationDomain(cs.degree, vk.k).extended_len()
+        self.nf, self.np = cs.num_fixed, len(cs.permutation_columns)
+        self._ext, self._base = ext, base
+
+    # ---- addresses -----------------------------------------------------------------------------------------------------------------
+    def _e(self, i: int) -> int:
+        return self._ext.ptr.value + i * self.en * 32
+
+    def _b(self, i: int) -> int:
+        return self._base.ptr.value + i * self.n * 32
+
+    def l0(self) -> int: return self._e(0)
+    def l_last(self) -> int: return self._e(1)
+    def l_active_row(self) -> int: return self._e(2)
+    def fixed_coset(self, i: int) -> int: return self._e(3 + i)
+    def permutation_coset(self, i: int) -> int: return self._e(3 + self.nf + i)
+    def fixed_values(self, i: int) -> int: return self._b(i)
+    def permutation_values(self, i: int) -> int: return self._b(self.nf + i)
+    def fixed_poly(self, i: int) -> int: return self._b(self.nf + self.np + i)
+    def permutation_poly(self, i: int) -> int: return self._b(2 * self.nf + self.np + i)
+
+    @staticmethod
+    def allocate(vk: VerifyingKey, cs: E.ConstraintSystem) -> "DeviceProvingKey":
+        n = 1 << vk.k
+        en = EvaluationDomain(cs.degree, vk.k).extended_len()
+        cols = cs.num_fixed + len(cs.permutation_columns)
+        ext = _DeviceBuffer(max(1, (3 + cols) * en * 32))
+        try:
+            base = _DeviceBuffer(max(1, 2 * cols * n * 32))
+        except Exception:
+            ext.free()
+            raise
+        return DeviceProvingKey(vk, cs, ext, base)
+
+    def to_host(self) -> ProvingKey:
+        n, en, nf, npc = self.n, self.en, self.nf, self.np
+        e = self._ext.download((3 + nf + npc, en, 4))
+        b = self._base.download((2 * (nf + npc), n, 4))
+        return ProvingKey(self.vk, e[0], e[1], e[2], [b[i] for i in range(nf)], [b[nf + npc + i] for i in range(nf)], [e[3 + i] for i in range(nf)],
+                          [b[nf + i] for i in range(npc)], [b[2 * nf + npc + i] for i in range(npc)], [e[3 + nf + i] for i in range(npc)])
+
+    @staticmethod
+    def from_host(pk: ProvingKey, cs: E.ConstraintSystem) -> "DeviceProvingKey":
+        d = DeviceProvingKey.allocate(pk.vk, cs)
+        try:
+            for i, a in enumerate([pk.l0, pk.l_last, pk.l_active_row] + list(pk.fixed_cosets) + list(pk.permutation_cosets)):
+                d._ext.upload(np.ascontiguousarray(a, dtype=np.uint64), i * d.en * 32)
+            for i, a in enumerate(list(pk.fixed_values) + list(pk.permutations) + list(pk.fixed_polys) + list(pk.permutation_polys)):
+                d._base.upload(np.ascontiguousarray(a, dtype=np.uint64), i * d.n * 32)
+        except Exception:
+            d.free()
+            raise
+        return d
+
+    def free(self) -> None:
+        self._ext.free()
+        self._base.free()
+
+    def __enter__(self) -> "DeviceProvingKey":
+        return self
+
+    def __exit__(self, *exc) -> None:
+        self.free()
+
+
+def _copy_device(dst: int, src: int, log_rows: int) -> None:
+    prog = E.RowProgram()
+    prog.emit(E.OP_MOV, 0, prog.column(0))
+    prog.run_device([src], log_rows, dst)
+
+
+def _sigma_to_device(assembly: Assembly, k: int, d_out: int) -> None:
+    """the sigma columns (Lagrange basis) written to d_out, column after column: omega^row from a row program, then one gather-multiply
+    per column (`zkhip_fr_gather_mul_device`); the mapping travels as 2 x 4 bytes per cell instead of 32"""
+    lib = _lib.load()
+    n, ncol = 1 << k, assembly.n_columns
+    if ncol == 0:
+        return
+    with _DeviceBuffer(n * 32) as d_pow, _DeviceBuffer(ncol * 32) as d_delta, _DeviceBuffer(2 * n * 4) as d_idx:
+        powers = E.RowProgram(omega=_omega(k))
+        powers.emit(E.OP_MOV, 0, E.RowProgram.ROWPOW)
+        powers.run_device([], k, d_pow.ptr.value)
+        d_delta.upload(fr_encode([pow(E.DELTA, c, R_MOD) for c in range(ncol)]))
+        for c in range(ncol):
+            d_idx.upload(np.ascontiguousarray(assembly.map_row[c], dtype=np.uint32))
+            d_idx.upload(np.ascontiguousarray(assembly.map_col[c], dtype=np.uint32), n * 4)
+            _lib.check(lib.zkhip_fr_gather_mul_device(d_pow.ptr, n, d_idx.ptr, d_delta.ptr, ncol, C.c_void_p(d_idx.ptr.value + n * 4), n,
+                                                      C.c_void_p(d_out + c * n * 32), None))
+        _lib.check(lib.zkhip_sync())                      # the index buffer is reused per column and freed on return
+
+
+def _commit_lagrange_device(params, d_columns: int, count: int) -> np.ndarray:
+    """commit_lagrange of `count` device-resident columns (n elements each, back to back) -> affine points: MSMs against the registered
+    g_lagrange (`zkhip_msm_g1_registered_device`), normalised together"""
+    lib = _lib.load()
+    if count == 0:
+        return np.zeros((0, 8), dtype=np.uint64)
+    n = 1 << params.k
+    with _DeviceBuffer(count * (96 + 64)) as d_out:
+        for i in range(count):
+            _lib.check(lib.zkhip_msm_g1_registered_device(params.g_lagrange.ctypes.data, C.c_void_p(d_columns + i * n * 32), n,
+                                                          C.c_void_p(d_out.ptr.value + i * 96), None))
+        _lib.check(lib.zkhip_g1_batch_normalize_device(d_out.ptr, count, C.c_void_p(d_out.ptr.value + count * 96), None))
+        return d_out.download((count, 8), count * 96)
+
+
+def keygen_device(params, cs: E.ConstraintSystem, fixed: Sequence[np.ndarray], assembly: Assembly, selectors: Sequence[np.ndarray] = ()) -> DeviceProvingKey:
+    """`keygen_vk` + `keygen_pk` with everything but the fixed columns' upload and the 64-byte commitments staying on the device: sigma
+    columns by gather, commitments against the registered g_lagrange, polys / cosets by the batched transforms.  The result equals
+    `keygen_pk(params, keygen_vk(...), ...)` element for element (`DeviceProvingKey.to_host()`)."""
+    lib = _lib.load()
+    k, n = params.k, 1 << params.k
+    if len(fixed) != cs.num_fixed or assembly.n_columns != len(cs.permutation_columns) or assembly.n != n:
+        raise ValueError("fixed columns / permutation assembly do not match the constraint system")
+    if n < cs.blinding_factors + 3:
+        raise ValueError("not enough rows available")
+    dom = EvaluationDomain(cs.degree, k)
+    en = dom.extended_len()
+    nf, npc = cs.num_fixed, len(cs.permutation_columns)
+    cols = nf + npc
+    pk = DeviceProvingKey.allocate(VerifyingKey(k, np.zeros((0, 8), dtype=np.uint64), np.zeros((0, 8), dtype=np.uint64), [np.asarray(s, dtype=bool) for s in selectors], cs), cs)
+    try:
+        for i, c in enumerate(fixed):
+            pk._base.upload(np.ascontiguousarray(c, dtype=np.uint64).reshape(n, 4), i * n * 32)
+        _sigma_to_device(assembly, k, pk.permutation_values(0) if npc else 0)
+        commits = _commit_lagrange_device(params, pk.fixed_values(0), cols)
+        pk.vk.fixed_commitments, pk.vk.permutation_commitments = commits[:nf], commits[nf:]
+        # values -> coefficients (copy, then the batched inverse transform in place) -> extended cosets
+        for i in range(cols):
+            _copy_device(pk._b(cols + i), pk._b(i), k)
+        if cols:
+            _lib.check(lib.zkhip_ifft_scaled_batch_device(C.c_void_p(pk._b(cols)), dom.omega_inv.ctypes.data, k, dom.ifft_divisor.ctypes.data, cols, n, None))
+            _lib.check(lib.zkhip_coeff_to_extended_device(C.c_void_p(pk._b(cols)), n, k, C.c_void_p(pk._e(3)), en, dom.extended_k, cols, dom.extended_omega.ctypes.data,
+                                                          dom.g_coset.ctypes.data, None))
+        # l0, l_last, l_active_row: indicator columns, transformed like the others
+        u = n - (cs.blinding_factors + 1)
+        one = fr_encode([1])[0]
+        ind = np.zeros((3, n, 4), dtype=np.uint64)
+        ind[0, 0] = one
+        ind[1, u] = one
+        ind[2, :u] = one
+        with _DeviceBuffer(3 * n * 32) as d_l:
+            d_l.upload(ind)
+            _lib.check(lib.zkhip_ifft_scaled_batch_device(d_l.ptr, dom.omega_inv.ctypes.data, k, dom.ifft_divisor.ctypes.data, 3, n, None))
+            _lib.check(lib.zkhip_coeff_to_extended_device(d_l.ptr, n, k, C.c_void_p(pk._e(0)), en, dom.extended_k, 3, dom.extended_omega.ctypes.data,
+                                                          dom.g_coset.ctypes.data, None))
+            _lib.check(lib.zkhip_sync())
+    except Exception:
+        pk.free()
+        raise
+    return pk
+
+
 def _commit_lagrange_affine(params, columns: Sequence[np.ndarray]) -> np.ndarray:
     """commit_lagrange of every column -> affine points (the verifying key stores `to_affine()` of the commitments): the commitments
     are normalised together on the GPU (`Curve::batch_normalize`, zkhip_g1_batch_normalize)"""
