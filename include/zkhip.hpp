@@ -655,6 +655,16 @@ class ParamsKZG {
     if (poly.size() > n_) throw std::invalid_argument("commit: polynomial longer than the SRS");
     return best_multiexp(poly.data(), poly.size(), g_.data(), poly.size());
   }
+  // the same for a polynomial that lives in HBM (the first poly.size() points of the registered table): result downloaded
+  G1 commit_device(const DeviceVec& poly, bool lagrange = false) const {
+    const std::vector<G1Affine>& b = lagrange ? g_lagrange_ : g_;
+    if (b.empty() || poly.size() > n_) throw std::invalid_argument("commit_device: no such basis / polynomial longer than the SRS");
+    DeviceVec d_out(3);
+    G1 out;
+    check(zkhip_msm_g1_registered_device(b.data()->x, poly.data(), poly.size(), d_out.data(), nullptr), "commit_device");
+    check(zkhip_download(&out, d_out.data(), sizeof(G1)), "commit_device download");
+    return out;
+  }
   // multi-column commit (not in the reference API: its provers commit column by column): K polynomials of equal length,
   // stored back to back, in one launch set
   std::vector<G1> commit_many(const std::vector<Fr>& polys, size_t len, bool lagrange = false) const {

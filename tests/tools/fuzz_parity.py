@@ -21,8 +21,15 @@ counts = {}
 def aff(x): return Cr.jac_to_affine(np.ascontiguousarray(x))
 
 def scalars(n, seed):
-    kind = rng.randrange(4)
+    kind = rng.randrange(5)
     if kind < 2: return Cr.gen_scalars(seed, n, kind)
+    if kind == 4:                                      # what real columns look like: uniform values with clusters of 1, -1, small constants
+        s = Cr.gen_scalars(seed, n, 0)
+        consts = F.fr_encode([1, R - 1, 2, rng.randrange(1 << 16), R - rng.randrange(1, 1 << 16)])
+        pick = np.random.default_rng(seed + 1)
+        mask = pick.random(n) < rng.choice([0.05, 0.3, 0.9])
+        s[mask] = consts[pick.integers(0, consts.shape[0], int(mask.sum()))]
+        return np.ascontiguousarray(s)
     if kind == 2:                                      # few distinct values: heavy buckets
         vals = Cr.gen_scalars(seed, rng.randint(1, 4), 0)
         return np.ascontiguousarray(vals[np.random.default_rng(seed).integers(0, vals.shape[0], n)])

@@ -81,16 +81,12 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk
     clock[0] = time.perf_counter()
     # ---- SRS -------------------------------------------------------------------------------------------------------------
     params = Z.ParamsKZG.setup(k, s)
-    d_g = torch.from_numpy(np.array(params.g).view(np.int64)).to(dev)            # (the params' arrays are read-only while registered)
-    d_gl = torch.from_numpy(np.array(params.g_lagrange).view(np.int64)).to(dev)
-    h_g, h_gl = C.c_uint64(0), C.c_uint64(0)
-    _lib.check(lib.zkhip_prepare_bases_device(d_g.data_ptr(), n, C.byref(h_g)))
-    _lib.check(lib.zkhip_prepare_bases_device(d_gl.data_ptr(), n, C.byref(h_gl)))
     lap("setup_srs")
+    h_g, h_gl = False, True                                                       # which of the params' registered tables a commit uses
 
-    def commit(handle, col):
+    def commit(lagrange, col):                                                     # params.commit / commit_lagrange of a device-resident column
         out = torch.zeros(12, dtype=torch.int64, device=dev)
-        _lib.check(lib.zkhip_msm_g1_prepared_device(handle, 0, col.data_ptr(), n, out.data_ptr(), None))
+        params.commit_device(col.data_ptr(), n, out.data_ptr(), lagrange=lagrange)
         return out
 
     def affine(jac):
@@ -169,7 +165,6 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk
             dpk = KG.DeviceProvingKey.from_host(pk, cs)
             del pk, pk2
             lap("pk_upload")
-        params.close()
 
         def from_key(ptr, log_rows):                                               # a working copy of one of the key's columns
             t_ = torch.empty((1 << log_rows, 4), dtype=torch.int64, device=dev)
@@ -305,7 +300,7 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk
 
         def commit_ptr(ptr):
             out = torch.zeros(12, dtype=torch.int64, device=dev)
-            _lib.check(lib.zkhip_msm_g1_prepared_device(h_g, 0, C.c_void_p(ptr), n, out.data_ptr(), None))
+            params.commit_device(ptr, n, out.data_ptr())
             return out.cpu().numpy().view(np.uint64)
 
         y_mo, v_mo, u_mo = (rng.randrange(1, R) for _ in range(3))
@@ -339,8 +334,7 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk
         torch.cuda.synchronize()
         if dpk is not None:
             dpk.free()
-        lib.zkhip_release_bases(h_g)
-        lib.zkhip_release_bases(h_gl)
+        params.close()
 
 
 if __name__ == "__main__":

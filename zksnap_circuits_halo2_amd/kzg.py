@@ -172,6 +172,13 @@ class ParamsKZG:
         assert poly.shape[0] <= self.n
         return best_multiexp(poly, self.g_lagrange[: poly.shape[0]])
 
+    def commit_device(self, d_poly: int, length: int, d_out: int, lagrange: bool = False, stream: int = 0) -> None:
+        """`commit` / `commit_lagrange` of a polynomial that lives in HBM (`length` elements at device address d_poly), against the
+        tables this object registered: the 96-byte Jacobian result is written to device address d_out, asynchronously on `stream`"""
+        bases = self.g_lagrange if lagrange else self.g
+        assert bases is not None and length <= self.n
+        _lib.check(_lib.load().zkhip_msm_g1_registered_device(bases.ctypes.data, d_poly, length, d_out, stream))
+
     def commit_many(self, polys: np.ndarray, lagrange: bool = False) -> np.ndarray:
         """Commit to K polynomials of equal length at once ((K, len, 4) uint64) -> (K, 12) uint64: one launch set."""
         polys = np.ascontiguousarray(polys, dtype=np.uint64)
