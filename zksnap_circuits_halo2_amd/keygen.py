@@ -33,7 +33,7 @@ from __future__ import annotations
 import ctypes as C
 import struct
 from dataclasses import dataclass, field
-from typing import BinaryIO, List, Optional, Sequence, Tuple
+from typing import BinaryIO, List, Optional, Sequence
 
 import numpy as np
 
