@@ -416,6 +416,27 @@ def extras(lib, _lib, F, torch, dev, stream) -> dict:
 
     ms_msm22 = timed(lambda: _lib.check(lib.zkhip_msm_g1_prepared_device(h22, 0, sc.data_ptr(), n, res.data_ptr(), stream)), 3)
     ms = timed(replay, 2)
+    # the same 2^22 MSM under scalar distributions that real columns have: buckets that hold a large share of all entries must not
+    # serialise anything (profiles/r02_scalar_distributions.txt, tools/skew_probe.py)
+    try:
+        one_w = torch.from_numpy(F.fr_encode([1])[0].view(np.int64)).to(dev)
+        neg_w = torch.from_numpy(F.fr_encode([R_MOD - 1])[0].view(np.int64)).to(dev)
+        keep = sc.clone()
+        dist = {}
+        def t_sc():
+            return round(timed(lambda: _lib.check(lib.zkhip_msm_g1_prepared_device(h22, 0, sc.data_ptr(), n, res.data_ptr(), stream)), 3), 3)
+        sc[::20] = neg_w
+        dist["uniform_5pct_equal_to_minus_one_ms"] = t_sc()
+        sc.zero_(); sc[::2] = one_w
+        dist["selector_half_ones_ms"] = t_sc()
+        sc[:] = one_w
+        dist["all_ones_ms"] = t_sc()
+        sc.copy_(keep)
+        del keep
+        dist["uniform_ms"] = round(ms_msm22, 3)
+        out["msm_2^22_scalar_distributions"] = dist
+    except Exception as exc:   # an extra: never fail the bench line
+        out["msm_2^22_scalar_distributions"] = {"error": repr(exc)}
     lib.zkhip_release_bases(h22)
     # the same call mix through the host-buffer entry points (what the plain two-function drop-in sees: every scalar vector and
     # every polynomial crosses PCIe from / to pageable host memory; the SRS is registered once, as INTEGRATION.md describes)

@@ -209,3 +209,52 @@ def test_msm_batched_non_power_of_two_fresh_context(lib, cref, n, batch):
             assert np.array_equal(cref.jac_to_affine(res[b]), _expect(cref, sc[b * stride: b * stride + n], T0, D)), b
     finally:
         _lib.check(lib.zkhip_release_bases(h))
+
+
+def test_msm_2p20_columns_of_equal_values_are_correct_and_not_serialised(lib, cref):
+    """Columns real circuits commit to -- a selector (half ones), bits, an all-ones column, uniform values with 5 % equal to -1 -- at
+    2^20 on the prepared path: each result against the structured-SRS identity, and none slower than 2.5 x the uniform case (their
+    buckets hold up to 2^20 entries; with one thread writing such a bucket's task records an all-ones column took 8 x the uniform
+    time: `profiles/r02_skewed_scalars.txt`)."""
+    import time
+
+    import torch
+
+    n = 1 << 20
+    T0, D = 0x5A4B534E41500999, 0x9E3779B97F4A7C15F39CC0605CEDC837
+    t0m, dm = F.fr_encode([T0])[0], F.fr_encode([D])[0]
+    bases = torch.empty(n * 8, dtype=torch.int64, device="cuda")
+    _lib.check(lib.zkhip_g1_gen_walk_device(t0m.ctypes.data, dm.ctypes.data, n, bases.data_ptr(), None))
+    h = C.c_uint64(0)
+    _lib.check(lib.zkhip_prepare_bases_device(bases.data_ptr(), n, C.byref(h)))
+    one, minus_one = F.fr_encode([1])[0], F.fr_encode([O.R_MOD - 1])[0]
+    uni = cref.gen_scalars(909, n, 0)
+    rng = np.random.default_rng(4)
+    cases = {"uniform": uni}
+    sel = np.zeros((n, 4), dtype=np.uint64); sel[::2] = one
+    cases["selector"] = sel
+    bits = np.zeros((n, 4), dtype=np.uint64); bits[rng.random(n) < 0.5] = one
+    cases["bits"] = bits
+    cases["all ones"] = np.tile(one, (n, 1))
+    mixed = uni.copy(); mixed[::20] = minus_one
+    cases["5% equal to -1"] = mixed
+    out = torch.zeros(12, dtype=torch.int64, device="cuda")
+    times = {}
+    try:
+        for name, sc in cases.items():
+            sc = np.ascontiguousarray(sc)
+            dsc = torch.from_numpy(sc.view(np.int64)).cuda()
+            run = lambda: _lib.check(lib.zkhip_msm_g1_prepared_device(h, 0, dsc.data_ptr(), n, out.data_ptr(), None))
+            run()
+            torch.cuda.synchronize()
+            exp = cref.jac_to_affine(cref.scalar_mul(cref.expected_scalar(sc, T0, D), cref.generator()))
+            assert np.array_equal(cref.jac_to_affine(out.cpu().numpy().view(np.uint64)), exp), name
+            t = time.perf_counter()
+            for _ in range(5):
+                run()
+            torch.cuda.synchronize()
+            times[name] = (time.perf_counter() - t) / 5
+    finally:
+        _lib.check(lib.zkhip_release_bases(h))
+    for name, t in times.items():
+        assert t < 2.5 * times["uniform"], (name, times)
