@@ -258,3 +258,49 @@ def test_msm_2p20_columns_of_equal_values_are_correct_and_not_serialised(lib, cr
         _lib.check(lib.zkhip_release_bases(h))
     for name, t in times.items():
         assert t < 2.5 * times["uniform"], (name, times)
+
+
+def test_batch_of_large_msms_overlapped_on_two_streams(lib, cref):
+    """`zkhip_msm_g1_prepared_batch_device` with wide-window tables (n = 2^20): the vectors alternate between the caller's stream and the
+    library's side stream; every result against the structured-SRS identity, also when the caller's stream is not the default one, with
+    a padded stride and an odd batch; the host-buffer form (`zkhip_msm_g1_batch` on a registered array) takes the same path."""
+    import torch
+
+    n, batch, stride = 1 << 20, 3, (1 << 20) + 8
+    T0, D = 0x5A4B534E41500AAA, 0x9E3779B97F4A7C15F39CC0605CEDC839
+    t0m, dm = F.fr_encode([T0])[0], F.fr_encode([D])[0]
+    bases = torch.empty(n * 8, dtype=torch.int64, device="cuda")
+    _lib.check(lib.zkhip_g1_gen_walk_device(t0m.ctypes.data, dm.ctypes.data, n, bases.data_ptr(), None))
+    h = C.c_uint64(0)
+    _lib.check(lib.zkhip_prepare_bases_device(bases.data_ptr(), n, C.byref(h)))
+    assert lib.zkhip_prepared_window_bits(h) > 16
+    vecs = [cref.gen_scalars(5100 + i, n, i % 2) for i in range(batch)]
+    host = np.zeros((batch, stride, 4), dtype=np.uint64)
+    for i, v in enumerate(vecs):
+        host[i, :n] = v
+    dsc = torch.from_numpy(host.view(np.int64)).cuda()
+    exp = [cref.jac_to_affine(cref.scalar_mul(cref.expected_scalar(v, T0, D), cref.generator())) for v in vecs]
+    try:
+        for st in (None, torch.cuda.Stream()):
+            out = torch.zeros((batch, 12), dtype=torch.int64, device="cuda")
+            if st is not None:
+                st.wait_stream(torch.cuda.current_stream())
+            _lib.check(lib.zkhip_msm_g1_prepared_batch_device(h, 0, dsc.data_ptr(), n, batch, stride, out.data_ptr(), C.c_void_p(st.cuda_stream) if st else None))
+            # results are complete when the CALLER's stream has drained (the side stream is joined to it)
+            (st or torch.cuda.current_stream()).synchronize()
+            got = out.cpu().numpy().view(np.uint64)
+            for i in range(batch):
+                assert np.array_equal(cref.jac_to_affine(got[i]), exp[i]), (i, st)
+    finally:
+        _lib.check(lib.zkhip_release_bases(h))
+    # host-buffer form on a registered array
+    hb = np.ascontiguousarray(bases.cpu().numpy().view(np.uint64).reshape(n, 8))
+    _lib.check(lib.zkhip_register_bases(hb.ctypes.data, n))
+    try:
+        two = np.ascontiguousarray(np.stack(vecs[:2]))
+        out = np.zeros((2, 12), dtype=np.uint64)
+        _lib.check(lib.zkhip_msm_g1_batch(two.ctypes.data, hb.ctypes.data, n, 2, out.ctypes.data))
+        for i in range(2):
+            assert np.array_equal(cref.jac_to_affine(out[i]), exp[i])
+    finally:
+        _lib.check(lib.zkhip_unregister_bases(hb.ctypes.data))

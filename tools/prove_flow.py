@@ -28,6 +28,9 @@ R = F.R_MOD
 BLIND = 5
 
 
+_SIDE_STREAM = None
+
+
 def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk_file=None):
     """pk_file: path -- the proving key is written there (`ProvingKey::write`, RawBytesUnchecked), read back, and the READ key is what the
     prover uses (the reference's wrapper does the same through build/*_pk.bin: /root/reference/aggregator/src/wrapper.rs:967-989, :1007-1034)"""
@@ -89,6 +92,24 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk
         params.commit_device(col.data_ptr(), n, out.data_ptr(), lagrange=lagrange)
         return out
 
+    # the current stream and one high-priority stream: streams of different priority never share a hardware queue (two streams of one
+    # priority may, and then run one after the other)
+    global _SIDE_STREAM
+    if _SIDE_STREAM is None:
+        _SIDE_STREAM = torch.cuda.Stream(priority=-1)       # kept between proofs, like the scratch set the library keys by it
+    side = [torch.cuda.current_stream(), _SIDE_STREAM]
+
+    def commit_all(lagrange, cols):
+        """independent commits alternate between two streams: one MSM's latency-bound reduction tail runs under the next one's accumulation
+        (tools/two_stream_msm.py: 5.31 -> 4.96 ms per 2^22 MSM); each stream has its own scratch set inside the library"""
+        outs = [torch.zeros(12, dtype=torch.int64, device=dev) for _ in cols]
+        cur = torch.cuda.current_stream()
+        side[1].wait_stream(cur)
+        for i, col in enumerate(cols):
+            params.commit_device(col.data_ptr(), n, outs[i].data_ptr(), lagrange=lagrange, stream=side[i % 2].cuda_stream)
+        cur.wait_stream(side[1])
+        return outs
+
     def affine(jac):
         return F.g1_decode_jacobian(jac.cpu().numpy().view(np.uint64))
 
@@ -123,7 +144,7 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk
         if corrupt == "copy":
             advice[0][21] = advice[0][22].clone()
         lap("witness_columns")
-        adv_commit = [commit(h_gl, a) for a in advice]                             # advice is committed in the Lagrange basis
+        adv_commit = commit_all(h_gl, advice)                                       # advice is committed in the Lagrange basis
         lap("commit_advice")
 
         # ---- keygen: the circuit's fixed columns and copy constraints -> verifying key, proving key -----------------------------------
@@ -236,8 +257,8 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk
             ifft_range(lo, hi)
         lap("lagrange_to_coeff")
         first_prover_poly = qc.sigma + len(perm_cols)                               # z sets, lookup product, permuted pair
-        prod_commit = [commit(h_g, coeff[i]) for i in range(first_prover_poly, ncol)]
-        a0_coeff_commit = commit(h_g, coeff[qc.advice])
+        prod_commit = commit_all(h_g, [coeff[i] for i in range(first_prover_poly, ncol)] + [coeff[qc.advice]])
+        a0_coeff_commit = prod_commit.pop()
         lap("commit_products")
         ext = torch.empty((ncol, en, 4), dtype=torch.int64, device=dev)
 
@@ -264,7 +285,7 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk
         _lib.check(lib.zkhip_extended_to_coeff_device(h_ext.data_ptr(), en, ek, dom.extended_omega_inv.ctypes.data, dom.extended_ifft_divisor.ctypes.data,
                                                       dom.g_coset.ctypes.data, h_coeff.data_ptr(), en, en, 1, None))
         lap("extended_to_coeff")
-        h_commit = [commit(h_g, h_coeff[i * n:(i + 1) * n]) for i in range(3)]
+        h_commit = commit_all(h_g, [h_coeff[i * n:(i + 1) * n] for i in range(3)])
         lap("commit_h")
 
         # ---- evaluations at x ----------------------------------------------------------------------------------------------------------

@@ -150,6 +150,8 @@ struct device_ctx {
   bool fixed_table_ready = false;
   dev_buf gather;                      // primary: the shards' 96-byte partials, one 96-byte slot per shard
   std::vector<hipEvent_t> shard_events;
+  hipStream_t side = nullptr;          // primary: second stream of a batch of large MSMs (high priority: never the caller's hardware queue)
+  hipEvent_t side_fork = nullptr, side_join = nullptr;
   worker* w = nullptr;                 // secondary devices only
 };
 
@@ -212,7 +214,7 @@ static scratch* scratch_for(device_ctx& d, hipStream_t stream) {
   if (d.scratch_by_stream.size() >= MAX_STREAM_SCRATCH + d.lanes.size()) {
     auto victim = d.scratch_by_stream.end();
     for (auto jt = d.scratch_by_stream.begin(); jt != d.scratch_by_stream.end(); ++jt) {
-      bool is_lane = false;
+      bool is_lane = jt->first == d.side && d.side != nullptr;
       for (auto& L : d.lanes) is_lane |= (L.stream == jt->first);
       if (is_lane) continue;
       if (victim == d.scratch_by_stream.end() || jt->second->last_use < victim->second->last_use) victim = jt;
@@ -307,6 +309,9 @@ static void destroy_device_ctx(device_ctx* d) {
     if (L.stream) (void)hipStreamDestroy(L.stream);
   }
   for (auto e : d->shard_events) (void)hipEventDestroy(e);
+  if (d->side_fork) (void)hipEventDestroy(d->side_fork);
+  if (d->side_join) (void)hipEventDestroy(d->side_join);
+  if (d->side) (void)hipStreamDestroy(d->side);
   d->fixed_table.release();
   d->gather.release();
   delete d;
@@ -596,7 +601,8 @@ int zkhip_msm_g1(const uint64_t* scalars, const uint64_t* bases, size_t n, uint6
 }
 
 // `batch` scalar vectors (contiguous, n elements each) against the same bases; out: batch Jacobian points.
-// Registered bases in one shard with a window <= 16 bits: one batched launch set; otherwise one MSM per vector.
+// Registered bases in one shard: one batched launch set (window <= 16 bits) or pairs of overlapping MSMs (wide windows); otherwise one
+// MSM per vector.
 int zkhip_msm_g1_batch(const uint64_t* scalars, const uint64_t* bases, size_t n, size_t batch, uint64_t* out_xyz) {
   if (!out_xyz || (n && batch && (!scalars || !bases))) { set_error("msm_batch: null pointer"); return ZKHIP_EINVAL; }
   if (batch == 0) return ZKHIP_OK;
@@ -608,7 +614,7 @@ int zkhip_msm_g1_batch(const uint64_t* scalars, const uint64_t* bases, size_t n,
   if (n) { guard_t g(g_mu); reg = find_registered(bases, n, &off); }
   const shard_t* one = nullptr;
   if (reg) for (auto& sh : reg->shards) if (sh.dev == 0 && off >= sh.lo && off + n <= sh.lo + sh.n) one = &sh;
-  if (!one || one->pb->c > 16 || batch * 96 > LANE_PINNED) {
+  if (!one || batch * 96 > LANE_PINNED || (one->pb->c > 16 && n * batch * 32 > ((size_t)4 << 30))) {   // (wide windows: the device path overlaps pairs of MSMs)
     for (size_t k = 0; k < batch; k++)
       if ((rc = host_msm(H, scalars + k * n * 4, bases, n, reg, off, out_xyz + k * 12)) != ZKHIP_OK) return rc;
     return ZKHIP_OK;
@@ -780,6 +786,36 @@ int zkhip_msm_g1_prepared_batch_device(uint64_t handle, size_t offset, const voi
   // tables built for wide windows (n >= 2^20) do not batch: those MSMs are throughput-bound one at a time
   size_t group = (pb->c > 16 || batch <= 1) ? 1 : batch;
   while (group > 1 && ((size_t)((256 + pb->c - 1) / pb->c) * n * group >= (1ull << 31) || (group << (pb->c - 1)) > (1ull << 22))) group = (group + 1) / 2;   // <= 4 Mi buckets per launch set
+  if (group == 1 && batch > 1 && n >= ((size_t)1 << 18)) {
+    // Large MSMs do not share a launch set, but two of them overlap: while one is in its latency-bound sort and reduction tail the
+    // other's accumulation fills the chip (measured: 2^20 1.50 -> 1.30 ms, 2^22 5.26 -> 4.87 ms per MSM).  Odd vectors go to a
+    // library-owned high-priority stream (streams of different priority never share a hardware queue) forked from / joined to the
+    // caller's stream with events; each stream has its own scratch set.
+    device_ctx& P = primary();
+    if (!P.side) {
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);          // hi = numerically lowest = greatest priority
+      HIPCHK(hipStreamCreateWithPriority(&P.side, hipStreamNonBlocking, hi));
+      HIPCHK(hipEventCreateWithFlags(&P.side_fork, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&P.side_join, hipEventDisableTiming));
+    }
+    scratch* sc2 = scratch_for(P, P.side);
+    const size_t ws_bytes = msm_workspace_bytes(n, pb->c, true, 1);
+    if ((rc = sc->ws.reserve(ws_bytes)) != ZKHIP_OK) return rc;
+    if ((rc = sc2->ws.reserve(ws_bytes)) != ZKHIP_OK) return rc;
+    HIPCHK(hipEventRecord(P.side_fork, s));
+    HIPCHK(hipStreamWaitEvent(P.side, P.side_fork, 0));
+    for (size_t k0 = 0; k0 < batch; k0++) {
+      const bool on_side = (k0 & 1) != 0;
+      scratch* use = on_side ? sc2 : sc;
+      rc = msm_g1_device((const uint32_t*)d_scalars + k0 * scalar_stride * 8, nullptr, n, (uint32_t*)d_out_xyz + k0 * 24, use->ws.p, use->ws.cap, 0, on_side ? P.side : s, pb,
+                         offset, 1, scalar_stride);
+      if (rc != ZKHIP_OK) break;
+    }
+    HIPCHK(hipEventRecord(P.side_join, P.side));               // also on an error: the caller's stream must not run ahead of the side stream
+    HIPCHK(hipStreamWaitEvent(s, P.side_join, 0));
+    return rc;
+  }
   for (size_t k0 = 0; k0 < batch; k0 += group) {
     const size_t kk = batch - k0 < group ? batch - k0 : group;
     if ((rc = sc->ws.reserve(msm_workspace_bytes(n, pb->c, true, kk))) != ZKHIP_OK) return rc;
