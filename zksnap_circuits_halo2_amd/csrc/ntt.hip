@@ -11,7 +11,7 @@
 //   * One workgroup owns a tile of J consecutive j (J * R = 2048 elements, 72 KiB of LDS as 9-limb values):
 //     cooperative coalesced load -> LDS, <= 3 rounds of <= 3 radix-2 stages in registers (8 elements per
 //     thread), LDS exchange between rounds, cooperative coalesced store.
-//   * B <= 9 bits per pass: 2^24 is three passes.  Twiddles w_M^t come from an M-entry table when
+//   * B <= 9 bits per pass: 2^24 is three passes.  Twiddles w_M^(k r) come from an M-entry table (laid out [r][k], the order read) when
 //     M <= 2^24 (HBM is plentiful: 36 B * M per (omega, log_n), cached) and from two 2^(log M / 2)-entry
 //     tables (one extra multiply) above that.
 //   * Values stay lazily reduced inside a pass (fp29.hpp); intermediate passes end with a ~50-instruction
@@ -53,6 +53,7 @@ struct pass_args {
   const uint32_t* tw_lo;          // w_M^t, t < 2^h (or t < M when tw_hi == nullptr)
   const uint32_t* tw_hi;          // w_M^(t 2^h)
   uint32_t h;
+  uint32_t tw_rk;                 // direct table in (r, k) layout: w_M^(k r) at index r * Ns + k
   uint32_t first, last;
   uint32_t in_len;                // first pass: elements >= in_len read as zero
   uint32_t out_len;               // last pass: elements >= out_len are not stored
@@ -150,7 +151,7 @@ __global__ void __launch_bounds__(2048 / E, E == 8 ? 2 : 4) k_ntt_pass(pass_args
       const uint32_t t = (j & (Ns - 1)) * r;
       fe tw;
       if (a.tw_hi == nullptr) {
-        tw = load_fe9(a.tw_lo, t);
+        tw = load_fe9(a.tw_lo, a.tw_rk ? (r << a.S) + (j & (Ns - 1)) : t);
       } else {
         tw = fe_mul<Fr>(load_fe9(a.tw_lo, t & ((1u << a.h) - 1)), load_fe9(a.tw_hi, t >> a.h));
       }
@@ -304,12 +305,14 @@ __global__ void k_ntt_pow2(const uint32_t* omega_ext_dev, uint32_t L, uint32_t* 
   }
 }
 
-// out[i] = (omega^(2^e0))^i for i < count, by square-and-multiply over the bits of i
-__global__ void __launch_bounds__(256) k_ntt_powers(const uint32_t* pw2, uint32_t e0, uint32_t count, uint32_t* out) {
+// out[i] = (omega^(2^e0))^i for i < count, by square-and-multiply over the bits of i.  rk_shift != 0: the pass-twiddle layout
+// out[r * Ns + k] = (omega^(2^e0))^(k r), Ns = 2^rk_shift -- the order k_ntt_pass reads them in (k runs with the lane index, so the
+// 36-byte entries of a wavefront's load are neighbours; in the plain power table they were k r apart, one memory transaction each)
+__global__ void __launch_bounds__(256) k_ntt_powers(const uint32_t* pw2, uint32_t e0, uint32_t count, uint32_t* out, uint32_t rk_shift) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   fe acc = fe_one<Fr>();
-  uint32_t bits = i, b = 0;
+  uint32_t bits = rk_shift ? (i >> rk_shift) * (i & ((1u << rk_shift) - 1)) : i, b = 0;
   while (bits) {
     if (bits & 1) acc = fe_mul<Fr>(acc, load_fe9(pw2, e0 + b));
     bits >>= 1;
@@ -338,7 +341,7 @@ __global__ void __launch_bounds__(256) k_mul_periodic(uint32_t* a, size_t n, con
 struct ntt_plan {
   uint32_t L = 0;
   int npass = 0;
-  uint32_t B[4] = {0, 0, 0, 0}, S[4] = {0, 0, 0, 0}, h[4] = {0, 0, 0, 0};
+  uint32_t B[4] = {0, 0, 0, 0}, S[4] = {0, 0, 0, 0}, h[4] = {0, 0, 0, 0}, rk[4] = {0, 0, 0, 0};
   uint32_t* pw2 = nullptr;
   uint32_t* tw_local[4] = {nullptr, nullptr, nullptr, nullptr};
   uint32_t* tw_lo[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -389,21 +392,22 @@ static int build_plan(const uint32_t omega_ext[8], uint32_t L, hipStream_t strea
       // local twiddles w_R^x = omega^(x * N/R), x < R/2
       const uint32_t cnt = 1u << (B - 1);
       if ((rc = plan_alloc(p, &p->tw_local[i], (size_t)cnt * 36)) != ZKHIP_OK) return rc;
-      hipLaunchKernelGGL(k_ntt_powers, dim3((cnt + 255) / 256), dim3(256), 0, stream, p->pw2, L - B, cnt, p->tw_local[i]);
+      hipLaunchKernelGGL(k_ntt_powers, dim3((cnt + 255) / 256), dim3(256), 0, stream, p->pw2, L - B, cnt, p->tw_local[i], 0u);
       if (i == 0) continue;
       // pass twiddles w_M^t = omega^(t * N/M), t < M
       if (logM <= NTT_DIRECT_TABLE_BITS) {   // direct table: 36 B * M of HBM, saves the table-combining multiply
         const uint32_t M = 1u << logM;
         p->h[i] = 0;
         if ((rc = plan_alloc(p, &p->tw_lo[i], (size_t)M * 36)) != ZKHIP_OK) return rc;
-        hipLaunchKernelGGL(k_ntt_powers, dim3((M + 255) / 256), dim3(256), 0, stream, p->pw2, L - logM, M, p->tw_lo[i]);
+        p->rk[i] = 1;                        // (S[i] >= 1 for every pass but the first)
+        hipLaunchKernelGGL(k_ntt_powers, dim3((M + 255) / 256), dim3(256), 0, stream, p->pw2, L - logM, M, p->tw_lo[i], p->S[i]);
       } else {
         const uint32_t h = (logM + 1) / 2, nlo = 1u << h, nhi = 1u << (logM - h);
         p->h[i] = h;
         if ((rc = plan_alloc(p, &p->tw_lo[i], (size_t)nlo * 36)) != ZKHIP_OK) return rc;
         if ((rc = plan_alloc(p, &p->tw_hi[i], (size_t)nhi * 36)) != ZKHIP_OK) return rc;
-        hipLaunchKernelGGL(k_ntt_powers, dim3((nlo + 255) / 256), dim3(256), 0, stream, p->pw2, L - logM, nlo, p->tw_lo[i]);
-        hipLaunchKernelGGL(k_ntt_powers, dim3((nhi + 255) / 256), dim3(256), 0, stream, p->pw2, L - logM + h, nhi, p->tw_hi[i]);
+        hipLaunchKernelGGL(k_ntt_powers, dim3((nlo + 255) / 256), dim3(256), 0, stream, p->pw2, L - logM, nlo, p->tw_lo[i], 0u);
+        hipLaunchKernelGGL(k_ntt_powers, dim3((nhi + 255) / 256), dim3(256), 0, stream, p->pw2, L - logM + h, nhi, p->tw_hi[i], 0u);
       }
     }
   }
@@ -505,7 +509,7 @@ int ntt_transform(const uint32_t* d_in, uint32_t in_len, uint32_t in_stride, uin
     pass_args a;
     memset(&a, 0, sizeof(a));
     a.L = L; a.S = p->S[i]; a.B = p->B[i];
-    a.tw_local = p->tw_local[i]; a.tw_lo = p->tw_lo[i]; a.tw_hi = p->tw_hi[i]; a.h = p->h[i];
+    a.tw_local = p->tw_local[i]; a.tw_lo = p->tw_lo[i]; a.tw_hi = p->tw_hi[i]; a.h = p->h[i]; a.tw_rk = p->rk[i];
     a.first = i == 0; a.last = i == p->npass - 1;
     a.in_len = in_len; a.out_len = out_len;
     a.in_scale = is; a.out_scale = os;
