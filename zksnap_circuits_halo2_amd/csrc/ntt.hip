@@ -109,11 +109,12 @@ __device__ __forceinline__ fe scale_pick(const scale_arg& s, uint32_t idx) {
   return fr_ext_to_internal(w);
 }
 
+// CH: fe_mul with single-chain product columns (see the launch site).
 // E = elements a thread holds in a round (log2 E radix-2 stages per LDS round trip).  E = 8: 256 threads per 2048-element tile, 3 stages
 // per round, 202 VGPRs -> 2 waves per SIMD.  E = 4 (default): 512 threads per tile, 2 stages per round, 123 VGPRs -> 4 waves per SIMD at
 // the price of one more LDS round trip per 8-bit pass (+5.6 % VALU instructions).  Measured equal within noise at 2^22 .. 2^26 (the
 // kernel runs at the VALU issue rate of its instruction mix either way: DESIGN.md section 4), E = 4 ahead on small transforms.
-template <int E>
+template <int E, bool CH>
 __global__ void __launch_bounds__(2048 / E, E == 8 ? 2 : 4) k_ntt_pass(pass_args a) {
   constexpr int VM = E == 8 ? 3 : 2;
   extern __shared__ uint32_t lds[];
@@ -140,7 +141,7 @@ __global__ void __launch_bounds__(2048 / E, E == 8 ? 2 : 4) k_ntt_pass(pass_args
         uint32_t w[8];
         load_words(src + (size_t)g * 8, w);
         x = fe_unpack<0>(w);
-        if (a.in_scale.period) x = fe_mul<Fr>(scale_pick(a.in_scale, g), x);
+        if (a.in_scale.period) x = fe_mul<Fr, CH>(scale_pick(a.in_scale, g), x);
       } else {
         x = fe_zero();
       }
@@ -153,9 +154,9 @@ __global__ void __launch_bounds__(2048 / E, E == 8 ? 2 : 4) k_ntt_pass(pass_args
       if (a.tw_hi == nullptr) {
         tw = load_fe9(a.tw_lo, a.tw_rk ? (r << a.S) + (j & (Ns - 1)) : t);
       } else {
-        tw = fe_mul<Fr>(load_fe9(a.tw_lo, t & ((1u << a.h) - 1)), load_fe9(a.tw_hi, t >> a.h));
+        tw = fe_mul<Fr, CH>(load_fe9(a.tw_lo, t & ((1u << a.h) - 1)), load_fe9(a.tw_hi, t >> a.h));
       }
-      x = fe_mul<Fr>(tw, x);
+      x = fe_mul<Fr, CH>(tw, x);
     }
     const uint32_t i = __brev(r) >> (32 - B);
     store_lds9(lds, i * J + jj, x);
@@ -192,7 +193,7 @@ __global__ void __launch_bounds__(2048 / E, E == 8 ? 2 : 4) k_ntt_pass(pass_args
           fe t = fe_norm(x[e + 2]);                         // trivial pair (e, e+2): t < 4p, N
           x[e + 2] = fe_sub_red(x[e], t, Fr::P6_S1);        // < 10p / 2^31
           x[e] = fe_add(x[e], t);                           // < 8p / 1.5*2^30
-          fe u1 = fe_mul<Fr>(w4, x[e + 3]);                 // pair (e+1, e+3): input < 5p / 1.5*2^30
+          fe u1 = fe_mul<Fr, CH>(w4, x[e + 3]);                 // pair (e+1, e+3): input < 5p / 1.5*2^30
           x[e + 3] = fe_sub_red(x[e + 1], u1, Fr::P3_S1);   // < 8p / 2.5*2^30
           x[e + 1] = fe_add(x[e + 1], u1);                  // < 7p / 2^31
         }
@@ -201,13 +202,13 @@ __global__ void __launch_bounds__(2048 / E, E == 8 ? 2 : 4) k_ntt_pass(pass_args
           fe t = fe_norm(x[4]);                             // trivial pair (0, 4): t < 8p, N
           x[4] = fe_sub_red(x[0], t, Fr::P10_S1);           // < 18p / 2.5*2^30
           x[0] = fe_add(x[0], t);                           // < 16p / 2^31
-          fe u1 = fe_mul<Fr>(w8, x[5]);                     // inputs: limbs <= 2.5*2^30 < 2^31.5
+          fe u1 = fe_mul<Fr, CH>(w8, x[5]);                     // inputs: limbs <= 2.5*2^30 < 2^31.5
           x[5] = fe_sub_red(x[1], u1, Fr::P3_S1);
           x[1] = fe_add(x[1], u1);
-          fe u2 = fe_mul<Fr>(w4, x[6]);
+          fe u2 = fe_mul<Fr, CH>(w4, x[6]);
           x[6] = fe_sub_red(x[2], u2, Fr::P3_S1);
           x[2] = fe_add(x[2], u2);
-          fe u3 = fe_mul<Fr>(w83, x[7]);
+          fe u3 = fe_mul<Fr, CH>(w83, x[7]);
           x[7] = fe_sub_red(x[3], u3, Fr::P3_S1);
           x[3] = fe_add(x[3], u3);
         }
@@ -221,7 +222,7 @@ __global__ void __launch_bounds__(2048 / E, E == 8 ? 2 : 4) k_ntt_pass(pass_args
               if ((e >> u) & 1) continue;          // e is the upper element of a pair
               const int f = e | (1 << u);
               const uint32_t lo_i = pos[e] & ((1u << st) - 1);
-              fe t = fe_mul<Fr>(load_fe9(a.tw_local, lo_i << (B - 1 - st)), x[f]);   // N x (limbs < 2^31.5)
+              fe t = fe_mul<Fr, CH>(load_fe9(a.tw_local, lo_i << (B - 1 - st)), x[f]);   // N x (limbs < 2^31.5)
               x[f] = fe_sub_red(x[e], t, Fr::P3_S1);                                   // x - t + 3p
               x[e] = fe_add(x[e], t);
             }
@@ -247,7 +248,7 @@ __global__ void __launch_bounds__(2048 / E, E == 8 ? 2 : 4) k_ntt_pass(pass_args
     uint32_t w[8];
     if (a.last) {
       if (d >= a.out_len) continue;
-      if (a.out_scale.period) fe_pack(fe_canon_lt2p<Fr>(fe_mul<Fr>(scale_pick(a.out_scale, d), x)), w);
+      if (a.out_scale.period) fe_pack(fe_canon_lt2p<Fr>(fe_mul<Fr, CH>(scale_pick(a.out_scale, d), x)), w);
       else fe_pack(fe_canon_lt3p<Fr>(fe_reduce_soft<Fr>(x)), w);   // x is N-form < 29p after the last round
     } else {
       fe_pack(fe_reduce_soft<Fr>(x), w);         // < 2p + 2^233 < 2^256: fits the 32-byte intermediate format
@@ -496,8 +497,9 @@ int ntt_transform(const uint32_t* d_in, uint32_t in_len, uint32_t in_stride, uin
     HIPCHK(hipGetDevice(&cur_dev));
     std::lock_guard<std::mutex> ag(attr_mu);
     if (!attr_set_dev[cur_dev & 63]) {
-      HIPCHK(hipFuncSetAttribute((const void*)k_ntt_pass<8>, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_LDS_WORDS * 4));
-      HIPCHK(hipFuncSetAttribute((const void*)k_ntt_pass<4>, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_LDS_WORDS * 4));
+      HIPCHK(hipFuncSetAttribute((const void*)k_ntt_pass<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_LDS_WORDS * 4));
+      HIPCHK(hipFuncSetAttribute((const void*)k_ntt_pass<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_LDS_WORDS * 4));
+      HIPCHK(hipFuncSetAttribute((const void*)k_ntt_pass<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_LDS_WORDS * 4));
       attr_set_dev[cur_dev & 63] = true;
     }
   }
@@ -519,8 +521,13 @@ int ntt_transform(const uint32_t* d_in, uint32_t in_len, uint32_t in_stride, uin
     a.src_stride = i == 0 ? in_stride : N;
     a.dst_stride = a.last ? out_stride : N;
     static const int elems = [] { const char* e = getenv("ZKHIP_NTT_ELEMS"); return e && atoi(e) == 8 ? 8 : 4; }();      // A/B knob
-    if (elems == 4 && tile >= 8) hipLaunchKernelGGL(k_ntt_pass<4>, dim3(N / tile, batch), dim3(tile / 4), (size_t)(lds_word_host(tile) + 16) * 4, stream, a);
-    else hipLaunchKernelGGL(k_ntt_pass<8>, dim3(N / tile, batch), dim3(tile / 8), (size_t)(lds_word_host(tile) + 16) * 4, stream, a);
+    // single-chain product columns (fp29.hpp fe_mul<P, CHAIN>: one run of multiply-adds per column instead of the partial sums LLVM's
+    // reassociation makes): with 4 elements per thread (113 VGPRs, 4 waves per SIMD) -3 % at every size (2^24: 2.35 -> 2.27 ms, same box);
+    // with 8 elements per thread it had cost 3.5x in round 1 (register pressure), which is why it was not used here before
+    static const bool chain = getenv("ZKHIP_NTT_PLAIN") == nullptr;       // A/B knob
+    if (elems == 4 && tile >= 8 && chain) hipLaunchKernelGGL((k_ntt_pass<4, true>), dim3(N / tile, batch), dim3(tile / 4), (size_t)(lds_word_host(tile) + 16) * 4, stream, a);
+    else if (elems == 4 && tile >= 8) hipLaunchKernelGGL((k_ntt_pass<4, false>), dim3(N / tile, batch), dim3(tile / 4), (size_t)(lds_word_host(tile) + 16) * 4, stream, a);
+    else hipLaunchKernelGGL((k_ntt_pass<8, false>), dim3(N / tile, batch), dim3(tile / 8), (size_t)(lds_word_host(tile) + 16) * 4, stream, a);
     prof_mark(stream, i == 0 ? "ntt_pass0" : (i == 1 ? "ntt_pass1" : (i == 2 ? "ntt_pass2" : "ntt_pass3")));
   }
   HIPCHK(hipGetLastError());
