@@ -15,6 +15,7 @@
 // back under 2r with one conditional subtraction of 2r.
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include "fp29.hpp"
@@ -157,7 +158,7 @@ __global__ void __launch_bounds__(256) k_row_vm(const vm_launch L) {
     fe t;
     if (op == ZKHIP_OP_MUL || op == ZKHIP_OP_SQR || op == ZKHIP_OP_MAD) {
       const fe b32 = op == ZKHIP_OP_SQR ? vm_times32(a) : vm_fetch<true, R>(L, ob, row, r, prev, xpow);
-      t = fe_mul<Fr>(a, b32);
+      t = fe_mul<Fr, true>(a, b32);      // single-chain product columns (fp29.hpp): -2 % on the wrapper quotient, same box
       if (op == ZKHIP_OP_MAD) t = vm_add(t, vm_fetch<false, R>(L, oc, row, r, prev, xpow));
     } else if (op == ZKHIP_OP_ADD) {
       t = vm_add(a, vm_fetch<false, R>(L, ob, row, r, prev, xpow));
