@@ -163,6 +163,49 @@ def test_two_host_threads_on_two_streams(lib, cref):
     assert len(ok) == 12 and all(ok.values()), ok
 
 
+def test_two_host_threads_share_the_side_stream_of_large_batches(lib, cref):
+    """two host threads, each on its own stream, call the batch entry point with wide-window tables at the same time: both use the
+    library's one side stream (fork / join events are recorded per call under the library lock), and every result must be right"""
+    import torch
+
+    n, batch = 1 << 20, 2
+    errors, ok = [], {}
+    t0m, dm = F.fr_encode([T0])[0], F.fr_encode([D])[0]
+    bases = torch.empty(n * 8, dtype=torch.int64, device="cuda")
+    _lib.check(lib.zkhip_g1_gen_walk_device(t0m.ctypes.data, dm.ctypes.data, n, bases.data_ptr(), None))
+    h = C.c_uint64(0)
+    _lib.check(lib.zkhip_prepare_bases_device(bases.data_ptr(), n, C.byref(h)))
+    assert lib.zkhip_prepared_window_bits(h) > 16
+    torch.cuda.synchronize()
+
+    def work(tid):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for rep in range(3):
+                    vecs = [cref.gen_scalars(9700 + 16 * tid + 2 * rep + i, n, i) for i in range(batch)]
+                    dsc = torch.from_numpy(np.ascontiguousarray(np.stack(vecs)).view(np.int64)).cuda()
+                    out = torch.zeros((batch, 12), dtype=torch.int64, device="cuda")
+                    st.synchronize()
+                    _lib.check(lib.zkhip_msm_g1_prepared_batch_device(h, 0, dsc.data_ptr(), n, batch, n, out.data_ptr(), st.cuda_stream))
+                    st.synchronize()
+                    got = out.cpu().numpy().view(np.uint64)
+                    for i in range(batch):
+                        exp = cref.jac_to_affine(cref.scalar_mul(cref.expected_scalar(vecs[i], T0, D), cref.generator()))
+                        ok[(tid, rep, i)] = bool(np.array_equal(cref.jac_to_affine(np.ascontiguousarray(got[i])), exp))
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    _lib.check(lib.zkhip_release_bases(h))
+    assert not errors, errors
+    assert len(ok) == 12 and all(ok.values()), ok
+
+
 def test_host_calls_overlap_on_lanes(lib, cref):
     """host-buffer calls from four threads: each borrows a lane (two by default), none holds the library lock while it waits for
     the device; all results right"""
