@@ -180,6 +180,8 @@ def main() -> None:
         # windows the library alternates the vectors between the caller's stream and its own side stream, so that one MSM's latency-bound
         # sort and reduction tail run under the other's accumulation.  Beside the headline, which stays one MSM after the other.
         try:
+            if args.no_extras:       # (the profiled command: its kernel statistics should hold single-stream launches only)
+                raise RuntimeError("skipped (--no-extras)")
             kb = 8
             many = d_scalars.reshape(-1, 4).repeat(kb, 1).contiguous()
             outs_b = torch.zeros(kb * 12, dtype=torch.int64, device=dev)
