@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(1024) k_coarse_pass(const int32_t* __restrict_
 
 // Coarse placement with the chunk sorted by group in LDS first (same reasoning as k_fine_sorted below): a workgroup takes
 // COARSE_CHUNK digits of one window, counting-sorts (reference, fine bucket) by group inside LDS and writes each group's run --
-// COARSE_CHUNK / G = 64 entries on average -- as neighbouring words.  LDS: cur[G] | delta[G] | refs[CH] | fines[CH].
+// COARSE_CHUNK / G = 64 entries on average -- as neighbouring words.  LDS: cur[G] | delta[G] | refs[CH] | fines[CH] | mask, wpre [CH / 32].
 constexpr uint32_t COARSE_CHUNK = 8192;
 __global__ void __launch_bounds__(1024) k_coarse_sorted(const int32_t* __restrict__ digits, uint32_t n_pad, uint32_t* __restrict__ gcursor,
                                                         uint32_t* __restrict__ stage_ref, uint16_t* __restrict__ stage_fine,
@@ -269,10 +269,12 @@ __global__ void __launch_bounds__(1024) k_coarse_sorted(const int32_t* __restric
   __shared__ uint32_t cur[MAX_GROUPS], delta[MAX_GROUPS];
   __shared__ uint32_t refs[COARSE_CHUNK];
   __shared__ uint16_t fines[COARSE_CHUNK];
+  __shared__ uint32_t mask[COARSE_CHUNK / 32], wpre[COARSE_CHUNK / 32];      // run-start bits of the sorted chunk and their word prefixes
   const int win = blockIdx.y;
   const uint32_t lo = blockIdx.x * COARSE_CHUNK, hi = min(n_pad, lo + COARSE_CHUNK);   // multiples of 8
   if (lo >= hi) return;
   if (threadIdx.x < MAX_GROUPS) cur[threadIdx.x] = 0;
+  if (threadIdx.x < COARSE_CHUNK / 32) mask[threadIdx.x] = 0;
   __syncthreads();
   const uint4* dv = reinterpret_cast<const uint4*>(digits + (size_t)win * n_pad);
   const uint32_t v_lo = lo >> 2, v_hi = hi >> 2;
@@ -297,7 +299,33 @@ __global__ void __launch_bounds__(1024) k_coarse_sorted(const int32_t* __restric
     const uint32_t l0 = x - s, l1 = l0 + c0;
     const uint32_t g0 = c0 ? atomicAdd(&gcursor[2 * threadIdx.x], c0) : 0u, g1 = c1 ? atomicAdd(&gcursor[2 * threadIdx.x + 1], c1) : 0u;
     cur[2 * threadIdx.x] = l0; cur[2 * threadIdx.x + 1] = l1;
-    delta[2 * threadIdx.x] = g0 - l0; delta[2 * threadIdx.x + 1] = g1 - l1;
+    // the way out without a search (as in k_fine_sorted): run-start bits, word prefixes, and delta indexed by a run's rank among the
+    // non-empty groups
+    const uint32_t nz = (c0 != 0) + (c1 != 0);
+    uint32_t y = nz;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(y, off, 64);
+      if ((int)threadIdx.x >= off) y += t;
+    }
+    uint32_t rank = y - nz;
+    if (c0) { delta[rank++] = g0 - l0; atomicOr(&mask[l0 >> 5], 1u << (l0 & 31)); }
+    if (c1) { delta[rank] = g1 - l1; atomicOr(&mask[l1 >> 5], 1u << (l1 & 31)); }
+    // word prefixes of the 256 mask words, four per lane (LDS operations of one wavefront complete in order: the bits are set; the
+    // fence keeps the compiler from moving the reads above the atomics)
+    __threadfence_block();
+    uint32_t pc[4], ps = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { pc[k] = (uint32_t)__popc(mask[4 * threadIdx.x + k]); ps += pc[k]; }
+    uint32_t z = ps;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(z, off, 64);
+      if ((int)threadIdx.x >= off) z += t;
+    }
+    uint32_t zb = z - ps;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { wpre[4 * threadIdx.x + k] = zb; zb += pc[k]; }
   }
   __syncthreads();
   const uint32_t rbase = ref_base + (uint32_t)win * ref_stride;
@@ -318,19 +346,14 @@ __global__ void __launch_bounds__(1024) k_coarse_sorted(const int32_t* __restric
   __syncthreads();
   const uint32_t total = cur[MAX_GROUPS - 1];                  // cur[g] = end of group g's run
   for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) {
-    uint32_t glo = 0, ghi = MAX_GROUPS - 1;
-    while (glo < ghi) { const uint32_t mid = (glo + ghi) >> 1; if (cur[mid] > i) ghi = mid; else glo = mid + 1; }
-    const uint32_t pos = delta[glo] + i;
+    const uint32_t r = wpre[i >> 5] + (uint32_t)__popc(mask[i >> 5] & ((2u << (i & 31)) - 1u)) - 1u;      // rank of the run position i lies in
+    const uint32_t pos = delta[r] + i;
     stage_ref[pos] = refs[i];
     stage_fine[pos] = fines[i];
   }
 }
 
 constexpr uint32_t SORT_CHUNK = 28672;   // entries per workgroup of the sorted fine scatter: 112 KiB of references in LDS
-// second shape for small groups (< 2^17 staged entries per group, i.e. 2^20 points): 20 Ki references + their 16-bit bucket ids
-// (120 KiB), no search on the way out.  Measured: 2^20 scatter 0.152 -> 0.110 ms; 2^21 0.240 -> 0.262, 2^22 0.509 -> 0.524 (shorter
-// runs, more reservations), so only the smallest wide-window size uses it.
-constexpr uint32_t SORT_CHUNK_IDS = 20480;
 
 // goff[g] = start of group g in the staging array (exclusive scan of the group counts), gcursor = copy; cstart[g] = index of the
 // group's first SORT_CHUNK-sized chunk in the numbering of k_fine_sorted's workgroups
@@ -359,15 +382,15 @@ __global__ void __launch_bounds__(64) k_group_offsets(const uint32_t* __restrict
 // owns SORT_CHUNK staged entries of one group of 2^FINE_BITS buckets, counting-sorts their references by bucket inside LDS, and
 // writes bucket runs: neighbouring lanes store neighbouring words (~7 entries per bucket and chunk).
 //   LDS: cur[FB] (histogram -> run starts -> run ends) | delta[FB] (global slot of a run minus its LDS position) | refs[SORT_CHUNK]
-// IDS: the second shape for small groups (SORT_CHUNK_IDS above): every sorted entry's 16-bit bucket id stays in LDS next to its
-// reference, so the way out is one lookup instead of a 12-step search over the run ends.
-template <bool IDS>
+//        | run-start bit mask and its word prefixes (SORT_CHUNK / 16 words)
+// (A second shape that kept every entry's 16-bit bucket id in LDS -- 20 Ki entries per chunk -- served the smallest wide size until the
+// rank structure below made the way out three reads for any chunk: 2^20 scatter 0.110 -> 0.101 ms, and the variant was removed.)
 __global__ void __launch_bounds__(1024) k_fine_sorted(const uint16_t* __restrict__ stage_fine, const uint32_t* __restrict__ stage_ref,
                                                       const uint32_t* __restrict__ goff, const uint32_t* __restrict__ cstart, int G,
                                                       uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
   extern __shared__ uint32_t hist[];
   constexpr uint32_t FB = 1u << FINE_BITS;
-  constexpr uint32_t CHUNK = IDS ? SORT_CHUNK_IDS : SORT_CHUNK;
+  constexpr uint32_t CHUNK = SORT_CHUNK;
   static_assert(FB == 4096, "one thread owns four buckets in the scan");
   __shared__ uint32_t wsum[16];
   uint32_t* cur = hist;
@@ -406,26 +429,60 @@ __global__ void __launch_bounds__(1024) k_fine_sorted(const uint16_t* __restrict
   for (int k = 0; k < 4; k++) { l[k] = run; run += c[k]; }
 #pragma unroll
   for (int k = 0; k < 4; k++) gb[k] = c[k] ? atomicAdd(&gl[4 * threadIdx.x + k], c[k]) : 0u;      // reserve the runs' slots
+  {
+    // Way out without a search: a bit per sorted position marks the run starts, wpre[w] counts the starts before 32-position word w, and
+    // delta is indexed by a run's RANK among the non-empty buckets -- entry i then finds its slot with three LDS reads (mask word and
+    // word prefix, then delta) where a binary search over the 4096 run ends took twelve dependent ones (30 % of this kernel at 2^22).
+    uint32_t* mask = refs + CHUNK;                             // CHUNK / 32 words
+    uint32_t* wpre = mask + CHUNK / 32;                        // CHUNK / 32 words
+    const uint32_t nz = (c[0] != 0) + (c[1] != 0) + (c[2] != 0) + (c[3] != 0);
+    uint32_t y = nz;                                           // rank of this thread's first non-empty bucket: a second scan, same shape
 #pragma unroll
-  for (int k = 0; k < 4; k++) { cur[4 * threadIdx.x + k] = l[k]; delta[4 * threadIdx.x + k] = gb[k] - l[k]; }
-  __syncthreads();
-  if constexpr (IDS) {
-    uint16_t* ids = reinterpret_cast<uint16_t*>(refs + CHUNK);
-    for (uint32_t p = start + threadIdx.x; p < end; p += blockDim.x) {
-      const uint32_t f = stage_fine[p], pos = atomicAdd(&cur[f], 1u);
-      refs[pos] = stage_ref[p];
-      ids[pos] = (uint16_t)f;
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(y, off, 64);
+      if (lane >= off) y += t;
+    }
+    __syncthreads();                                           // wsum is read by everyone above
+    if (lane == 63) wsum[wave] = y;
+    for (uint32_t w2 = threadIdx.x; w2 < CHUNK / 32; w2 += blockDim.x) mask[w2] = 0;
+    __syncthreads();
+    uint32_t rank = y - nz;
+#pragma unroll
+    for (int i = 0; i < 16; i++) if (i < wave) rank += wsum[i];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      cur[4 * threadIdx.x + k] = l[k];
+      if (c[k]) {
+        delta[rank++] = gb[k] - l[k];
+        atomicOr(&mask[l[k] >> 5], 1u << (l[k] & 31));
+      }
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < cnt_n; i += blockDim.x) sorted[delta[ids[i]] + i] = refs[i];
-  } else {
+    // word prefixes: CHUNK / 32 = 896 <= 1024 words, one per thread
+    const uint32_t pc = threadIdx.x < CHUNK / 32 ? (uint32_t)__popc(mask[threadIdx.x]) : 0u;
+    uint32_t z = pc;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(z, off, 64);
+      if (lane >= off) z += t;
+    }
+    __syncthreads();
+    if (lane == 63) wsum[wave] = z;
+    __syncthreads();
+    uint32_t zb = z - pc;
+#pragma unroll
+    for (int i = 0; i < 16; i++) if (i < wave) zb += wsum[i];
+    if (threadIdx.x < CHUNK / 32) wpre[threadIdx.x] = zb;
+  }
+  __syncthreads();
+  {
     for (uint32_t p = start + threadIdx.x; p < end; p += blockDim.x) refs[atomicAdd(&cur[stage_fine[p]], 1u)] = stage_ref[p];
     __syncthreads();
-    // cur[b] is now the end of bucket b's run; entry i belongs to the first bucket whose run ends after i
+    const uint32_t* mask = refs + CHUNK;
+    const uint32_t* wpre = mask + CHUNK / 32;
     for (uint32_t i = threadIdx.x; i < cnt_n; i += blockDim.x) {
-      uint32_t lo = 0, hi = FB - 1;                             // invariant: answer in [lo, hi]; 12 LDS reads (a proportional first guess
-      while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (cur[mid] > i) hi = mid; else lo = mid + 1; }   // with linear probing measured slower)
-      sorted[delta[lo] + i] = refs[i];
+      const uint32_t r = wpre[i >> 5] + (uint32_t)__popc(mask[i >> 5] & ((2u << (i & 31)) - 1u)) - 1u;     // rank of the run position i lies in
+      sorted[delta[r] + i] = refs[i];
     }
   }
 }
@@ -1252,13 +1309,11 @@ int msm_build_tasks(const uint32_t* d_scalars, size_t n, size_t batch, size_t sc
   if (!attr_set) {
     HIPCHK(hipFuncSetAttribute((const void*)k_sort_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)k_sort_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void*)k_fine_sorted<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * (1 << FINE_BITS) + SORT_CHUNK) * 4));
-    HIPCHK(hipFuncSetAttribute((const void*)k_fine_sorted<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * (1 << FINE_BITS) + SORT_CHUNK_IDS) * 4 + SORT_CHUNK_IDS * 2));
+    HIPCHK(hipFuncSetAttribute((const void*)k_fine_sorted, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * (1 << FINE_BITS) + SORT_CHUNK + SORT_CHUNK / 16) * 4));
     attr_set = true;
   }
   const int G = wide ? (int)(B >> FINE_BITS) : 1;                      // coarse groups
-  const bool sort_ids = (size_t)W * n < ((size_t)G << 17);           // fewer than 2^17 staged entries per group on average
-  const uint32_t sort_chunk = sort_ids ? SORT_CHUNK_IDS : SORT_CHUNK;
+  const uint32_t sort_chunk = SORT_CHUNK;
   const uint32_t sort_chunks = (uint32_t)(((size_t)W * n + sort_chunk - 1) / sort_chunk) + (uint32_t)G;     // upper bound of the fine passes' chunks; surplus workgroups return at once
   const uint32_t wb_stride = shared_buckets ? 0u : B;
   if (wide) {
@@ -1287,10 +1342,8 @@ int msm_build_tasks(const uint32_t* d_scalars, size_t n, size_t batch, size_t sc
   prof_mark(stream, "scan");
   // 4. scatter
   if (wide) {
-    if (sort_ids) hipLaunchKernelGGL(k_fine_sorted<true>, dim3(sort_chunks), dim3(1024), (size_t)(2u * (1u << FINE_BITS) + SORT_CHUNK_IDS) * 4 + SORT_CHUNK_IDS * 2, stream,
-                                     stage_fine, stage_ref, gcounters + 128, gcounters + 512, G, cursor, sorted);
-    else hipLaunchKernelGGL(k_fine_sorted<false>, dim3(sort_chunks), dim3(1024), (size_t)(2u * (1u << FINE_BITS) + SORT_CHUNK) * 4, stream, stage_fine, stage_ref,
-                            gcounters + 128, gcounters + 512, G, cursor, sorted);
+    hipLaunchKernelGGL(k_fine_sorted, dim3(sort_chunks), dim3(1024), (size_t)(2u * (1u << FINE_BITS) + SORT_CHUNK + SORT_CHUNK / 16) * 4, stream, stage_fine, stage_ref,
+                       gcounters + 128, gcounters + 512, G, cursor, sorted);
   }
   else hipLaunchKernelGGL(k_sort_pass<true>, dim3(chunks, W, K), dim3(1024), lds, stream, (const int16_t*)digits, n_pad, chunk, c, cursor, sorted, wb_stride, ref_base, ref_stride);
   prof_mark(stream, "scatter");
