@@ -511,7 +511,7 @@ __global__ void __launch_bounds__(1024) k_fine_count(const uint16_t* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-// 3. exclusive scan of u32 (three small kernels).  MODE 0: identity, MODE 1: ceil(x / 2^task_shift)
+// 3. exclusive scans of the bucket counts (three small kernels).  MODE 0: identity, MODE 1: ceil(x / 2^task_shift)
 // ------------------------------------------------------------------------------------------------
 constexpr int SCAN_BLOCK = 256, SCAN_PER_THREAD = 16, SCAN_TILE = SCAN_BLOCK * SCAN_PER_THREAD;
 
@@ -543,52 +543,55 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* l
   return base + x - v;
 }
 
-template <int MODE>
-__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_sums(const uint32_t* __restrict__ in, uint32_t n,
-                                                          uint32_t* __restrict__ block_sums, uint32_t task_shift) {
+// Both scans of the bucket counts in one pass (bucket sets above SCAN_SINGLE_MAX): the offsets (MODE 0) and the task offsets (MODE 1:
+// ceil(count / 2^task_shift)) read the same array, and the second scan's three launches (~5 us each, 1 % of a 2^20 MSM) disappear.
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_sums2(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ sums0,
+                                                           uint32_t* __restrict__ sums1, uint32_t task_shift) {
   __shared__ uint32_t lds[4];
-  uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
-  uint32_t s = 0;
+  const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
+  uint32_t s0 = 0, s1 = 0;
 #pragma unroll
-  for (int i = 0; i < SCAN_PER_THREAD; i++) if (base + i < n) s += scan_xform<MODE>(in[base + i], task_shift);
-  uint32_t total;
-  block_exclusive_scan(s, lds, total);
-  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+  for (int i = 0; i < SCAN_PER_THREAD; i++) if (base + i < n) { const uint32_t v = in[base + i]; s0 += v; s1 += scan_xform<1>(v, task_shift); }
+  uint32_t t0, t1;
+  block_exclusive_scan(s0, lds, t0);
+  block_exclusive_scan(s1, lds, t1);
+  if (threadIdx.x == 0) { sums0[blockIdx.x] = t0; sums1[blockIdx.x] = t1; }
 }
 
-__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_top(uint32_t* __restrict__ block_sums, uint32_t nb,
-                                                         uint32_t* __restrict__ total_out) {
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_top2(uint32_t* __restrict__ sums0, uint32_t* __restrict__ sums1, uint32_t nb,
+                                                          uint32_t* __restrict__ total0, uint32_t* __restrict__ total1) {
   __shared__ uint32_t lds[4];
-  uint32_t running = 0;
+  uint32_t run0 = 0, run1 = 0;
   for (uint32_t base = 0; base < nb; base += SCAN_BLOCK) {
-    uint32_t i = base + threadIdx.x;
-    uint32_t v = i < nb ? block_sums[i] : 0, total;
-    uint32_t ex = block_exclusive_scan(v, lds, total);
-    if (i < nb) block_sums[i] = running + ex;
-    running += total;
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v0 = i < nb ? sums0[i] : 0, v1 = i < nb ? sums1[i] : 0;
+    uint32_t t0, t1;
+    const uint32_t e0 = block_exclusive_scan(v0, lds, t0), e1 = block_exclusive_scan(v1, lds, t1);
+    if (i < nb) { sums0[i] = run0 + e0; sums1[i] = run1 + e1; }
+    run0 += t0; run1 += t1;
   }
-  if (threadIdx.x == 0) *total_out = running;
+  if (threadIdx.x == 0) { *total0 = run0; *total1 = run1; }
 }
 
-// out[i] = exclusive prefix; out2 (optional) gets a copy (used as the scatter cursor); out[n] = total
-template <int MODE>
-__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply(const uint32_t* __restrict__ in, uint32_t n,
-                                                           const uint32_t* __restrict__ block_sums,
-                                                           const uint32_t* __restrict__ total,
-                                                           uint32_t* __restrict__ out, uint32_t* __restrict__ out2, uint32_t task_shift) {
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply2(const uint32_t* __restrict__ in, uint32_t n, const uint32_t* __restrict__ sums0,
+                                                            const uint32_t* __restrict__ sums1, const uint32_t* __restrict__ total0,
+                                                            const uint32_t* __restrict__ total1, uint32_t* __restrict__ offset,
+                                                            uint32_t* __restrict__ cursor, uint32_t* __restrict__ task_off, uint32_t task_shift) {
   __shared__ uint32_t lds[4];
-  uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
-  uint32_t v[SCAN_PER_THREAD], s = 0;
+  const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_THREAD;
+  uint32_t v[SCAN_PER_THREAD], s0 = 0, s1 = 0;
 #pragma unroll
-  for (int i = 0; i < SCAN_PER_THREAD; i++) { v[i] = base + i < n ? scan_xform<MODE>(in[base + i], task_shift) : 0; s += v[i]; }
-  uint32_t tot;
-  uint32_t ex = block_exclusive_scan(s, lds, tot) + block_sums[blockIdx.x];
+  for (int i = 0; i < SCAN_PER_THREAD; i++) { v[i] = base + i < n ? in[base + i] : 0; s0 += v[i]; s1 += scan_xform<1>(v[i], task_shift); }
+  uint32_t t0, t1;
+  uint32_t e0 = block_exclusive_scan(s0, lds, t0) + sums0[blockIdx.x];
+  uint32_t e1 = block_exclusive_scan(s1, lds, t1) + sums1[blockIdx.x];
 #pragma unroll
   for (int i = 0; i < SCAN_PER_THREAD; i++) {
-    if (base + i < n) { out[base + i] = ex; if (out2) out2[base + i] = ex; }
-    ex += v[i];
+    if (base + i < n) { offset[base + i] = e0; cursor[base + i] = e0; task_off[base + i] = e1; }
+    e0 += v[i];
+    e1 += scan_xform<1>(v[i], task_shift);
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = *total;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { offset[n] = *total0; task_off[n] = *total1; }
 }
 
 // The same scan as ONE workgroup, for up to SCAN_SINGLE_MAX values = one tile of 1024 threads x 8 (bucket sets of c <= 14: the
@@ -1335,9 +1338,9 @@ int msm_build_tasks(const uint32_t* d_scalars, size_t n, size_t batch, size_t sc
   if (scan_single) {
     hipLaunchKernelGGL(k_scan_single<0>, dim3(1), dim3(1024), 0, stream, count, (uint32_t)NB, counters + 0, offset, cursor, 0u, (uint32_t*)nullptr);
   } else {
-    hipLaunchKernelGGL(k_scan_sums<0>, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, count, NB, bsum1, 0u);
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_BLOCK), 0, stream, bsum1, nblk, counters + 0);
-    hipLaunchKernelGGL(k_scan_apply<0>, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, count, NB, bsum1, counters + 0, offset, cursor, 0u);
+    hipLaunchKernelGGL(k_scan_sums2, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, count, NB, bsum1, bsum2, task_shift);
+    hipLaunchKernelGGL(k_scan_top2, dim3(1), dim3(SCAN_BLOCK), 0, stream, bsum1, bsum2, nblk, counters + 0, counters + 1);
+    hipLaunchKernelGGL(k_scan_apply2, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, count, NB, bsum1, bsum2, counters + 0, counters + 1, offset, cursor, task_off, task_shift);
   }
   prof_mark(stream, "scan");
   // 4. scatter
@@ -1354,9 +1357,7 @@ int msm_build_tasks(const uint32_t* d_scalars, size_t n, size_t batch, size_t sc
     hipLaunchKernelGGL(k_make_tasks, dim3(task_blocks), dim3(256), 0, stream, offset, task_off, NB, tasks, task_shift, counters + 2, (uint32_t*)nullptr, lay.seq_parts,
                        counters + 3, lay.heavy, lay.heavy_cap);
   } else {
-    hipLaunchKernelGGL(k_scan_sums<1>, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, count, NB, bsum2, task_shift);
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_BLOCK), 0, stream, bsum2, nblk, counters + 1);
-    hipLaunchKernelGGL(k_scan_apply<1>, dim3(nblk), dim3(SCAN_BLOCK), 0, stream, count, NB, bsum2, counters + 1, task_off, (uint32_t*)nullptr, task_shift);
+    // (the task offsets came out of the dual scan of step 3)
     hipLaunchKernelGGL(k_make_tasks, dim3(task_blocks), dim3(256), 0, stream, offset, task_off, NB, tasks, task_shift, counters + 2, counters + 32, lay.seq_parts,
                        counters + 3, lay.heavy, lay.heavy_cap);
     hipLaunchKernelGGL(k_order_offsets, dim3(1), dim3(64), 0, stream, counters + 32, counters + 192);
