@@ -216,7 +216,10 @@ int zkhip_msm_g1_prepared_device(uint64_t handle, size_t offset, const void *d_s
 int zkhip_msm_g1_registered_device(const uint64_t *bases, const void *d_scalars, size_t n, void *d_out_xyz, void *stream);
 /* `batch` scalar vectors (vector k at d_scalars + k * scalar_stride elements) against the same prepared bases in one launch
  * set -- e.g. all advice columns of a circuit: small MSMs (k = 13..17) then run at large-MSM throughput.  d_out_xyz: batch
- * Jacobian results, 96 bytes each. */
+ * Jacobian results, 96 bytes each.  Tables with wide windows (n >= 2^20) do not share a launch set; their vectors run alternately
+ * on `stream` and on a high-priority stream the library owns (forked from and joined to `stream` with events), so that one MSM's
+ * latency-bound sort and reduction tail run under the next one's accumulation: all results are complete once `stream` has
+ * drained, as for any other `_device` call. */
 int zkhip_msm_g1_prepared_batch_device(uint64_t handle, size_t offset, const void *d_scalars, size_t n, size_t batch, size_t scalar_stride,
                                        void *d_out_xyz, void *stream);
 /* window-size override for experiments (0 = automatic) */
