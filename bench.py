@@ -583,7 +583,7 @@ def extras(lib, _lib, F, torch, dev, stream) -> dict:
         d_s2 = torch.from_numpy(synth_scalars(n2, 4242).view(np.int64)).to(dev)
         d_o2 = torch.zeros(24, dtype=torch.int64, device=dev)
         ms_g2 = timed(lambda: _lib.check(lib.zkhip_msm_g2_device(d_s2.data_ptr(), d_b2.data_ptr(), n2, d_o2.data_ptr(), stream)), 3)
-        out["msm_g2_2^16"] = {"ms": round(ms_g2, 3), "Mpoints_per_s": round(n2 / ms_g2 / 1e3, 2), "note": "general path, single-lane Fq2 arithmetic; not on the prover's path"}
+        out["msm_g2_2^16"] = {"ms": round(ms_g2, 3), "Mpoints_per_s": round(n2 / ms_g2 / 1e3, 2), "note": "general path; not on the prover's path"}
         del d_b2, d_s2
     except Exception as exc:   # an extra: never fail the bench line
         out["msm_g2_2^16"] = {"error": repr(exc)}

@@ -43,6 +43,24 @@ def test_g2_point_ops_vs_oracle(lib):
         assert [dec(r) for r in out] == [f(P, Q) for P, Q in zip(Pa, Pb)], op
 
 
+def test_g2_quad_cooperative_point_ops_vs_oracle(lib):
+    """the quad formulas (csrc/ec2_quad.hpp: four lanes share every Fq2 product) that the G2 MSM's combine / pyramid / window-sum / fold
+    kernels use: 2 a + b and 4 a against the oracle, incl. identities, 2 a = b (the doubling case inside the addition) and 2 a = -b"""
+    g = O.SplitMix64(78)
+    n = 40
+    Pa = [O.g2_scalar_mul(g.fr(), O.G2_GEN) for _ in range(n)]
+    Pb = [O.g2_scalar_mul(g.fr(), O.G2_GEN) for _ in range(n)]
+    Pa[3] = None; Pb[4] = None; Pa[5] = None; Pb[5] = None
+    Pb[6] = O.g2_add(Pa[6], Pa[6])                                            # 2 a + b with b = 2 a: equal points
+    Pb[7] = O.g2_neg(O.g2_add(Pa[7], Pa[7]))                                  # b = -2 a: the sum is the identity
+    a, b = enc(Pa), enc(Pb)
+    dbl = lambda P: O.g2_add(P, P)
+    for op, f in ((3, lambda P, Q: O.g2_add(dbl(P), Q)), (4, lambda P, Q: dbl(dbl(P)))):
+        out = np.zeros((n, 24), dtype=np.uint64)
+        _lib.check(lib.zkhip_test_g2_op(op, a.ctypes.data, b.ctypes.data, out.ctypes.data, n))
+        assert [dec(r) for r in out] == [f(P, Q) for P, Q in zip(Pa, Pb)], op
+
+
 @pytest.mark.parametrize("n", [0, 1, 2, 3, 33, 257])
 def test_g2_msm_vs_naive_oracle(lib, n):
     g = O.SplitMix64(500 + n)

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include "ec2.hpp"
+#include "ec2_quad.hpp"
 #include "zkhip_internal.hpp"
 
 namespace zkhip {
@@ -54,7 +55,8 @@ __device__ __forceinline__ xyzz2 xyzz2_shfl_xor(const xyzz2& a, int mask) {
 
 // 8 adjacent lanes per bucket: lane q sums the task partials q, q + 8, ..., three xor-shuffle steps add the lane sums (a bucket with a
 // single task was written by k2_accumulate).  A short top window puts thousands of entries into a handful of buckets: with one thread
-// per bucket their partials were a chain of 256 dependent additions (5 ms of a 19 ms MSM at 2^16).
+// per bucket their partials were a chain of 256 dependent additions (5 ms of a 19 ms MSM at 2^16).  (Quads instead of lanes were
+// measured slower here: 2^19 buckets x 32 lanes is throughput, not latency.)
 __global__ void __launch_bounds__(64) k2_combine(const uint32_t* __restrict__ task_off, uint32_t nbuckets, const uint32_t* __restrict__ partials,
                                                  uint32_t* __restrict__ buckets) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -95,46 +97,87 @@ __global__ void __launch_bounds__(64) k2_pyramid_step(const uint32_t* __restrict
   store_xyzz2(wo, tid, xyzz2_add(load_xyzz2(wi, ia), load_xyzz2(wi, ib)));
 }
 
+// the same step with one quad per addition, for steps far smaller than the chip (their time is the latency of one addition)
+__global__ void __launch_bounds__(64) k2_pyramid_step_quad(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t N, int s, uint32_t in_stride,
+                                                           uint32_t out_stride) {
+  const uint32_t per_win = N / 2 + (uint32_t)s * (N / 4);
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t tid = gid >> 2, q = gid & 3;
+  if (tid >= per_win) return;                     // whole quads leave together
+  const int win = blockIdx.y;
+  const uint32_t* wi = in + (size_t)win * in_stride * 72;
+  uint32_t* wo = out + (size_t)win * out_stride * 72;
+  uint32_t ia, ib;
+  if (tid < N / 2) {
+    ia = 2 * tid; ib = 2 * tid + 1;
+  } else {
+    const uint32_t r = tid - N / 2, l = r / (N / 4), u = r % (N / 4);
+    if ((int)l == s - 1) { ia = 4 * u + 1; ib = 4 * u + 3; }
+    else { ia = N + l * (N / 2) + 2 * u; ib = ia + 1; }
+  }
+  const xyzz2 r = xyzz2_add_quad(load_xyzz2(wi, ia), load_xyzz2(wi, ib), q);
+  if (q == 0) store_xyzz2(wo, tid, r);
+}
+
 // window sum = X0 + X1 + sum_l 2^l Z^l + 2^nz X1 (state after the last pyramid step: X has 2 elements, Z^0 .. Z^(nz-1) one each).
 // One 32-lane group per window, a shuffle tree over the terms (nz + 2 <= 32).
-__global__ void __launch_bounds__(64) k2_window_sum(const uint32_t* __restrict__ in, uint32_t in_stride, int nz, uint32_t* __restrict__ winsum, int W) {
-  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int win = gid >> 5, lane = gid & 31;
+__global__ void __launch_bounds__(128) k2_window_sum(const uint32_t* __restrict__ in, uint32_t in_stride, int nz, uint32_t* __restrict__ winsum, int W) {
+  // one quad per term (32 terms, two wavefronts) per window; doubling chains and the addition tree on the quad formulas; the two
+  // wavefronts meet through LDS for the last addition
+  __shared__ __attribute__((aligned(16))) uint32_t xch[72];
+  const int win = blockIdx.x, term = threadIdx.x >> 2;
+  const uint32_t q = threadIdx.x & 3;
+  const uint32_t* wi = in + (size_t)win * in_stride * 72;
   xyzz2 acc = xyzz2_identity();
-  if (win < W) {
-    const uint32_t* wi = in + (size_t)win * in_stride * 72;
-    int dbl = 0;
-    if (lane < nz) { acc = load_xyzz2(wi, 2 + lane); dbl = lane; }
-    else if (lane == nz) { acc = load_xyzz2(wi, 1); dbl = nz; }
-    else if (lane == nz + 1) acc = xyzz2_add(load_xyzz2(wi, 0), load_xyzz2(wi, 1));
+  int dbl = 0;
+  if (term < nz) { acc = load_xyzz2(wi, 2 + term); dbl = term; }
+  else if (term == nz) { acc = load_xyzz2(wi, 1); dbl = nz; }
+  else if (term == nz + 1) acc = xyzz2_add_quad(load_xyzz2(wi, 0), load_xyzz2(wi, 1), q);
 #pragma unroll 1
-    for (int i = 0; i < dbl; i++) acc = xyzz2_dbl(acc);
+  for (int i = 0; i < dbl; i++) acc = xyzz2_dbl_quad(acc, q);
+#pragma unroll 1
+  for (int mask = 4; mask < 64; mask <<= 1) acc = xyzz2_add_quad(acc, xyzz2_shfl_xor(acc, mask), q);
+  if (threadIdx.x == 64) store_xyzz2(xch, 0, acc);      // sum of terms 16..31
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    acc = xyzz2_add_quad(acc, load_xyzz2(xch, 0), q);
+    if (q == 0) store_xyzz2(winsum, win, acc);
   }
-#pragma unroll 1
-  for (int mask = 1; mask < 32; mask <<= 1) acc = xyzz2_add(acc, xyzz2_shfl_xor(acc, mask));
-  if (win < W && lane == 0) store_xyzz2(winsum, win, acc);
 }
 
 // result = sum_w 2^(c w) winsum[w], written as a Jacobian G2 point (48 words)
 __global__ void __launch_bounds__(64) k2_fold(const uint32_t* __restrict__ winsum, int W, int c, uint32_t* __restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  // One thread's work is uniform, and left to itself the compiler moves ALL of it to the scalar unit (no 32 x 32 -> 64 multiply-add
-  // there: a doubling then takes ~48 us and this fold 12 ms of a 19 ms MSM).  An opaque zero in a vector register keeps the addresses,
-  // and with them the arithmetic, on the vector unit.
-  uint32_t vz;
-  asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
-  const uint32_t* ws = winsum + vz;
-  xyzz2 acc = load_xyzz2(ws, W - 1);
+  // one quad: c (W - 1) dependent doublings are the whole cost.  (As one thread this was uniform work, which the compiler moved to the
+  // scalar unit -- no 32 x 32 -> 64 multiply-add there: 48 us per doubling, 12 ms of a 19 ms MSM; kept on the vector unit 20 us; on the
+  // quad formulas ~8 us.)
+  if (threadIdx.x >= 4 || blockIdx.x != 0) return;
+  const uint32_t q = threadIdx.x;
+  xyzz2 acc = load_xyzz2(winsum, W - 1);
   for (int w = W - 2; w >= 0; w--) {
 #pragma unroll 1
-    for (int i = 0; i < c; i++) acc = xyzz2_dbl(acc);
-    acc = xyzz2_add(acc, load_xyzz2(ws, w));
+    for (int i = 0; i < c; i++) acc = xyzz2_dbl_quad(acc, q);
+    acc = xyzz2_add_quad(acc, load_xyzz2(winsum, w), q);
   }
-  store_jacobian2(acc, out);
+  if (q == 0) store_jacobian2(acc, out);
 }
 
 __global__ void __launch_bounds__(64) k2_store_identity(uint32_t* __restrict__ out) {
   if (threadIdx.x == 0 && blockIdx.x == 0) store_jacobian2(xyzz2_identity(), out);
+}
+
+// parity hook for the quad formulas: out[i] = a[i] + b[i] (op 3), 2 a[i] (op 4); four lanes per row
+__global__ void __launch_bounds__(64) k2_test_op_quad(int op, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint32_t* __restrict__ out, size_t n) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = gid >> 2;
+  const uint32_t q = (uint32_t)(gid & 3);
+  if (i >= n) return;
+  const affine2_words pa = load_affine2(a, i), pb = load_affine2(b, i);
+  xyzz2 A = xyzz2_identity(), B = xyzz2_identity();
+  fe2 x, y;
+  if (!affine2_is_identity(pa)) { affine2_coords(pa, false, x, y); xyzz2_madd(A, x, y); A = xyzz2_dbl(A); }     // (a general representative: 2 a[i])
+  if (!affine2_is_identity(pb)) { affine2_coords(pb, false, x, y); xyzz2_madd(B, x, y); }
+  const xyzz2 r = op == 4 ? xyzz2_dbl_quad(A, q) : xyzz2_add_quad(A, B, q);      // 4 a[i]  /  2 a[i] + b[i]
+  if (q == 0) store_jacobian2(r, out + i * 48);
 }
 
 // parity hook: out[i] = a[i] + b[i] (op 0), 2 a[i] (op 1), a[i] - b[i] (op 2) as Jacobian G2 points
@@ -196,7 +239,8 @@ int msm_g2_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   int s = 1;
   while (N > 2) {
     const uint32_t per_win = N / 2 + (uint32_t)s * (N / 4);
-    hipLaunchKernelGGL(k2_pyramid_step, dim3((per_win + 63) / 64, tv.WB), dim3(64), 0, stream, cur, nxt, N, s, in_stride, per_win);
+    if ((size_t)per_win * tv.WB <= 32768) hipLaunchKernelGGL(k2_pyramid_step_quad, dim3((4 * per_win + 63) / 64, tv.WB), dim3(64), 0, stream, cur, nxt, N, s, in_stride, per_win);
+    else hipLaunchKernelGGL(k2_pyramid_step, dim3((per_win + 63) / 64, tv.WB), dim3(64), 0, stream, cur, nxt, N, s, in_stride, per_win);
     uint32_t* t = cur; cur = nxt; nxt = t;
     in_stride = per_win;
     N >>= 1;
@@ -204,7 +248,7 @@ int msm_g2_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   }
   const int nz = s - 1;
   prof_mark(stream, "pyramid_g2");
-  hipLaunchKernelGGL(k2_window_sum, dim3((tv.WB * 32 + 63) / 64), dim3(64), 0, stream, cur, in_stride, nz, tv.winsum, tv.WB);
+  hipLaunchKernelGGL(k2_window_sum, dim3(tv.WB), dim3(128), 0, stream, cur, in_stride, nz, tv.winsum, tv.WB);
   hipLaunchKernelGGL(k2_fold, dim3(1), dim3(64), 0, stream, tv.winsum, tv.WB, c, d_out);
   prof_mark(stream, "fold_g2");
   HIPCHK(hipGetLastError());
@@ -213,7 +257,8 @@ int msm_g2_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
 
 int test_g2_op(int op, const uint32_t* d_a, const uint32_t* d_b, uint32_t* d_out, size_t n, hipStream_t stream) {
   if (n == 0) return ZKHIP_OK;
-  hipLaunchKernelGGL(k2_test_op, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, op, d_a, d_b, d_out, n);
+  if (op >= 3) hipLaunchKernelGGL(k2_test_op_quad, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, stream, op, d_a, d_b, d_out, n);
+  else hipLaunchKernelGGL(k2_test_op, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, op, d_a, d_b, d_out, n);
   return hipGetLastError() == hipSuccess ? ZKHIP_OK : ZKHIP_EHIP;
 }
 
