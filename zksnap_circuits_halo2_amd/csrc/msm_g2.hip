@@ -58,7 +58,7 @@ __device__ __forceinline__ xyzz2 xyzz2_shfl_xor(const xyzz2& a, int mask) {
 // per bucket their partials were a chain of 256 dependent additions (5 ms of a 19 ms MSM at 2^16).  (Quads instead of lanes were
 // measured slower here: 2^19 buckets x 32 lanes is throughput, not latency.)
 __global__ void __launch_bounds__(64) k2_combine(const uint32_t* __restrict__ task_off, uint32_t nbuckets, const uint32_t* __restrict__ partials,
-                                                 uint32_t* __restrict__ buckets) {
+                                                 uint32_t* __restrict__ buckets, uint32_t seq_parts) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t k = gid >> 3, q = gid & 7;
   const bool live = k < nbuckets;                 // whole groups of 8 lanes are live or dead together
@@ -67,6 +67,7 @@ __global__ void __launch_bounds__(64) k2_combine(const uint32_t* __restrict__ ta
   if (live) {
     const uint32_t t = task_off[k];
     m = task_off[k + 1] - t;
+    if (m > seq_parts) m = 1;                     // a heavy bucket: k2_combine_heavy's (treated here like the single-task case: nothing to do)
     if (m != 1) {
 #pragma unroll 1
       for (uint32_t j = q; j < m; j += 8) acc = xyzz2_add(acc, load_xyzz2(partials, t + j));
@@ -75,6 +76,31 @@ __global__ void __launch_bounds__(64) k2_combine(const uint32_t* __restrict__ ta
 #pragma unroll 1
   for (int mask = 1; mask < 8; mask <<= 1) acc = xyzz2_add(acc, xyzz2_shfl_xor(acc, mask));
   if (live && q == 0 && m != 1) store_xyzz2(buckets, k, acc);
+}
+
+// heavy buckets (more than seq_parts partials: the list k_make_tasks collects, msm.hip section 7; a short top window makes a few dozen of
+// them): a wavefront per bucket -- 64 lanes sum the partials 64 apart, an LDS tree adds the lane sums.  The list holds one entry per
+// 2048-partial slice; the slice-0 entry stands for the whole bucket here (G2 MSMs are small).
+__global__ void __launch_bounds__(64) k2_combine_heavy(const uint32_t* __restrict__ task_off, const uint32_t* __restrict__ partials, uint32_t* __restrict__ buckets,
+                                                       const uint32_t* __restrict__ heavy_count, const uint2* __restrict__ heavy, uint32_t heavy_cap) {
+  __shared__ __attribute__((aligned(16))) uint32_t xch[32 * 72];
+  const uint32_t nh = min(*heavy_count, heavy_cap);
+  for (uint32_t i = blockIdx.x; i < nh; i += gridDim.x) {          // uniform over the workgroup
+    const uint2 e = heavy[i];
+    if (e.y != 0) continue;
+    const uint32_t k = e.x, t = task_off[k], m = task_off[k + 1] - t;
+    xyzz2 acc = xyzz2_identity();
+#pragma unroll 1
+    for (uint32_t j = threadIdx.x; j < m; j += 64) acc = xyzz2_add(acc, load_xyzz2(partials, t + j));
+#pragma unroll 1
+    for (uint32_t half = 32; half >= 1; half >>= 1) {
+      __syncthreads();
+      if (threadIdx.x >= half && threadIdx.x < 2 * half) store_xyzz2(xch, threadIdx.x - half, acc);
+      __syncthreads();
+      if (threadIdx.x < half) acc = xyzz2_add(acc, load_xyzz2(xch, threadIdx.x));
+    }
+    if (threadIdx.x == 0) store_xyzz2(buckets, k, acc);
+  }
 }
 
 // pyramid step (see msm.hip section 8 for the state layout): sum_k (k + 1) B_k = Tot + sum_l 2^l T_l
@@ -231,7 +257,8 @@ int msm_g2_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
     hipLaunchKernelGGL(k2_accumulate, dim3(blocks), dim3(64), 0, stream, tv.ntasks, tv.order, tv.sorted, d_bases, tv.partials, tv.pyrA);
   }
   prof_mark(stream, "accumulate_g2");
-  hipLaunchKernelGGL(k2_combine, dim3((unsigned)(((size_t)tv.NB * 8 + 63) / 64)), dim3(64), 0, stream, tv.task_off, tv.NB, tv.partials, tv.pyrA);
+  hipLaunchKernelGGL(k2_combine, dim3((unsigned)(((size_t)tv.NB * 8 + 63) / 64)), dim3(64), 0, stream, tv.task_off, tv.NB, tv.partials, tv.pyrA, tv.seq_parts);
+  hipLaunchKernelGGL(k2_combine_heavy, dim3(256), dim3(64), 0, stream, tv.task_off, tv.partials, tv.pyrA, tv.heavy_count, (const uint2*)tv.heavy, tv.heavy_cap);
   prof_mark(stream, "combine_g2");
   uint32_t* cur = tv.pyrA;
   uint32_t* nxt = tv.pyrB;
