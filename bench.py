@@ -47,7 +47,7 @@ def profile_read(lib):
     return [(names[i].value.decode(), ms[i]) for i in range(max(k, 0))]
 
 
-def main() -> None:
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -56,19 +56,99 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the NTT / wrapper-replay extras")
     ap.add_argument("--no-general-path", action="store_true", help="skip the unregistered-bases MSM (rocprofv3 runs: keeps per-kernel averages to the headline path)")
-    args = ap.parse_args()
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="CPU rehearsal of the --gpus N launcher: the ranks rendezvous over gloo, time an empty step and rank 0 prints a line that is "
+                         "marked as a self-test (no GPU work, no metric)")
+    return ap.parse_args(argv)
+
+
+def fail(msg: str, code: int = 2):
+    print("bench.py: " + msg, file=sys.stderr, flush=True)
+    sys.exit(code)
+
+
+def launch_ranks(args, argv) -> int:
+    """`python bench.py --gpus N` outside a torchrun environment: start the N ranks ourselves (one process per GPU) and return the job's exit
+    status.  This process has not touched HIP (nothing below initialises a device; the device COUNT does not), it starts the ranks as child
+    processes -- never a re-exec -- and rank 0's JSON line reaches stdout through the inherited descriptor."""
+    import socket
+    import subprocess
+
+    if not args.launcher_selftest:
+        import torch
+
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            fail(f"--gpus {args.gpus} asked for, {have} HIP device(s) visible: refusing to run a {args.gpus}-GPU measurement on fewer GPUs", 3)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # RCCL / dmabuf IPC on this driver
+    env["ZKHIP_BENCH_LAUNCHED_BY"] = "bench.py"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def launcher_selftest(rank: int, world: int, args) -> None:
+    """What a rank does under --launcher-selftest: the rendezvous, the barrier-bracketed timing and the max over ranks of the real step
+    loop, on gloo, around an empty step."""
+    import torch
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo")
+        dist.barrier()
+    t = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    if world > 1:
+        dist.barrier()
+    el = torch.tensor([time.perf_counter() - t], dtype=torch.float64)
+    ranks = torch.tensor([1], dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ranks)
+    if rank == 0:
+        print(json.dumps({"launcher_selftest": True, "n_gpus": world, "ranks_seen": int(ranks.item()), "steps": args.steps, "warmup": args.warmup,
+                          "launched_by": os.environ.get("ZKHIP_BENCH_LAUNCHED_BY", "external torchrun"), "metric": None, "value": None}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def main() -> None:
+    args = parse_args()
+    # ---- who starts the ranks ---------------------------------------------------------------------------------------------------------
+    # The metric is "Mpoints/sec at 1/2/4/8 MI355X": --gpus N must mean N ranks on N GPUs or no number at all.  Under torchrun (the driver's
+    # form for N > 1) WORLD_SIZE is set and must equal --gpus; without it, N > 1 starts the ranks here, before anything touches the GPU.
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus < 1:
+        fail(f"--gpus {args.gpus}: need at least one GPU")
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+    if env_world is not None and int(env_world) != args.gpus:
+        fail(f"--gpus {args.gpus} but WORLD_SIZE={env_world}: the launcher's rank count and --gpus disagree; refusing to report n_gpus for a job of another size")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(env_world or "1")
+    if args.launcher_selftest:
+        launcher_selftest(rank, world, args)
+        return
 
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if torch.cuda.device_count() <= local_rank or torch.cuda.device_count() < world:
+        fail(f"rank {rank}: local rank {local_rank} of {world} needs {world} visible HIP devices, {torch.cuda.device_count()} found", 3)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cpu_group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+        cpu_group = dist.new_group(backend="gloo")      # host-side waits that must not occupy the GPUs (the single-process leg at the end)
 
     from zksnap_circuits_halo2_amd import _lib, fields as F
     from zksnap_circuits_halo2_amd.multi_gpu import gather_fold_device
@@ -165,9 +245,9 @@ def main() -> None:
             for name, ms in profile_read(lib):
                 gen_s.setdefault(name, []).append(ms)
         lib.zkhip_profile_enable(0)
-        # per phase: the mean of the launches with the single largest sample left out (one run in a dozen shows one launch of one phase
-        # three times its usual length: a clock or scheduling event on the box, not the kernel)
-        trimmed = lambda v: (sum(v) - max(v)) / (len(v) - 1) if len(v) > 1 else v[0]
+        # per phase: the MEDIAN of the launches (one run in a dozen shows one launch of one phase three times its usual length: a clock or
+        # scheduling event on the box, not the kernel; dropping only the maximum would bias the figure downward)
+        trimmed = lambda v: float(np.median(v))
         acc = {k_: trimmed(v) for k_, v in acc_s.items()}
         gen = {k_: trimmed(v) for k_, v in gen_s.items()}
         # arbitrary (unregistered) bases: per-window bucket sets + window fold
@@ -223,7 +303,7 @@ def main() -> None:
             traffic, traffic_source = None, None
         result["roofline"] = {"bound": "hbm", "kernel": "k_accumulate", "achieved": round(achieved, 2), "peak": 8000.0,
                               "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": traffic_source,
-                              "avg_launch_ms": round(t_acc, 4), "avg_launch_how": "mean of 8 launches by in-library HIP events on the launch stream, largest sample left out",
+                              "avg_launch_ms": round(t_acc, 4), "avg_launch_how": "median of 8 launches by in-library HIP events on the launch stream",
                               "algorithmic_bytes_per_launch": alg_bytes,
                               "whole_msm_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / 8000.0, 5),
                               "note": "256-bit modular-integer work: ALU-bound, not HBM-bound (DESIGN.md)"}
@@ -249,6 +329,23 @@ def main() -> None:
         except Exception as exc:   # an extra: never fail the bench line
             if rank == 0:
                 result["config4_wrapper_k24_msm"] = {"error": repr(exc)}
+
+    # N > 1, last: the SAME configs[4] MSM driven by ONE process over all N cards through the C ABI (zkhip_init([0..N-1]) + registered shards) --
+    # the path a Rust host would use -- on rank 0, while the other ranks have released their buffers and wait on the host (gloo) so that
+    # their cards are idle.  Re-initialising the library drops rank 0's earlier handles: nothing below needs them.
+    if world > 1 and not args.no_extras:
+        del d_bases, d_scalars
+        torch.cuda.synchronize()
+        if rank != 0:
+            lib.zkhip_shutdown()
+        torch.cuda.empty_cache()
+        dist.barrier(group=cpu_group)
+        if rank == 0:
+            try:
+                result["config4_wrapper_k24_msm"]["single_process_c_abi"] = c_abi_config4(lib, _lib, F, torch, dev, stream, devices=list(range(world)), shards=world)
+            except Exception as exc:   # an extra: never fail the bench line
+                result["config4_wrapper_k24_msm"]["single_process_c_abi"] = {"error": repr(exc)}
+        dist.barrier(group=cpu_group)
 
     if rank == 0 and world == 1 and not args.no_extras:
         result.update(extras(lib, _lib, F, torch, dev, stream))
@@ -313,16 +410,35 @@ def config4_leg(lib, _lib, F, torch, dist, dev, stream, rank, world, gather_fold
         return {"workload": f"BASELINE configs[4]: 2^24-point MSM, 2^{per.bit_length() - 1} points per GPU x {world} GPUs, all_gather(96 B) + fold, device-resident",
                 "scaling": "strong", "ms_per_msm": round(ms, 4), "Mpoints_per_s": round(total / ms / 1e3, 1), "steps": steps}
     # one card: 8 virtual shards through the C ABI
+    return c_abi_config4(lib, _lib, F, torch, dev, stream, devices=[dev.index or 0], shards=8)
+
+
+def c_abi_config4(lib, _lib, F, torch, dev, stream, devices, shards) -> dict:
+    """BASELINE configs[4] the way a single Rust `create_proof` process would drive it (/root/reference/aggregator/src/wrapper.rs:129):
+    ONE process, zkhip_init(devices), zkhip_register_bases on the 2^24-point SRS (one prepared table of 2^24 / shards points per shard, shard s
+    on devices[s % ndev]), then the commit two ways -- zkhip_msm_g1 with host scalars (PCIe-inclusive: the plain two-function boundary) and
+    zkhip_msm_g1_registered_device with the scalars resident in the primary device's HBM (each other device pulls its slice over xGMI, runs its
+    shard, returns 96 bytes; fold on the primary).  One card: `shards` virtual shards; N cards: one shard per card."""
+    total = 1 << 24
+    T0, D = CONFIG4_T0, CONFIG4_D
+    dd = F.fr_encode([D])[0]
+    ndev = len(devices)
+    devs = (C.c_int * ndev)(*devices)
+    _lib.check(lib.zkhip_init(devs, ndev))          # a different device list shuts the library down first (handles of earlier legs are gone)
     g = torch.empty(total * 8, dtype=torch.int64, device=dev)
     t0 = F.fr_encode([T0])[0]
     _lib.check(lib.zkhip_g1_gen_walk_device(t0.ctypes.data, dd.ctypes.data, total, g.data_ptr(), stream))
     torch.cuda.synchronize()
     h_g = g.cpu().numpy().view(np.uint64).reshape(total, 8).copy()
+    del g
+    torch.cuda.empty_cache()
     h_sc = synth_scalars(total, 0x5A4B534E41500103)
     out = np.zeros(12, dtype=np.uint64)
-    res = {"workload": "BASELINE configs[4] rehearsed on one card: 2^24-point MSM as 8 virtual shards of 2^21 points (zkhip_set_msm_shards(8) + "
-                       "zkhip_register_bases + zkhip_msm_g1: per-shard tables, per-shard Pippenger, gather of the 96-byte partials, fold)"}
-    _lib.check(lib.zkhip_set_msm_shards(8))
+    res = {"workload": f"BASELINE configs[4] through the C ABI of one process: 2^24-point MSM as {shards} shards of 2^{(total // shards).bit_length() - 1} points on "
+                       f"{ndev} device(s) (zkhip_init + zkhip_set_msm_shards({shards}) + zkhip_register_bases: per-shard tables, per-shard Pippenger, "
+                       "gather of the 96-byte partials on the primary device, fold)",
+           "devices": list(devices), "shards": shards}
+    _lib.check(lib.zkhip_set_msm_shards(shards))
     try:
         t = time.perf_counter()
         _lib.check(lib.zkhip_register_bases(h_g.ctypes.data, total))
@@ -334,40 +450,30 @@ def config4_leg(lib, _lib, F, torch, dist, dev, stream, rank, world, gather_fold
         ms_host = (time.perf_counter() - t) / 3 * 1e3
         res["host_buffers_ms_per_msm"] = round(ms_host, 2)        # scalars cross PCIe (512 MiB per call)
         res["host_buffers_Mpoints_per_s"] = round(total / ms_host / 1e3, 1)
+        # device-resident scalars (primary device) against the same registered shards
+        sc = torch.from_numpy(h_sc.view(np.int64)).to(dev)
+        fin = torch.zeros(12, dtype=torch.int64, device=dev)
+        run = lambda: _lib.check(lib.zkhip_msm_g1_registered_device(h_g.ctypes.data, sc.data_ptr(), total, fin.data_ptr(), stream))
+        run()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t) / 3 * 1e3
+        same = F.g1_decode_jacobian(fin.cpu().numpy().view(np.uint64)[:12]) == F.g1_decode_jacobian(out)
+        res.update({"device_resident_c_abi_ms": round(ms, 3), "device_resident_ms_per_msm": round(ms, 3), "device_resident_Mpoints_per_s": round(total / ms / 1e3, 1),
+                    "host_and_device_paths_agree": bool(same)})
+        if ndev == 1:
+            res["per_shard_ms"] = round(ms / shards, 3)
+            res["note"] = "one card: the shards run one after the other; on N cards they run concurrently (expected ~ per_shard_ms x shards / N + the slice copy and the exchange)"
+        else:
+            res["note"] = "N cards, one process: secondary devices copy their scalar slice from the primary's HBM (hipMemcpyPeerAsync), partials return as 96-byte peer copies"
+        del sc
     finally:
         lib.zkhip_unregister_bases(h_g.ctypes.data)
         lib.zkhip_set_msm_shards(0)
     del h_g
-    # kernel side of the same partition: eight prepared shards, device-resident scalars, partials folded on the device
-    per = total // 8
-    hs = []
-    for s_i in range(8):
-        hh = C.c_uint64(0)
-        _lib.check(lib.zkhip_prepare_bases_device(g.data_ptr() + s_i * per * 64, per, C.byref(hh)))
-        hs.append(hh)
-    sc = torch.from_numpy(h_sc.view(np.int64)).to(dev)
-    parts = torch.zeros(12 * 8, dtype=torch.int64, device=dev)
-    fin = torch.zeros(12, dtype=torch.int64, device=dev)
-
-    def step():
-        for s_i in range(8):
-            _lib.check(lib.zkhip_msm_g1_prepared_device(hs[s_i], 0, sc.data_ptr() + s_i * per * 32, per, parts.data_ptr() + s_i * 96, stream))
-        _lib.check(lib.zkhip_g1_sum_device(parts.data_ptr(), 8, fin.data_ptr(), stream))
-
-    step()
-    torch.cuda.synchronize()
-    t = time.perf_counter()
-    for _ in range(3):
-        step()
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t) / 3 * 1e3
-    same = F.g1_decode_jacobian(fin.cpu().numpy().view(np.uint64)[:12]) == F.g1_decode_jacobian(out)
-    for hh in hs:
-        lib.zkhip_release_bases(hh)
-    res.update({"device_resident_ms_per_msm": round(ms, 3), "device_resident_Mpoints_per_s": round(total / ms / 1e3, 1),
-                "per_shard_ms": round(ms / 8, 3), "host_and_device_paths_agree": bool(same),
-                "note": "on 8 GPUs the eight shards run concurrently: expected time ~ per_shard_ms + exchange; measured on one card here"})
-    del g, sc
     torch.cuda.empty_cache()
     return res
 
