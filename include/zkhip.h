@@ -195,6 +195,10 @@ int zkhip_upload(void *d_dst, const void *src, size_t bytes);
 int zkhip_download(void *dst, const void *d_src, size_t bytes);
 /* wait for everything this process has queued on the device */
 int zkhip_sync(void);
+/* wait for the work queued on one stream.  zkhip_upload / zkhip_download are blocking copies on HIP's legacy default stream: a stream
+ * created with hipStreamNonBlocking (every library-owned stream, every torch side stream) is NOT ordered against them, so a host that
+ * enqueues `_device` calls on such a stream calls this before it reads their results back. */
+int zkhip_stream_sync(void *stream);
 
 /* ---- device-resident variants (pointers are HIP device pointers; stream is a hipStream_t; NULL = HIP's default stream 0, ordered
  * with the caller's other default-stream work -- e.g. what torch.cuda.current_stream().cuda_stream is when no stream was set) --- */
@@ -211,9 +215,17 @@ int zkhip_prepared_window_bits(uint64_t handle);
 int zkhip_msm_g1_prepared_device(uint64_t handle, size_t offset, const void *d_scalars, size_t n, void *d_out_xyz, void *stream);
 /* Device-resident scalars against an array pinned with zkhip_register_bases: `bases` is the HOST pointer the caller would pass to
  * zkhip_msm_g1 (any sub-range of a registered array), the scalars and the result live in HBM.  This is `params.commit(&poly)` for a
- * polynomial that never left the device, against the same tables the host-buffer calls use.  ZKHIP_EINVAL when the range is not
- * registered or spans several shards. */
+ * polynomial that never left the device, against the same tables the host-buffer calls use.  A range that spans several shards (several
+ * devices named in zkhip_init, or virtual shards) fans out like the host-buffer call: every secondary device pulls its slice of the scalars
+ * from the primary device's HBM (peer copy over xGMI), runs its shard on a stream of its own and returns its 96-byte partial; the fold runs
+ * on `stream`, which is the only stream the caller has to wait for (SURVEY.md section 8(e) with the scalars resident in HBM).
+ * ZKHIP_EINVAL when the range is not inside a registered array. */
 int zkhip_msm_g1_registered_device(const uint64_t *bases, const void *d_scalars, size_t n, void *d_out_xyz, void *stream);
+/* `batch` device-resident scalar vectors (vector k at d_scalars + k * scalar_stride elements) against the same registered range, e.g. all
+ * advice columns of a circuit; d_out_xyz: batch Jacobian results.  Vectors share launch sets per shard when the shard's table has
+ * windows of <= 16 bits. */
+int zkhip_msm_g1_registered_batch_device(const uint64_t *bases, const void *d_scalars, size_t n, size_t batch, size_t scalar_stride, void *d_out_xyz,
+                                         void *stream);
 /* `batch` scalar vectors (vector k at d_scalars + k * scalar_stride elements) against the same prepared bases in one launch
  * set -- e.g. all advice columns of a circuit: small MSMs (k = 13..17) then run at large-MSM throughput.  d_out_xyz: batch
  * Jacobian results, 96 bytes each.  Tables with wide windows (n >= 2^20) do not share a launch set; their vectors run alternately

@@ -280,6 +280,130 @@ def test_multi_device_path_on_duplicate_contexts(lib, cref):
         _lib.check(lib.zkhip_init(None, 0))
 
 
+def _registered_device(lib, bases_host, d_sc, n, batch=1, stride=None, stream=None):
+    """zkhip_msm_g1_registered(_batch)_device with the scalars at torch tensor d_sc; returns (batch, 12) uint64"""
+    import torch
+
+    out = torch.zeros((batch, 12), dtype=torch.int64, device="cuda")
+    if batch == 1 and stride is None:
+        _lib.check(lib.zkhip_msm_g1_registered_device(bases_host.ctypes.data, d_sc.data_ptr(), n, out.data_ptr(), stream))
+    else:
+        _lib.check(lib.zkhip_msm_g1_registered_batch_device(bases_host.ctypes.data, d_sc.data_ptr(), n, batch, stride if stride is not None else n, out.data_ptr(), stream))
+    torch.cuda.synchronize()
+    return np.ascontiguousarray(out.cpu().numpy().view(np.uint64))
+
+
+@pytest.mark.parametrize("n", [10007, (1 << 17) + 3])
+def test_device_resident_commit_over_virtual_shards(lib, cref, restore_shards, n):
+    """zkhip_msm_g1_registered_device on a range that spans several shards (round 2 returned EINVAL here): 1 / 3 / 8 virtual shards give the
+    unsharded point and the structured-SRS point, for the whole array, for sub-ranges across shard boundaries and for a batch of vectors
+    with a padded stride"""
+    import torch
+
+    bases = _walk_host(lib, n)
+    sc = cref.gen_scalars(9800 + n % 13, n, 0)
+    sc[7] = 0
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    exp = _expect(cref, sc, T0)
+    batch, stride = 3, n + 5
+    vecs = [cref.gen_scalars(9810 + i, n, i % 2) for i in range(batch)]
+    padded = np.zeros((batch, stride, 4), dtype=np.uint64)
+    for i, v in enumerate(vecs):
+        padded[i, :n] = v
+    d_vecs = torch.from_numpy(padded.view(np.int64)).cuda()
+    exp_vecs = [_expect(cref, v, T0) for v in vecs]
+    for S in (1, 3, 8):
+        _lib.check(lib.zkhip_set_msm_shards(S))
+        _lib.check(lib.zkhip_register_bases(bases.ctypes.data, n))
+        try:
+            assert np.array_equal(cref.jac_to_affine(_registered_device(lib, bases, d_sc, n)[0]), exp), S
+            for lo, hi in ((3, 100), (n // 8 - 50, n // 8 + 60), (0, n - 1), (n // 3 - 1, 2 * n // 3 + 5), (n - 9, n)):
+                got = _registered_device(lib, bases[lo:], d_sc.view(-1, 4)[lo:], hi - lo)[0]
+                assert np.array_equal(cref.jac_to_affine(got), _expect(cref, np.ascontiguousarray(sc[lo:hi]), (T0 + lo * D) % O.R_MOD)), (S, lo, hi)
+            got = _registered_device(lib, bases, d_vecs, n, batch, stride)
+            for i in range(batch):
+                assert np.array_equal(cref.jac_to_affine(got[i]), exp_vecs[i]), (S, i)
+            # on a caller stream of its own: the fold is ordered on that stream
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                assert np.array_equal(cref.jac_to_affine(_registered_device(lib, bases, d_sc, n, stream=st.cuda_stream)[0]), exp), S
+        finally:
+            _lib.check(lib.zkhip_unregister_bases(bases.ctypes.data))
+    # n = 0 and an unregistered pointer
+    assert F.g1_decode_jacobian(_registered_device(lib, bases, d_sc, 0)[0]) is None
+    out = torch.zeros(12, dtype=torch.int64, device="cuda")
+    assert lib.zkhip_msm_g1_registered_device(bases.ctypes.data, d_sc.data_ptr(), n, out.data_ptr(), None) == -1
+
+
+def test_device_resident_commit_on_duplicate_contexts(lib, cref):
+    """the same with three device contexts on the one card (ZKHIP_TEST_DUPLICATE_DEVICES): the secondary contexts wait for the caller's
+    stream by event, pull their scalar slices with peer copies, run on their own streams and return their partials with peer copies; the
+    caller's stream waits for their events and folds.  Host-buffer calls (worker threads, the secondaries' lanes) interleave with it."""
+    import torch
+
+    n = (1 << 16) + 11
+    lib.zkhip_shutdown()
+    os.environ["ZKHIP_TEST_DUPLICATE_DEVICES"] = "1"
+    try:
+        devs = (C.c_int * 3)(0, 0, 0)
+        _lib.check(lib.zkhip_init(devs, 3))
+        bases = _walk_host(lib, n)
+        sc = cref.gen_scalars(9900, n, 0)
+        d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+        exp = _expect(cref, sc, T0)
+        batch = 4
+        vecs = [cref.gen_scalars(9910 + i, n, i % 2) for i in range(batch)]
+        d_vecs = torch.from_numpy(np.ascontiguousarray(np.stack(vecs)).view(np.int64)).cuda()
+        for S in (3, 7):
+            _lib.check(lib.zkhip_set_msm_shards(S))
+            _lib.check(lib.zkhip_register_bases(bases.ctypes.data, n))
+            try:
+                for rep in range(3):
+                    assert np.array_equal(cref.jac_to_affine(_registered_device(lib, bases, d_sc, n)[0]), exp), (S, rep)
+                    assert np.array_equal(cref.jac_to_affine(_msm(lib, sc, bases)), exp), (S, rep)          # host-buffer path in between
+                lo, hi = n // 3 - 100, n // 3 + 100
+                got = _registered_device(lib, bases[lo:], d_sc.view(-1, 4)[lo:], hi - lo)[0]
+                assert np.array_equal(cref.jac_to_affine(got), _expect(cref, np.ascontiguousarray(sc[lo:hi]), (T0 + lo * D) % O.R_MOD)), S
+                got = _registered_device(lib, bases, d_vecs, n, batch, n)
+                for i in range(batch):
+                    assert np.array_equal(cref.jac_to_affine(got[i]), _expect(cref, vecs[i], T0)), (S, i)
+                # scalars produced on the caller's stream right before the call: the secondaries must wait for them
+                st = torch.cuda.Stream()
+                with torch.cuda.stream(st):
+                    d2 = torch.zeros_like(d_sc)
+                    for _ in range(20):
+                        d2.copy_(d_vecs[0].reshape(-1))
+                    d2.copy_(d_sc)
+                    out = torch.zeros(12, dtype=torch.int64, device="cuda")
+                    _lib.check(lib.zkhip_msm_g1_registered_device(bases.ctypes.data, d2.data_ptr(), n, out.data_ptr(), st.cuda_stream))
+                    d2_after = None
+                st.synchronize()
+                assert np.array_equal(cref.jac_to_affine(np.ascontiguousarray(out.cpu().numpy().view(np.uint64))), exp), S
+            finally:
+                _lib.check(lib.zkhip_unregister_bases(bases.ctypes.data))
+    finally:
+        lib.zkhip_shutdown()
+        del os.environ["ZKHIP_TEST_DUPLICATE_DEVICES"]
+        _lib.check(lib.zkhip_init(None, 0))
+
+
+def test_config4_device_resident_8_shards_of_2p21(lib, cref, restore_shards):
+    """BASELINE configs[4] with the scalars resident in HBM: the 2^24-point commit as 8 registered shards of 2^21 points through
+    zkhip_msm_g1_registered_device"""
+    import torch
+
+    n = 1 << 24
+    bases = _walk_host(lib, n)
+    sc = cref.gen_scalars(92401, n, 0)
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    _lib.check(lib.zkhip_set_msm_shards(8))
+    _lib.check(lib.zkhip_register_bases(bases.ctypes.data, n))
+    try:
+        assert np.array_equal(cref.jac_to_affine(_registered_device(lib, bases, d_sc, n)[0]), _expect(cref, sc, T0))
+    finally:
+        _lib.check(lib.zkhip_unregister_bases(bases.ctypes.data))
+
+
 def _config4_worker(rank, world, port, q):
     """one rank of bench.py's configs[4] leg (world > 1 branch), gloo in place of RCCL, all ranks on the one card of the test box"""
     import os

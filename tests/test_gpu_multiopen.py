@@ -54,6 +54,13 @@ def test_gwc_create_proof_on_a_known_trapdoor_srs(lib, cref):
             W = prover.create_proof(queries, v)
             W2 = prover.create_proof(queries, v)                     # a second proof reuses the prover's buffers
             assert all(np.array_equal(cref.jac_to_affine(a), cref.jac_to_affine(b)) for a, b in zip(W, W2))      # (Jacobian representatives differ run to run)
+            # on a non-blocking side stream (every torch side stream is one): the host reads inside create_proof are ordered behind it
+            import torch
+            st = torch.cuda.Stream()
+            fresh = [M.ProverQuery(points[pt], d_polys[pi].value) for pi, pt in plan]
+            W3 = prover.create_proof(fresh, v, stream=st.cuda_stream)
+            assert all(np.array_equal(cref.jac_to_affine(a), cref.jac_to_affine(b)) for a, b in zip(W, W3))
+            assert [q.eval for q in fresh] == [q.eval for q in queries]
             prover.close()
             sets = M.construct_intermediate_sets(queries)
             assert [z for z, _ in sets] == points and [len(qs) for _, qs in sets] == [4, 2, 2] and len(W) == 3
@@ -131,6 +138,11 @@ def test_shplonk_create_proof_on_a_known_trapdoor_srs(lib, cref):
         H, Hp = sh.create_proof(queries, y, v, u)
         H2, Hp2 = sh.create_proof(queries, y, v, u)                  # buffers reused
         assert np.array_equal(cref.jac_to_affine(H), cref.jac_to_affine(H2)) and np.array_equal(cref.jac_to_affine(Hp), cref.jac_to_affine(Hp2))
+        import torch
+        st = torch.cuda.Stream()                                     # non-blocking: not ordered against the legacy default stream
+        fresh = [M.ProverQuery(pt, d_polys[pi].value) for pi, pt in plan]
+        H3, Hp3 = sh.create_proof(fresh, y, v, u, stream=st.cuda_stream)
+        assert np.array_equal(cref.jac_to_affine(H), cref.jac_to_affine(H3)) and np.array_equal(cref.jac_to_affine(Hp), cref.jac_to_affine(Hp3))
         sh.close()
         sets, T = M.construct_rotation_sets(queries)
         ptr_to_idx = {d.value: i for i, d in enumerate(d_polys)}

@@ -50,6 +50,7 @@ _SIGS = {
     "zkhip_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "zkhip_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "zkhip_sync": (C.c_int, []),
+    "zkhip_stream_sync": (C.c_int, [C.c_void_p]),
     "zkhip_msm_g1_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "zkhip_prepare_bases_device": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]),
     "zkhip_g1_fft_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
@@ -77,6 +78,7 @@ _SIGS = {
     "zkhip_g1_check_points": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]),
     "zkhip_g1_check_points_device": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64), C.c_void_p]),
     "zkhip_msm_g1_registered_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "zkhip_msm_g1_registered_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]),
     "zkhip_fr_gather_mul_device": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "zkhip_g1_compress": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]),
     "zkhip_g1_compress_device": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),

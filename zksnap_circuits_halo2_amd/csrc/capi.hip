@@ -88,9 +88,9 @@ struct dev_buf {       // grow-only device scratch (hipFree waits for the device
 };
 
 struct scratch {       // one user at a time: the calls of one stream
-  dev_buf ws, scalars, bases, poly, poly2, small, ntt_tmp, vm;
+  dev_buf ws, scalars, bases, poly, poly2, small, ntt_tmp, vm, gather;
   uint64_t last_use = 0;
-  void release() { ws.release(); scalars.release(); bases.release(); poly.release(); poly2.release(); small.release(); ntt_tmp.release(); vm.release(); }
+  void release() { ws.release(); scalars.release(); bases.release(); poly.release(); poly2.release(); small.release(); ntt_tmp.release(); vm.release(); gather.release(); }
 };
 
 struct lane {          // host-buffer calls: a library-owned stream + (through the stream) a scratch set + a pinned result buffer
@@ -153,6 +153,11 @@ struct device_ctx {
   hipStream_t side = nullptr;          // primary: second stream of a batch of large MSMs (high priority: never the caller's hardware queue)
   hipEvent_t side_fork = nullptr, side_join = nullptr;
   worker* w = nullptr;                 // secondary devices only
+  // device-resident sharded commits (zkhip_msm_g1_registered_device over several shards): a secondary device runs its shards on `fan`, a
+  // stream of its own (not the lane its worker thread drives for host-buffer calls), behind `fan_ready` of the primary device (recorded on
+  // the caller's stream: the scalars are complete) and records `fan_done` for the caller's stream to wait on before the fold
+  hipStream_t fan = nullptr;
+  hipEvent_t fan_ready = nullptr, fan_done = nullptr;
 };
 
 struct shard_t {       // points [lo, lo + n) of a registered array, prepared on device `dev`
@@ -214,7 +219,7 @@ static scratch* scratch_for(device_ctx& d, hipStream_t stream) {
   if (d.scratch_by_stream.size() >= MAX_STREAM_SCRATCH + d.lanes.size()) {
     auto victim = d.scratch_by_stream.end();
     for (auto jt = d.scratch_by_stream.begin(); jt != d.scratch_by_stream.end(); ++jt) {
-      bool is_lane = jt->first == d.side && d.side != nullptr;
+      bool is_lane = (jt->first == d.side && d.side != nullptr) || (jt->first == d.fan && d.fan != nullptr);
       for (auto& L : d.lanes) is_lane |= (L.stream == jt->first);
       if (is_lane) continue;
       if (victim == d.scratch_by_stream.end() || jt->second->last_use < victim->second->last_use) victim = jt;
@@ -312,6 +317,9 @@ static void destroy_device_ctx(device_ctx* d) {
   if (d->side_fork) (void)hipEventDestroy(d->side_fork);
   if (d->side_join) (void)hipEventDestroy(d->side_join);
   if (d->side) (void)hipStreamDestroy(d->side);
+  if (d->fan_ready) (void)hipEventDestroy(d->fan_ready);
+  if (d->fan_done) (void)hipEventDestroy(d->fan_done);
+  if (d->fan) (void)hipStreamDestroy(d->fan);
   d->fixed_table.release();
   d->gather.release();
   delete d;
@@ -751,25 +759,141 @@ int zkhip_msm_g1_prepared_device(uint64_t handle, size_t offset, const void* d_s
   return msm_g1_device((const uint32_t*)d_scalars, nullptr, n, (uint32_t*)d_out_xyz, sc->ws.p, sc->ws.cap, 0, s, pb, offset);
 }
 
+}  // extern "C"
+
+namespace zkhip {
+
+// `batch` prepared MSMs of n points each on one device (current device = pb's), results at d_out + k * 24 words: tables with windows of
+// <= 16 bits share launch sets (groups of vectors, each with its own bucket set), wider ones run one vector after the other.
+// vectors of a batch that share one launch set: all of them for windows <= 16 bits, within 2^31 sorted entries and 4 Mi buckets
+static size_t batch_group(const prepared_bases* pb, size_t n, size_t batch) {
+  size_t group = (pb->c > 16 || batch <= 1) ? 1 : std::min<size_t>(batch, 65535);
+  while (group > 1 && ((size_t)((256 + pb->c - 1) / pb->c) * n * group >= (1ull << 31) || (group << (pb->c - 1)) > (1ull << 22))) group = (group + 1) / 2;
+  return group;
+}
+
+static int prepared_batch_enqueue(scratch* sc, hipStream_t s, const prepared_bases* pb, size_t pb_off, const uint32_t* d_scalars, size_t n, size_t batch,
+                                  size_t scalar_stride, uint32_t* d_out) {
+  int rc;
+  const size_t group = batch_group(pb, n, batch);
+  if ((rc = sc->ws.reserve(msm_workspace_bytes(n, pb->c, true, group))) != ZKHIP_OK) return rc;
+  for (size_t k0 = 0; k0 < batch; k0 += group) {
+    const size_t kk = batch - k0 < group ? batch - k0 : group;
+    rc = msm_g1_device(d_scalars + k0 * scalar_stride * 8, nullptr, n, d_out + k0 * 24, sc->ws.p, sc->ws.cap, 0, s, pb, pb_off, kk, scalar_stride);
+    if (rc != ZKHIP_OK) return rc;
+  }
+  return ZKHIP_OK;
+}
+
+// Device-resident scalars (primary device, caller's stream s) against a registered array whose range [off, off + n) spans several shards
+// (SURVEY.md section 8(e) partitioning, with the scalars already in HBM): every shard the range touches runs its own prepared Pippenger on
+// its device.  The primary device's pieces run on s.  A secondary device waits for the scalars (event on s), pulls its slice of every
+// vector from the primary's HBM over xGMI (hipMemcpyPeerAsync: 32 B x n / S per vector -- 64 MiB per GPU for configs[4], about a
+// millisecond beside a 2.9 ms shard MSM), runs its pieces on its own stream and sends each 96-byte partial back into the gather buffer of
+// the caller's stream; s waits for the secondaries' events and folds: out[k] = sum over pieces of partial[piece][k].  Asynchronous like
+// every `_device` call: nothing here waits for a device.  g_mu held by the caller.
+static int registered_device_msm(const std::shared_ptr<registered_t>& reg, size_t off, const uint32_t* d_scalars, size_t n, size_t batch, size_t stride,
+                                 uint32_t* d_out, hipStream_t s) {
+  int rc;
+  device_ctx& P = primary();
+  scratch* sc = scratch_for(P, s);
+  std::vector<piece_t> pieces;
+  for (auto& sh : reg->shards) {
+    const size_t lo = std::max(off, sh.lo), hi = std::min(off + n, sh.lo + sh.n);
+    if (lo < hi) pieces.push_back({sh.dev, lo - off, hi - lo, sh.pb, lo - sh.lo});
+  }
+  if (pieces.size() == 1 && pieces[0].dev == 0)
+    return prepared_batch_enqueue(sc, s, pieces[0].pb, pieces[0].pb_off, d_scalars, n, batch, stride, d_out);
+  const size_t np = pieces.size();
+  if ((rc = sc->gather.reserve(np * batch * 96)) != ZKHIP_OK) return rc;
+  uint32_t* gather = (uint32_t*)sc->gather.p;                     // [piece][vector] 96-byte slots
+  bool remote = false;
+  for (auto& p : pieces) remote |= p.dev != 0;
+  if (remote) {
+    if (!P.fan_ready) HIPCHK(hipEventCreateWithFlags(&P.fan_ready, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(P.fan_ready, s));
+  }
+  // the secondaries first: their copies and kernels start while this thread is still enqueueing the primary's pieces
+  int rc_remote = ZKHIP_OK;
+  std::vector<size_t> waited;
+  for (size_t d = 1; d < g_ctx.devs.size() && rc_remote == ZKHIP_OK; d++) {
+    std::vector<size_t> mine;
+    for (size_t i = 0; i < np; i++) if ((size_t)pieces[i].dev == d) mine.push_back(i);
+    if (mine.empty()) continue;
+    device_ctx* D = g_ctx.devs[d];
+    if (hipSetDevice(D->device) != hipSuccess) { set_error("hipSetDevice(%d) failed", D->device); rc_remote = ZKHIP_ENODEV; break; }
+    auto body = [&]() -> int {
+      if (!D->fan) {
+        HIPCHK(hipStreamCreateWithFlags(&D->fan, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&D->fan_done, hipEventDisableTiming));
+      }
+      scratch* dsc = scratch_for(*D, D->fan);
+      size_t sc_elems = 0;
+      for (size_t i : mine) sc_elems = std::max(sc_elems, pieces[i].n);
+      int r;
+      if ((r = dsc->scalars.reserve(sc_elems * batch * 32)) != ZKHIP_OK) return r;
+      if ((r = dsc->small.reserve(4096 + batch * 96)) != ZKHIP_OK) return r;
+      size_t ws_bytes = 0;                                        // sized once for the largest piece (growing it later would free it under queued work)
+      for (size_t i : mine) ws_bytes = std::max(ws_bytes, msm_workspace_bytes(pieces[i].n, pieces[i].pb->c, true, batch_group(pieces[i].pb, pieces[i].n, batch)));
+      if ((r = dsc->ws.reserve(ws_bytes)) != ZKHIP_OK) return r;
+      HIPCHK(hipStreamWaitEvent(D->fan, P.fan_ready, 0));
+      for (size_t i : mine) {
+        const piece_t& p = pieces[i];
+        uint32_t* slice = (uint32_t*)dsc->scalars.p;              // vector k of this piece at slice + k * p.n * 8 words
+        for (size_t k = 0; k < batch; k++)
+          HIPCHK(hipMemcpyPeerAsync(slice + k * p.n * 8, D->device, d_scalars + (k * stride + p.lo) * 8, P.device, p.n * 32, D->fan));
+        uint32_t* part = (uint32_t*)((char*)dsc->small.p + 4096);
+        if ((r = prepared_batch_enqueue(dsc, D->fan, p.pb, p.pb_off, slice, p.n, batch, p.n, part)) != ZKHIP_OK) return r;
+        HIPCHK(hipMemcpyPeerAsync(gather + i * batch * 24, P.device, part, D->device, batch * 96, D->fan));
+      }
+      return ZKHIP_OK;
+    };
+    rc_remote = body();
+    if (D->fan_done && D->fan) { (void)hipEventRecord(D->fan_done, D->fan); waited.push_back(d); }   // also after an error: s must not run ahead of work already queued
+  }
+  if (hipSetDevice(P.device) != hipSuccess) { set_error("hipSetDevice(%d) failed", P.device); return ZKHIP_ENODEV; }
+  int rc_local = ZKHIP_OK;
+  {
+    size_t ws_bytes = 0;
+    for (auto& p : pieces) if (p.dev == 0) ws_bytes = std::max(ws_bytes, msm_workspace_bytes(p.n, p.pb->c, true, batch_group(p.pb, p.n, batch)));
+    rc_local = sc->ws.reserve(ws_bytes);
+  }
+  for (size_t i = 0; i < np && rc_local == ZKHIP_OK && rc_remote == ZKHIP_OK; i++) {
+    const piece_t& p = pieces[i];
+    if (p.dev != 0) continue;
+    rc_local = prepared_batch_enqueue(sc, s, p.pb, p.pb_off, d_scalars + p.lo * 8, p.n, batch, stride, gather + i * batch * 24);
+  }
+  for (size_t d : waited) HIPCHK(hipStreamWaitEvent(s, g_ctx.devs[d]->fan_done, 0));
+  if (rc_remote != ZKHIP_OK) return rc_remote;
+  if (rc_local != ZKHIP_OK) return rc_local;
+  return sum_jacobian_device(gather, (int)np, d_out, s, batch);
+}
+
+}  // namespace zkhip
+
+extern "C" {
+
 // device-resident scalars against bases pinned with zkhip_register_bases (`bases` = a host pointer into a registered array): the commit
-// of a polynomial that lives in HBM against the SRS the host registered, without a second table (zkhip_prepare_bases_device)
-int zkhip_msm_g1_registered_device(const uint64_t* bases, const void* d_scalars, size_t n, void* d_out_xyz, void* stream) {
+// of a polynomial that lives in HBM against the SRS the host registered, without a second table (zkhip_prepare_bases_device).  A range
+// that spans several shards fans out over their devices (registered_device_msm above).
+int zkhip_msm_g1_registered_batch_device(const uint64_t* bases, const void* d_scalars, size_t n, size_t batch, size_t scalar_stride, void* d_out_xyz,
+                                         void* stream) {
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
-  if (!d_out_xyz || (n && (!d_scalars || !bases))) { set_error("msm_registered: null pointer"); return ZKHIP_EINVAL; }
+  if (batch == 0) return ZKHIP_OK;
+  if (!d_out_xyz || (n && (!d_scalars || !bases)) || (batch > 1 && scalar_stride < n)) { set_error("msm_registered: bad argument"); return ZKHIP_EINVAL; }
   hipStream_t s = caller_stream(stream);
-  scratch* sc = scratch_for(primary(), s);
-  if (n == 0) return msm_g1_device(nullptr, nullptr, 0, (uint32_t*)d_out_xyz, nullptr, 0, 0, s);
+  if (n == 0) return msm_g1_device(nullptr, nullptr, 0, (uint32_t*)d_out_xyz, nullptr, 0, 0, s, nullptr, 0, batch, 0);
   size_t off = 0;
   std::shared_ptr<registered_t> reg = find_registered(bases, n, &off);
   if (!reg) { set_error("msm_registered: the range is not inside a registered array"); return ZKHIP_EINVAL; }
-  const shard_t* one = nullptr;
-  for (auto& sh : reg->shards) if (sh.dev == 0 && off >= sh.lo && off + n <= sh.lo + sh.n) one = &sh;
-  if (!one) { set_error("msm_registered: the range spans several shards (use the host-buffer entry point, which fans out)"); return ZKHIP_EINVAL; }
-  if ((rc = sc->ws.reserve(msm_workspace_bytes(n, one->pb->c, true))) != ZKHIP_OK) return rc;
-  // the table outlives the enqueued work: zkhip_unregister_bases synchronises every device before the last reference goes
-  return msm_g1_device((const uint32_t*)d_scalars, nullptr, n, (uint32_t*)d_out_xyz, sc->ws.p, sc->ws.cap, 0, s, one->pb, off - one->lo);
+  // the tables outlive the enqueued work: zkhip_unregister_bases synchronises every device before the last reference goes
+  return registered_device_msm(reg, off, (const uint32_t*)d_scalars, n, batch, scalar_stride, (uint32_t*)d_out_xyz, s);
+}
+
+int zkhip_msm_g1_registered_device(const uint64_t* bases, const void* d_scalars, size_t n, void* d_out_xyz, void* stream) {
+  return zkhip_msm_g1_registered_batch_device(bases, d_scalars, n, 1, n, d_out_xyz, stream);
 }
 
 int zkhip_msm_g1_prepared_batch_device(uint64_t handle, size_t offset, const void* d_scalars, size_t n, size_t batch, size_t scalar_stride,
@@ -1261,6 +1385,12 @@ int zkhip_download(void* dst, const void* d_src, size_t bytes) {
   if (bytes && (!dst || !d_src)) { set_error("download: null pointer"); return ZKHIP_EINVAL; }
   if (bytes == 0) return ZKHIP_OK;
   HIPCHK(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+  return ZKHIP_OK;
+}
+
+int zkhip_stream_sync(void* stream) {
+  { guard_t g(g_mu); int rc = ensure_init(); if (rc != ZKHIP_OK) return rc; }
+  HIPCHK(hipStreamSynchronize(caller_stream(stream)));
   return ZKHIP_OK;
 }
 

@@ -1114,12 +1114,15 @@ __global__ void __launch_bounds__(64) k_store_results(const uint32_t* __restrict
 
 // sum of `m` Jacobian points (multi-GPU partial fold): out = sum in[i].  One wave of 16 quads on the quad formulas, then a
 // 4-step shuffle tree (8 GPUs: depth 3 additions instead of 8 sequential ones).
-__global__ void __launch_bounds__(64) k_sum_jacobian(const uint32_t* __restrict__ in, int m, uint32_t* __restrict__ out) {
-  if (blockIdx.x != 0) return;
+// Workgroup b: out[b] = sum over i < m of in[i * stride + b] (96-byte Jacobian points).  One workgroup with stride 1 is the plain fold of
+// m gathered partial sums; `count` workgroups with stride = count fold the [shard][vector] partials of a batched sharded commit.
+__global__ void __launch_bounds__(64) k_sum_jacobian(const uint32_t* __restrict__ in, int m, uint32_t* __restrict__ out, uint32_t stride) {
   const uint32_t q = threadIdx.x & 3;
   const int grp = threadIdx.x >> 2;                 // 16 quads: quad g sums points g, g + 16, ...
+  in += (size_t)blockIdx.x * 24;
+  out += (size_t)blockIdx.x * 24;
   xyzz acc = xyzz_identity();
-  for (int i = grp; i < m; i += 16) acc = xyzz_add_quad(acc, load_jacobian(in + (size_t)i * 24), q);
+  for (int i = grp; i < m; i += 16) acc = xyzz_add_quad(acc, load_jacobian(in + (size_t)i * stride * 24), q);
 #pragma unroll 1
   for (int mask = 4; mask < 64; mask <<= 1) {
     if ((mask >> 2) >= m && mask > 4) break;        // quads >= m hold the identity: higher steps add nothing
@@ -1381,7 +1384,7 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
                   size_t scalar_stride) {
   if (batch == 0) return ZKHIP_OK;
   if (n == 0) {
-    for (size_t k = 0; k < batch; k++) hipLaunchKernelGGL(k_sum_jacobian, dim3(1), dim3(64), 0, stream, (const uint32_t*)nullptr, 0, d_out + k * 24);
+    for (size_t k = 0; k < batch; k++) hipLaunchKernelGGL(k_sum_jacobian, dim3(1), dim3(64), 0, stream, (const uint32_t*)nullptr, 0, d_out + k * 24, 1u);
     HIPCHK(hipGetLastError());
     return ZKHIP_OK;
   }
@@ -1967,8 +1970,9 @@ int g1_fft_device(const uint32_t* d_in, int in_format, uint32_t* d_out, int out_
   return ZKHIP_OK;
 }
 
-int sum_jacobian_device(const uint32_t* d_in, int m, uint32_t* d_out, hipStream_t stream) {
-  hipLaunchKernelGGL(k_sum_jacobian, dim3(1), dim3(64), 0, stream, d_in, m, d_out);
+int sum_jacobian_device(const uint32_t* d_in, int m, uint32_t* d_out, hipStream_t stream, size_t count) {
+  if (count == 0) return ZKHIP_OK;
+  hipLaunchKernelGGL(k_sum_jacobian, dim3((uint32_t)count), dim3(64), 0, stream, d_in, m, d_out, (uint32_t)count);
   HIPCHK(hipGetLastError());
   return ZKHIP_OK;
 }

@@ -58,7 +58,8 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
                   size_t scalar_stride = 0);
 int prepare_bases_device(const uint32_t* d_bases, size_t n, hipStream_t stream, prepared_bases** out, int c_override = 0);
 void release_prepared(prepared_bases* pb);
-int sum_jacobian_device(const uint32_t* d_in, int m, uint32_t* d_out, hipStream_t stream);
+// d_out[b] = sum over i < m of d_in[i * count + b], b < count (count = 1: the plain fold of m points)
+int sum_jacobian_device(const uint32_t* d_in, int m, uint32_t* d_out, hipStream_t stream, size_t count = 1);
 size_t g1_batch_normalize_workspace(size_t n);
 int g1_batch_normalize_device(const uint32_t* d_in, size_t n, uint32_t* d_out, void* ws, size_t ws_bytes, hipStream_t stream);
 size_t g1_fft_workspace(size_t n);

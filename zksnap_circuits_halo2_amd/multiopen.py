@@ -59,6 +59,7 @@ def evaluate_queries(queries: Sequence[ProverQuery], k: int, stream: int = 0) ->
             x = fr_encode([point])[0]
             _lib.check(lib.zkhip_fr_eval_polynomial_batch_device(ptrs, len(qs), n, x.ctypes.data, out, stream))
             host = np.zeros((len(qs), 4), dtype=np.uint64)
+            _lib.check(lib.zkhip_stream_sync(stream))        # zkhip_download copies on the legacy default stream: not ordered behind a non-blocking `stream`
             _lib.check(lib.zkhip_download(host.ctypes.data, out, host.nbytes))
         finally:
             lib.zkhip_free(out)
@@ -105,7 +106,8 @@ class _BufferPool:
 
 class ProverGWC:
     """`ProverGWC::new(params)` / `create_proof(transcript, queries)`; `commit` is a callable taking the device address of 2^k
-    coefficients and returning the commitment (12 uint64 limbs, Jacobian) -- e.g. a prepared-table MSM over `params.g`"""
+    coefficients and returning the commitment (12 uint64 limbs, Jacobian) -- e.g. a prepared-table MSM over `params.g`.  `create_proof`
+    enqueues on `stream` (any HIP stream, blocking or not) and drains it before every host read and before every call of `commit`."""
 
     def __init__(self, k: int, commit):
         self.k, self.n, self.commit = k, 1 << k, commit
@@ -130,6 +132,7 @@ class ProverGWC:
                 zw = fr_encode([z])[0]
                 _lib.check(lib.zkhip_fr_kate_division_device(C.c_void_p(batch), n, zw.ctypes.data, C.c_void_p(quot), stream))
                 _zero_at(quot, n - 1, stream)           # the quotient has n - 1 coefficients; the commitment takes n scalars
+                _lib.check(lib.zkhip_stream_sync(stream))     # `commit` runs on a stream of its own choosing: hand it finished coefficients
                 witnesses.append(np.array(self.commit(quot), dtype=np.uint64).reshape(12))
         finally:
             _lib.check(lib.zkhip_sync())
@@ -272,6 +275,7 @@ class ProverSHPLONK:
             vpow = [pow(v, i, R_MOD) for i in range(len(sets))]
             h_x = alloc()
             E.linear_combination_program(vpow).run_device(quotients, self.k, h_x, stream=stream)
+            _lib.check(lib.zkhip_stream_sync(stream))         # `commit` runs on a stream of its own choosing: hand it finished coefficients
             H = np.array(self.commit(h_x), dtype=np.uint64).reshape(12)
             # ---- L(X) and the final quotient ----------------------------------------------------------------------------------------------
             z_diffs = [_vanishing_at([p for p in super_points if p not in rs.points], u) for rs in sets]
@@ -296,10 +300,12 @@ class ProverSHPLONK:
             chk = tmp + (n - 1) * 32
             _lib.check(lib.zkhip_fr_eval_polynomial_device(C.c_void_p(l_x), n, uw.ctypes.data, C.c_void_p(chk), stream))
             res = np.zeros(4, dtype=np.uint64)
+            _lib.check(lib.zkhip_stream_sync(stream))
             _lib.check(lib.zkhip_download(res.ctypes.data, C.c_void_p(chk), 32))
             if res.any():
                 raise ArithmeticError("SHPLONK: L(u) != 0 -- inconsistent queries (an evaluation does not match its polynomial)")
             final = self._divide(l_x, tmp, [u], stream)
+            _lib.check(lib.zkhip_stream_sync(stream))
             Hp = np.array(self.commit(final), dtype=np.uint64).reshape(12)
             return H, Hp
         finally:
