@@ -40,11 +40,19 @@ def synth_scalars(n: int, seed: int, kind: str = "uniform") -> np.ndarray:
     return a
 
 
-def profile_read(lib):
+def profile_read(lib, counts: dict = None):
+    """phases of the last profiled call: [(name, ms)] with the marks of one name summed (the wide MSM marks accumulate / combine once per
+    bucket-range piece); `counts` receives how many marks each name had"""
     ms = (C.c_double * 32)()
     names = ((C.c_char * 64) * 32)()
     k = lib.zkhip_profile_read(ms, names, 32)
-    return [(names[i].value.decode(), ms[i]) for i in range(max(k, 0))]
+    per = {}
+    for i in range(max(k, 0)):
+        nm = names[i].value.decode()
+        per[nm] = per.get(nm, 0.0) + ms[i]
+        if counts is not None:
+            counts[nm] = counts.get(nm, 0) + 1
+    return list(per.items())
 
 
 def parse_args(argv=None):

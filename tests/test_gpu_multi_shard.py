@@ -372,11 +372,10 @@ def test_device_resident_commit_on_duplicate_contexts(lib, cref):
                 with torch.cuda.stream(st):
                     d2 = torch.zeros_like(d_sc)
                     for _ in range(20):
-                        d2.copy_(d_vecs[0].reshape(-1))
+                        d2.copy_(d_vecs[0])
                     d2.copy_(d_sc)
                     out = torch.zeros(12, dtype=torch.int64, device="cuda")
                     _lib.check(lib.zkhip_msm_g1_registered_device(bases.ctypes.data, d2.data_ptr(), n, out.data_ptr(), st.cuda_stream))
-                    d2_after = None
                 st.synchronize()
                 assert np.array_equal(cref.jac_to_affine(np.ascontiguousarray(out.cpu().numpy().view(np.uint64))), exp), S
             finally:

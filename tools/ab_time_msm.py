@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A/B helper: median / min time of the prepared MSM (2^L) over many runs, and the median of every phase (in-library HIP events).
-  ab_time_msm.py [log_n=20] [reps=100] [label]      knobs: ZKHIP_MAX_WINDOW (cap the prepared window), ZKHIP_TASK_SHIFT (task length 2^s)
+  ab_time_msm.py [log_n=20] [reps=100] [label]      knobs: ZKHIP_MAX_WINDOW (cap the prepared window), ZKHIP_TASK_SHIFT (task length 2^s),
+  ZKHIP_MSM_PIECES (bucket-range pieces of the wide path), ZKHIP_NO_OVERLAP=1 (no second stream: the pieces run one after the other)
 Run the variants alternately in one gpurun call: box-to-box differences (+-4 %) exceed most single-kernel effects."""
 import os, sys, ctypes as C, statistics as st
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
@@ -33,6 +34,8 @@ lib.zkhip_profile_enable(1)
 for _ in range(30):
     run(); torch.cuda.synchronize()
     k = lib.zkhip_profile_read(ms, names, 32)
-    for i in range(k): acc.setdefault(names[i].value.decode(), []).append(ms[i])
+    per = {}
+    for i in range(k): per[names[i].value.decode()] = per.get(names[i].value.decode(), 0.0) + ms[i]     # a phase may be marked once per bucket-range piece
+    for nm, v in per.items(): acc.setdefault(nm, []).append(v)
 lib.zkhip_profile_enable(0)
 print(f"{sys.argv[3] if len(sys.argv) > 3 else '':8s} msm median {st.median(ts):.4f} min {min(ts):.4f} | " + " ".join(f"{k} {st.median(v):.4f}" for k, v in acc.items()))
