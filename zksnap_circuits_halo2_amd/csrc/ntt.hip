@@ -8,9 +8,9 @@
 //   * Stockham autosort: pass p with Ns = prod(previous radices), R = 2^B reads  x_r = src[j + r N/R]
 //     (contiguous in j), multiplies by w_(Ns R)^(k r), k = j mod Ns, does an R-point DFT and writes
 //     dst[(j/Ns) Ns R + k + r Ns].  No bit-reversal pass, every pass streams coalesced runs.
-//   * One workgroup owns a tile of J consecutive j (J * R = 2048 elements, 72 KiB of LDS as 9-limb values):
-//     cooperative coalesced load -> LDS, <= 3 rounds of <= 3 radix-2 stages in registers (8 elements per
-//     thread), LDS exchange between rounds, cooperative coalesced store.
+//   * One workgroup owns a tile of J consecutive j (J * R = 1024 elements, 36 KiB of LDS as 9-limb values; up to 2048):
+//     cooperative coalesced load -> LDS, rounds of 2 radix-2 stages in registers (4 elements per
+//     thread; 3 stages / 8 elements as a variant), LDS exchange between rounds, cooperative coalesced store.
 //   * B <= 9 bits per pass: 2^24 is three passes.  Twiddles w_M^(k r) come from an M-entry table (laid out [r][k], the order read) when
 //     M <= 2^24 (HBM is plentiful: 36 B * M per (omega, log_n), cached) and from two 2^(log M / 2)-entry
 //     tables (one extra multiply) above that.
@@ -55,6 +55,7 @@ struct pass_args {
   uint32_t h;
   uint32_t tw_rk;                 // direct table in (r, k) layout: w_M^(k r) at index r * Ns + k
   uint32_t first, last;
+  uint32_t tile;                  // elements per workgroup (<= NTT_TILE)
   uint32_t in_len;                // first pass: elements >= in_len read as zero
   uint32_t out_len;               // last pass: elements >= out_len are not stored
   scale_arg in_scale, out_scale;
@@ -120,7 +121,7 @@ __global__ void __launch_bounds__(2048 / E, E == 8 ? 2 : 4) k_ntt_pass(pass_args
   extern __shared__ uint32_t lds[];
   const uint32_t B = a.B, R = 1u << B, L = a.L;
   const uint32_t N = 1u << L;
-  const uint32_t tile = N < NTT_TILE ? N : NTT_TILE;
+  const uint32_t tile = a.tile;
   const uint32_t J = tile >> B;
   const uint32_t logJ = 31 - __builtin_clz(J);
   const uint32_t j0 = blockIdx.x * J;
@@ -503,7 +504,12 @@ int ntt_transform(const uint32_t* d_in, uint32_t in_len, uint32_t in_stride, uin
       attr_set_dev[cur_dev & 63] = true;
     }
   }
-  const uint32_t tile = N < NTT_TILE ? N : NTT_TILE;
+  // Elements per workgroup.  1024 (256 threads, 36 KiB of LDS, four workgroups per CU) against the 2048 the kernel was written for (two
+  // workgroups per CU): a barrier or an LDS round trip parks 4 of a SIMD's waves instead of 8, and a pass keeps 128-byte runs on both
+  // sides.  Measured on one box, 2048 / 1024 / 512: 2^13 0.0465 / 0.0355 / 0.0349 ms, 2^22 0.586 / 0.557 / 0.590, 2^24 2.341 / 2.301 / 2.452
+  // (profiles/r03_ntt_tile_ab.txt).  ZKHIP_NTT_TILE = 512 | 1024 | 2048 is the A/B knob.
+  static const uint32_t tile_knob = [] { const char* e = getenv("ZKHIP_NTT_TILE"); const int v = e ? atoi(e) : 0; return (v == 512 || v == 1024 || v == 2048) ? (uint32_t)v : 1024u; }();
+  const uint32_t tile = N < tile_knob ? N : tile_knob;
   if ((p->npass >= 2 && !tmp0) || (p->npass >= 3 && !tmp1)) { set_error("ntt: missing scratch buffer"); return ZKHIP_EINVAL; }
   uint32_t* tmp[2] = {tmp0, tmp1};
   prof_begin(stream);
@@ -513,7 +519,7 @@ int ntt_transform(const uint32_t* d_in, uint32_t in_len, uint32_t in_stride, uin
     a.L = L; a.S = p->S[i]; a.B = p->B[i];
     a.tw_local = p->tw_local[i]; a.tw_lo = p->tw_lo[i]; a.tw_hi = p->tw_hi[i]; a.h = p->h[i]; a.tw_rk = p->rk[i];
     a.first = i == 0; a.last = i == p->npass - 1;
-    a.in_len = in_len; a.out_len = out_len;
+    a.in_len = in_len; a.out_len = out_len; a.tile = tile;
     a.in_scale = is; a.out_scale = os;
     // buffer chain: in -> tmp0 -> tmp1 -> tmp0 -> ... -> out
     a.src = i == 0 ? d_in : tmp[(i - 1) & 1];
