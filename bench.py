@@ -9,7 +9,8 @@ sharded by point range) + the partial-sum exchange (all_gather of 96-byte Jacobi
 device).  Scalars and bases are resident in HBM before the timed region; prints ONE JSON line on rank 0.
 Extra keys: "roofline" (dominant kernel = bucket accumulation, HIP-event timed inside the library on the launch
 stream), "cpu_baseline" (oracle/cpu_ref.c = restatement of the reference's best_multiexp on the host cores),
-"phases_ms", "ntt" and "wrapper_replay" (MSM+NTT call mix of one wrapper-circuit proof at k = 22, device-resident).
+"phases_ms", "ntt", "wrapper_replay" (MSM+NTT call mix of one wrapper-circuit proof at k = 22, device-resident), "value_2p22",
+"wrapper_replay_k24" (the same mix at k = 24 = BASELINE configs[4], one card + the 8-card projection), "prover_flow_k13_wide" / "prover_flow_k15_wide".
 """
 from __future__ import annotations
 
@@ -357,6 +358,13 @@ def main() -> None:
 
     if rank == 0 and world == 1 and not args.no_extras:
         result.update(extras(lib, _lib, F, torch, dev, stream))
+        # the wrapper-size MSM (BASELINE configs[3]: k = 22, /root/reference/aggregator/benches/wrapper_circuit.rs:21) beside the headline
+        if "msm_2^22" in result:
+            result["value_2p22"] = result["msm_2^22"]["Mpoints_per_s"]
+        try:
+            result["wrapper_replay_k24"] = wrapper_replay_k24(lib, _lib, F, torch, dev, stream, result.get("config4_wrapper_k24_msm", {}))
+        except Exception as exc:   # an extra: never fail the bench line
+            result["wrapper_replay_k24"] = {"error": repr(exc)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.log_n, d_scalars, d_bases, d_out, n)
@@ -697,7 +705,23 @@ def extras(lib, _lib, F, torch, dev, stream) -> dict:
         d_s2 = torch.from_numpy(synth_scalars(n2, 4242).view(np.int64)).to(dev)
         d_o2 = torch.zeros(24, dtype=torch.int64, device=dev)
         ms_g2 = timed(lambda: _lib.check(lib.zkhip_msm_g2_device(d_s2.data_ptr(), d_b2.data_ptr(), n2, d_o2.data_ptr(), stream)), 3)
-        out["msm_g2_2^16"] = {"ms": round(ms_g2, 3), "Mpoints_per_s": round(n2 / ms_g2 / 1e3, 2), "note": "general path; not on the prover's path"}
+        # the result is checked, not discarded: base i = (1000003 (i % 64 + 1)) G2, so MSM = [sum a_i 1000003 (i % 64 + 1)] G2 (host integers of the
+        # package's srs module; the scalars' integer values a = words / 2^256 mod r)
+        h_s2 = d_s2.cpu().numpy().view(np.uint64).reshape(n2, 4)
+        r_inv = pow(1 << 256, -1, R_MOD)
+        want_k = 0
+        for i in range(n2):
+            a_i = sum(int(h_s2[i, j]) << (64 * j) for j in range(4)) * r_inv % R_MOD
+            want_k = (want_k + a_i * 1000003 * (i % 64 + 1)) % R_MOD
+        jac = d_o2.cpu().numpy().view(np.uint64)[:24]
+        mont_inv = pow(1 << 256, -1, _srs.Q_MOD)
+        v = [sum(int(jac[4 * c_ + j]) << (64 * j) for j in range(4)) * mont_inv % _srs.Q_MOD for c_ in range(6)]
+        X, Y, Zc = (v[0], v[1]), (v[2], v[3]), (v[4], v[5])
+        iz = _srs._f2inv(Zc)
+        iz2 = _srs._f2mul(iz, iz)
+        got_pt = (_srs._f2mul(X, iz2), _srs._f2mul(Y, _srs._f2mul(iz2, iz)))
+        out["msm_g2_2^16"] = {"ms": round(ms_g2, 3), "Mpoints_per_s": round(n2 / ms_g2 / 1e3, 2), "result_equals_structured_identity": bool(got_pt == _srs.g2_mul(want_k)),
+                              "note": "general path; not on the prover's path"}
         del d_b2, d_s2
     except Exception as exc:   # an extra: never fail the bench line
         out["msm_g2_2^16"] = {"error": repr(exc)}
@@ -728,9 +752,96 @@ def extras(lib, _lib, F, torch, dev, stream) -> dict:
                                   "note": "no transcript (seeded challenges); the proving key's columns (fixed, l_0/l_last/l_active, sigma) are transformed under keygen_* and not counted, as pk.fixed_cosets / pk.permutation.cosets are in the reference"}
     except Exception as exc:   # an extra: never fail the bench line
         out["prover_flow_k22"] = {"error": repr(exc)}
+    # the same flow at the small circuits' real width (columns sized by calculate_params(Some(20)): /root/reference/voter/benches/voter_circuit.rs:49-51,
+    # /root/reference/aggregator/benches/state_transition_circuit.rs:48-50): voter-like k = 13 with 256 gate + 8 lookup columns, state-transition-like
+    # k = 15 with 64 + 8; commits batched per phase; quotient, grand products, lookup permutations and the SHPLONK multi-open included
+    for name, kk, gg, ll in (("prover_flow_k13_wide", 13, 256, 8), ("prover_flow_k15_wide", 15, 64, 8)):
+        try:
+            flows = [prove_flow.run(kk, gg, seed=kk + r, verbose=False, lookups=ll) for r in range(2)]
+            assert all(all(f["checks"].values()) for f in flows), [f["checks"] for f in flows]
+            flow = min(flows, key=lambda f: f["prove_ms"])
+            out[name] = {"prove_ms": round(flow["prove_ms"], 2), "proofs_per_s_device_portion": round(1e3 / flow["prove_ms"], 2), "gate_columns": gg, "lookup_columns": ll,
+                         "columns": flow["columns"], "msms": flow["msms"], "multiopen_queries": flow["queries"], "quotient_program_insns": flow["program_insns"],
+                         "checks": flow["checks"], "timings_ms": {kk_: round(v, 2) for kk_, v in flow["timings_ms"].items()},
+                         "note": "no transcript, no witness generation; keygen_* not counted (the key is per circuit)"}
+        except Exception as exc:   # an extra: never fail the bench line
+            out[name] = {"error": repr(exc)}
     tot = ms + out["prover_phases_k22"]["total_ms"]
     out["wrapper_replay"]["with_prover_phases_ms"] = round(tot, 2)          # + quotient, grand products, multiopen (8(f) rows 1-3)
     out["wrapper_replay"]["proofs_per_s_device_portion"] = round(1e3 / tot, 3)
+    return out
+
+
+def wrapper_replay_k24(lib, _lib, F, torch, dev, stream, c4: dict) -> dict:
+    """BASELINE configs[4] as an OP MIX (SURVEY.md 8(d) Config 5: the wrapper's call mix at n = 2^24, extended 2^26;
+    /root/reference/aggregator/benches/wrapper_circuit.rs:21,61-68 at k + 2): 18 MSM 2^24 + 13 iNTT 2^24 + 13 NTT 2^26 + 1 iNTT 2^26,
+    device-resident on ONE card (13 GiB of prepared table, 2 GiB per extended polynomial + two scratch copies), MSM and NTT parts timed
+    separately, and the 8-GPU projection: the MSMs sharded by point range (2^21 per card: `per_shard_ms` of the configs[4] leg) + the
+    exchange, the transforms unsharded on the primary card (north star: NTT stays single-GPU)."""
+    from zksnap_circuits_halo2_amd.fields import R_MOD, omega_for
+
+    k, ek = 24, 26
+    n, en = 1 << k, 1 << ek
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / reps * 1e3
+
+    t0, dd = F.fr_encode([24242424])[0], F.fr_encode([0x9E3779B97F4A7C15])[0]
+    g = torch.empty(n * 8, dtype=torch.int64, device=dev)
+    _lib.check(lib.zkhip_g1_gen_walk_device(t0.ctypes.data, dd.ctypes.data, n, g.data_ptr(), stream))
+    torch.cuda.synchronize()
+    h = C.c_uint64(0)
+    _lib.check(lib.zkhip_prepare_bases_device(g.data_ptr(), n, C.byref(h)))
+    del g
+    torch.cuda.empty_cache()
+    sc = torch.from_numpy(synth_scalars(n, 2424).view(np.int64)).to(dev)
+    ext = torch.from_numpy(synth_scalars(en, 2626).view(np.int64)).to(dev)
+    res = torch.zeros(16, dtype=torch.int64, device=dev)
+    om_i = F.fr_encode([pow(omega_for(k), -1, R_MOD)])[0]
+    div = F.fr_encode([pow(n, -1, R_MOD)])[0]
+    om_e = F.fr_encode([omega_for(ek)])[0]
+    om_ei = F.fr_encode([pow(omega_for(ek), -1, R_MOD)])[0]
+    div_e = F.fr_encode([pow(en, -1, R_MOD)])[0]
+
+    def msms():
+        for _ in range(18):
+            _lib.check(lib.zkhip_msm_g1_prepared_device(h, 0, sc.data_ptr(), n, res.data_ptr(), stream))
+
+    def ntts():
+        for _ in range(13):
+            _lib.check(lib.zkhip_ifft_scaled_device(sc.data_ptr(), om_i.ctypes.data, k, div.ctypes.data, stream))
+        for _ in range(13):
+            _lib.check(lib.zkhip_ntt_fr_device(ext.data_ptr(), om_e.ctypes.data, ek, stream))
+        _lib.check(lib.zkhip_ifft_scaled_device(ext.data_ptr(), om_ei.ctypes.data, ek, div_e.ctypes.data, stream))
+
+    try:
+        ms_msm = timed(msms, 1)
+        ms_ntt = timed(ntts, 1)
+        ms_all = timed(lambda: (msms(), ntts()), 1)
+        one_ntt26 = timed(lambda: _lib.check(lib.zkhip_ntt_fr_device(ext.data_ptr(), om_e.ctypes.data, ek, stream)), 2)
+    finally:
+        lib.zkhip_release_bases(h)
+        del sc, ext
+        torch.cuda.empty_cache()
+    out = {"workload": "k=24: 18 MSM 2^24 + 13 iNTT 2^24 + 13 NTT 2^26 + 1 iNTT 2^26, device-resident, ONE card",
+           "ms": round(ms_all, 2), "msm_part_ms": round(ms_msm, 2), "ntt_part_ms": round(ms_ntt, 2), "ms_per_msm_2^24": round(ms_msm / 18, 3),
+           "ms_per_ntt_2^26": round(one_ntt26, 3), "Mpoints_per_s_2^24": round(n / (ms_msm / 18) / 1e3, 1),
+           "proofs_per_s_msm_ntt_portion": round(1e3 / ms_all, 3),
+           "note": "MSM+NTT portion only (no witness, transcript, quotient); the prepared table of 2^24 points is 13 GiB of the card's 288"}
+    shard = c4.get("per_shard_ms")
+    if shard:
+        # 8 cards: every MSM = one 2^21-point shard per card (measured: per_shard_ms of config4_wrapper_k24_msm, the same kernels on 2^21 points) +
+        # the exchange (8 x 96 bytes + fold, ~0.03 ms measured at N = 1 with the gather degenerated to a copy); transforms stay on one card
+        proj = 18 * (shard + 0.03) + ms_ntt
+        out["projection_8_gpus"] = {"ms": round(proj, 2), "proofs_per_s_msm_ntt_portion": round(1e3 / proj, 3),
+                                    "how": f"18 x (per_shard_ms {shard} + 0.03 exchange) + ntt_part_ms {round(ms_ntt, 2)}: MSM / 8, NTT unsharded -- a PROJECTION from one card's measurements, not a measurement on 8",
+                                    "ntt_share_of_projection": round(ms_ntt / proj, 3)}
     return out
 
 
@@ -959,6 +1070,9 @@ def cpu_baseline(log_n, d_scalars, d_bases, d_out, n) -> dict:
             "cores_usable": usable, "sched_affinity": affinity, "cgroup_cpu_max": quota, "os_cpu_count": os.cpu_count(),
             "gpu_result_matches": agree, "thread_sweep_msm_2^20": sweep, "ntt_best_fft": ntt,
             "msm_2^22_s": round(dt22, 3), "small_circuit_mixes": small,
+            "wrapper_shape_mix_k24": {"s": round(18 * 4 * dt22 + 13 * ntt["2^24"]["s"] + 14 * 4 * (26.0 / 24.0) * ntt["2^24"]["s"], 1),
+                                      "how": "EXTRAPOLATED, nothing at 2^24 / 2^26 was run on the CPU: 18 x (2^24 MSM = 4 x the timed 2^22) + 13 x (timed 2^24 best_fft) + "
+                                             "14 x (2^26 best_fft = 4 x 26/24 x the timed 2^24: n log n)"},
             "wrapper_shape_mix": {"s": round(mix, 2), "proofs_per_s_msm_ntt_portion": round(1.0 / mix, 4),
                                   "how": "18 x (2^22 MSM, timed as 4 x 2^20) + 13 x (2^22 best_fft) + 14 x (2^24 best_fft), one op of each kind timed and multiplied",
                                   "note": "restatement of the reference's CPU algorithms, not `cargo bench`: no witness generation, no transcript, and the 4x64 field multiply here is plain C (halo2curves uses assembly, roughly 2x faster per multiply)"},

@@ -27,6 +27,7 @@ extern "C" {
 #define ZKHIP_ENODEV (-2)  /* no HIP device / init failed */
 #define ZKHIP_EHIP (-3)    /* HIP runtime error, see zkhip_last_error() */
 #define ZKHIP_ENOMEM (-4)  /* device allocation failed */
+#define ZKHIP_EBUSY (-5)   /* zkhip_init with a different device list while host-buffer calls are running */
 
 /* ---- lifecycle ----------------------------------------------------------------------------------- */
 /* Name the HIP devices this process drives (`zkhip_init(const int *devices, int ndev)`).  devices == NULL
@@ -34,7 +35,8 @@ extern "C" {
  * other vector operation runs there, and `_device` pointers are pointers into its memory.  With ndev > 1 the MSM over registered
  * bases is sharded by point range over all the devices (zkhip_register_bases below) -- the 8 GPUs of one node behind one
  * `create_proof` process (/root/reference/aggregator/src/wrapper.rs:129).  Lazy init on first use is allowed (device 0).
- * Calling it again with the same list is a no-op; with a different list it shuts the library down first.
+ * Calling it again with the same list is a no-op; with a different list it shuts the library down first (ZKHIP_EBUSY while
+ * host-buffer calls of other threads are still running).
  * Environment: ZKHIP_DEVICE (default device), ZKHIP_SHARDS (see zkhip_set_msm_shards), ZKHIP_HOST_LANES (1..4, default 2: host-buffer
  * calls that may be in flight at once, each with its own stream and scratch memory). */
 int zkhip_init(const int *devices, int ndev);

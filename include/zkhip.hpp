@@ -264,6 +264,21 @@ inline std::array<uint64_t, 16> g2_decompress(const unsigned char in[64], int fl
   std::memcpy(out.data() + 8, y.c0.l, 32); std::memcpy(out.data() + 12, y.c1.l, 32);
   return out;
 }
+// `G2Affine::read_raw`'s validity check for the two G2 points of a RawBytes parameter file: canonical Montgomery residues and (0, 0) or
+// y^2 = x^3 + 3 / (9 + u) on the twist (what srs.py's reader checks in the Python mirror)
+inline bool g2_is_valid(const std::array<uint64_t, 16>& g2) {
+  bool zero = true;
+  for (uint64_t w : g2) zero = zero && w == 0;
+  if (zero) return true;
+  Fq c[4];
+  for (int i = 0; i < 4; i++) {
+    if (geq(g2.data() + 4 * i, Q_MOD)) return false;
+    std::memcpy(c[i].l, g2.data() + 4 * i, 32);
+  }
+  const Fq2 x{c[0], c[1]}, y{c[2], c[3]};
+  const Fq2 twist_b = f2_mul(Fq2{fq_from_u64(3), Fq{}}, f2_invert(Fq2{fq_from_u64(9), fq_one()}));
+  return f2_mul(y, y) == f2_add(f2_mul(f2_mul(x, x), x), twist_b);
+}
 }  // namespace detail
 
 // ---- halo2_proofs::arithmetic ----------------------------------------------------------------------------------
@@ -497,7 +512,15 @@ class ParamsKZG {
       : k_(k), n_((uint64_t)1 << k), g_(std::move(g)), g_lagrange_(std::move(g_lagrange)) {
     if (g_.size() != n_ || (!g_lagrange_.empty() && g_lagrange_.size() != n_)) throw std::invalid_argument("ParamsKZG: SRS length != 2^k");
     check(zkhip_register_bases(g_.data()->x, g_.size()), "ParamsKZG::register g");
-    if (!g_lagrange_.empty()) check(zkhip_register_bases(g_lagrange_.data()->x, g_lagrange_.size()), "ParamsKZG::register g_lagrange");
+    if (!g_lagrange_.empty()) {
+      // a constructor that throws runs no destructor: g_ must not stay registered over memory that is about to be freed
+      const int rc = zkhip_register_bases(g_lagrange_.data()->x, g_lagrange_.size());
+      if (rc != ZKHIP_OK) {
+        const std::string why = zkhip_last_error();
+        (void)zkhip_unregister_bases(g_.data()->x);
+        throw std::runtime_error("ParamsKZG::register g_lagrange: " + why);
+      }
+    }
   }
   ~ParamsKZG() {
     if (!g_.empty()) zkhip_unregister_bases(g_.data()->x);
@@ -586,6 +609,7 @@ class ParamsKZG {
       if (bad < n) throw std::runtime_error("ParamsKZG::read: g holds a point that is not on the curve");
       halo2::check(zkhip_g1_check_points(reinterpret_cast<const uint64_t*>(gl.data()), (size_t)n, &bad), "zkhip_g1_check_points");
       if (bad < n) throw std::runtime_error("ParamsKZG::read: g_lagrange holds a point that is not on the curve");
+      if (!detail::g2_is_valid(g2) || !detail::g2_is_valid(s_g2)) throw std::runtime_error("ParamsKZG::read: g2 / s_g2 is not a point of the twist");
     }
     ParamsKZG p(k, std::move(g), std::move(gl));
     p.set_g2(g2, s_g2);

@@ -97,3 +97,84 @@ def test_g2_msm_device_resident_matches_host_api(lib, cref):
     _lib.check(lib.zkhip_msm_g2_device(d_sc.data_ptr(), d_bs.data_ptr(), n, out.data_ptr(), None))
     torch.cuda.synchronize()
     assert dec(out.cpu().numpy().view(np.uint64)) == dec(A.best_multiexp_g2(sc, pts))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the sizes the bench times (2^16: windows of 16 bits, 2^15 buckets per window, tasks of 64) and one ragged size above, on a walk that the
+# DEVICE extends: 256 host-made points + a per-block shift, added elementwise by the G2 addition kernel, normalised on the host with one
+# shared inversion (the big-integer oracle would need minutes to walk 2^17 points and invert every z)
+def _f2_batch_inv(zs):
+    pref, run = [], (1, 0)
+    for z in zs:
+        pref.append(run)
+        run = O.f2_mul(run, z)
+    inv = O.f2_inv(run)
+    out = [None] * len(zs)
+    for i in range(len(zs) - 1, -1, -1):
+        out[i] = O.f2_mul(inv, pref[i])
+        inv = O.f2_mul(inv, zs[i])
+    return out
+
+
+def device_walk(lib, t0, d, n, block=256):
+    """limbs ((n, 16) uint64) of [(t0 + i d) G2 for i < n]"""
+    assert n % block == 0
+    base = walk(t0, d, block)
+    step = O.g2_scalar_mul(block * d % O.R_MOD, O.G2_GEN)
+    shifts, S = [], None
+    for _ in range(n // block):
+        shifts.append(S)
+        S = O.g2_add(S, step)
+    a = np.tile(enc(base), (n // block, 1))
+    b = np.repeat(enc(shifts), block, axis=0)
+    out = np.zeros((n, 24), dtype=np.uint64)
+    _lib.check(lib.zkhip_test_g2_op(0, a.ctypes.data, b.ctypes.data, out.ctypes.data, n))
+    def jac_of(row):                                                # (X, Y, Z) as Fq2 triples, not normalised (no point of a walk is the identity)
+        v = [O.from_mont(O.from_limbs([int(x) for x in row[4 * c:4 * c + 4]]), O.Q_MOD) for c in range(6)]
+        return (v[0], v[1]), (v[2], v[3]), (v[4], v[5])
+
+    jac = [jac_of(r) for r in out]
+    assert all(J[2] != (0, 0) for J in jac)
+    zi = _f2_batch_inv([J[2] for J in jac])                          # one inversion for all the z
+    pts = []
+    for (X, Y, Z), iz in zip(jac, zi):
+        iz2 = O.f2_mul(iz, iz)
+        pts.append((O.f2_mul(X, iz2), O.f2_mul(Y, O.f2_mul(iz2, iz))))
+    assert O.g2_on_curve(pts[0]) and O.g2_on_curve(pts[-1]) and pts[block + 1] == O.g2_scalar_mul((t0 + (block + 1) * d) % O.R_MOD, O.G2_GEN)
+    return enc(pts)
+
+
+@pytest.fixture(scope="module")
+def g2_walk_2p17(lib):
+    t0, d = 0x5A4B534E41500002 + 171717, 0x9E3779B97F4A7C15F39CC0605CEDC835
+    n = (1 << 17) + 256
+    return t0, d, device_walk(lib, t0, d, n)
+
+
+@pytest.mark.parametrize("n,kind", [(1 << 16, 0), ((1 << 17) + 3, 1)])
+def test_g2_msm_at_the_bench_shape(lib, cref, g2_walk_2p17, n, kind):
+    """2^16 uniform scalars (what bench.py times as msm_g2_2^16) and 2^17 + 3 witness-like scalars: MSM(a, (t0 + i d) G2) = [sum a_i (t0 + i d)] G2"""
+    t0, d, pts = g2_walk_2p17
+    sc = cref.gen_scalars(8850 + kind, n, kind)
+    got = dec(A.best_multiexp_g2(sc, np.ascontiguousarray(pts[:n])))
+    assert got == O.g2_scalar_mul(cref.expected_scalar(sc, t0, d), O.G2_GEN)
+
+
+@pytest.mark.parametrize("case", ["all_equal", "selector", "ones_and_minus_ones", "one_bucket_per_window"])
+def test_g2_msm_skewed_scalars(lib, cref, g2_walk_2p17, case):
+    """the skew cases of the G1 suite: a column of equal values / of selector bits puts a large share of all entries into one bucket of every
+    window (heavy buckets, cooperative task records); 1 and -1 cancel pairwise inside buckets"""
+    t0, d, pts = g2_walk_2p17
+    n = 1 << 14
+    one, minus_one = F.fr_encode([1])[0], F.fr_encode([O.R_MOD - 1])[0]
+    sc = np.zeros((n, 4), dtype=np.uint64)
+    if case == "all_equal":
+        sc[:] = F.fr_encode([0x1234567890ABCDEF1234567890ABCDEF])[0]
+    elif case == "selector":
+        sc[::2] = one
+    elif case == "ones_and_minus_ones":
+        sc[::2] = one; sc[1::2] = minus_one
+    else:
+        sc[:] = F.fr_encode([sum(5 << (16 * w) for w in range(16))])[0]          # digit 5 in every 16-bit window
+    got = dec(A.best_multiexp_g2(sc, np.ascontiguousarray(pts[:n])))
+    assert got == O.g2_scalar_mul(cref.expected_scalar(sc, t0, d), O.G2_GEN)

@@ -162,6 +162,27 @@ def test_device_resident_prover_flow(lib, k, gate_cols):
     assert not bad["quotient_is_a_polynomial"] and not bad["permutation_product_closes"]
 
 
+@pytest.mark.parametrize("k,gate_cols,lookups", [(7, 3, 2), (13, 256, 8), (15, 64, 8)])
+def test_device_resident_prover_flow_wide(lib, k, gate_cols, lookups):
+    """the small circuits' REAL shape: the standalone voter / state-transition benches size their columns with
+    `calculate_params(Some(20))` (/root/reference/voter/benches/voter_circuit.rs:49-51,
+    /root/reference/aggregator/benches/state_transition_circuit.rs:48-50; browser config 412 advice + 11 lookup columns,
+    /root/reference/voter/frontend/app/worker.js:95-102) -- hundreds of gate columns and several lookup columns, where the tests above use
+    <= 4 and one.  Same flow, same invariants, all the columns of a phase committed through the batched registered-bases entry point; the
+    quotient program then names hundreds of columns and runs in thousands of instructions."""
+    from tools import prove_flow
+
+    res = prove_flow.run(k, gate_cols, seed=70 + k, verbose=False, lookups=lookups)
+    assert all(res["checks"].values()), res["checks"]
+    assert res["columns"] == (gate_cols + 2) + (gate_cols + lookups) + 3 + (gate_cols + lookups + 1) + -(-(gate_cols + lookups + 1) // 2) + 3 * lookups
+    assert res["program_registers"] <= _lib.VM_REGS and res["program_insns"] > 4 * gate_cols
+    bad = prove_flow.run(k, gate_cols, seed=70 + k, corrupt="gate", verbose=False, lookups=lookups)["checks"]
+    assert not bad["quotient_is_a_polynomial"] and bad["permutation_product_closes"] and bad["lookup_product_closes"]
+    if k <= 13:
+        bad = prove_flow.run(k, gate_cols, seed=70 + k, corrupt="copy", verbose=False, lookups=lookups)["checks"]
+        assert not bad["quotient_is_a_polynomial"] and not bad["permutation_product_closes"]
+
+
 # ---------------------------------------------------------------- keygen_vk / keygen_pk, ProvingKey files (SURVEY.md 8(f) row 4)
 def test_keygen_against_the_oracle(lib, cref):
     """keygen.py on the toy circuit: sigma columns = the cycles' delta^col * omega^row; the verifying key's commitments = the oracle's

@@ -132,6 +132,41 @@ def test_evaluate_h_matches_reference_formulas(lib, k, extended_k, gate_cols):
     assert got == exp
 
 
+def halo2_lib_wide_cs(gate_cols, lookups):
+    """the same shape at the width the reference's small circuits really have (`calculate_params(Some(20))`:
+    /root/reference/voter/benches/voter_circuit.rs:49-51, /root/reference/aggregator/benches/state_transition_circuit.rs:48-50): `gate_cols`
+    vertical gates, `lookups` range lookups on columns of their own, every advice column and a fixed column in the permutation"""
+    A, Lk = gate_cols, lookups
+    gates = [[E.Fixed(i) * (E.Advice(i, 0) + E.Advice(i, 1) * E.Advice(i, 2) - E.Advice(i, 3))] for i in range(A)]
+    lks = [E.Lookup([E.Advice(A + j)], [E.Fixed(A)]) for j in range(Lk)]
+    perm = [("advice", i) for i in range(A + Lk)] + [("fixed", A + 1), ("instance", 0)]
+    return E.ConstraintSystem(num_fixed=A + 2, num_advice=A + Lk, num_instance=1, gates=gates, lookups=lks,
+                              permutation_columns=perm, blinding_factors=5, degree=4)
+
+
+@pytest.mark.parametrize("k,extended_k,gate_cols,lookups", [(5, 7, 64, 8), (6, 8, 256, 8), (7, 9, 64, 8)])
+def test_evaluate_h_wide_matches_reference_formulas(lib, k, extended_k, gate_cols, lookups):
+    """`evaluate_h` of a WIDE constraint system (64 / 256 gate columns, 8 lookups: hundreds of columns, thousands of instructions, the
+    register allocator and the column-pointer table at their real load) against the oracle's direct restatement of the formulas, row for row"""
+    rng = random.Random(200 + k + gate_cols)
+    cs = halo2_lib_wide_cs(gate_cols, lookups)
+    qc = E.quotient_columns(cs)
+    assert qc.total > 4 * gate_cols // 2 + 3 * lookups
+    rows = 1 << extended_k
+    cols = [[rng.randrange(R) for _ in range(rows)] for _ in range(qc.total)]
+    beta, gamma, theta, y = (rng.randrange(R) for _ in range(4))
+    prog = E.evaluate_h_program(cs, k, extended_k, beta, gamma, theta, y)
+    assert len(prog.insns) > 4 * gate_cols and prog.n_columns == qc.total
+    got = run_host(prog, cols, extended_k)
+    sets = cs.num_permutation_sets
+    exp = O.evaluate_h_direct(
+        cs, k, extended_k, cols[qc.fixed:qc.fixed + cs.num_fixed], cols[qc.advice:qc.advice + cs.num_advice],
+        cols[qc.instance:qc.instance + cs.num_instance], cols[qc.l0], cols[qc.l_last], cols[qc.l_active_row],
+        cols[qc.sigma:qc.sigma + len(cs.permutation_columns)], cols[qc.perm_product:qc.perm_product + sets],
+        [tuple(cols[qc.lookup + 3 * i + j] for j in range(3)) for i in range(len(cs.lookups))], beta, gamma, theta, y)
+    assert got == exp
+
+
 def test_evaluate_h_device_resident_large_spot_check(lib):
     """k = 14 / extended 16 on device-resident columns; 150 rows (incl. the wrap-around rows) against the interpreter"""
     import torch

@@ -7,10 +7,14 @@ quotient commitments -- the steps of [DEP] halo2-axiom plonk/prover.rs in the or
   permute_expression_pair, grand products) -> Lagrange -> coefficients (batched iNTT) -> commitments -> extended coset (batched NTT)
   -> fused quotient program -> / (X^n - 1) -> inverse extended transform -> h commitments -> evaluations at x.
 
-Circuit: `gate_cols` advice columns with the vertical gate q (a + b c - d) on rows 0, 4, 8, ..., one range-lookup column against a
-2^bits-entry table, copy constraints across advice / fixed columns, 5 blinding rows.  Checks (the prover's own invariants): both
+Circuit: `gate_cols` advice columns with the vertical gate q (a + b c - d) on rows 0, 4, 8, ..., `lookups` range-lookup columns against a
+2^bits-entry table, copy constraints across advice / fixed columns, 5 blinding rows.  The small circuits of the reference size their columns
+with `calculate_params(Some(20))` (/root/reference/voter/benches/voter_circuit.rs:49-51,
+/root/reference/aggregator/benches/state_transition_circuit.rs:48-50; the browser config is 412 advice + 11 lookup columns at k = 15:
+/root/reference/voter/frontend/app/worker.js:95-102): `run(13, 256, lookups=8)` and `run(15, 64, lookups=8)` are those shapes, with all
+the columns of a phase committed through ONE batched call (`zkhip_msm_g1_registered_batch_device`) as a Rust host would have to.  Checks (the prover's own invariants): both
 grand products close, the quotient is a polynomial (coefficients of degree >= 3n vanish), commit_lagrange(column) = commit(coefficients).
-There is no transcript: challenges are seeded.  Usage: prove_flow.py [k] [gate_cols]   (default 16 4)."""
+There is no transcript: challenges are seeded.  Usage: prove_flow.py [k] [gate_cols] [lookups]   (default 16 4 1)."""
 import ctypes as C
 import os
 import random
@@ -31,7 +35,7 @@ BLIND = 5
 _SIDE_STREAM = None
 
 
-def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk_file=None):
+def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk_file=None, lookups=1, batched=None):
     """pk_file: path -- the proving key is written there (`ProvingKey::write`, RawBytesUnchecked), read back, and the READ key is what the
     prover uses (the reference's wrapper does the same through build/*_pk.bin: /root/reference/aggregator/src/wrapper.rs:967-989, :1007-1034)"""
     from zksnap_circuits_halo2_amd import keygen as KG
@@ -45,7 +49,9 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk
     beta, gamma, theta, y, x, s = (rng.randrange(1, R) for _ in range(6))
     dom = Z.EvaluationDomain(4, k)
     ek, en = dom.extended_k, dom.extended_len()
-    G = gate_cols
+    G, NL = gate_cols, lookups
+    if batched is None:
+        batched = k <= 17                # small MSMs are latency-bound one at a time: all columns of a phase in one launch set
     t = {}
     clock = [time.perf_counter()]
 
@@ -101,7 +107,13 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk
 
     def commit_all(lagrange, cols):
         """independent commits alternate between two streams: one MSM's latency-bound reduction tail runs under the next one's accumulation
-        (tools/two_stream_msm.py: 5.31 -> 4.96 ms per 2^22 MSM); each stream has its own scratch set inside the library"""
+        (tools/two_stream_msm.py: 5.31 -> 4.96 ms per 2^22 MSM); each stream has its own scratch set inside the library.
+        batched (small k): the columns are gathered into one array and committed by one call"""
+        if batched and len(cols) > 1:
+            stack = torch.stack(list(cols)).contiguous()
+            outs_b = torch.zeros((len(cols), 12), dtype=torch.int64, device=dev)
+            params.commit_many_device(stack.data_ptr(), n, len(cols), n, outs_b.data_ptr(), lagrange=lagrange)
+            return [outs_b[i] for i in range(len(cols))]
         outs = [torch.zeros(12, dtype=torch.int64, device=dev) for _ in cols]
         cur = torch.cuda.current_stream()
         side[1].wait_stream(cur)
@@ -121,14 +133,21 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk
         fixed = [sel.clone() for _ in range(G)] + [rand_fr(n), small_ints(rows % (1 << lookup_bits))]        # q_0.., fconst, table
         fconst, table = fixed[G], fixed[G + 1]
         advice = [rand_fr(n) for _ in range(G)]
-        lk = small_ints(torch.randint(0, 1 << lookup_bits, (n,), dtype=torch.int64, device=dev))
-        lk[u:] = rand_fr(n - u)
-        advice.append(lk)
-        perm_cols = [("advice", i) for i in range(G + 1)] + [("fixed", G)]         # every advice column and the constants column
-        pcol = lambda c: advice[c] if c <= G else fconst
-        cycles = [[(0, 1), (G + 1, 2)], [(G, 10), (G, 20)], [(0, 13), (G, 30)], [(0, 17), (0, 21), (G + 1, 5)]]
-        for cyc in cycles:                # equal values along every cycle (a cycle through the lookup column carries a table value)
-            src = next(((c, r) for c, r in cyc if c == G), cyc[0])
+        lks = []
+        for _ in range(NL):
+            lk = small_ints(torch.randint(0, 1 << lookup_bits, (n,), dtype=torch.int64, device=dev))
+            lk[u:] = rand_fr(n - u)
+            lks.append(lk)
+            advice.append(lk)
+        FC = G + NL                                                                # index of the constants column among the permutation columns
+        perm_cols = [("advice", i) for i in range(G + NL)] + [("fixed", G)]        # every advice column and the constants column
+        pcol = lambda c: advice[c] if c < FC else fconst
+        cycles = [[(0, 1), (FC, 2)], [(G, 10), (G, 20)], [(0, 13), (G, 30)], [(0, 17), (0, 21), (FC, 5)]]
+        cycles += [[(G + j, 40 + j), (G, 60 + j)] for j in range(1, NL)]           # lookup column j <-> lookup column 0
+        if G > 1:
+            cycles += [[(G - 1, 5), (FC, 7)], [(G // 2, 9), (G - 1, 25)]]          # the far gate columns take part in the permutation too
+        for cyc in cycles:                # equal values along every cycle (a cycle through a lookup column carries a table value)
+            src = next(((c, r) for c, r in cyc if G <= c < FC), cyc[0])
             v = pcol(src[0])[src[1]].clone()
             for c, r in cyc:
                 pcol(c)[r] = v
@@ -150,9 +169,9 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk
         # ---- keygen: the circuit's fixed columns and copy constraints -> verifying key, proving key -----------------------------------
         omega = F.omega_for(k)
         cs = E.ConstraintSystem(
-            num_fixed=G + 2, num_advice=G + 1, num_instance=0,
+            num_fixed=G + 2, num_advice=G + NL, num_instance=0,
             gates=[[E.Fixed(i) * (E.Advice(i, 0) + E.Advice(i, 1) * E.Advice(i, 2) - E.Advice(i, 3))] for i in range(G)],
-            lookups=[E.Lookup([E.Advice(G)], [E.Fixed(G + 1)])], permutation_columns=perm_cols, blinding_factors=BLIND, degree=4)
+            lookups=[E.Lookup([E.Advice(G + j)], [E.Fixed(G + 1)]) for j in range(NL)], permutation_columns=perm_cols, blinding_factors=BLIND, degree=4)
         assembly = KG.Assembly(n, len(perm_cols))
         for cyc in cycles:
             for (c1, r1), (c2, r2) in zip(cyc, cyc[1:]):
@@ -211,21 +230,24 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk
         lap("permutation_products")
 
         # ---- lookup argument ---------------------------------------------------------------------------------------------------
-        pa, ps = rand_fr(n), rand_fr(n)                                             # rows >= u stay random (blinding)
-        _lib.check(lib.zkhip_lookup_permute_device(lk.data_ptr(), table.data_ptr(), u, pa.data_ptr(), ps.data_ptr(), None))
         pn, pd = E.lookup_product_programs(1, 1, beta, gamma, theta)
-        zl = run_prog(pn, [lk, table], k)
-        den = run_prog(pd, [pa, ps], k)
-        _lib.check(lib.zkhip_fr_grand_product_device(zl.data_ptr(), den.data_ptr(), n, zl.data_ptr(), None))
-        lookup_closes = F.fr_decode(zl[u].cpu().numpy().view(np.uint64))[0] == 1
-        zl[u + 1:] = rand_fr(n - u - 1)
+        lookup_cols, lookup_closes = [], True
+        for lk in lks:
+            pa, ps = rand_fr(n), rand_fr(n)                                         # rows >= u stay random (blinding)
+            _lib.check(lib.zkhip_lookup_permute_device(lk.data_ptr(), table.data_ptr(), u, pa.data_ptr(), ps.data_ptr(), None))
+            zl = run_prog(pn, [lk, table], k)
+            den = run_prog(pd, [pa, ps], k)
+            _lib.check(lib.zkhip_fr_grand_product_device(zl.data_ptr(), den.data_ptr(), n, zl.data_ptr(), None))
+            lookup_closes = lookup_closes and F.fr_decode(zl[u].cpu().numpy().view(np.uint64))[0] == 1
+            zl[u + 1:] = rand_fr(n - u - 1)
+            lookup_cols += [zl, pa, ps]
         lap("lookup_permute_and_product")
 
         # ---- Lagrange -> coefficients, commitments, extended coset ---------------------------------------------------------------
         l0 = torch.zeros((n, 4), dtype=torch.int64, device=dev); l0[0] = ONE
         l_last = torch.zeros((n, 4), dtype=torch.int64, device=dev); l_last[u] = ONE
         l_active = torch.where((rows < u)[:, None], ONE[None, :], torch.zeros_like(ONE)[None, :]).contiguous()
-        lagrange = fixed + advice + [l0, l_last, l_active] + sigma + z_sets + [zl, pa, ps]
+        lagrange = fixed + advice + [l0, l_last, l_active] + sigma + z_sets + lookup_cols
         qc = E.quotient_columns(cs)
         assert len(lagrange) == qc.total
         ncol = len(lagrange)
@@ -305,7 +327,8 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk
         for i in range(G):                                         # gate advice columns: the vertical gate reads rows 0 .. 3
             for r in range(4):
                 queries.append(MO.ProverQuery(rot(r), coeff[qc.advice + i].data_ptr()))
-        queries.append(MO.ProverQuery(rot(0), coeff[qc.advice + G].data_ptr()))     # lookup advice
+        for j in range(NL):                                        # lookup advice
+            queries.append(MO.ProverQuery(rot(0), coeff[qc.advice + G + j].data_ptr()))
         for i in range(qc.sigma, qc.sigma + len(perm_cols)):       # permutation polynomials (proving key)
             queries.append(MO.ProverQuery(rot(0), coeff[i].data_ptr()))
         for si in range(cs.num_permutation_sets):                  # permutation products: x, omega x, and the last usable row for chaining
@@ -313,9 +336,10 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk
             queries += [MO.ProverQuery(rot(0), zi), MO.ProverQuery(rot(1), zi)]
             if si + 1 < cs.num_permutation_sets:
                 queries.append(MO.ProverQuery(rot(u), zi))
-        zl_i, pa_i, ps_i = (coeff[qc.lookup + t].data_ptr() for t in range(3))
-        queries += [MO.ProverQuery(rot(0), zl_i), MO.ProverQuery(rot(1), zl_i), MO.ProverQuery(rot(0), pa_i), MO.ProverQuery(rot(-1), pa_i),
-                    MO.ProverQuery(rot(0), ps_i)]
+        for j in range(NL):
+            zl_i, pa_i, ps_i = (coeff[qc.lookup + 3 * j + t].data_ptr() for t in range(3))
+            queries += [MO.ProverQuery(rot(0), zl_i), MO.ProverQuery(rot(1), zl_i), MO.ProverQuery(rot(0), pa_i), MO.ProverQuery(rot(-1), pa_i),
+                        MO.ProverQuery(rot(0), ps_i)]
         for i in range(3):                                         # the quotient's pieces
             queries.append(MO.ProverQuery(rot(0), h_coeff[i * n:].data_ptr()))
 
@@ -343,13 +367,14 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk
         prove_ms = sum(v for kk, v in t.items() if kk not in ("setup_srs", "witness_columns", "stack_columns", "pk_file_round_trip", "pk_upload") and not kk.startswith("keygen_"))
         n_proof_cols = sum(hi - lo for lo, hi in proof_ranges)
         if verbose:
-            print(f"k={k} gate_cols={G}: {ncol} columns ({n_proof_cols} witness-dependent, {ncol - n_proof_cols} of the proving key), {n_msm} MSMs of 2^{k}, "
+            print(f"k={k} gate_cols={G} lookups={NL}{' (batched commits)' if batched else ''}: {ncol} columns ({n_proof_cols} witness-dependent, {ncol - n_proof_cols} of the proving key), {n_msm} MSMs of 2^{k}, "
                   f"{n_proof_cols} iNTT 2^{k}, {n_proof_cols} NTT 2^{ek}, 1 iNTT 2^{ek} per proof")
             for name, ms in t.items():
                 print(f"  {name:28s} {ms:9.3f} ms")
             print(f"  {'prover steps (no setup/witness)':28s} {prove_ms:9.3f} ms")
             print("  checks:", checks)
-        return {"timings_ms": t, "prove_ms": prove_ms, "checks": checks, "columns": ncol, "proof_columns": n_proof_cols, "msms": n_msm,
+        return {"timings_ms": t, "prove_ms": prove_ms, "checks": checks, "columns": ncol, "proof_columns": n_proof_cols, "msms": n_msm, "queries": len(queries),
+                "program_insns": len(prog.insns), "program_registers": 1 + max([ins[1] for ins in prog.insns] + [o[1] for ins in prog.insns for o in ins[2:5] if o[0] == E.SRC_REG]),
                 "keygen_ms": t.get("keygen_vk", 0.0) + t.get("keygen_pk", 0.0) + t.get("keygen_device", 0.0), "pk_file_bytes": pk_bytes}
     finally:
         torch.cuda.synchronize()
@@ -361,5 +386,6 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk
 if __name__ == "__main__":
     kk = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     gg = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-    res = run(kk, gg)
+    ll = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    res = run(kk, gg, lookups=ll)
     sys.exit(0 if all(res["checks"].values()) else 1)

@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <functional>
 #include <map>
 #include <memory>
@@ -67,6 +68,39 @@ void prof_mark(hipStream_t stream, const char* name) {
 
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s failed: %s", #x, hipGetErrorString(e_)); return ZKHIP_EHIP; } } while (0)
+
+// roctx ranges, one per C-ABI call, so that `rocprofv3 --marker-trace --kernel-trace` attributes kernels to entry points (the tracing
+// counterpart of the reference's per-phase `start_timer!` lines).  The marker library is looked up at run time
+// (rocprofiler-sdk's roctx, else roctracer's): no link dependency, and plain no-ops where neither is installed or ZKHIP_NO_ROCTX is set.
+struct roctx_api {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+};
+static const roctx_api& roctx() {
+  static const roctx_api api = [] {
+    roctx_api a;
+    if (getenv("ZKHIP_NO_ROCTX")) return a;
+    void* h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_LAZY | RTLD_LOCAL);
+    if (!h) h = dlopen("librocprofiler-sdk-roctx.so", RTLD_LAZY | RTLD_LOCAL);
+    if (!h) h = dlopen("libroctx64.so.4", RTLD_LAZY | RTLD_LOCAL);
+    if (!h) h = dlopen("libroctx64.so", RTLD_LAZY | RTLD_LOCAL);
+    if (h) {
+      a.push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+      a.pop = (int (*)())dlsym(h, "roctxRangePop");
+      if (!a.push || !a.pop) a.push = nullptr, a.pop = nullptr;
+    }
+    return a;
+  }();
+  return api;
+}
+struct api_range {
+  bool on;
+  explicit api_range(const char* name) : on(roctx().push != nullptr) { if (on) (void)roctx().push(name); }
+  ~api_range() { if (on) (void)roctx().pop(); }
+  api_range(const api_range&) = delete;
+  api_range& operator=(const api_range&) = delete;
+};
+#define ZK_API_RANGE() zkhip::api_range zk_api_range_(__func__)
 
 struct dev_buf {       // grow-only device scratch (hipFree waits for the device, so growing under queued work is safe)
   void* p = nullptr;
@@ -333,6 +367,7 @@ typedef std::lock_guard<std::recursive_mutex> guard_t;
 extern "C" {
 
 int zkhip_init(const int* devices, int ndev) {
+  ZK_API_RANGE();
   guard_t g(g_mu);
   if (ndev < 0 || ndev > 64) { set_error("zkhip_init: ndev = %d out of range", ndev); return ZKHIP_EINVAL; }
   int count = 0;
@@ -352,6 +387,9 @@ int zkhip_init(const int* devices, int ndev) {
     bool same = g_ctx.devs.size() == want.size();
     for (size_t i = 0; same && i < want.size(); i++) same = g_ctx.devs[i]->device == want[i];
     if (same) return ensure_init();
+    // a host-buffer call in flight holds a lane without the lock; shutdown would wait for it on a mutex this thread holds twice
+    // (condition_variable_any releases one level only): refuse instead of deadlocking
+    for (auto& L : primary().lanes) if (L.busy) { set_error("zkhip_init: a different device list while host-buffer calls are in flight"); return ZKHIP_EBUSY; }
     zkhip_shutdown();
   }
   int lanes = 2;                                            // host-buffer calls that may be in flight at once
@@ -392,6 +430,7 @@ int zkhip_init(const int* devices, int ndev) {
 }
 
 void zkhip_shutdown(void) {
+  ZK_API_RANGE();
   std::unique_lock<std::recursive_mutex> lk(g_mu);
   if (!g_ctx.ready) return;
   // host-buffer calls in flight hold a lane without the lock: let them finish
@@ -450,6 +489,7 @@ int zkhip_msm_window_bits(size_t n) { return msm_pick_window(n); }
 
 // ---- MSM -----------------------------------------------------------------------------------------
 int zkhip_msm_g1_device_c(const void* d_scalars, const void* d_bases, size_t n, void* d_out_xyz, int window_bits, void* stream) {
+  ZK_API_RANGE();
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
@@ -462,6 +502,7 @@ int zkhip_msm_g1_device_c(const void* d_scalars, const void* d_bases, size_t n, 
 }
 
 int zkhip_msm_g1_device(const void* d_scalars, const void* d_bases, size_t n, void* d_out_xyz, void* stream) {
+  ZK_API_RANGE();
   return zkhip_msm_g1_device_c(d_scalars, d_bases, n, d_out_xyz, 0, stream);
 }
 
@@ -599,6 +640,7 @@ static int host_msm(lane_hold& H, const uint64_t* scalars, const uint64_t* bases
 extern "C" {
 
 int zkhip_msm_g1(const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t out_xyz[12]) {
+  ZK_API_RANGE();
   if (!out_xyz || (n && (!scalars || !bases))) { set_error("msm: null pointer"); return ZKHIP_EINVAL; }
   lane_hold H;
   if (H.rc != ZKHIP_OK) return H.rc;
@@ -612,6 +654,7 @@ int zkhip_msm_g1(const uint64_t* scalars, const uint64_t* bases, size_t n, uint6
 // Registered bases in one shard: one batched launch set (window <= 16 bits) or pairs of overlapping MSMs (wide windows); otherwise one
 // MSM per vector.
 int zkhip_msm_g1_batch(const uint64_t* scalars, const uint64_t* bases, size_t n, size_t batch, uint64_t* out_xyz) {
+  ZK_API_RANGE();
   if (!out_xyz || (n && batch && (!scalars || !bases))) { set_error("msm_batch: null pointer"); return ZKHIP_EINVAL; }
   if (batch == 0) return ZKHIP_OK;
   lane_hold H;
@@ -648,6 +691,7 @@ int zkhip_msm_g1_batch(const uint64_t* scalars, const uint64_t* bases, size_t n,
 }
 
 int zkhip_register_bases(const uint64_t* bases, size_t n) {
+  ZK_API_RANGE();
   if (!bases || n == 0) { set_error("register_bases: empty"); return ZKHIP_EINVAL; }
   {
     guard_t g(g_mu);
@@ -698,6 +742,7 @@ int zkhip_register_bases(const uint64_t* bases, size_t n) {
 }
 
 int zkhip_unregister_bases(const uint64_t* bases) {
+  ZK_API_RANGE();
   std::shared_ptr<registered_t> reg;
   {
     guard_t g(g_mu);
@@ -712,10 +757,12 @@ int zkhip_unregister_bases(const uint64_t* bases) {
 }
 
 int zkhip_prepare_bases_device(const void* d_bases, size_t n, uint64_t* handle) {
+  ZK_API_RANGE();
   return zkhip_prepare_bases_device_c(d_bases, n, 0, handle);
 }
 
 int zkhip_prepare_bases_device_c(const void* d_bases, size_t n, int window_bits, uint64_t* handle) {
+  ZK_API_RANGE();
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
@@ -746,6 +793,7 @@ int zkhip_prepared_window_bits(uint64_t handle) {
 }
 
 int zkhip_msm_g1_prepared_device(uint64_t handle, size_t offset, const void* d_scalars, size_t n, void* d_out_xyz, void* stream) {
+  ZK_API_RANGE();
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
@@ -878,6 +926,7 @@ extern "C" {
 // that spans several shards fans out over their devices (registered_device_msm above).
 int zkhip_msm_g1_registered_batch_device(const uint64_t* bases, const void* d_scalars, size_t n, size_t batch, size_t scalar_stride, void* d_out_xyz,
                                          void* stream) {
+  ZK_API_RANGE();
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
@@ -893,11 +942,13 @@ int zkhip_msm_g1_registered_batch_device(const uint64_t* bases, const void* d_sc
 }
 
 int zkhip_msm_g1_registered_device(const uint64_t* bases, const void* d_scalars, size_t n, void* d_out_xyz, void* stream) {
+  ZK_API_RANGE();
   return zkhip_msm_g1_registered_batch_device(bases, d_scalars, n, 1, n, d_out_xyz, stream);
 }
 
 int zkhip_msm_g1_prepared_batch_device(uint64_t handle, size_t offset, const void* d_scalars, size_t n, size_t batch, size_t scalar_stride,
                                        void* d_out_xyz, void* stream) {
+  ZK_API_RANGE();
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
@@ -951,6 +1002,7 @@ int zkhip_msm_g1_prepared_batch_device(uint64_t handle, size_t offset, const voi
 }
 
 int zkhip_g1_sum_device(const void* d_points_xyz, int m, void* d_out_xyz, void* stream) {
+  ZK_API_RANGE();
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
@@ -959,6 +1011,7 @@ int zkhip_g1_sum_device(const void* d_points_xyz, int m, void* d_out_xyz, void* 
 }
 
 int zkhip_g1_sum(const uint64_t* points_xyz, int m, uint64_t out_xyz[12]) {
+  ZK_API_RANGE();
   if (m < 0 || !out_xyz || (m && !points_xyz)) { set_error("g1_sum: bad argument"); return ZKHIP_EINVAL; }
   lane_hold H;
   if (H.rc != ZKHIP_OK) return H.rc;
@@ -1019,6 +1072,7 @@ static int device_transform(const void* d_in, uint32_t in_len, size_t in_stride,
 extern "C" {
 
 int zkhip_ntt_fr_batch_device(void* d_a, const uint64_t omega[4], uint32_t log_n, uint32_t batch, size_t stride, void* stream) {
+  ZK_API_RANGE();
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
@@ -1029,6 +1083,7 @@ int zkhip_ntt_fr_batch_device(void* d_a, const uint64_t omega[4], uint32_t log_n
 
 int zkhip_ifft_scaled_batch_device(void* d_a, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4], uint32_t batch, size_t stride,
                                    void* stream) {
+  ZK_API_RANGE();
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
@@ -1038,6 +1093,7 @@ int zkhip_ifft_scaled_batch_device(void* d_a, const uint64_t omega_inv[4], uint3
 }
 
 int zkhip_ntt_fr_device(void* d_a, const uint64_t omega[4], uint32_t log_n, void* stream) {
+  ZK_API_RANGE();
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
@@ -1048,6 +1104,7 @@ int zkhip_ntt_fr_device(void* d_a, const uint64_t omega[4], uint32_t log_n, void
 }
 
 int zkhip_ifft_scaled_device(void* d_a, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4], void* stream) {
+  ZK_API_RANGE();
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
@@ -1058,6 +1115,7 @@ int zkhip_ifft_scaled_device(void* d_a, const uint64_t omega_inv[4], uint32_t lo
 }
 
 int zkhip_mul_periodic_device(void* d_a, size_t n, const void* d_table, uint32_t period, void* stream) {
+  ZK_API_RANGE();
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
@@ -1095,6 +1153,7 @@ extern "C" {
 
 // `batch` contiguous polynomials of 2^log_n elements, transformed in place in one launch set
 int zkhip_ntt_fr_batch(uint64_t* a, const uint64_t omega[4], uint32_t log_n, uint32_t batch) {
+  ZK_API_RANGE();
   if (!a || !omega || log_n > 28) { set_error("ntt_batch: bad argument"); return ZKHIP_EINVAL; }
   if (batch == 0) return ZKHIP_OK;
   lane_hold H;
@@ -1113,11 +1172,13 @@ int zkhip_ntt_fr_batch(uint64_t* a, const uint64_t omega[4], uint32_t log_n, uin
 }
 
 int zkhip_ntt_fr(uint64_t* a, const uint64_t omega[4], uint32_t log_n) {
+  ZK_API_RANGE();
   const size_t N = (size_t)1 << (log_n > 28 ? 0 : log_n);
   return host_transform(a, N, a, N, log_n, omega, nullptr, 0, nullptr, 0);
 }
 
 int zkhip_ifft_scaled(uint64_t* a, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4]) {
+  ZK_API_RANGE();
   if (!divisor) { set_error("ifft: null divisor"); return ZKHIP_EINVAL; }
   const size_t N = (size_t)1 << (log_n > 28 ? 0 : log_n);
   return host_transform(a, N, a, N, log_n, omega_inv, nullptr, 0, (const uint32_t*)divisor, 1);
@@ -1148,6 +1209,7 @@ static void coset_scales(const uint64_t zeta[4], const uint64_t* divisor, uint32
 extern "C" {
 
 int zkhip_coeff_to_extended(const uint64_t* a, uint32_t k, uint64_t* out, uint32_t ext_k, const uint64_t ext_omega[4], const uint64_t zeta[4]) {
+  ZK_API_RANGE();
   if (!a || !out || !ext_omega || !zeta || k > ext_k || ext_k > 28) { set_error("coeff_to_extended: bad argument"); return ZKHIP_EINVAL; }
   uint32_t sc[24];
   coset_scales(zeta, nullptr, sc);
@@ -1156,6 +1218,7 @@ int zkhip_coeff_to_extended(const uint64_t* a, uint32_t k, uint64_t* out, uint32
 
 int zkhip_extended_to_coeff(uint64_t* a, uint32_t ext_k, const uint64_t ext_omega_inv[4], const uint64_t ext_divisor[4],
                             const uint64_t zeta[4], uint64_t* out, size_t out_len) {
+  ZK_API_RANGE();
   if (!a || !out || !ext_omega_inv || !ext_divisor || !zeta || ext_k > 28) { set_error("extended_to_coeff: bad argument"); return ZKHIP_EINVAL; }
   uint32_t sc[24];
   coset_scales(zeta, ext_divisor, sc);
@@ -1165,6 +1228,7 @@ int zkhip_extended_to_coeff(uint64_t* a, uint32_t ext_k, const uint64_t ext_omeg
 // device-resident forms, `batch` polynomials per launch set (polynomial b at base + b * stride elements)
 int zkhip_coeff_to_extended_device(const void* d_a, size_t a_stride, uint32_t k, void* d_out, size_t out_stride, uint32_t ext_k, uint32_t batch,
                                    const uint64_t ext_omega[4], const uint64_t zeta[4], void* stream) {
+  ZK_API_RANGE();
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
@@ -1178,6 +1242,7 @@ int zkhip_coeff_to_extended_device(const void* d_a, size_t a_stride, uint32_t k,
 
 int zkhip_extended_to_coeff_device(const void* d_a, size_t a_stride, uint32_t ext_k, const uint64_t ext_omega_inv[4], const uint64_t ext_divisor[4],
                                    const uint64_t zeta[4], void* d_out, size_t out_stride, size_t out_len, uint32_t batch, void* stream) {
+  ZK_API_RANGE();
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
@@ -1190,6 +1255,7 @@ int zkhip_extended_to_coeff_device(const void* d_a, size_t a_stride, uint32_t ex
 }
 
 int zkhip_mul_periodic(uint64_t* a, size_t n, const uint64_t* table, uint32_t period) {
+  ZK_API_RANGE();
   if ((n && !a) || !table || period == 0) { set_error("mul_periodic: bad argument"); return ZKHIP_EINVAL; }
   if (n == 0) return ZKHIP_OK;
   lane_hold H;
@@ -1208,6 +1274,7 @@ int zkhip_mul_periodic(uint64_t* a, size_t n, const uint64_t* table, uint32_t pe
 
 // ---- row a7: Fr-vector primitives ---------------------------------------------------------------------
 int zkhip_fr_eval_polynomial_device(const void* d_poly, size_t n, const uint64_t point[4], void* d_out, void* stream) {
+  ZK_API_RANGE();
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
@@ -1219,6 +1286,7 @@ int zkhip_fr_eval_polynomial_device(const void* d_poly, size_t n, const uint64_t
 }
 
 int zkhip_fr_eval_polynomial_batch_device(const void* const* d_polys, size_t count, size_t n, const uint64_t point[4], void* d_out, void* stream) {
+  ZK_API_RANGE();
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
@@ -1232,6 +1300,7 @@ int zkhip_fr_eval_polynomial_batch_device(const void* const* d_polys, size_t cou
 }
 
 int zkhip_fr_kate_division_device(const void* d_a, size_t n, const uint64_t b[4], void* d_q, void* stream) {
+  ZK_API_RANGE();
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
@@ -1243,6 +1312,7 @@ int zkhip_fr_kate_division_device(const void* d_a, size_t n, const uint64_t b[4]
 }
 
 int zkhip_fr_batch_invert_device(void* d_a, size_t n, void* stream) {
+  ZK_API_RANGE();
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
@@ -1254,6 +1324,7 @@ int zkhip_fr_batch_invert_device(void* d_a, size_t n, void* stream) {
 }
 
 int zkhip_fr_prefix_product_device(const void* d_v, size_t n, void* d_out, void* stream) {
+  ZK_API_RANGE();
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
@@ -1292,23 +1363,27 @@ static int host_vec_op(int op, const uint64_t* in, size_t n_in, const uint64_t* 
 extern "C" {
 
 int zkhip_fr_eval_polynomial(const uint64_t* poly, size_t n, const uint64_t point[4], uint64_t out[4]) {
+  ZK_API_RANGE();
   if (!point || !out || (n && !poly)) { set_error("eval_polynomial: null pointer"); return ZKHIP_EINVAL; }
   return host_vec_op(0, poly, n, point, out, 1);
 }
 
 int zkhip_fr_kate_division(const uint64_t* a, size_t n, const uint64_t b[4], uint64_t* q) {
+  ZK_API_RANGE();
   if (!b || (n > 1 && (!a || !q))) { set_error("kate_division: null pointer"); return ZKHIP_EINVAL; }
   if (n < 2) return ZKHIP_OK;
   return host_vec_op(1, a, n, b, q, n - 1);
 }
 
 int zkhip_fr_batch_invert(uint64_t* a, size_t n) {
+  ZK_API_RANGE();
   if (n && !a) { set_error("batch_invert: null pointer"); return ZKHIP_EINVAL; }
   if (n == 0) return ZKHIP_OK;
   return host_vec_op(2, a, n, nullptr, a, n);
 }
 
 int zkhip_fr_prefix_product(const uint64_t* v, size_t n, uint64_t* out) {
+  ZK_API_RANGE();
   if (n && (!v || !out)) { set_error("prefix_product: null pointer"); return ZKHIP_EINVAL; }
   if (n == 0) return ZKHIP_OK;
   return host_vec_op(3, v, n, nullptr, out, n);
@@ -1317,6 +1392,7 @@ int zkhip_fr_prefix_product(const uint64_t* v, size_t n, uint64_t* out) {
 // ---- lookup argument: permute_expression_pair ----------------------------------------------------------------------
 int zkhip_lookup_permute_device(const void* d_input, const void* d_table, size_t usable_rows, void* d_permuted_input, void* d_permuted_table,
                                 void* stream) {
+  ZK_API_RANGE();
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
@@ -1330,6 +1406,7 @@ int zkhip_lookup_permute_device(const void* d_input, const void* d_table, size_t
 }
 
 int zkhip_lookup_permute(const uint64_t* input, const uint64_t* table, size_t usable_rows, uint64_t* permuted_input, uint64_t* permuted_table) {
+  ZK_API_RANGE();
   if (usable_rows && (!input || !table || !permuted_input || !permuted_table)) { set_error("lookup_permute: null pointer"); return ZKHIP_EINVAL; }
   if (usable_rows == 0) return ZKHIP_OK;
   lane_hold H;
@@ -1352,6 +1429,7 @@ int zkhip_lookup_permute(const uint64_t* input, const uint64_t* table, size_t us
 
 // ---- device buffers for hosts that do not link HIP -------------------------------------------------------------
 int zkhip_alloc(size_t bytes, void** d_ptr) {
+  ZK_API_RANGE();
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
@@ -1363,6 +1441,7 @@ int zkhip_alloc(size_t bytes, void** d_ptr) {
 }
 
 int zkhip_free(void* d_ptr) {
+  ZK_API_RANGE();
   guard_t g(g_mu);
   if (!d_ptr) return ZKHIP_OK;
   int rc = ensure_init();
@@ -1373,6 +1452,7 @@ int zkhip_free(void* d_ptr) {
 }
 
 int zkhip_upload(void* d_dst, const void* src, size_t bytes) {
+  ZK_API_RANGE();
   { guard_t g(g_mu); int rc = ensure_init(); if (rc != ZKHIP_OK) return rc; }
   if (bytes && (!d_dst || !src)) { set_error("upload: null pointer"); return ZKHIP_EINVAL; }
   if (bytes == 0) return ZKHIP_OK;
@@ -1381,6 +1461,7 @@ int zkhip_upload(void* d_dst, const void* src, size_t bytes) {
 }
 
 int zkhip_download(void* dst, const void* d_src, size_t bytes) {
+  ZK_API_RANGE();
   { guard_t g(g_mu); int rc = ensure_init(); if (rc != ZKHIP_OK) return rc; }
   if (bytes && (!dst || !d_src)) { set_error("download: null pointer"); return ZKHIP_EINVAL; }
   if (bytes == 0) return ZKHIP_OK;
@@ -1389,12 +1470,14 @@ int zkhip_download(void* dst, const void* d_src, size_t bytes) {
 }
 
 int zkhip_stream_sync(void* stream) {
+  ZK_API_RANGE();
   { guard_t g(g_mu); int rc = ensure_init(); if (rc != ZKHIP_OK) return rc; }
   HIPCHK(hipStreamSynchronize(caller_stream(stream)));
   return ZKHIP_OK;
 }
 
 int zkhip_sync(void) {
+  ZK_API_RANGE();
   { guard_t g(g_mu); int rc = ensure_init(); if (rc != ZKHIP_OK) return rc; }
   HIPCHK(hipDeviceSynchronize());
   return ZKHIP_OK;
@@ -1403,6 +1486,7 @@ int zkhip_sync(void) {
 // ---- section 8(f): row programs and grand products -------------------------------------------------------------
 int zkhip_fr_eval_rows_device(const zkhip_vm_program* prog, const void* const* d_columns, uint32_t n_columns, uint32_t log_rows,
                               int accumulate, void* d_out, void* stream) {
+  ZK_API_RANGE();
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
@@ -1416,6 +1500,7 @@ int zkhip_fr_eval_rows_device(const zkhip_vm_program* prog, const void* const* d
 
 int zkhip_fr_eval_rows(const zkhip_vm_program* prog, const uint64_t* const* columns, uint32_t n_columns, uint32_t log_rows,
                        int accumulate, uint64_t* out) {
+  ZK_API_RANGE();
   int rc;
   if ((rc = row_vm_validate(prog, n_columns, log_rows, accumulate)) != ZKHIP_OK) return rc;
   if (!out || (n_columns && !columns)) { set_error("eval_rows: null pointer"); return ZKHIP_EINVAL; }
@@ -1440,6 +1525,7 @@ int zkhip_fr_eval_rows(const zkhip_vm_program* prog, const uint64_t* const* colu
 
 int zkhip_fr_gather_mul_device(const void* d_a, size_t a_len, const void* d_index_a, const void* d_b, size_t b_len, const void* d_index_b, size_t n,
                                void* d_out, void* stream) {
+  ZK_API_RANGE();
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
@@ -1452,6 +1538,7 @@ int zkhip_fr_gather_mul_device(const void* d_a, size_t a_len, const void* d_inde
 }
 
 int zkhip_fr_grand_product_device(const void* d_num, void* d_den, size_t n, void* d_z, void* stream) {
+  ZK_API_RANGE();
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
@@ -1464,6 +1551,7 @@ int zkhip_fr_grand_product_device(const void* d_num, void* d_den, size_t n, void
 }
 
 int zkhip_fr_grand_product(const uint64_t* num, const uint64_t* den, size_t n, uint64_t* z) {
+  ZK_API_RANGE();
   if (n && (!num || !den || !z)) { set_error("grand_product: null pointer"); return ZKHIP_EINVAL; }
   if (n == 0) return ZKHIP_OK;
   lane_hold H;
@@ -1488,6 +1576,7 @@ int zkhip_profile_enable(int on) {
 }
 
 int zkhip_profile_read(double* ms, char (*names)[64], int max) {
+  ZK_API_RANGE();
   guard_t g(g_mu);
   if (!g_prof_ev_ready || g_prof_n == 0) return 0;
   if (hipEventSynchronize(g_prof_ev[g_prof_n]) != hipSuccess) { set_error("profile_read: event sync failed"); return ZKHIP_EHIP; }
@@ -1501,6 +1590,7 @@ int zkhip_profile_read(double* ms, char (*names)[64], int max) {
 }
 
 int zkhip_g1_fixed_base_mul_device(const void* d_scalars, size_t n, void* d_out, void* stream) {
+  ZK_API_RANGE();
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
@@ -1520,6 +1610,7 @@ int zkhip_g1_fixed_base_mul_device(const void* d_scalars, size_t n, void* d_out,
 }
 
 int zkhip_g1_fft_device(void* d_points_xyz, const uint64_t omega[4], uint32_t log_n, void* stream) {
+  ZK_API_RANGE();
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
@@ -1533,6 +1624,7 @@ int zkhip_g1_fft_device(void* d_points_xyz, const uint64_t omega[4], uint32_t lo
 }
 
 int zkhip_g_to_lagrange_device(const void* d_g, uint32_t k, void* d_g_lagrange, void* stream) {
+  ZK_API_RANGE();
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
@@ -1551,6 +1643,7 @@ int zkhip_g_to_lagrange_device(const void* d_g, uint32_t k, void* d_g_lagrange, 
 }
 
 int zkhip_g1_gen_walk_device(const uint64_t t0[4], const uint64_t d[4], size_t n, void* d_out, void* stream) {
+  ZK_API_RANGE();
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
@@ -1563,6 +1656,7 @@ int zkhip_g1_gen_walk_device(const uint64_t t0[4], const uint64_t d[4], size_t n
 
 // ---- Curve::batch_normalize: Jacobian commitments -> affine (what create_proof writes into the transcript) ------------------------
 int zkhip_g1_batch_normalize_device(const void* d_points_xyz, size_t n, void* d_out_affine, void* stream) {
+  ZK_API_RANGE();
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
@@ -1575,6 +1669,7 @@ int zkhip_g1_batch_normalize_device(const void* d_points_xyz, size_t n, void* d_
 }
 
 int zkhip_g1_batch_normalize(const uint64_t* points_xyz, size_t n, uint64_t* out_affine) {
+  ZK_API_RANGE();
   if (n && (!points_xyz || !out_affine)) { set_error("batch_normalize: null pointer"); return ZKHIP_EINVAL; }
   if (n == 0) return ZKHIP_OK;
   lane_hold H;
@@ -1593,6 +1688,7 @@ int zkhip_g1_batch_normalize(const uint64_t* points_xyz, size_t n, uint64_t* out
 
 // ---- G2 MSM: best_multiexp::<G2Affine> -------------------------------------------------------------------------------
 int zkhip_msm_g2_device(const void* d_scalars, const void* d_bases, size_t n, void* d_out_xyz, void* stream) {
+  ZK_API_RANGE();
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
@@ -1604,6 +1700,7 @@ int zkhip_msm_g2_device(const void* d_scalars, const void* d_bases, size_t n, vo
 }
 
 int zkhip_msm_g2(const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t out_xyz[24]) {
+  ZK_API_RANGE();
   if (!out_xyz || (n && (!scalars || !bases))) { set_error("msm_g2: null pointer"); return ZKHIP_EINVAL; }
   lane_hold H;
   if (H.rc != ZKHIP_OK) return H.rc;
@@ -1626,6 +1723,7 @@ int zkhip_msm_g2(const uint64_t* scalars, const uint64_t* bases, size_t n, uint6
 
 // ---- SRS / key-file validation: every point canonical and on the curve (RawBytes readers) ------------------------------
 int zkhip_g1_check_points_device(const void* d_points, size_t n, uint64_t* first_bad, void* stream) {
+  ZK_API_RANGE();
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
@@ -1642,6 +1740,7 @@ int zkhip_g1_check_points_device(const void* d_points, size_t n, uint64_t* first
 }
 
 int zkhip_g1_check_points(const uint64_t* points, size_t n, uint64_t* first_bad) {
+  ZK_API_RANGE();
   if (!first_bad || (n && !points)) { set_error("g1_check_points: null pointer"); return ZKHIP_EINVAL; }
   lane_hold H;
   if (H.rc != ZKHIP_OK) return H.rc;
@@ -1664,6 +1763,7 @@ int zkhip_g1_check_points(const uint64_t* points, size_t n, uint64_t* first_bad)
 
 // ---- SerdeFormat::Processed: compressed G1 points (serde.hip) -------------------------------------------------------------
 int zkhip_g1_compress_device(const void* d_points, size_t n, void* d_out32, int flag_layout, void* stream) {
+  ZK_API_RANGE();
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
@@ -1672,6 +1772,7 @@ int zkhip_g1_compress_device(const void* d_points, size_t n, void* d_out32, int 
 }
 
 int zkhip_g1_decompress_device(const void* d_in32, size_t n, void* d_points, int flag_layout, uint64_t* first_bad, void* stream) {
+  ZK_API_RANGE();
   guard_t g(g_mu);
   int rc = ensure_init();
   if (rc != ZKHIP_OK) return rc;
@@ -1690,6 +1791,7 @@ int zkhip_g1_decompress_device(const void* d_in32, size_t n, void* d_points, int
 }
 
 int zkhip_g1_compress(const uint64_t* points, size_t n, uint8_t* out32, int flag_layout) {
+  ZK_API_RANGE();
   if ((n && (!points || !out32)) || flag_layout < 0 || flag_layout > 1) { set_error("g1_compress: bad argument"); return ZKHIP_EINVAL; }
   if (n == 0) return ZKHIP_OK;
   lane_hold H;
@@ -1709,6 +1811,7 @@ int zkhip_g1_compress(const uint64_t* points, size_t n, uint8_t* out32, int flag
 }
 
 int zkhip_g1_decompress(const uint8_t* in32, size_t n, uint64_t* points, int flag_layout, uint64_t* first_bad) {
+  ZK_API_RANGE();
   if (!first_bad || (n && (!in32 || !points)) || flag_layout < 0 || flag_layout > 1) { set_error("g1_decompress: bad argument"); return ZKHIP_EINVAL; }
   *first_bad = n;
   if (n == 0) return ZKHIP_OK;
@@ -1736,6 +1839,7 @@ int zkhip_g1_decompress(const uint8_t* in32, size_t n, uint64_t* points, int fla
 
 // ---- parity hooks ----------------------------------------------------------------------------------
 int zkhip_test_field_op(int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+  ZK_API_RANGE();
   if (field < 0 || field > 1 || op < 0 || op > 3 || (n && (!a || !b || !out))) { set_error("test_field_op: bad argument"); return ZKHIP_EINVAL; }
   if (n == 0) return ZKHIP_OK;
   lane_hold H;
@@ -1753,6 +1857,7 @@ int zkhip_test_field_op(int field, int op, const uint64_t* a, const uint64_t* b,
 }
 
 int zkhip_test_g1_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out_xyz, size_t n) {
+  ZK_API_RANGE();
   if (op < 0 || op > 4 || (n && (!a || !b || !out_xyz))) { set_error("test_g1_op: bad argument"); return ZKHIP_EINVAL; }
   if (n == 0) return ZKHIP_OK;
   lane_hold H;
@@ -1770,6 +1875,7 @@ int zkhip_test_g1_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out
 }
 
 int zkhip_test_g2_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out_xyz, size_t n) {
+  ZK_API_RANGE();
   if (op < 0 || op > 4 || (n && (!a || !b || !out_xyz))) { set_error("test_g2_op: bad argument"); return ZKHIP_EINVAL; }
   if (n == 0) return ZKHIP_OK;
   lane_hold H;

@@ -35,7 +35,7 @@
 namespace zkhip {
 
 using Fr = FrParams;
-constexpr uint32_t NTT_TILE = 2048;
+constexpr uint32_t NTT_TILE_MAX = 2048;   // largest tile the LDS layout and the launch bounds are sized for
 constexpr int NTT_MAX_BITS = 9;
 constexpr uint32_t NTT_DIRECT_TABLE_BITS = 24;   // pass twiddles w_M^t as one M-entry table up to M = 2^24 (604 MB), two-level above
 
@@ -55,7 +55,7 @@ struct pass_args {
   uint32_t h;
   uint32_t tw_rk;                 // direct table in (r, k) layout: w_M^(k r) at index r * Ns + k
   uint32_t first, last;
-  uint32_t tile;                  // elements per workgroup (<= NTT_TILE)
+  uint32_t tile;                  // elements per workgroup (<= NTT_TILE_MAX)
   uint32_t in_len;                // first pass: elements >= in_len read as zero
   uint32_t out_len;               // last pass: elements >= out_len are not stored
   scale_arg in_scale, out_scale;
@@ -78,7 +78,7 @@ __device__ __forceinline__ void store_fe9(uint32_t* p, uint32_t idx, const fe& a
 // (element 64 m + 8 e + jj over the lanes' (m, jj)) and the bit-reversed initial stores hit 8 banks out of 64; the two pad terms
 // make those patterns (nearly) conflict-free and leave the contiguous ones as they were.
 __device__ __forceinline__ uint32_t lds_word(uint32_t e) { return 9u * e + 8u * (e >> 6) + (e >> 8); }
-constexpr uint32_t NTT_LDS_WORDS = 9u * 2048u + 8u * 32u + 8u + 16u;   // NTT_TILE = 2048
+constexpr uint32_t NTT_LDS_WORDS = 9u * NTT_TILE_MAX + 8u * 32u + 8u + 16u;
 static inline uint32_t lds_word_host(uint32_t e) { return 9u * e + 8u * (e >> 6) + (e >> 8); }
 __device__ __forceinline__ fe load_lds9(const uint32_t* p, uint32_t idx) {
   fe r;

@@ -55,11 +55,14 @@ class ParamsKZG:
             for a in registered:
                 lib.zkhip_unregister_bases(a.ctypes.data)
             raise
+        # (np.ascontiguousarray hands back the caller's own array when it already is contiguous uint64: remember which arrays were
+        # writeable and give that back when the registration ends, so that a caller's array is not left read-only for good)
+        was_writeable = [bool(a.flags.writeable) for a in arrays]
         for a in arrays:
             a.flags.writeable = False
         import weakref
 
-        self._finalizer = weakref.finalize(self, _unregister_arrays, arrays)
+        self._finalizer = weakref.finalize(self, _unregister_arrays, arrays, was_writeable)
 
     @classmethod
     def setup(cls, k: int, s: int) -> "ParamsKZG":
@@ -179,6 +182,14 @@ class ParamsKZG:
         assert bases is not None and length <= self.n
         _lib.check(_lib.load().zkhip_msm_g1_registered_device(bases.ctypes.data, d_poly, length, d_out, stream))
 
+    def commit_many_device(self, d_polys: int, length: int, count: int, stride: int, d_out: int, lagrange: bool = False, stream: int = 0) -> None:
+        """`count` polynomials that live in HBM (polynomial i: `length` elements at d_polys + i * stride elements) committed by one call
+        against the registered tables -- all advice columns of a circuit: small MSMs share launch sets (include/zkhip.h
+        zkhip_msm_g1_registered_batch_device); `count` Jacobian results (96 bytes each) at device address d_out, asynchronously on `stream`"""
+        bases = self.g_lagrange if lagrange else self.g
+        assert bases is not None and length <= self.n and stride >= length
+        _lib.check(_lib.load().zkhip_msm_g1_registered_batch_device(bases.ctypes.data, d_polys, length, count, stride, d_out, stream))
+
     def commit_many(self, polys: np.ndarray, lagrange: bool = False) -> np.ndarray:
         """Commit to K polynomials of equal length at once ((K, len, 4) uint64) -> (K, 12) uint64: one launch set."""
         polys = np.ascontiguousarray(polys, dtype=np.uint64)
@@ -200,10 +211,16 @@ class ParamsKZG:
         self.close()
 
 
-def _unregister_arrays(arrays) -> None:
+def _unregister_arrays(arrays, was_writeable=()) -> None:
     try:
         lib = _lib.load()
     except Exception:   # noqa: BLE001  (interpreter shutdown)
         return
     for a in arrays:
         lib.zkhip_unregister_bases(a.ctypes.data)
+    for a, w in zip(arrays, was_writeable):
+        if w:
+            try:
+                a.flags.writeable = True
+            except ValueError:   # a view of a read-only base
+                pass
