@@ -122,8 +122,9 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise ImportError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+    path = os.environ.get("ZKHIP_LIB_PATH", LIB_PATH)      # A/B measurements of two builds on one box (tools/): never set in production
+    if not os.path.exists(path):
+        raise ImportError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc, gfx950).  There is no CPU fallback.")
     # Load order matters: libtorch_hip.so asks for "libamdhip64.so" (no version), so if libzkhip.so came first and bound
     # /opt/rocm's libamdhip64.so.7, torch would later load its own bundled copy -> two HIP runtimes in one process, and the
@@ -132,7 +133,7 @@ def load() -> C.CDLL:
         import torch  # noqa: F401
     except ImportError:
         pass
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)  # AttributeError = header/library mismatch
         fn.restype = res

@@ -110,13 +110,54 @@ __device__ __forceinline__ fe scale_pick(const scale_arg& s, uint32_t idx) {
   return fr_ext_to_internal(w);
 }
 
+// One element from global memory, ready for the first round: zero-padded / input-scaled on the first pass, multiplied by the pass
+// twiddle w_M^(k r) on the later ones (row r, column j of the pass's source matrix: element j + r N/R).
+template <bool CH>
+__device__ __forceinline__ fe ntt_fetch(const pass_args& a, const uint32_t* __restrict__ src, uint32_t r, uint32_t j, uint32_t NR, uint32_t Ns) {
+  const uint32_t g = j + r * NR;
+  if (a.first) {
+    if (g >= a.in_len) return fe_zero();
+    uint32_t w[8];
+    load_words(src + (size_t)g * 8, w);
+    fe x = fe_unpack<0>(w);
+    if (a.in_scale.period) x = fe_mul<Fr, CH>(scale_pick(a.in_scale, g), x);
+    return x;
+  }
+  uint32_t w[8];
+  load_words(src + (size_t)g * 8, w);
+  const uint32_t t = (j & (Ns - 1)) * r;
+  fe tw;
+  if (a.tw_hi == nullptr) {
+    tw = load_fe9(a.tw_lo, a.tw_rk ? (r << a.S) + (j & (Ns - 1)) : t);
+  } else {
+    tw = fe_mul<Fr, CH>(load_fe9(a.tw_lo, t & ((1u << a.h) - 1)), load_fe9(a.tw_hi, t >> a.h));
+  }
+  return fe_mul<Fr, CH>(tw, fe_unpack<0>(w));
+}
+
+// One result to global memory: destination index d of (row rp, column j) in the Stockham order; the caller's scale or a soft reduction
+// on the last pass, the 32-byte intermediate format otherwise.
+template <bool CH>
+__device__ __forceinline__ void ntt_emit(const pass_args& a, uint32_t* __restrict__ dst, uint32_t rp, uint32_t j, uint32_t B, uint32_t Ns, fe x) {
+  const uint32_t d = ((j >> a.S) << (a.S + B)) + (j & (Ns - 1)) + (rp << a.S);
+  uint32_t w[8];
+  if (a.last) {
+    if (d >= a.out_len) return;
+    if (a.out_scale.period) fe_pack(fe_canon_lt2p<Fr>(fe_mul<Fr, CH>(scale_pick(a.out_scale, d), x)), w);
+    else fe_pack(fe_canon_lt3p<Fr>(fe_reduce_soft<Fr>(x)), w);   // x is N-form < 29p after the last round
+  } else {
+    fe_pack(fe_reduce_soft<Fr>(x), w);         // < 2p + 2^233 < 2^256: fits the 32-byte intermediate format
+  }
+  store_words(dst + (size_t)d * 8, w);
+}
+
 // CH: fe_mul with single-chain product columns (see the launch site).
 // E = elements a thread holds in a round (log2 E radix-2 stages per LDS round trip).  E = 8: 256 threads per 2048-element tile, 3 stages
 // per round, 202 VGPRs -> 2 waves per SIMD.  E = 4 (default): 512 threads per tile, 2 stages per round, 123 VGPRs -> 4 waves per SIMD at
 // the price of one more LDS round trip per 8-bit pass (+5.6 % VALU instructions).  Measured equal within noise at 2^22 .. 2^26 (the
 // kernel runs at the VALU issue rate of its instruction mix either way: DESIGN.md section 4), E = 4 ahead on small transforms.
 template <int E, bool CH>
-__global__ void __launch_bounds__(2048 / E, E == 8 ? 2 : 4) k_ntt_pass(pass_args a) {
+__global__ void __launch_bounds__(2048 / E) __attribute__((amdgpu_waves_per_eu(E == 8 ? 2 : 4, E == 8 ? 2 : 4))) k_ntt_pass(pass_args a) {
   constexpr int VM = E == 8 ? 3 : 2;
   extern __shared__ uint32_t lds[];
   const uint32_t B = a.B, R = 1u << B, L = a.L;
@@ -131,130 +172,126 @@ __global__ void __launch_bounds__(2048 / E, E == 8 ? 2 : 4) k_ntt_pass(pass_args
   const uint32_t* const src = a.src + (size_t)blockIdx.y * a.src_stride * 8;
   uint32_t* const dst = a.dst + (size_t)blockIdx.y * a.dst_stride * 8;
 
-  // ---- load: global order (r, jj) -> LDS position (bitrev(r), jj) --------------------------------
-  for (uint32_t idx = threadIdx.x; idx < tile; idx += nthreads) {
-    const uint32_t r = idx >> logJ, jj = idx & (J - 1);
-    const uint32_t j = j0 + jj;
-    const uint32_t g = j + r * NR;
-    fe x;
-    if (a.first) {
-      if (g < a.in_len) {
-        uint32_t w[8];
-        load_words(src + (size_t)g * 8, w);
-        x = fe_unpack<0>(w);
-        if (a.in_scale.period) x = fe_mul<Fr, CH>(scale_pick(a.in_scale, g), x);
-      } else {
-        x = fe_zero();
-      }
-    } else {
-      uint32_t w[8];
-      load_words(src + (size_t)g * 8, w);
-      x = fe_unpack<0>(w);
-      const uint32_t t = (j & (Ns - 1)) * r;
-      fe tw;
-      if (a.tw_hi == nullptr) {
-        tw = load_fe9(a.tw_lo, a.tw_rk ? (r << a.S) + (j & (Ns - 1)) : t);
-      } else {
-        tw = fe_mul<Fr, CH>(load_fe9(a.tw_lo, t & ((1u << a.h) - 1)), load_fe9(a.tw_hi, t >> a.h));
-      }
-      x = fe_mul<Fr, CH>(tw, x);
-    }
-    const uint32_t i = __brev(r) >> (32 - B);
-    store_lds9(lds, i * J + jj, x);
-  }
-  __syncthreads();
+  // The first round reads its elements from global memory and the last one writes its results there whenever that keeps the runs a
+  // wavefront touches contiguous: a thread (m, jj) holds the rows pos[e] of column jj, lanes run over jj first, so a load covers J
+  // consecutive elements of a source row (always the case), and a store J consecutive elements of a destination run when Ns >= J
+  // (every pass but the first, whose runs are R elements of ONE column: those are transposed through the LDS tile as before).
+  // Against staging both ends through LDS: two of the five LDS round trips and barriers of an 8-bit pass less (2^24: see DESIGN.md section 4).
+  const bool direct_store = Ns >= J;
 
   // ---- rounds of <= 3 in-register stages ----------------------------------------------------------
-  {
-    const uint32_t jj = threadIdx.x & (J - 1), m = threadIdx.x >> logJ;
-    uint32_t s = 0;
-    while (s < B) {
-      const uint32_t v = (B - s) < (uint32_t)VM ? (B - s) : (uint32_t)VM;
-      fe x[E];
-      uint32_t pos[E];
+  const uint32_t jj = threadIdx.x & (J - 1), m = threadIdx.x >> logJ;
+  // generic stages u < v of a round that starts at stage s
+  auto stages = [&](fe (&x)[E], const uint32_t (&pos)[E], uint32_t s, uint32_t v) {
 #pragma unroll
-      for (int e = 0; e < E; e++) {
-        const uint32_t rest = (m << (VM - v)) | ((uint32_t)e >> v);
-        const uint32_t lo = rest & ((1u << s) - 1), hi = rest >> s;
-        pos[e] = (hi << (s + v)) | (((uint32_t)e & ((1u << v) - 1)) << s) | lo;
-        x[e] = load_lds9(lds, pos[e] * J + jj);
-      }
-      if (s == 0) {
-        // First round (v == VM, lo == 0): twiddles depend only on the register index and 7 of the 12 (E = 4: 3 of the 4) are w^0 = 1, so
-        // those butterflies need no multiply.  Inputs are N-form < 2p.  Bounds (value / limb) are noted per stage.
-        const fe w4 = load_fe9(a.tw_local, 1u << (B - 2));
+    for (int u = 0; u < VM; u++) {
+      if ((uint32_t)u < v) {
+        const uint32_t st = s + u;
 #pragma unroll
-        for (int e = 0; e < E; e += 2) {                    // stage 0: all trivial.  x' < 4p / 2^30, y' < 5p / 1.5*2^30
-          fe t = x[e + 1];
-          x[e + 1] = fe_sub_red(x[e], t, Fr::P3_S1);
+        for (int e = 0; e < E; e++) {
+          if ((e >> u) & 1) continue;          // e is the upper element of a pair
+          const int f = e | (1 << u);
+          const uint32_t lo_i = pos[e] & ((1u << st) - 1);
+          fe t = fe_mul<Fr, CH>(load_fe9(a.tw_local, lo_i << (B - 1 - st)), x[f]);   // N x (limbs < 2^31.5)
+          x[f] = fe_sub_red(x[e], t, Fr::P3_S1);                                   // x - t + 3p
           x[e] = fe_add(x[e], t);
         }
-#pragma unroll
-        for (int e = 0; e < E; e += 4) {                    // stage 1
-          fe t = fe_norm(x[e + 2]);                         // trivial pair (e, e+2): t < 4p, N
-          x[e + 2] = fe_sub_red(x[e], t, Fr::P6_S1);        // < 10p / 2^31
-          x[e] = fe_add(x[e], t);                           // < 8p / 1.5*2^30
-          fe u1 = fe_mul<Fr, CH>(w4, x[e + 3]);                 // pair (e+1, e+3): input < 5p / 1.5*2^30
-          x[e + 3] = fe_sub_red(x[e + 1], u1, Fr::P3_S1);   // < 8p / 2.5*2^30
-          x[e + 1] = fe_add(x[e + 1], u1);                  // < 7p / 2^31
-        }
-        if constexpr (E == 8) {                             // stage 2
-          const fe w8 = load_fe9(a.tw_local, 1u << (B - 3)), w83 = load_fe9(a.tw_local, 3u << (B - 3));
-          fe t = fe_norm(x[4]);                             // trivial pair (0, 4): t < 8p, N
-          x[4] = fe_sub_red(x[0], t, Fr::P10_S1);           // < 18p / 2.5*2^30
-          x[0] = fe_add(x[0], t);                           // < 16p / 2^31
-          fe u1 = fe_mul<Fr, CH>(w8, x[5]);                     // inputs: limbs <= 2.5*2^30 < 2^31.5
-          x[5] = fe_sub_red(x[1], u1, Fr::P3_S1);
-          x[1] = fe_add(x[1], u1);
-          fe u2 = fe_mul<Fr, CH>(w4, x[6]);
-          x[6] = fe_sub_red(x[2], u2, Fr::P3_S1);
-          x[2] = fe_add(x[2], u2);
-          fe u3 = fe_mul<Fr, CH>(w83, x[7]);
-          x[7] = fe_sub_red(x[3], u3, Fr::P3_S1);
-          x[3] = fe_add(x[3], u3);
-        }
-      } else {
-#pragma unroll
-        for (int u = 0; u < VM; u++) {
-          if ((uint32_t)u < v) {
-            const uint32_t st = s + u;
-  #pragma unroll
-            for (int e = 0; e < E; e++) {
-              if ((e >> u) & 1) continue;          // e is the upper element of a pair
-              const int f = e | (1 << u);
-              const uint32_t lo_i = pos[e] & ((1u << st) - 1);
-              fe t = fe_mul<Fr, CH>(load_fe9(a.tw_local, lo_i << (B - 1 - st)), x[f]);   // N x (limbs < 2^31.5)
-              x[f] = fe_sub_red(x[e], t, Fr::P3_S1);                                   // x - t + 3p
-              x[e] = fe_add(x[e], t);
-            }
-          }
-        }
       }
+    }
+  };
+  auto positions = [&](uint32_t (&pos)[E], uint32_t s, uint32_t v) {
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const uint32_t rest = (m << (VM - v)) | ((uint32_t)e >> v);
+      const uint32_t lo = rest & ((1u << s) - 1), hi = rest >> s;
+      pos[e] = (hi << (s + v)) | (((uint32_t)e & ((1u << v) - 1)) << s) | lo;
+    }
+  };
+  uint32_t s = 0;
+  {
+    // ---- first round: elements straight from global memory (tile position p holds source row bitrev_B(p): the pass's decimation)
+    const uint32_t v = B < (uint32_t)VM ? B : (uint32_t)VM;
+    fe x[E];
+    uint32_t pos[E];
+    positions(pos, 0, v);
+    // (a compile-time loop: `#pragma unroll` leaves this one rolled -- the body holds two asm-block multiplications -- and a rolled loop
+    // indexes x[] dynamically, i.e. keeps it in scratch)
+    static_for<0, E>([&](auto ec) {
+      constexpr int e = decltype(ec)::value;
+      x[e] = ntt_fetch<CH>(a, src, __brev(pos[e]) >> (32 - B), j0 + jj, NR, Ns);
+    });
+    if (v == (uint32_t)VM) {
+      // v == VM, lo == 0: twiddles depend only on the register index and 7 of the 12 (E = 4: 3 of the 4) are w^0 = 1, so
+      // those butterflies need no multiply.  Inputs are N-form < 2p.  Bounds (value / limb) are noted per stage.
+      const fe w4 = load_fe9(a.tw_local, 1u << (B - 2));
+#pragma unroll
+      for (int e = 0; e < E; e += 2) {                    // stage 0: all trivial.  x' < 4p / 2^30, y' < 5p / 1.5*2^30
+        fe t = x[e + 1];
+        x[e + 1] = fe_sub_red(x[e], t, Fr::P3_S1);
+        x[e] = fe_add(x[e], t);
+      }
+#pragma unroll
+      for (int e = 0; e < E; e += 4) {                    // stage 1
+        fe t = fe_norm(x[e + 2]);                         // trivial pair (e, e+2): t < 4p, N
+        x[e + 2] = fe_sub_red(x[e], t, Fr::P6_S1);        // < 10p / 2^31
+        x[e] = fe_add(x[e], t);                           // < 8p / 1.5*2^30
+        fe u1 = fe_mul<Fr, CH>(w4, x[e + 3]);                 // pair (e+1, e+3): input < 5p / 1.5*2^30
+        x[e + 3] = fe_sub_red(x[e + 1], u1, Fr::P3_S1);   // < 8p / 2.5*2^30
+        x[e + 1] = fe_add(x[e + 1], u1);                  // < 7p / 2^31
+      }
+      if constexpr (E == 8) {                             // stage 2
+        const fe w8 = load_fe9(a.tw_local, 1u << (B - 3)), w83 = load_fe9(a.tw_local, 3u << (B - 3));
+        fe t = fe_norm(x[4]);                             // trivial pair (0, 4): t < 8p, N
+        x[4] = fe_sub_red(x[0], t, Fr::P10_S1);           // < 18p / 2.5*2^30
+        x[0] = fe_add(x[0], t);                           // < 16p / 2^31
+        fe u1 = fe_mul<Fr, CH>(w8, x[5]);                     // inputs: limbs <= 2.5*2^30 < 2^31.5
+        x[5] = fe_sub_red(x[1], u1, Fr::P3_S1);
+        x[1] = fe_add(x[1], u1);
+        fe u2 = fe_mul<Fr, CH>(w4, x[6]);
+        x[6] = fe_sub_red(x[2], u2, Fr::P3_S1);
+        x[2] = fe_add(x[2], u2);
+        fe u3 = fe_mul<Fr, CH>(w83, x[7]);
+        x[7] = fe_sub_red(x[3], u3, Fr::P3_S1);
+        x[3] = fe_add(x[3], u3);
+      }
+    } else {
+      stages(x, pos, 0, v);
+    }
+    if (v == B && direct_store) {
+      static_for<0, E>([&](auto ec) { constexpr int e = decltype(ec)::value; ntt_emit<CH>(a, dst, pos[e], j0 + jj, B, Ns, fe_norm(x[e])); });
+    } else {
 #pragma unroll
       for (int e = 0; e < E; e++) store_lds9(lds, pos[e] * J + jj, fe_norm(x[e]));
       __syncthreads();
-      s += v;
     }
+    s = v;
   }
+  while (s < B) {
+    const uint32_t v = (B - s) < (uint32_t)VM ? (B - s) : (uint32_t)VM;
+    fe x[E];
+    uint32_t pos[E];
+    positions(pos, s, v);
+#pragma unroll
+    for (int e = 0; e < E; e++) x[e] = load_lds9(lds, pos[e] * J + jj);
+    stages(x, pos, s, v);
+    if (s + v == B && direct_store) {
+      static_for<0, E>([&](auto ec) { constexpr int e = decltype(ec)::value; ntt_emit<CH>(a, dst, pos[e], j0 + jj, B, Ns, fe_norm(x[e])); });
+    } else {
+#pragma unroll
+      for (int e = 0; e < E; e++) store_lds9(lds, pos[e] * J + jj, fe_norm(x[e]));
+      __syncthreads();
+    }
+    s += v;
+  }
+  if (direct_store) return;
 
-  // ---- store: destination order (a, r', b), b = jj mod q fastest, q = min(Ns, J) -------------------
+  // ---- store through the tile: destination order (a, r', b), b = jj mod q fastest, q = min(Ns, J) ----
   const uint32_t q = Ns < J ? Ns : J;
   const uint32_t logq = 31 - __builtin_clz(q);
   for (uint32_t idx = threadIdx.x; idx < tile; idx += nthreads) {
     const uint32_t b = idx & (q - 1), rp = (idx >> logq) & (R - 1), aa = idx >> (logq + B);
     const uint32_t jj = aa * q + b;
-    const uint32_t j = j0 + jj;
-    const uint32_t d = ((j >> a.S) << (a.S + B)) + (j & (Ns - 1)) + (rp << a.S);
-    fe x = load_lds9(lds, rp * J + jj);
-    uint32_t w[8];
-    if (a.last) {
-      if (d >= a.out_len) continue;
-      if (a.out_scale.period) fe_pack(fe_canon_lt2p<Fr>(fe_mul<Fr, CH>(scale_pick(a.out_scale, d), x)), w);
-      else fe_pack(fe_canon_lt3p<Fr>(fe_reduce_soft<Fr>(x)), w);   // x is N-form < 29p after the last round
-    } else {
-      fe_pack(fe_reduce_soft<Fr>(x), w);         // < 2p + 2^233 < 2^256: fits the 32-byte intermediate format
-    }
-    store_words(dst + (size_t)d * 8, w);
+    ntt_emit<CH>(a, dst, rp, j0 + jj, B, Ns, load_lds9(lds, rp * J + jj));
   }
 }
 
@@ -498,7 +535,6 @@ int ntt_transform(const uint32_t* d_in, uint32_t in_len, uint32_t in_stride, uin
     HIPCHK(hipGetDevice(&cur_dev));
     std::lock_guard<std::mutex> ag(attr_mu);
     if (!attr_set_dev[cur_dev & 63]) {
-      HIPCHK(hipFuncSetAttribute((const void*)k_ntt_pass<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_LDS_WORDS * 4));
       HIPCHK(hipFuncSetAttribute((const void*)k_ntt_pass<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_LDS_WORDS * 4));
       HIPCHK(hipFuncSetAttribute((const void*)k_ntt_pass<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NTT_LDS_WORDS * 4));
       attr_set_dev[cur_dev & 63] = true;
@@ -526,14 +562,13 @@ int ntt_transform(const uint32_t* d_in, uint32_t in_len, uint32_t in_stride, uin
     a.dst = a.last ? d_out : tmp[i & 1];
     a.src_stride = i == 0 ? in_stride : N;
     a.dst_stride = a.last ? out_stride : N;
-    static const int elems = [] { const char* e = getenv("ZKHIP_NTT_ELEMS"); return e && atoi(e) == 8 ? 8 : 4; }();      // A/B knob
     // single-chain product columns (fp29.hpp fe_mul<P, CHAIN>: one run of multiply-adds per column instead of the partial sums LLVM's
-    // reassociation makes): with 4 elements per thread (113 VGPRs, 4 waves per SIMD) -3 % at every size (2^24: 2.35 -> 2.27 ms, same box);
-    // with 8 elements per thread it had cost 3.5x in round 1 (register pressure), which is why it was not used here before
+    // reassociation makes): -3 % at every size with 4 elements per thread (2^24: 2.35 -> 2.27 ms, same box).  The 8-elements-per-thread
+    // shape of round 1 (2 waves per SIMD) measured equal within noise in round 2 and is no longer instantiated.
     static const bool chain = getenv("ZKHIP_NTT_PLAIN") == nullptr;       // A/B knob
-    if (elems == 4 && tile >= 8 && chain) hipLaunchKernelGGL((k_ntt_pass<4, true>), dim3(N / tile, batch), dim3(tile / 4), (size_t)(lds_word_host(tile) + 16) * 4, stream, a);
-    else if (elems == 4 && tile >= 8) hipLaunchKernelGGL((k_ntt_pass<4, false>), dim3(N / tile, batch), dim3(tile / 4), (size_t)(lds_word_host(tile) + 16) * 4, stream, a);
-    else hipLaunchKernelGGL((k_ntt_pass<8, false>), dim3(N / tile, batch), dim3(tile / 8), (size_t)(lds_word_host(tile) + 16) * 4, stream, a);
+    const unsigned threads = tile >= 4 ? tile / 4 : 1;
+    if (chain) hipLaunchKernelGGL((k_ntt_pass<4, true>), dim3(N / tile, batch), dim3(threads), (size_t)(lds_word_host(tile) + 16) * 4, stream, a);
+    else hipLaunchKernelGGL((k_ntt_pass<4, false>), dim3(N / tile, batch), dim3(threads), (size_t)(lds_word_host(tile) + 16) * 4, stream, a);
     prof_mark(stream, i == 0 ? "ntt_pass0" : (i == 1 ? "ntt_pass1" : (i == 2 ? "ntt_pass2" : "ntt_pass3")));
   }
   HIPCHK(hipGetLastError());
