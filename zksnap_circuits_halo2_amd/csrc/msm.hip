@@ -223,13 +223,18 @@ __global__ void __launch_bounds__(1024) k_coarse_pass(const int32_t* __restrict_
   __syncthreads();
   const uint4* dv = reinterpret_cast<const uint4*>(digits + (size_t)win * n_pad);
   const uint32_t v_lo = lo >> 2, v_hi = hi >> 2;
-  for (uint32_t vi = v_lo + threadIdx.x; vi < v_hi; vi += blockDim.x) {
-    const uint4 q = dv[vi];
-    const int32_t d4[4] = {(int32_t)q.x, (int32_t)q.y, (int32_t)q.z, (int32_t)q.w};
+  for (uint32_t vi = v_lo + threadIdx.x; vi < v_hi; vi += 4 * blockDim.x) {        // four vector loads in flight per lane
+    uint4 q[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int32_t d = d4[k];
-      if (d != 0) atomicAdd(&cnt[((uint32_t)(d < 0 ? -d : d) - 1) >> FINE_BITS], 1u);
+    for (int u = 0; u < 4; u++) { const uint32_t vj = vi + u * blockDim.x; q[u] = vj < v_hi ? dv[vj] : make_uint4(0, 0, 0, 0); }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int32_t d4[4] = {(int32_t)q[u].x, (int32_t)q[u].y, (int32_t)q[u].z, (int32_t)q[u].w};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int32_t d = d4[k];
+        if (d != 0) atomicAdd(&cnt[((uint32_t)(d < 0 ? -d : d) - 1) >> FINE_BITS], 1u);
+      }
     }
   }
   __syncthreads();
@@ -278,14 +283,16 @@ __global__ void __launch_bounds__(1024) k_coarse_sorted(const int32_t* __restric
   __syncthreads();
   const uint4* dv = reinterpret_cast<const uint4*>(digits + (size_t)win * n_pad);
   const uint32_t v_lo = lo >> 2, v_hi = hi >> 2;
-  for (uint32_t vi = v_lo + threadIdx.x; vi < v_hi; vi += blockDim.x) {
-    const uint4 q = dv[vi];
-    const int32_t d4[4] = {(int32_t)q.x, (int32_t)q.y, (int32_t)q.z, (int32_t)q.w};
+  // COARSE_CHUNK / 4 = 2048 vectors for 1024 lanes: a lane's two vectors are loaded together (independent loads), counted, and kept in
+  // registers for the placement below -- the digits are read once
+  static_assert(COARSE_CHUNK == 8192, "a lane owns two 4-digit vectors of the chunk");
+  const uint32_t vi = v_lo + threadIdx.x, vj = vi + 1024u;
+  const uint4 q0 = vi < v_hi ? dv[vi] : make_uint4(0, 0, 0, 0), q1 = vj < v_hi ? dv[vj] : make_uint4(0, 0, 0, 0);
+  const int32_t d8[8] = {(int32_t)q0.x, (int32_t)q0.y, (int32_t)q0.z, (int32_t)q0.w, (int32_t)q1.x, (int32_t)q1.y, (int32_t)q1.z, (int32_t)q1.w};
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int32_t d = d4[k];
-      if (d != 0) atomicAdd(&cur[((uint32_t)(d < 0 ? -d : d) - 1) >> FINE_BITS], 1u);
-    }
+  for (int k = 0; k < 8; k++) {
+    const int32_t d = d8[k];
+    if (d != 0) atomicAdd(&cur[((uint32_t)(d < 0 ? -d : d) - 1) >> FINE_BITS], 1u);
   }
   __syncthreads();
   if (threadIdx.x < 64) {            // one wavefront: exclusive scan of the MAX_GROUPS = 128 counts (two per lane), then the reservations
@@ -329,18 +336,14 @@ __global__ void __launch_bounds__(1024) k_coarse_sorted(const int32_t* __restric
   }
   __syncthreads();
   const uint32_t rbase = ref_base + (uint32_t)win * ref_stride;
-  for (uint32_t vi = v_lo + threadIdx.x; vi < v_hi; vi += blockDim.x) {
-    const uint4 q = dv[vi];
-    const int32_t d4[4] = {(int32_t)q.x, (int32_t)q.y, (int32_t)q.z, (int32_t)q.w};
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int32_t d = d4[k];
-      if (d != 0) {
-        const uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1;
-        const uint32_t pos = atomicAdd(&cur[b >> FINE_BITS], 1u);
-        refs[pos] = (rbase + vi * 4 + k) | (d < 0 ? 0x80000000u : 0u);
-        fines[pos] = (uint16_t)(b & ((1u << FINE_BITS) - 1));
-      }
+  for (int k = 0; k < 8; k++) {
+    const int32_t d = d8[k];
+    if (d != 0) {
+      const uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1;
+      const uint32_t pos = atomicAdd(&cur[b >> FINE_BITS], 1u);
+      refs[pos] = (rbase + (k < 4 ? vi : vj) * 4 + (k & 3)) | (d < 0 ? 0x80000000u : 0u);
+      fines[pos] = (uint16_t)(b & ((1u << FINE_BITS) - 1));
     }
   }
   __syncthreads();
@@ -385,6 +388,23 @@ __global__ void __launch_bounds__(64) k_group_offsets(const uint32_t* __restrict
 //        | run-start bit mask and its word prefixes (SORT_CHUNK / 16 words)
 // (A second shape that kept every entry's 16-bit bucket id in LDS -- 20 Ki entries per chunk -- served the smallest wide size until the
 // rank structure below made the way out three reads for any chunk: 2^20 scatter 0.110 -> 0.101 ms, and the variant was removed.)
+// LDS histogram of the fine bucket ids of staged entries [start, end).  The sort kernels spent 77 - 84 % of their cycles parked
+// (profiles/r02_rocprofv3_pmc_sq_issue.txt): with one load per lane and iteration, each feeding an LDS atomic, every trip exposes a full
+// memory latency.  Four independent loads are issued before the first atomic.
+#ifndef ZKHIP_FINE_BATCH
+#define ZKHIP_FINE_BATCH 7
+#endif
+constexpr int FINE_BATCH = ZKHIP_FINE_BATCH;      // measured (2 / 4 / 7 / 14 / 28 loads in flight per lane): see (profiles/r03_msm_sort_pipelining_ab.txt)
+__device__ __forceinline__ void fine_histogram(const uint16_t* __restrict__ stage_fine, uint32_t start, uint32_t end, uint32_t* __restrict__ cur) {
+  for (uint32_t p = start + threadIdx.x; p < end; p += FINE_BATCH * blockDim.x) {
+    uint32_t f[FINE_BATCH];
+#pragma unroll
+    for (int k = 0; k < FINE_BATCH; k++) { const uint32_t q = p + k * blockDim.x; f[k] = q < end ? stage_fine[q] : 0xffffffffu; }
+#pragma unroll
+    for (int k = 0; k < FINE_BATCH; k++) if (f[k] != 0xffffffffu) atomicAdd(&cur[f[k]], 1u);
+  }
+}
+
 __global__ void __launch_bounds__(1024) k_fine_sorted(const uint16_t* __restrict__ stage_fine, const uint32_t* __restrict__ stage_ref,
                                                       const uint32_t* __restrict__ goff, const uint32_t* __restrict__ cstart, int G,
                                                       uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
@@ -404,7 +424,7 @@ __global__ void __launch_bounds__(1024) k_fine_sorted(const uint16_t* __restrict
   const uint32_t start = goff[g] + (w - cstart[g]) * CHUNK, end = min(goff[g + 1], start + CHUNK), cnt_n = end - start;
   for (uint32_t b = threadIdx.x; b < FB; b += blockDim.x) cur[b] = 0;
   __syncthreads();
-  for (uint32_t p = start + threadIdx.x; p < end; p += blockDim.x) atomicAdd(&cur[stage_fine[p]], 1u);
+  fine_histogram(stage_fine, start, end, cur);
   __syncthreads();
   // exclusive scan over the 4096 counts: thread t owns buckets 4t .. 4t + 3
   uint32_t c[4], l[4], s = 0;
@@ -476,7 +496,14 @@ __global__ void __launch_bounds__(1024) k_fine_sorted(const uint16_t* __restrict
   }
   __syncthreads();
   {
-    for (uint32_t p = start + threadIdx.x; p < end; p += blockDim.x) refs[atomicAdd(&cur[stage_fine[p]], 1u)] = stage_ref[p];
+    // (FINE_BATCH entries per lane in flight, as in fine_histogram)
+    for (uint32_t p = start + threadIdx.x; p < end; p += FINE_BATCH * blockDim.x) {
+      uint32_t f[FINE_BATCH], r[FINE_BATCH];
+#pragma unroll
+      for (int k = 0; k < FINE_BATCH; k++) { const uint32_t q = p + k * blockDim.x; f[k] = q < end ? stage_fine[q] : 0xffffffffu; r[k] = q < end ? stage_ref[q] : 0u; }
+#pragma unroll
+      for (int k = 0; k < FINE_BATCH; k++) if (f[k] != 0xffffffffu) refs[atomicAdd(&cur[f[k]], 1u)] = r[k];
+    }
     __syncthreads();
     const uint32_t* mask = refs + CHUNK;
     const uint32_t* wpre = mask + CHUNK / 32;
@@ -501,7 +528,7 @@ __global__ void __launch_bounds__(1024) k_fine_count(const uint16_t* __restrict_
   const uint32_t start = goff[g] + (w - cstart[g]) * chunk, end = min(goff[g + 1], start + chunk);
   for (uint32_t b = threadIdx.x; b < FB; b += blockDim.x) cur[b] = 0;
   __syncthreads();
-  for (uint32_t p = start + threadIdx.x; p < end; p += blockDim.x) atomicAdd(&cur[stage_fine[p]], 1u);
+  fine_histogram(stage_fine, start, end, cur);
   __syncthreads();
   uint32_t* gl = count + (size_t)g * FB;
   for (uint32_t b = threadIdx.x; b < FB; b += blockDim.x) {
