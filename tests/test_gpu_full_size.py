@@ -249,15 +249,23 @@ def test_msm_2p20_columns_of_equal_values_are_correct_and_not_serialised(lib, cr
             torch.cuda.synchronize()
             exp = cref.jac_to_affine(cref.scalar_mul(cref.expected_scalar(sc, T0, D), cref.generator()))
             assert np.array_equal(cref.jac_to_affine(out.cpu().numpy().view(np.uint64)), exp), name
-            t = time.perf_counter()
-            for _ in range(5):
-                run()
-            torch.cuda.synchronize()
-            times[name] = (time.perf_counter() - t) / 5
+            # device time (HIP events on the stream), best of three: a shared box may stretch any single run
+            best = float("inf")
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    run()
+                e1.record()
+                e1.synchronize()
+                best = min(best, e0.elapsed_time(e1) / 3)
+            times[name] = best
     finally:
         _lib.check(lib.zkhip_release_bases(h))
+    # the regression this guards against is not subtle: with one thread writing a heavy bucket's task records / one chain summing its partials,
+    # the all-ones column took 8 x the uniform case (12.3 vs 1.5 ms).  A generous bound on best-of-three device times cannot flake on a noisy box.
     for name, t in times.items():
-        assert t < 2.5 * times["uniform"], (name, times)
+        assert t < 4.0 * times["uniform"], (name, times)
 
 
 def test_batch_of_large_msms_overlapped_on_two_streams(lib, cref):

@@ -212,20 +212,25 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk
             return t_
 
         sigma = [from_key(dpk.permutation_values(i), k) for i in range(len(perm_cols))]
-        z_sets, last_z = [], 1
+        # every set's product starts at 1 and is computed without a host round trip; ONE read-back of the sets' last usable values then gives the
+        # chaining factors z_k[0] = z_{k-1}[u] (with hundreds of columns a per-set read-back was most of this phase)
+        z_sets = []
         for si in range(cs.num_permutation_sets):
             lo, hi = si * cs.chunk_len, min((si + 1) * cs.chunk_len, len(perm_cols))
             vals = [pcol(c) for c in range(lo, hi)]
             num = run_prog(E.permutation_numerator_program(hi - lo, lo, beta, gamma, k), vals, k)
             den = run_prog(E.permutation_denominator_program(hi - lo, beta, gamma), vals + sigma[lo:hi], k)
             _lib.check(lib.zkhip_fr_grand_product_device(num.data_ptr(), den.data_ptr(), n, num.data_ptr(), None))
+            z_sets.append(num)
+        lasts = F.fr_decode(torch.stack([z[u] for z in z_sets]).cpu().numpy().view(np.uint64).reshape(-1, 4))
+        last_z = 1
+        for si, own_last in enumerate(lasts):
             if last_z != 1:                                                        # chain: z_k[0] = z_{k-1}[u]
                 sc = E.RowProgram()
                 sc.emit(E.OP_MUL, 0, sc.column(0), sc.constant(last_z))
-                num = run_prog(sc, [num], k)
-            last_z = F.fr_decode(num[u].cpu().numpy().view(np.uint64))[0]
-            num[u + 1:] = rand_fr(n - u - 1)                                       # blinding rows
-            z_sets.append(num)
+                z_sets[si] = run_prog(sc, [z_sets[si]], k)
+            last_z = last_z * own_last % R
+            z_sets[si][u + 1:] = rand_fr(n - u - 1)                                # blinding rows
         perm_closes = last_z == 1
         lap("permutation_products")
 
