@@ -65,7 +65,7 @@ def fuzz_msm(seed):
         lib.zkhip_release_bases(h)
 
 def fuzz_ntt(seed):
-    L = rng.randint(0, 17)
+    L = rng.choice([rng.randint(0, 17), rng.randint(9, 21)])      # (one / two / three passes; tiles of 1024 elements from L = 10)
     a = Cr.gen_scalars(seed, 1 << L, rng.randrange(2))
     om = F.fr_encode([F.omega_for(L)])[0]
     ref = a.copy(); Cr.best_fft(ref, om, L, 4)
@@ -186,6 +186,22 @@ def fuzz_sharded(seed):
             _lib.check(lib.zkhip_msm_g1(sub.ctypes.data, hb[off:].ctypes.data, m, out.ctypes.data))
             exp = aff(Cr.scalar_mul(Cr.expected_scalar(sub, (T0 + off * D) % R, D), Cr.generator()))
             assert np.array_equal(aff(out), exp), f"sharded msm n={n} S={S} off={off} m={m}"
+            # the same range with the scalars resident in HBM (round 3: fans out over the shards), alone and as a batch with a padded stride
+            dsub = torch.from_numpy(sub.view(np.int64)).cuda()
+            dout = torch.zeros(12, dtype=torch.int64, device="cuda")
+            _lib.check(lib.zkhip_msm_g1_registered_device(hb[off:].ctypes.data, dsub.data_ptr(), m, dout.data_ptr(), None))
+            torch.cuda.synchronize()
+            assert np.array_equal(aff(dout.cpu().numpy().view(np.uint64)), exp), f"sharded device-resident msm n={n} S={S} off={off} m={m}"
+            Bt, pad = rng.randint(1, 4), rng.choice([0, 3, 16])
+            vecs = [np.ascontiguousarray(scalars(n, seed + 7 * b + 1)[off:off + m]) for b in range(Bt)]
+            dv = torch.zeros((Bt, m + pad, 4), dtype=torch.int64, device="cuda")
+            for b in range(Bt): dv[b, :m] = torch.from_numpy(vecs[b].view(np.int64)).cuda()
+            douts = torch.zeros((Bt, 12), dtype=torch.int64, device="cuda")
+            _lib.check(lib.zkhip_msm_g1_registered_batch_device(hb[off:].ctypes.data, dv.data_ptr(), m, Bt, m + pad, douts.data_ptr(), None))
+            torch.cuda.synchronize()
+            for b in range(Bt):
+                eb = aff(Cr.scalar_mul(Cr.expected_scalar(vecs[b], (T0 + off * D) % R, D), Cr.generator()))
+                assert np.array_equal(aff(douts[b].cpu().numpy().view(np.uint64)), eb), f"sharded device-resident batch n={n} S={S} off={off} m={m} b={b}/{Bt}"
     finally:
         lib.zkhip_unregister_bases(hb.ctypes.data)
         lib.zkhip_set_msm_shards(0)
