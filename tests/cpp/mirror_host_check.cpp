@@ -59,6 +59,22 @@ int main(int argc, char** argv) {
     const bool fr_ok = D::sub_fr(D::add_fr(a, b), b) == a && D::add_fr(a, D::neg_fr(a)) == Fr{} && D::mul(a, D::invert(a)) == D::one() &&
                        D::add_fr(D::neg_fr(D::one()), D::one()) == Fr{};
     if (fr_ok) flags |= 8;
+    // g2_is_valid (the RawBytes reader's check of g2 / s_g2): every input point passes, a point with one coordinate bumped does not,
+    // a non-canonical limb pattern does not
+    bool valid_ok = true;
+    for (const auto& p : pts) {
+      valid_ok = valid_ok && D::g2_is_valid(p);
+      bool zero = true;
+      for (uint64_t w : p) zero = zero && w == 0;
+      if (zero) continue;
+      auto bad = p;
+      bad[8] ^= 1;                                               // y.c0 off by one limb bit: not on the twist
+      valid_ok = valid_ok && !D::g2_is_valid(bad);
+      auto big = p;
+      big[3] = ~(uint64_t)0;                                     // x.c0 >= q: not a canonical residue
+      valid_ok = valid_ok && !D::g2_is_valid(big);
+    }
+    if (valid_ok) flags |= 16;
   }
   fwrite(&flags, 8, 1, out);
   fclose(out);

@@ -403,6 +403,42 @@ def test_config4_device_resident_8_shards_of_2p21(lib, cref, restore_shards):
         _lib.check(lib.zkhip_unregister_bases(bases.ctypes.data))
 
 
+def test_reinit_with_other_devices_while_a_host_call_runs_is_refused(lib, cref):
+    """zkhip_init with a different device list used to wait for the running host-buffer calls on a mutex it held twice (a deadlock: the lane
+    holder could never take the lock to give its lane back); it now returns ZKHIP_EBUSY while a lane is busy and re-initialises afterwards"""
+    L = 24
+    a = cref.gen_scalars(9950, 1 << L, 0)
+    om = F.fr_encode([F.omega_for(L)])[0]
+    rcs, done = [], threading.Event()
+
+    def long_call():
+        rcs.append(lib.zkhip_ntt_fr(a.ctypes.data, om.ctypes.data, L))        # 512 MiB each way over PCIe: tens of milliseconds on a lane
+        done.set()
+
+    os.environ["ZKHIP_TEST_DUPLICATE_DEVICES"] = "1"
+    try:
+        devs = (C.c_int * 2)(0, 0)
+        t = threading.Thread(target=long_call)
+        t.start()
+        seen = []
+        while not done.is_set():
+            rc = lib.zkhip_init(devs, 2)
+            seen.append(rc)
+            if rc == 0:
+                break                                  # the call had already finished (or not yet begun): the re-init went through
+        t.join()
+        assert rcs == [0]
+        assert all(rc in (0, -5) for rc in seen), seen
+        if -5 in seen:
+            assert b"in flight" in lib.zkhip_last_error()
+        _lib.check(lib.zkhip_init(devs, 2))            # nothing is running now: accepted
+        assert lib.zkhip_device_count() == 2
+    finally:
+        lib.zkhip_shutdown()
+        del os.environ["ZKHIP_TEST_DUPLICATE_DEVICES"]
+        _lib.check(lib.zkhip_init(None, 0))
+
+
 def _config4_worker(rank, world, port, q):
     """one rank of bench.py's configs[4] leg (world > 1 branch), gloo in place of RCCL, all ranks on the one card of the test box"""
     import os

@@ -76,4 +76,4 @@ def test_cpp_mirror_host_arithmetic_with_sanitizers(tmp_path):
     off += 32 * len(xs)
     assert coeffs == M._interpolate(xs, ys)
     flags, = struct.unpack("<Q", out[off:off + 8])
-    assert flags == 0b1111, bin(flags)
+    assert flags == 0b11111, bin(flags)          # bit 4: g2_is_valid accepts the points and rejects off-curve / non-canonical ones
