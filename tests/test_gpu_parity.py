@@ -143,6 +143,42 @@ def test_msm_every_window_size(lib, cref, c):
     assert np.array_equal(got, structured_expect(cref, sc, t0, d))
 
 
+@pytest.mark.parametrize("c", [0, 2, 4, 8, 13, 16])
+def test_msm_general_path_glv_edge_scalars(lib, cref, c):
+    """the general path splits k = k1 + lambda k2 (csrc/msm.hip k_digits_glv).  Scalars chosen by their HALVES: magnitudes that put a window at
+    exactly 2^(c-1) (the digit -2^(c-1) of a negative half must not wrap in int16), halves of either sign, zero halves, the largest magnitudes
+    the decomposition can produce, k = 0 / 1 / r - 1, and lambda itself (k1 = 0, k2 = 1)"""
+    import torch
+
+    lam = 0xb3c4d79d41a917585bfc41088d8daaa78b17ea66b99c90dd
+    r = O.R_MOD
+    halves = [0, 1, -1, 1 << 15, -(1 << 15), (1 << 15) + (1 << 31), -((1 << 15) + (1 << 31) + (1 << 47)), (1 << 7), -(1 << 7), (1 << 3) | (1 << 7) | (1 << 11),
+              (1 << 126) + 12345, -((1 << 126) + 999), 0x7fff7fff7fff7fff7fff7fff7fff7fff, -0x7fff7fff7fff7fff7fff7fff7fff7fff, 0x80008000800080008000800080008000 >> 2,
+              -(0x80008000800080008000800080008000 >> 2)]
+    ks = [0, 1, r - 1, lam, r - lam, (lam * lam) % r]
+    ks += [(a + lam * b) % r for a in halves for b in halves]
+    g = O.SplitMix64(4242 + c)
+    ks += [g.fr() for _ in range(64)]
+    n = len(ks)
+    bases, t0, d = cref.gen_bases(21, n)
+    sc = F.fr_encode(ks)
+    dsc = torch.from_numpy(sc.view(np.int64)).cuda()
+    dbs = torch.from_numpy(bases.view(np.int64)).cuda()
+    dout = torch.zeros(12, dtype=torch.int64, device="cuda")
+    _lib.check(lib.zkhip_msm_g1_device_c(dsc.data_ptr(), dbs.data_ptr(), n, dout.data_ptr(), c, None))
+    torch.cuda.synchronize()
+    assert np.array_equal(aff(cref, dout.cpu().numpy().view(np.uint64)), structured_expect(cref, sc, t0, d))
+    # one scalar at a time: a wrong digit cannot hide behind a cancellation
+    for i in (6, 7, 10, 11, 12, 40, 41, 100, 101, 180, 250):
+        if i >= n:
+            continue
+        _lib.check(lib.zkhip_msm_g1_device_c(dsc.data_ptr() + 32 * i, dbs.data_ptr() + 64 * i, 1, dout.data_ptr(), c, None))
+        torch.cuda.synchronize()
+        got = aff(cref, dout.cpu().numpy().view(np.uint64))
+        one = np.ascontiguousarray(sc[i:i + 1])
+        assert np.array_equal(got, aff(cref, cref.best_multiexp(one, np.ascontiguousarray(bases[i:i + 1]), 1))), (c, i, hex(ks[i]))
+
+
 def test_msm_heavy_buckets_and_degenerate_inputs(cref):
     n = 1 << 15
     bases, t0, d = cref.gen_bases(31, 64)

@@ -189,3 +189,64 @@ def test_g2_oracle_public_facts():
     one = O.limbs4(O.to_mont(1, O.Q_MOD))
     assert O.g2_jac_from_limbs(enc + one + [0, 0, 0, 0]) == O.G2_GEN
     assert enc == [int(x) for x in srs.g2_encode(srs.G2_GENERATOR)]
+
+
+def test_glv_parameters_of_the_general_path_msm():
+    """csrc/msm.hip splits the scalars of the general-path MSM with the curve's endomorphism phi(x, y) = (beta x, y) = lambda (x, y).  The constants
+    in the kernel source are re-derived here: lambda / beta are matching cube roots of unity (checked on the generator), the lattice basis comes out
+    of the extended Euclid on (r, lambda), g1 / g2 are its rounded quotients, and the word-level decomposition the kernel performs (floors,
+    differences mod 2^160) stays below 9/8 (a1 + a2) < 0.979 * 2^127 -- so the signed recoding never carries out of the top window."""
+    import math
+    import os
+    import random
+    import re
+
+    r, q = O.R_MOD, O.Q_MOD
+    lam = 0xb3c4d79d41a917585bfc41088d8daaa78b17ea66b99c90dd
+    beta = 0x59e26bcea0d48bacd4f263f1acdb5c4f5763473177fffffe
+    assert pow(lam, 3, r) == 1 and lam != 1 and pow(beta, 3, q) == 1 and beta != 1
+    G = O.G1_GEN
+    assert O.scalar_mul(lam, G) == (beta * G[0] % q, G[1])
+    P = O.scalar_mul(0xC0FFEE, G)
+    assert O.scalar_mul(lam, P) == (beta * P[0] % q, P[1])
+    # extended Euclid on (r, lambda): the two short vectors (a, b) with a + b lambda = 0 mod r
+    rows = [(r, 1, 0), (lam, 0, 1)]
+    while rows[-1][0] != 0:
+        (r0, s0, t0), (r1, s1, t1) = rows[-2], rows[-1]
+        qq = r0 // r1
+        rows.append((r0 - qq * r1, s0 - qq * s1, t0 - qq * t1))
+    sq = math.isqrt(r)
+    li = next(i for i in range(len(rows) - 1) if rows[i][0] >= sq and rows[i + 1][0] < sq)
+    a1, b1 = rows[li + 1][0], -rows[li + 1][2]
+    a2, b2 = min(((rows[li][0], -rows[li][2]), (rows[li + 2][0], -rows[li + 2][2])), key=lambda v: v[0] ** 2 + v[1] ** 2)
+    assert (a1 + b1 * lam) % r == 0 and (a2 + b2 * lam) % r == 0
+    assert (a1, -b1, a2, b2) == (0x89d3256894d213e3, 0x6f4d8248eeb859fc8211bbeb7d4f1128, 0x6f4d8248eeb859fd0be4e1541221250b, 0x89d3256894d213e3)
+    rdiv = lambda a, n: (2 * a + n) // (2 * n)
+    g1, g2 = rdiv(b2 << 256, r), rdiv((-b1) << 256, r)
+    words = lambda v, n: [(v >> (32 * i)) & 0xffffffff for i in range(n)]
+    # the kernel source carries exactly these words
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "zksnap_circuits_halo2_amd", "csrc", "msm.hip")).read()
+    def in_source(name, vals):
+        m = re.search(r"constexpr uint32_t %s\[\d+\] = \{([^}]*)\}" % name, src)
+        assert m, name
+        assert [int(x.strip().rstrip("u"), 16) for x in m.group(1).split(",")] == vals, name
+    in_source("G1", words(g1, 3)); in_source("G2", words(g2, 5)); in_source("A1", words(a1, 2)); in_source("A2", words(a2, 4)); in_source("NB1", words(-b1, 4))
+    in_source("BETA_EXT", words(beta * (1 << 256) % q, 8))
+    M = (1 << 160) - 1
+    rnd = random.Random(99)
+    worst = 0
+    for k in [0, 1, 2, r - 1, r - 2, lam, r - lam, r // 2, r // 3] + [rnd.randrange(r) for _ in range(20000)] + [rnd.randrange(1 << rnd.randrange(1, 254)) for _ in range(5000)]:
+        c1, c2 = (k * g1) >> 256, (k * g2) >> 256
+        assert c1 < 1 << 64 and c2 < 1 << 128
+        k1 = ((k & M) - ((c1 * a1) & M) - ((c2 * a2) & M)) & M
+        k2 = (((c1 * -b1) & M) - ((c2 * b2) & M)) & M
+        v = []
+        for x in (k1, k2):
+            neg = x >> 159
+            mag = (-x) & M if neg else x
+            worst = max(worst, mag)
+            v.append(-mag if neg else mag)
+        assert (v[0] + v[1] * lam - k) % r == 0
+    # floors of the APPROXIMATE quotients: c = floor(x + e) with |e| <= k / 2^257 < 1/8, so |k_i| < (1 + 1/8) (a1 + a2) -- which must leave room for the
+    # signed recoding's carry in the top window when the windows cover exactly 128 bits (8-bit windows: top value <= 125, + 1 < 128)
+    assert worst < (a1 + a2) * 9 // 8 + (1 << 64) < (1 << 127) - (1 << 120)

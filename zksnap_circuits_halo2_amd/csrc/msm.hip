@@ -133,6 +133,152 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ sca
 }
 
 // ------------------------------------------------------------------------------------------------
+// 1'. GLV digits (general path: arbitrary, unprepared bases).  BN254 has the endomorphism phi(x, y) = (beta x, y) = lambda (x, y) with
+//     lambda^3 = 1 in Fr, beta^3 = 1 in Fq, so k P = k1 P + k2 phi(P) with |k1|, |k2| < 2^127: the MSM over n points and 254-bit scalars
+//     becomes one over 2n points (P_i, phi(P_i)) and 127-bit scalars -- the same number of digit entries (W' = ceil(128 / c) windows x 2n),
+//     half the bucket sets, and a window fold of 128 - c dependent doublings instead of 256 - c (the fold is one quad's latency chain:
+//     0.60 of 2.3 ms at 2^20, 0.70 of 1.25 ms at 2^17).  Decomposition (the lattice basis of the published GLV parameters of the curve,
+//     re-derived here with the extended Euclid on (r, lambda) and checked in tests/test_oracle.py):
+//         v1 = (a1, b1) = (0x89d3256894d213e3, -0x6f4d8248eeb859fc8211bbeb7d4f1128),  v2 = (a2, b2) = (0x6f4d8248eeb859fd0be4e1541221250b, 0x89d3256894d213e3)
+//         c1 = floor(k g1 / 2^256), g1 = round(2^256 b2 / r);   c2 = floor(k g2 / 2^256), g2 = round(2^256 (-b1) / r)
+//         k1 = k - c1 a1 - c2 a2,   k2 = c1 (-b1) - c2 b2          (k1 + lambda k2 = k mod r for ANY c1, c2: the rounding only bounds the size)
+//     With floors of the approximate quotients (c = floor(x + e), |e| <= k / 2^257 < 1/8) |k_i| < 9/8 (|a1| + |a2|) < 0.979 * 2^127, so the
+//     signed recoding never carries out of the top window (msm_windows adds a window for the two window sizes where it would).
+//     Differences are taken mod 2^160 (sign = bit 159).
+// ------------------------------------------------------------------------------------------------
+namespace glv {
+__device__ constexpr uint32_t G1[3] = {0xc7e0b3d7u, 0xd91d232eu, 0x2u};
+__device__ constexpr uint32_t G2[5] = {0x391eb18eu, 0x7a7bd9d4u, 0xa773d2cfu, 0x4ccef014u, 0x2u};
+__device__ constexpr uint32_t A1[2] = {0x94d213e3u, 0x89d32568u};                               // = b2
+__device__ constexpr uint32_t A2[4] = {0x1221250bu, 0x0be4e154u, 0xeeb859fdu, 0x6f4d8248u};
+__device__ constexpr uint32_t NB1[4] = {0x7d4f1128u, 0x8211bbebu, 0xeeb859fcu, 0x6f4d8248u};    // -b1
+// beta (the cube root of unity in Fq with phi = lambda for this lambda), Montgomery-256 words
+__device__ constexpr uint32_t BETA_EXT[8] = {0xd782e155u, 0x71930c11u, 0xffbe3323u, 0xa6bb947cu, 0xd4741444u, 0xaa303344u, 0x26594943u, 0x2c3b3f0du};
+
+// out[0 .. NO) = low NO words of a (NA words) * b (NB words)
+template <int NA, int NB, int NO>
+__device__ __forceinline__ void mul_low(const uint32_t (&a)[NA], const uint32_t* __restrict__ b, uint32_t (&out)[NO]) {
+#pragma unroll
+  for (int i = 0; i < NO; i++) out[i] = 0;
+#pragma unroll
+  for (int i = 0; i < NA; i++) {
+    uint32_t carry = 0;
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+      if (i + j < NO) {
+        const uint64_t t = (uint64_t)a[i] * b[j] + out[i + j] + carry;
+        out[i + j] = (uint32_t)t;
+        carry = (uint32_t)(t >> 32);
+      }
+    }
+    if (i + NB < NO) out[i + NB] = carry;      // (this word has not been written by an earlier row: rows ascend)
+  }
+}
+
+// magnitude (4 words) and sign of a two's-complement 160-bit value whose magnitude is below 2^127
+__device__ __forceinline__ bool abs160(uint32_t (&v)[5], uint32_t (&mag)[4]) {
+  const bool neg = (v[4] >> 31) != 0;
+  uint32_t carry = neg ? 1u : 0u;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const uint32_t w = neg ? ~v[i] : v[i];
+    const uint32_t t = w + carry;
+    carry = (t < w) ? 1u : 0u;
+    mag[i] = t;
+  }
+  return neg;
+}
+
+// k (canonical, 8 words) -> |k1|, sign(k1), |k2|, sign(k2)
+__device__ __forceinline__ void decompose(const uint32_t (&k)[8], uint32_t (&m1)[4], bool& s1, uint32_t (&m2)[4], bool& s2) {
+  uint32_t t1[11], t2[13];
+  mul_low<8, 3, 11>(k, G1, t1);
+  mul_low<8, 5, 13>(k, G2, t2);
+  const uint32_t c1[2] = {t1[8], t1[9]};                           // < 2^64
+  const uint32_t c2[4] = {t2[8], t2[9], t2[10], t2[11]};           // < 2^127
+  uint32_t p[5], q[5], v[5];
+  mul_low<2, 2, 5>(c1, A1, p);                                     // c1 a1 (< 2^128: exact in 5 words)
+  mul_low<4, 4, 5>(c2, A2, q);                                     // c2 a2 mod 2^160
+  uint64_t borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 5; i++) {                                    // v = k - p - q mod 2^160
+    const uint64_t d = (uint64_t)k[i] - p[i] - q[i] - borrow;
+    v[i] = (uint32_t)d;
+    borrow = (d >> 32) ? ((~(d >> 32) + 1) & 3) : 0;               // 0, 1 or 2 borrowed
+  }
+  s1 = abs160(v, m1);
+  mul_low<2, 4, 5>(c1, NB1, p);                                    // c1 (-b1) mod 2^160
+  mul_low<4, 2, 5>(c2, A1, q);                                     // c2 b2 (b2 = a1)
+  borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 5; i++) {                                    // v = p - q mod 2^160
+    const uint64_t d = (uint64_t)p[i] - q[i] - borrow;
+    v[i] = (uint32_t)d;
+    borrow = (d >> 32) ? 1 : 0;
+  }
+  s2 = abs160(v, m2);
+}
+}  // namespace glv
+
+// digits of both halves: point i (k1, base P_i) in column i, point n + i (k2, base phi(P_i)) in column n + i of the [W][n2_pad] array
+__global__ void __launch_bounds__(256) k_digits_glv(const uint32_t* __restrict__ scalars, int16_t* __restrict__ digits, uint32_t n, uint32_t n2_pad, int c, int W) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n2_pad - 2 * n) {                         // padding columns: digit 0 = "no entry"
+    for (int win = 0; win < W; win++) digits[(size_t)win * n2_pad + 2 * n + i] = 0;
+  }
+  if (i >= n) return;
+  uint32_t w[8];
+  load_words(scalars + (size_t)i * 8, w);
+  fe c32;
+#pragma unroll
+  for (int k = 0; k < NL; k++) c32.l[k] = FrParams::FROM_EXT_CANON[k];
+  fe s = fe_canon_lt2p<FrParams>(fe_mul<FrParams>(c32, fe_unpack<0>(w)));      // Montgomery-256 -> the integer k < r
+  fe_pack(s, w);
+  uint32_t m[2][4];
+  bool neg[2];
+  glv::decompose(w, m[0], neg[0], m[1], neg[1]);
+  const uint32_t half = 1u << (c - 1), mask = (1u << c) - 1;
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    uint32_t carry = 0;
+    int16_t* col = digits + (size_t)h * n + i;
+    for (int win = 0; win < W; win++) {
+      const int bit = win * c;
+      uint32_t v = 0;
+      if (bit < 128) {
+        const int wi = bit >> 5, sh = bit & 31;
+        uint64_t two = m[h][wi];
+        if (wi + 1 < 4) two |= (uint64_t)m[h][wi + 1] << 32;
+        v = (uint32_t)(two >> sh) & mask;
+      }
+      v += carry;
+      // digits of +m lie in [-2^(c-1), 2^(c-1)); a negative half stores -d, so its recoding takes the mirrored range (-2^(c-1), 2^(c-1)]
+      // (at c = 16 the digit +2^15 does not exist in int16: -(-2^15) would wrap)
+      int32_t d;
+      if (neg[h] ? (v > half) : (v >= half)) { d = (int32_t)v - (int32_t)(1u << c); carry = 1; } else { d = (int32_t)v; carry = 0; }
+      col[(size_t)win * n2_pad] = (int16_t)(neg[h] ? -d : d);
+    }
+  }
+}
+
+// endo[i] = phi(bases[i]) = (beta x, y) in the G1Affine memory format; the identity (0, 0) stays the identity
+__global__ void __launch_bounds__(256) k_endo_bases(const uint32_t* __restrict__ bases, uint32_t n, uint32_t* __restrict__ endo) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  affine_words pt = load_affine(bases, i);
+  uint32_t bw[8], xw[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) bw[k] = glv::BETA_EXT[k];
+  const fe beta = fe_mul<Fq>(fe_one<Fq>(), fe_from_ext_lazy(bw));            // internal form
+  fe_to_ext<Fq>(fe_mul<Fq>(beta, fe_from_ext_lazy(pt.x)), xw);
+  uint4* o = reinterpret_cast<uint4*>(endo + (size_t)i * 16);
+  o[0] = make_uint4(xw[0], xw[1], xw[2], xw[3]);
+  o[1] = make_uint4(xw[4], xw[5], xw[6], xw[7]);
+  o[2] = make_uint4(pt.y[0], pt.y[1], pt.y[2], pt.y[3]);
+  o[3] = make_uint4(pt.y[4], pt.y[5], pt.y[6], pt.y[7]);
+}
+
+// ------------------------------------------------------------------------------------------------
 // 2. count / 4. scatter: grid (chunks, W), LDS histogram of B = 2^(c-1) u32 counters
 // ------------------------------------------------------------------------------------------------
 // Both passes are latency-bound if written naively (one 2-byte load per thread per iteration): digits are read 8 at a
@@ -851,7 +997,13 @@ template <bool TABLE>
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) k_accumulate(const task_t* __restrict__ tasks, const uint32_t* __restrict__ ntasks_p,
                                                     const uint4* __restrict__ order, const uint32_t* __restrict__ sorted,
                                                     const uint32_t* __restrict__ bases, uint32_t* __restrict__ partials,
-                                                    uint32_t* __restrict__ buckets) {
+                                                    uint32_t* __restrict__ buckets, const uint32_t* __restrict__ bases2, uint32_t split) {
+  // general path with GLV digits: point references >= split are the endomorphism images, a second array (bases2[ref - split]); the
+  // prepared path (TABLE) has one table and ignores both
+  auto point = [&](uint32_t idx) -> affine_words {
+    if constexpr (!TABLE) { if (idx >= split) return load_affine(bases2, idx - split); }
+    return load_affine(bases, idx);
+  };
   const uint32_t ntasks = *ntasks_p;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ntasks; i += gridDim.x * blockDim.x) {
     const uint4 rec = order[i];            // tasks run longest-first; partial t stays in bucket order
@@ -860,7 +1012,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))
     xyzz acc = xyzz_identity();
     const uint32_t* refs = sorted + tk.start;
     uint32_t ref = rec.w;
-    affine_words pt = load_affine(bases, ref & 0x7fffffffu);
+    affine_words pt = point(ref & 0x7fffffffu);
     uint32_t j = 0;
     if constexpr (TABLE) {             // the first point is a copy (peeled: merging it with the addition in one loop body costs 30 VGPRs)
       if (!affine_is_identity(pt)) {
@@ -871,7 +1023,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))
       }
       if (tk.len > 1) {
         ref = refs[1];
-        pt = load_affine(bases, ref & 0x7fffffffu);
+        pt = point(ref & 0x7fffffffu);
       }
       j = 1;
     }
@@ -880,7 +1032,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))
       uint32_t cref = ref;
       if (j + 1 < tk.len) {            // prefetch the next point under the current addition
         ref = refs[j + 1];
-        pt = load_affine(bases, ref & 0x7fffffffu);
+        pt = point(ref & 0x7fffffffu);
       }
       if (affine_is_identity(cur)) continue;
       fe x2, y2;
@@ -1169,14 +1321,31 @@ static bool msm_top_window_is_degenerate(int c) {
   return top_bits > 0 && top_bits < 6;
 }
 
+// general path: GLV halves the scalars (k_digits_glv): 2n points, 127-bit magnitudes, W = ceil(128 / c) windows.  ZKHIP_NO_GLV=1: the
+// plain 254-bit digits (A/B knob).
+static bool msm_glv_enabled() {
+  static const bool on = getenv("ZKHIP_NO_GLV") == nullptr;
+  return on;
+}
+// windows of c bits: ceil(256 / c) for 254-bit scalars (the signed recoding's last carry lands in the spare top bits); for the GLV halves
+// (magnitudes below 0.979 * 2^127) ceil(128 / c), plus one when the top window would otherwise overflow: with c W = 128 the top window
+// holds up to 0.49 * 2^c and a carry of 1 must still leave it below 2^(c-1) -- true for c = 8 (125 + 1 < 128) and c = 16, not for c = 2
+// and c = 4; every other window size has spare bits above bit 127
+static inline int msm_windows(int c, bool glv) {
+  if (!glv) return (256 + c - 1) / c;
+  return (128 + c - 1) / c + ((c == 2 || c == 4) ? 1 : 0);
+}
+
 int msm_pick_window(size_t n) {
-  // cost model in field multiplications: W * (10 n + 2 * 14 * 2^(c-1)), W = ceil(256 / c); c <= 16 (int16 digits, 128 KiB LDS)
+  // cost model in field multiplications: W * (10 n' + 2 * 14 * 2^(c-1)); c <= 16 (int16 digits, 128 KiB LDS).  Without GLV n' = n points
+  // and W = ceil(256 / c); with it n' = 2 n and W = ceil(128 / c).  Window sizes whose top window would hold 1..5 bits are skipped.
+  const bool glv = msm_glv_enabled();
   int best = 16;
   double best_cost = 1e300;
   for (int c = 2; c <= 16; c++) {
-    if (msm_top_window_is_degenerate(c)) continue;
-    double W = (256 + c - 1) / c;
-    double cost = W * (10.0 * (double)n + 28.0 * (double)(1u << (c - 1)));
+    const int Wi = msm_windows(c, glv), top_bits = (glv ? 127 : 254) - (Wi - 1) * c;
+    if (top_bits > 0 && top_bits < 6) continue;
+    const double cost = (double)Wi * (10.0 * (double)(glv ? 2 * n : n) + 28.0 * (double)(1u << (c - 1)));
     if (cost < best_cost) { best_cost = cost; best = c; }
   }
   return best;
@@ -1213,6 +1382,7 @@ struct msm_layout {
   uint32_t *gcounters, *counters, *count, *sorted, *offset, *cursor, *task_off, *bsum1, *bsum2;
   task_t* tasks; uint4* order;
   uint32_t *partials, *pyrA, *pyrB, *winsum;
+  uint32_t* endo;               // GLV (general path): phi(bases), n points
   int combine_lanes;            // lanes that sum one bucket's partials in the combine step
   uint32_t seq_parts;           // partials per bucket that step sums; buckets with more are "heavy"
   uint2* heavy; uint32_t heavy_cap;      // list of (heavy bucket, slice) entries (count: counters[3])
@@ -1242,9 +1412,11 @@ static uint32_t msm_task_shift(size_t entries /* W n K */, size_t NB) {
   return task_shift;
 }
 
-static msm_layout msm_lay_out(char* base, size_t n, size_t K, int c, bool prepared, size_t xyzz_bytes = 144) {
+// n_in: scalars per vector.  glv: the sort sees 2 n_in points (a point and its endomorphism image) and ceil(128 / c) windows.
+static msm_layout msm_lay_out(char* base, size_t n_in, size_t K, int c, bool prepared, size_t xyzz_bytes = 144, bool glv = false) {
   msm_layout L;
-  const size_t W = (256 + c - 1) / c, B = (size_t)1 << (c - 1), WB = prepared ? K : W, NB = WB * B;
+  const size_t n = glv ? 2 * n_in : n_in;
+  const size_t W = (size_t)msm_windows(c, glv), B = (size_t)1 << (c - 1), WB = prepared ? K : W, NB = WB * B;
   const bool wide = c > 16;
   const size_t nk = n * K, entries = W * nk;
   const size_t n_pad = (n + 7) & ~(size_t)7;
@@ -1281,13 +1453,17 @@ static msm_layout msm_lay_out(char* base, size_t n, size_t K, int c, bool prepar
   L.pyrA = (uint32_t*)carve(WB * B * xyzz_bytes);          // pyramid ping-pong: per bucket set N + (s-1) N/2 <= B elements at every step
   L.pyrB = (uint32_t*)carve(WB * B * xyzz_bytes);
   L.winsum = (uint32_t*)carve((W + K) * xyzz_bytes);       // window / bucket-set sums
+  L.endo = glv ? (uint32_t*)carve(n_in * 64) : nullptr;
   L.total = (size_t)(p - base);
   return L;
 }
 
+// GLV applies to the G1 general path: arbitrary bases, one scalar vector (the prepared path has its doublings in the table already)
+static inline bool msm_uses_glv(bool prepared, size_t batch, size_t xyzz_bytes) { return !prepared && batch == 1 && xyzz_bytes == 144 && msm_glv_enabled(); }
+
 size_t msm_workspace_bytes(size_t n_one, int c, bool prepared, size_t batch, size_t xyzz_bytes) {
   if (n_one == 0 || batch == 0) return 0;
-  return msm_lay_out(nullptr, n_one, batch, c, prepared, xyzz_bytes).total;
+  return msm_lay_out(nullptr, n_one, batch, c, prepared, xyzz_bytes, msm_uses_glv(prepared, batch, xyzz_bytes)).total;
 }
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s failed: %s", #x, hipGetErrorString(e_)); return ZKHIP_EHIP; } } while (0)
@@ -1295,17 +1471,19 @@ size_t msm_workspace_bytes(size_t n_one, int c, bool prepared, size_t batch, siz
 // Steps 1 - 5 (digits, bucket sort, tasks, execution order): everything that depends on the scalars only, shared by the curves.
 // `shared_buckets`: one bucket set per MSM of the batch for all windows (prepared G1 tables) instead of one per window.
 // ref_base / ref_stride: point reference of entry i of window w = ref_base + w * ref_stride + i.
-int msm_build_tasks(const uint32_t* d_scalars, size_t n, size_t batch, size_t scalar_stride, int c, bool shared_buckets, uint32_t ref_base, uint32_t ref_stride,
-                    size_t xyzz_bytes, void* ws, size_t ws_bytes, hipStream_t stream, msm_tasks_view* out) {
+int msm_build_tasks(const uint32_t* d_scalars, size_t n_in, size_t batch, size_t scalar_stride, int c, bool shared_buckets, uint32_t ref_base, uint32_t ref_stride,
+                    size_t xyzz_bytes, void* ws, size_t ws_bytes, hipStream_t stream, msm_tasks_view* out, bool glv) {
   const uint32_t K = (uint32_t)batch;
   const bool wide = c > 16;                         // two-level bucket sort, int32 digits
-  const int W = (256 + c - 1) / c;
+  const int W = msm_windows(c, glv);
+  if (glv && (K != 1 || wide || shared_buckets)) { set_error("msm: GLV digits are for one vector of the general path"); return ZKHIP_EINVAL; }
+  const size_t n = glv ? 2 * n_in : n_in;           // points the sort sees
   const uint32_t B = 1u << (c - 1);
   const int WB = shared_buckets ? (int)K : W;      // number of bucket sets
   const uint32_t NB = (uint32_t)WB * B;
   if ((size_t)W * n * K >= (1ull << 32) || (size_t)WB * B >= (1ull << 31)) { set_error("msm: W*n*batch overflows 32-bit slot index"); return ZKHIP_EINVAL; }
   if (wide && (!shared_buckets || K != 1)) { set_error("msm: windows above 16 bits need one shared bucket set"); return ZKHIP_EINVAL; }
-  const msm_layout lay = msm_lay_out((char*)ws, n, K, c, shared_buckets, xyzz_bytes);
+  const msm_layout lay = msm_lay_out((char*)ws, n_in, K, c, shared_buckets, xyzz_bytes, glv);
   if (ws_bytes < lay.total) { set_error("msm: workspace too small (%zu < %zu bytes)", ws_bytes, lay.total); return ZKHIP_EINVAL; }
   const uint32_t task_shift = lay.task_shift;
   const uint32_t n_pad = (uint32_t)((n + 7) & ~(size_t)7);
@@ -1324,7 +1502,8 @@ int msm_build_tasks(const uint32_t* d_scalars, size_t n, size_t batch, size_t sc
   const size_t nk = n * K, max_tasks = lay.max_tasks;
   (void)nk; (void)max_tasks;
   const unsigned dblocks = (unsigned)(((size_t)K * n_pad + 255) / 256);
-  if (wide) hipLaunchKernelGGL(k_digits<int32_t>, dim3(dblocks), dim3(256), 0, stream, d_scalars, (int32_t*)digits, (uint32_t)n, n_pad, c, W, K, sstride);
+  if (glv) hipLaunchKernelGGL(k_digits_glv, dim3((unsigned)((std::max<size_t>(n_in, 8) + 255) / 256)), dim3(256), 0, stream, d_scalars, (int16_t*)digits, (uint32_t)n_in, n_pad, c, W);
+  else if (wide) hipLaunchKernelGGL(k_digits<int32_t>, dim3(dblocks), dim3(256), 0, stream, d_scalars, (int32_t*)digits, (uint32_t)n, n_pad, c, W, K, sstride);
   else hipLaunchKernelGGL(k_digits<int16_t>, dim3(dblocks), dim3(256), 0, stream, d_scalars, (int16_t*)digits, (uint32_t)n, n_pad, c, W, K, sstride);
   prof_mark(stream, "digits");
   // 2. count
@@ -1398,6 +1577,7 @@ int msm_build_tasks(const uint32_t* d_scalars, size_t n, size_t batch, size_t sc
   out->tasks = tasks; out->ntasks = counters + 1; out->max_parts = counters + 2; out->order = order; out->sorted = sorted; out->task_off = task_off;
   out->partials = lay.partials; out->pyrA = lay.pyrA; out->pyrB = lay.pyrB; out->winsum = lay.winsum;
   out->combine_lanes = lay.combine_lanes; out->seq_parts = lay.seq_parts; out->heavy_count = counters + 3; out->heavy = lay.heavy; out->heavy_cap = lay.heavy_cap; out->heavy_done = lay.heavy_done;
+  out->endo = lay.endo;
   HIPCHK(hipGetLastError());
   return ZKHIP_OK;
 }
@@ -1426,9 +1606,11 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
     d_bases = prepared->table;
   }
   msm_tasks_view tv;
+  const bool glv = msm_uses_glv(prepared != nullptr, batch, 144);
   int rc = msm_build_tasks(d_scalars, n, batch, scalar_stride, c, prepared != nullptr, prepared ? (uint32_t)prepared_off : 0u, prepared ? (uint32_t)prepared->n : 0u,
-                           144, ws, ws_bytes, stream, &tv);
+                           144, ws, ws_bytes, stream, &tv, glv);
   if (rc != ZKHIP_OK) return rc;
+  if (glv) hipLaunchKernelGGL(k_endo_bases, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_bases, (uint32_t)n, tv.endo);
   const int WB = tv.WB;
   const uint32_t B = tv.B, NB = tv.NB;
   const size_t max_tasks = tv.max_tasks;
@@ -1441,8 +1623,9 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
   {
     uint32_t blocks = (uint32_t)((max_tasks + 127) / 128);
     if (blocks > 256 * 64) blocks = 256 * 64;
-    if (prepared) hipLaunchKernelGGL(k_accumulate<true>, dim3(blocks), dim3(128), 0, stream, tasks, counters + 1, order, sorted, d_bases, partials, pyrA);
-    else hipLaunchKernelGGL(k_accumulate<false>, dim3(blocks), dim3(128), 0, stream, tasks, counters + 1, order, sorted, d_bases, partials, pyrA);
+    if (prepared) hipLaunchKernelGGL(k_accumulate<true>, dim3(blocks), dim3(128), 0, stream, tasks, counters + 1, order, sorted, d_bases, partials, pyrA, (const uint32_t*)nullptr, 0xffffffffu);
+    else hipLaunchKernelGGL(k_accumulate<false>, dim3(blocks), dim3(128), 0, stream, tasks, counters + 1, order, sorted, d_bases, partials, pyrA, (const uint32_t*)tv.endo,
+                            glv ? (uint32_t)n : 0xffffffffu);
   }
   prof_mark(stream, "accumulate");
   // 7. combine: one launch (per-bucket sums + the heavy-bucket workgroups)
