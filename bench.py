@@ -301,12 +301,12 @@ def main() -> None:
         try:   # PMC-measured HBM bytes of this kernel at this size: NOT measured by this run -- collected in separate rocprofv3 --pmc passes of
                # this same command (tools/collect_profiles.sh) and committed; the file names the commit it was collected at
             if args.log_n == 20:
-                for cand in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+                for cand in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
                     path = os.path.join(ROOT, "profiles", cand)
                     if os.path.exists(path):
                         rec = json.load(open(path))
                         traffic = rec["k_accumulate"]["hbm_bytes_per_launch"]
-                        traffic_source = f"profiles/{cand}@{rec.get('commit', 'round-1 head')} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch; a committed constant, not a live counter)"
+                        traffic_source = f"profiles/{cand}@{rec.get('commit', 'round-1 head')} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch -- the x2 is the guide's gfx950 correction for coalesced streams, an assumption for 64-byte gathers: the file also holds the raw counter; a committed constant, not a live counter)"
                         break
         except Exception:
             traffic, traffic_source = None, None

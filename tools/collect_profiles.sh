@@ -4,7 +4,7 @@
 # rocprofv3 passes: kernel stats of the bench command, kernel stats of the full bench, FETCH_SIZE / WRITE_SIZE (separate passes),
 # SQ issue/wait counters of the MSM + NTT workload (separate passes, --kernel-trace only).
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
@@ -20,10 +20,14 @@ echo "pmc hbm done"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $O/${TAG}_pmc_sq_a -- python3 $R/tools/prof_msm.py 20 3 24 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVES -d $O/${TAG}_pmc_sq_b -- python3 $R/tools/prof_msm.py 20 3 24 > /dev/null 2>&1
 echo "pmc sq done"
+# roctx ranges of the C ABI (one per call): marker trace + kernel trace of a short MSM / NTT workload
+rocprofv3 --marker-trace --kernel-trace --stats -d $O/${TAG}_marker -- python3 $R/tools/prof_msm.py 20 2 22 > $O/${TAG}_marker.log 2>&1 || true
+(find $O/${TAG}_marker -name "*marker*" | head -5; f=$(find $O/${TAG}_marker -name "*marker_api_trace.csv" | head -1); [ -n "$f" ] && (head -1 "$f"; grep -c zkhip "$f"; cut -d, -f1-4 "$f" | grep zkhip | sort | uniq -c | sort -rn | head -20); f2=$(find $O/${TAG}_marker -name "*marker*stats.csv" | head -1); [ -n "$f2" ] && head -20 "$f2") > $O/${TAG}_marker_trace.txt 2>&1 || true
+echo "marker done"
 cd $R
 python3 tools/summarize_prof.py stats $O/${TAG}_prof_msm $O/${TAG}_kernel_stats_bench_msm2p20.csv
 python3 tools/summarize_prof.py stats $O/${TAG}_prof_full $O/${TAG}_kernel_stats_bench_full.csv
 python3 tools/summarize_prof.py pmc $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write $O/${TAG}_pmc_hbm_bytes_bench.txt $O/${TAG}_pmc_traffic.json
 python3 tools/summarize_prof.py sq $O/${TAG}_pmc_sq_a $O/${TAG}_pmc_sq_b $O/${TAG}_pmc_sq_issue.txt
-rm -rf $O/${TAG}_prof_msm $O/${TAG}_prof_full $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write $O/${TAG}_pmc_sq_a $O/${TAG}_pmc_sq_b
+rm -rf $O/${TAG}_prof_msm $O/${TAG}_prof_full $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write $O/${TAG}_pmc_sq_a $O/${TAG}_pmc_sq_b $O/${TAG}_marker
 echo "summaries written"
