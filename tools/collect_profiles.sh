@@ -22,7 +22,7 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVES
 echo "pmc sq done"
 # roctx ranges of the C ABI (one per call): marker trace + kernel trace of a short MSM / NTT workload
 rocprofv3 --marker-trace --kernel-trace --stats -d $O/${TAG}_marker -- python3 $R/tools/prof_msm.py 20 2 22 > $O/${TAG}_marker.log 2>&1 || true
-(find $O/${TAG}_marker -name "*marker*" | head -5; f=$(find $O/${TAG}_marker -name "*marker_api_trace.csv" | head -1); [ -n "$f" ] && (head -1 "$f"; grep -c zkhip "$f"; cut -d, -f1-4 "$f" | grep zkhip | sort | uniq -c | sort -rn | head -20); f2=$(find $O/${TAG}_marker -name "*marker*stats.csv" | head -1); [ -n "$f2" ] && head -20 "$f2") > $O/${TAG}_marker_trace.txt 2>&1 || true
+python3 $R/tools/marker_summary.py $O/${TAG}_marker $O/${TAG}_marker_trace.txt || true
 echo "marker done"
 cd $R
 python3 tools/summarize_prof.py stats $O/${TAG}_prof_msm $O/${TAG}_kernel_stats_bench_msm2p20.csv
