@@ -1366,6 +1366,10 @@ int msm_pick_window_prepared(size_t n) {
     if (c > 16 && n < ((size_t)1 << 20)) continue;   // measured (median of 60, c = 16 / c = 20): 2^20 1.83 / 1.67 ms, 2^21 3.32 / 2.95 on one box; the crossover was at 2^22 before the wide sort wrote bucket runs
     if (cost < best_cost) { best_cost = cost; best = c; }
   }
+  // small MSMs are latency-bound (their cost is the depth of the reduction tail and the task chains, which the multiplication count above
+  // does not see): measured end to end under every window size (tools/small_window_probe.py), the model's choice is the fastest or within
+  // 1 % of it except at 2^14 .. 2^15 points, where 15 bits beat its 13 / 16 (2^14: 0.257 vs 0.270 ms, 2^15: 0.310 vs 0.336 ms)
+  if (n >= ((size_t)1 << 14) && n < ((size_t)3 << 14)) best = 15;
   if (const char* e = getenv("ZKHIP_MAX_WINDOW")) { int m = atoi(e); if (m >= 2 && best > m) best = m; }   // A/B knob
   return best;
 }
