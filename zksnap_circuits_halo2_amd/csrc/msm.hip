@@ -33,6 +33,8 @@ namespace zkhip {
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+constexpr int FINE_BITS = 12;           // wide windows: a bucket id = (coarse group, 12-bit fine id); MAX_GROUPS = 2^(20 - 1 - 12) groups at c = 20
+constexpr int MAX_GROUPS = 128;
 constexpr int MAX_TASK_LEN = 128;       // tasks are 2^task_shift entries, task_shift <= 7 (length histograms hold MAX_TASK_LEN + 1 counters)
 constexpr int TASK_SHIFT = 6;           // 64 entries per accumulate task: short tasks keep the tail of the launch balanced
                                         // (measured at 2^22: 5.9 ms with 64-entry tasks, 6.9 ms with 256, 8.1 ms with 512)
@@ -130,6 +132,50 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ sca
     if (v >= half) { d = (int32_t)v - (int32_t)(1u << c); carry = 1; } else { d = (int32_t)v; carry = 0; }
     digits[(size_t)win * row + i] = (DIGIT)d;
   }
+}
+
+// Wide windows (one vector, int32 digits): the same digits, and the coarse groups' entry counts on the way -- the two-level sort needs the
+// group sizes before it can place anything, and counting them used to be a pass of its own over the 52 bytes of digits per scalar
+// (k_coarse_pass<false>).  A workgroup of 1024 threads walks its scalars with a grid stride, counts in LDS and merges its 2^(c-13) counters
+// with one global atomic each at the end: at most 256 workgroups, so at most 32 K atomics on the 128 words (the naive form -- one
+// 256-thread workgroup per 256 scalars, 0.5 M atomics -- was measured in round 1: +39 us in this kernel for the -33 us it saved).
+__global__ void __launch_bounds__(1024) k_digits_wide(const uint32_t* __restrict__ scalars, int32_t* __restrict__ digits, uint32_t n, uint32_t n_pad,
+                                                       int c, int W, uint32_t* __restrict__ gcount) {
+  __shared__ uint32_t cnt[MAX_GROUPS];
+  if (threadIdx.x < MAX_GROUPS) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t half = 1u << (c - 1), mask = (1u << c) - 1;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += gridDim.x * blockDim.x) {
+    if (i >= n) {                                   // padding entries: digit 0 = "no entry"
+      for (int win = 0; win < W; win++) digits[(size_t)win * n_pad + i] = 0;
+      continue;
+    }
+    uint32_t w[8];
+    load_words(scalars + (size_t)i * 8, w);
+    fe c32;
+#pragma unroll
+    for (int k = 0; k < NL; k++) c32.l[k] = FrParams::FROM_EXT_CANON[k];
+    fe sv = fe_canon_lt2p<FrParams>(fe_mul<FrParams>(c32, fe_unpack<0>(w)));
+    fe_pack(sv, w);
+    uint32_t carry = 0;
+    for (int win = 0; win < W; win++) {
+      const int bit = win * c;
+      uint32_t v = 0;
+      if (bit < 256) {
+        const int wi = bit >> 5, sh = bit & 31;
+        uint64_t two = w[wi];
+        if (wi + 1 < 8) two |= (uint64_t)w[wi + 1] << 32;
+        v = (uint32_t)(two >> sh) & mask;
+      }
+      v += carry;
+      int32_t d;
+      if (v >= half) { d = (int32_t)v - (int32_t)(1u << c); carry = 1; } else { d = (int32_t)v; carry = 0; }
+      digits[(size_t)win * n_pad + i] = d;
+      if (d != 0) atomicAdd(&cnt[((uint32_t)(d < 0 ? -d : d) - 1) >> FINE_BITS], 1u);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < MAX_GROUPS && cnt[threadIdx.x]) atomicAdd(&gcount[threadIdx.x], cnt[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -353,8 +399,6 @@ __global__ void __launch_bounds__(1024) k_sort_pass(const int16_t* __restrict__ 
 //       fine    per group, the 2^12 "fine" buckets: LDS histogram, atomics into the global counts (k_fine_count), scan, then
 //               k_fine_sorted: reservation and a counting sort of the chunk inside LDS, so that bucket runs leave as runs.
 // ------------------------------------------------------------------------------------------------
-constexpr int FINE_BITS = 12;
-constexpr int MAX_GROUPS = 128;
 
 // (Recomputing the digits from the scalars in both passes instead of storing them as int32 was tried and measured slower:
 // 0.139 vs 0.117 ms at 2^20, 1.75 vs 1.3 ms at 2^24.)
@@ -1507,7 +1551,15 @@ int msm_build_tasks(const uint32_t* d_scalars, size_t n_in, size_t batch, size_t
   (void)nk; (void)max_tasks;
   const unsigned dblocks = (unsigned)(((size_t)K * n_pad + 255) / 256);
   if (glv) hipLaunchKernelGGL(k_digits_glv, dim3((unsigned)((std::max<size_t>(n_in, 8) + 255) / 256)), dim3(256), 0, stream, d_scalars, (int16_t*)digits, (uint32_t)n_in, n_pad, c, W);
-  else if (wide) hipLaunchKernelGGL(k_digits<int32_t>, dim3(dblocks), dim3(256), 0, stream, d_scalars, (int32_t*)digits, (uint32_t)n, n_pad, c, W, K, sstride);
+  else if (wide) {
+    static const bool fused_count = getenv("ZKHIP_NO_FUSED_COUNT") == nullptr;      // A/B knob
+    if (fused_count) {
+      const unsigned wblocks = (unsigned)std::min<size_t>(((size_t)n_pad + 1023) / 1024, 256);
+      hipLaunchKernelGGL(k_digits_wide, dim3(wblocks), dim3(1024), 0, stream, d_scalars, (int32_t*)digits, (uint32_t)n, n_pad, c, W, gcounters);
+    } else {
+      hipLaunchKernelGGL(k_digits<int32_t>, dim3(dblocks), dim3(256), 0, stream, d_scalars, (int32_t*)digits, (uint32_t)n, n_pad, c, W, K, sstride);
+    }
+  }
   else hipLaunchKernelGGL(k_digits<int16_t>, dim3(dblocks), dim3(256), 0, stream, d_scalars, (int16_t*)digits, (uint32_t)n, n_pad, c, W, K, sstride);
   prof_mark(stream, "digits");
   // 2. count
@@ -1533,8 +1585,10 @@ int msm_build_tasks(const uint32_t* d_scalars, size_t n_in, size_t batch, size_t
   const uint32_t sort_chunks = (uint32_t)(((size_t)W * n + sort_chunk - 1) / sort_chunk) + (uint32_t)G;     // upper bound of the fine passes' chunks; surplus workgroups return at once
   const uint32_t wb_stride = shared_buckets ? 0u : B;
   if (wide) {
-    hipLaunchKernelGGL(k_coarse_pass<false>, dim3(chunks, W), dim3(1024), 0, stream, (const int32_t*)digits, n_pad, chunk, gcounters, (uint32_t*)nullptr,
-                       (uint16_t*)nullptr, ref_base, ref_stride);
+    static const bool fused_count2 = getenv("ZKHIP_NO_FUSED_COUNT") == nullptr;
+    if (!fused_count2)        // (otherwise k_digits_wide has counted the groups)
+      hipLaunchKernelGGL(k_coarse_pass<false>, dim3(chunks, W), dim3(1024), 0, stream, (const int32_t*)digits, n_pad, chunk, gcounters, (uint32_t*)nullptr,
+                         (uint16_t*)nullptr, ref_base, ref_stride);
     hipLaunchKernelGGL(k_group_offsets, dim3(1), dim3(64), 0, stream, gcounters, G, gcounters + 128, gcounters + 384, gcounters + 512, sort_chunk);
     static_assert(MAX_GROUPS == 128, "k_coarse_sorted scans two groups per lane of one wavefront");
     hipLaunchKernelGGL(k_coarse_sorted, dim3((n_pad + COARSE_CHUNK - 1) / COARSE_CHUNK, W), dim3(1024), 0, stream, (const int32_t*)digits, n_pad, gcounters + 384,
