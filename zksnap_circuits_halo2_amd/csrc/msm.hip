@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ sca
 
 // Wide windows (one vector, int32 digits): the same digits, and the coarse groups' entry counts on the way -- the two-level sort needs the
 // group sizes before it can place anything, and counting them used to be a pass of its own over the 52 bytes of digits per scalar
-// (k_coarse_pass<false>).  A workgroup of 1024 threads walks its scalars with a grid stride, counts in LDS and merges its 2^(c-13) counters
+// (k_coarse_count).  A workgroup of 1024 threads walks its scalars with a grid stride, counts in LDS and merges its 2^(c-13) counters
 // with one global atomic each at the end: at most 256 workgroups, so at most 32 K atomics on the 128 words (the naive form -- one
 // 256-thread workgroup per 256 scalars, 0.5 M atomics -- was measured in round 1: +39 us in this kernel for the -33 us it saved).
 __global__ void __launch_bounds__(1024) k_digits_wide(const uint32_t* __restrict__ scalars, int32_t* __restrict__ digits, uint32_t n, uint32_t n_pad,
@@ -402,10 +402,9 @@ __global__ void __launch_bounds__(1024) k_sort_pass(const int16_t* __restrict__ 
 
 // (Recomputing the digits from the scalars in both passes instead of storing them as int32 was tried and measured slower:
 // 0.139 vs 0.117 ms at 2^20, 1.75 vs 1.3 ms at 2^24.)
-template <bool SCATTER>
-__global__ void __launch_bounds__(1024) k_coarse_pass(const int32_t* __restrict__ digits, uint32_t n_pad, uint32_t chunk,
-                                                      uint32_t* __restrict__ gcount_or_cursor, uint32_t* __restrict__ stage_ref,
-                                                      uint16_t* __restrict__ stage_fine, uint32_t ref_base, uint32_t ref_stride) {
+// The group counts as a pass of their own over the stored digits: what the pipeline ran until round 3, when the counts moved into the digit
+// kernel (k_digits_wide); kept as the A/B reference (ZKHIP_NO_FUSED_COUNT=1).
+__global__ void __launch_bounds__(1024) k_coarse_count(const int32_t* __restrict__ digits, uint32_t n_pad, uint32_t chunk, uint32_t* __restrict__ gcount) {
   __shared__ uint32_t cnt[MAX_GROUPS];
   const int win = blockIdx.y;
   const uint32_t lo = blockIdx.x * chunk, hi = min(n_pad, lo + chunk);   // multiples of 8
@@ -428,30 +427,7 @@ __global__ void __launch_bounds__(1024) k_coarse_pass(const int32_t* __restrict_
     }
   }
   __syncthreads();
-  if (!SCATTER) {
-    if (threadIdx.x < MAX_GROUPS && cnt[threadIdx.x]) atomicAdd(&gcount_or_cursor[threadIdx.x], cnt[threadIdx.x]);
-    return;
-  }
-  if (threadIdx.x < MAX_GROUPS) {
-    const uint32_t v = cnt[threadIdx.x];
-    cnt[threadIdx.x] = v ? atomicAdd(&gcount_or_cursor[threadIdx.x], v) : 0u;
-  }
-  __syncthreads();
-  const uint32_t rbase = ref_base + (uint32_t)win * ref_stride;
-  for (uint32_t vi = v_lo + threadIdx.x; vi < v_hi; vi += blockDim.x) {
-    const uint4 q = dv[vi];
-    const int32_t d4[4] = {(int32_t)q.x, (int32_t)q.y, (int32_t)q.z, (int32_t)q.w};
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int32_t d = d4[k];
-      if (d != 0) {
-        const uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1;
-        const uint32_t pos = atomicAdd(&cnt[b >> FINE_BITS], 1u);
-        stage_ref[pos] = (rbase + vi * 4 + k) | (d < 0 ? 0x80000000u : 0u);
-        stage_fine[pos] = (uint16_t)(b & ((1u << FINE_BITS) - 1));
-      }
-    }
-  }
+  if (threadIdx.x < MAX_GROUPS && cnt[threadIdx.x]) atomicAdd(&gcount[threadIdx.x], cnt[threadIdx.x]);
 }
 
 // Coarse placement with the chunk sorted by group in LDS first (same reasoning as k_fine_sorted below): a workgroup takes
@@ -1587,8 +1563,7 @@ int msm_build_tasks(const uint32_t* d_scalars, size_t n_in, size_t batch, size_t
   if (wide) {
     static const bool fused_count2 = getenv("ZKHIP_NO_FUSED_COUNT") == nullptr;
     if (!fused_count2)        // (otherwise k_digits_wide has counted the groups)
-      hipLaunchKernelGGL(k_coarse_pass<false>, dim3(chunks, W), dim3(1024), 0, stream, (const int32_t*)digits, n_pad, chunk, gcounters, (uint32_t*)nullptr,
-                         (uint16_t*)nullptr, ref_base, ref_stride);
+      hipLaunchKernelGGL(k_coarse_count, dim3(chunks, W), dim3(1024), 0, stream, (const int32_t*)digits, n_pad, chunk, gcounters);
     hipLaunchKernelGGL(k_group_offsets, dim3(1), dim3(64), 0, stream, gcounters, G, gcounters + 128, gcounters + 384, gcounters + 512, sort_chunk);
     static_assert(MAX_GROUPS == 128, "k_coarse_sorted scans two groups per lane of one wavefront");
     hipLaunchKernelGGL(k_coarse_sorted, dim3((n_pad + COARSE_CHUNK - 1) / COARSE_CHUNK, W), dim3(1024), 0, stream, (const int32_t*)digits, n_pad, gcounters + 384,
