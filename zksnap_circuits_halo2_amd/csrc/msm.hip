@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ sca
 // Wide windows (one vector, int32 digits): the same digits, and the coarse groups' entry counts on the way -- the two-level sort needs the
 // group sizes before it can place anything, and counting them used to be a pass of its own over the 52 bytes of digits per scalar
 // (k_coarse_count).  A workgroup of 1024 threads walks its scalars with a grid stride, counts in LDS and merges its 2^(c-13) counters
-// with one global atomic each at the end: at most 256 workgroups, so at most 32 K atomics on the 128 words (the naive form -- one
+// with one global atomic each at the end: 512 - 1024 workgroups, so at most 128 K atomics on the 128 words (the naive form -- one
 // 256-thread workgroup per 256 scalars, 0.5 M atomics -- was measured in round 1: +39 us in this kernel for the -33 us it saved).
 __global__ void __launch_bounds__(1024) k_digits_wide(const uint32_t* __restrict__ scalars, int32_t* __restrict__ digits, uint32_t n, uint32_t n_pad,
                                                        int c, int W, uint32_t* __restrict__ gcount) {
@@ -1530,7 +1530,11 @@ int msm_build_tasks(const uint32_t* d_scalars, size_t n_in, size_t batch, size_t
   else if (wide) {
     static const bool fused_count = getenv("ZKHIP_NO_FUSED_COUNT") == nullptr;      // A/B knob
     if (fused_count) {
-      const unsigned wblocks = (unsigned)std::min<size_t>(((size_t)n_pad + 1023) / 1024, 256);
+      // workgroups: 512 up to 2^21 scalars, 1024 above (measured 256 / 512 / 1024 at 2^20: digits 0.041 / 0.036 / 0.040 ms; 256 / 1024 / 4096 at
+      // 2^22: 0.129 / 0.110 / 0.112 -- fewer workgroups leave a lane several scalars with exposed loads, more multiply the contended atomics)
+      static const unsigned wg_knob = [] { const char* e = getenv("ZKHIP_DIGIT_WGS"); const int v = e ? atoi(e) : 0; return v >= 64 && v <= 4096 ? (unsigned)v : 0u; }();   // A/B knob
+      const unsigned wg_cap = wg_knob ? wg_knob : (n_pad > (1u << 21) ? 1024u : 512u);
+      const unsigned wblocks = (unsigned)std::min<size_t>(((size_t)n_pad + 1023) / 1024, wg_cap);
       hipLaunchKernelGGL(k_digits_wide, dim3(wblocks), dim3(1024), 0, stream, d_scalars, (int32_t*)digits, (uint32_t)n, n_pad, c, W, gcounters);
     } else {
       hipLaunchKernelGGL(k_digits<int32_t>, dim3(dblocks), dim3(256), 0, stream, d_scalars, (int32_t*)digits, (uint32_t)n, n_pad, c, W, K, sstride);
