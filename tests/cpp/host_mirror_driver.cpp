@@ -80,8 +80,13 @@ int main(int argc, char** argv) {
       fwrite(&c1, sizeof(G1), 1, out);
       fwrite(&c2, sizeof(G1), 1, out);
       // ParamsKZG::write -> read: the same bytes come back, and the re-read parameters commit to the same point
-      ParamsKZG::G2Bytes g2{}, s_g2{};
-      for (int i = 0; i < 16; i++) { g2[i] = 0x1111111111111111ULL * (uint64_t)(i + 1); s_g2[i] = ~g2[i]; }
+      // real G2 points (the EIP-197 generator and its double, Montgomery limbs): the RawBytes reader checks g2 / s_g2 against the twist
+      const ParamsKZG::G2Bytes g2 = {0x8e83b5d102bc2026ULL, 0xdceb1935497b0172ULL, 0xfbb8264797811adfULL, 0x19573841af96503bULL, 0xafb4737da84c6140ULL, 0x6043dd5a5802d8c4ULL,
+                                     0x09e950fc52a02f86ULL, 0x14fef0833aea7b6bULL, 0x619dfa9d886be9f6ULL, 0xfe7fd297f59e9b78ULL, 0xff9e1a62231b7dfeULL, 0x28fd7eebae9e4206ULL,
+                                     0x64095b56c71856eeULL, 0xdc57f922327d3cbbULL, 0x55f935be33351076ULL, 0x0da4a0e693fd6482ULL};
+      const ParamsKZG::G2Bytes s_g2 = {0x42d3ae372af7a579ULL, 0xd2f609cbc0a293b5ULL, 0x57c1c76166f89cedULL, 0x2ee858391ef2cc42ULL, 0xa856e093920a72b8ULL, 0x63806a546d033f3eULL,
+                                       0x1e7eeefa55543decULL, 0x056ca0f5743c0a90ULL, 0xbcd0a4b05c092587ULL, 0x5977f684ad4ff6baULL, 0x4fde1ced78e96a59ULL, 0x02750f99cf18d82eULL,
+                                       0x332573d63fab5b02ULL, 0xa83429e5be54f062ULL, 0xaee376c3d20111f4ULL, 0x0e103b8b9272ef7dULL};
       ps.set_g2(g2, s_g2);
       std::stringstream file;
       ps.write(file);
@@ -96,7 +101,12 @@ int main(int argc, char** argv) {
       bool threw_trunc = false;
       std::stringstream cut(bytes.substr(0, bytes.size() - 1));
       try { ParamsKZG::read(cut); } catch (const std::runtime_error&) { threw_trunc = true; }
-      const uint64_t trunc = threw_trunc ? 1 : 0;
+      std::string forged = bytes;
+      forged[bytes.size() - 256 + 64] ^= 1;                       // one bit of g2's y.c0: no longer on the twist
+      bool threw_g2 = false, unchecked_ok = false;
+      { std::stringstream f(forged); try { ParamsKZG::read(f); } catch (const std::runtime_error&) { threw_g2 = true; } }
+      { std::stringstream f(forged); try { ParamsKZG::read(f, false); unchecked_ok = true; } catch (const std::runtime_error&) {} }
+      const uint64_t trunc = (threw_trunc && threw_g2 && unchecked_ok) ? 1 : 0;
       fwrite(&trunc, 8, 1, out);
       // g_to_lagrange(g) reproduces the Lagrange basis that setup built from the trapdoor
       const std::vector<G1Affine> gl = g_to_lagrange(ps.get_g(), k);

@@ -123,8 +123,9 @@ struct dev_buf {       // grow-only device scratch (hipFree waits for the device
 
 struct scratch {       // one user at a time: the calls of one stream
   dev_buf ws, scalars, bases, poly, poly2, small, ntt_tmp, vm, gather;
+  vm_staging vm_stage;                 // pinned host staging of the row programs' blobs (rowvm.hip)
   uint64_t last_use = 0;
-  void release() { ws.release(); scalars.release(); bases.release(); poly.release(); poly2.release(); small.release(); ntt_tmp.release(); vm.release(); gather.release(); }
+  void release() { ws.release(); scalars.release(); bases.release(); poly.release(); poly2.release(); small.release(); ntt_tmp.release(); vm.release(); gather.release(); vm_stage.release(); }
 };
 
 struct lane {          // host-buffer calls: a library-owned stream + (through the stream) a scratch set + a pinned result buffer
@@ -1495,7 +1496,7 @@ int zkhip_fr_eval_rows_device(const zkhip_vm_program* prog, const void* const* d
   hipStream_t s = caller_stream(stream);
   scratch* sc = scratch_for(primary(), s);
   if ((rc = sc->vm.reserve(row_vm_workspace_bytes(prog, n_columns, log_rows))) != ZKHIP_OK) return rc;
-  return row_vm_device(prog, d_columns, n_columns, log_rows, accumulate, (uint32_t*)d_out, sc->vm.p, sc->vm.cap, s);
+  return row_vm_device(prog, d_columns, n_columns, log_rows, accumulate, (uint32_t*)d_out, sc->vm.p, sc->vm.cap, s, &sc->vm_stage);
 }
 
 int zkhip_fr_eval_rows(const zkhip_vm_program* prog, const uint64_t* const* columns, uint32_t n_columns, uint32_t log_rows,

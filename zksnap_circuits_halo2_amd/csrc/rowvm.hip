@@ -28,7 +28,7 @@ constexpr int VM_MAX_REGS = ZKHIP_VM_REGS;   // kernel variants exist for 6 / 8 
 constexpr uint32_t POW_LO_BITS = 12;   // omega^row = hi[row >> 12] * lo[row & 4095]
 
 struct vm_launch {
-  const uint4* prog;            // n_insns x 16 bytes
+  const void* prog;             // n_insns x vm_uop (64 bytes: the instruction with its operands' addresses resolved by the host)
   uint32_t n_insns;
   uint32_t result_reg;
   const uint32_t* const* cols;  // n_columns device pointers
@@ -115,63 +115,181 @@ __device__ __forceinline__ void vm_reg_set(fe (&r)[R], uint32_t i, const fe& v) 
   }
 }
 
-// operand fetch; TIMES32: the value scaled by 2^5 (second factor of a product)
-template <bool TIMES32, int R>
-__device__ __forceinline__ fe vm_fetch(const vm_launch& L, uint32_t opnd, uint64_t row, const fe (&r)[R], const fe& prev, const fe& xpow) {
+// Memory operands (a column at a rotation, a constant) are loaded ONE INSTRUCTION AHEAD: the loop decodes instruction pc + 1 before it
+// executes instruction pc and issues the loads of its first two operands into a second word buffer, so a load's latency runs under the
+// previous instruction's arithmetic (a field multiplication is ~250 wave-instructions).  Before: every instruction loaded its operands and
+// waited -- SQ counters on the wrapper quotient: 48.9 % of the wave cycles parked at s_waitcnt (profiles/r03_rowvm_prefetch_ab.txt).
+__device__ __forceinline__ bool vm_is_mem(uint32_t opnd) { const uint32_t kind = opnd & 0xff; return kind == ZKHIP_SRC_COLUMN || kind == ZKHIP_SRC_CONST; }
+__device__ __forceinline__ bool vm_uses_b(uint32_t op) { return op == ZKHIP_OP_MUL || op == ZKHIP_OP_MAD || op == ZKHIP_OP_ADD || op == ZKHIP_OP_SUB; }
+
+// The program, the rotation offsets, the column pointers and the constants are the same for every lane and are not written by the kernel:
+// they are read through the CONSTANT address space, i.e. with scalar loads (s_load_*) into SGPRs.  Read as ordinary global memory the
+// compiler must assume that the kernel's own stores alias them, and every instruction fetch / pointer fetch became a VECTOR load followed by
+// s_waitcnt vmcnt(0) -- which also drains every operand load in flight, so nothing could be prefetched (ISA of round 2's kernel).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ZK_CONSTANT_AS __attribute__((address_space(4)))
+#define ZK_GLOBAL_AS __attribute__((address_space(1)))
+#else        // (the host pass only parses the kernels)
+#define ZK_CONSTANT_AS
+#define ZK_GLOBAL_AS
+#endif
+typedef const ZK_CONSTANT_AS uint32_t* vm_c32;
+typedef const ZK_CONSTANT_AS uint64_t* vm_c64;
+struct vm_u128 { uint32_t x, y, z, w; };                      // (a plain struct: HIP's uint4 has no constructor from another address space)
+typedef const ZK_CONSTANT_AS vm_u128* vm_c128;
+typedef const ZK_GLOBAL_AS vm_u128* vm_g128;
+
+// the 8 words of a memory operand.  Branch-free: the address is built with scalar selects -- a column's base pointer and rotation offset, a
+// constant's address, or (register / PREV / ROWPOW operands, whose words are never looked at) the start of the constants -- and the two
+// 16-byte loads are issued UNCONDITIONALLY.  With loads behind uniform branches the compiler placed s_waitcnt vmcnt(0) at the joins and at
+// the loop header, which serialised every prefetch; straight-line loads let it count (vmcnt(4): the four loads of the next instruction stay
+// in flight while this one's words are used).  A dummy load is one cache line for the whole wavefront.
+__device__ __forceinline__ void vm_load_words(const vm_launch& L, uint32_t opnd, uint64_t row, uint32_t (&w)[8]) {
   const uint32_t kind = opnd & 0xff, rot = (opnd >> 8) & 0xff, index = opnd >> 16;
-  if (kind == ZKHIP_SRC_COLUMN || kind == ZKHIP_SRC_CONST) {
-    uint32_t w[8];
-    if (kind == ZKHIP_SRC_COLUMN) {
-      const uint64_t rr = (row + L.rot_off[rot]) & (L.rows - 1);
-      load_words(L.cols[index] + rr * 8, w);
-    } else {
-      load_words(L.consts + (size_t)index * 8, w);
-    }
-    return TIMES32 ? fe_unpack<5>(w) : fe_unpack<0>(w);
-  }
-  fe v = kind == ZKHIP_SRC_REG ? vm_reg_get(r, index) : (kind == ZKHIP_SRC_PREV ? prev : xpow);
+  const bool is_col = kind == ZKHIP_SRC_COLUMN, is_const = kind == ZKHIP_SRC_CONST;
+  const uint64_t col_base = ((vm_c64)L.cols)[is_col ? index : 0u];
+  const uint32_t off = ((vm_c32)L.rot_off)[is_col ? rot : 0u];
+  const uint64_t base = is_col ? col_base : (uint64_t)(L.consts + (size_t)(is_const ? index : 0u) * 8);
+  const uint64_t rr = (row + off) & (is_col ? L.rows - 1 : 0ull);
+  const vm_g128 p = (vm_g128)(base + rr * 32);
+  const vm_u128 lo = p[0], hi = p[1];
+  w[0] = lo.x; w[1] = lo.y; w[2] = lo.z; w[3] = lo.w; w[4] = hi.x; w[5] = hi.y; w[6] = hi.z; w[7] = hi.w;
+}
+
+// operand value from its prefetched words (memory kinds) or from the register file / prev / omega^row; TIMES32: scaled by 2^5
+// out[row] as it was (PREV) and omega^row (ROWPOW) are per-row values a program reads a handful of times: they live in LDS (limb-major,
+// one word per lane and limb: conflict-free), not in 18 VGPRs next to the register file and the prefetch buffers
+constexpr uint32_t VM_THREADS = 256;
+__device__ __forceinline__ fe vm_lds_get(const uint32_t* __restrict__ base) {
+  fe v;
+#pragma unroll
+  for (int i = 0; i < NL; i++) v.l[i] = base[i * VM_THREADS + threadIdx.x];
+  return v;
+}
+__device__ __forceinline__ void vm_lds_put(uint32_t* __restrict__ base, const fe& v) {
+#pragma unroll
+  for (int i = 0; i < NL; i++) base[i * VM_THREADS + threadIdx.x] = v.l[i];
+}
+
+template <bool TIMES32, int R>
+__device__ __forceinline__ fe vm_operand(uint32_t opnd, const uint32_t (&w)[8], const fe (&r)[R], const uint32_t* s_prev, const uint32_t* s_pow) {
+  const uint32_t kind = opnd & 0xff, index = opnd >> 16;
+  if (kind == ZKHIP_SRC_COLUMN || kind == ZKHIP_SRC_CONST) return TIMES32 ? fe_unpack<5>(w) : fe_unpack<0>(w);
+  fe v = kind == ZKHIP_SRC_REG ? vm_reg_get(r, index) : vm_lds_get(kind == ZKHIP_SRC_PREV ? s_prev : s_pow);
   return TIMES32 ? vm_times32(v) : v;
 }
 
+// one instruction: operands a / b come with their words already loaded (wa / wb); a memory operand c (MAD's addend) is loaded here
 template <int R>
-__global__ void __launch_bounds__(256) k_row_vm(const vm_launch L) {
+__device__ __forceinline__ void vm_execute(const vm_launch& L, uint32_t head, uint32_t oa, uint32_t ob, uint32_t oc, const uint32_t (&wa)[8], const uint32_t (&wb)[8],
+                                           uint64_t row, fe (&r)[R], const uint32_t* s_prev, const uint32_t* s_pow) {
+  const uint32_t op = head & 0xff, dst = (head >> 8) & 0xff;
+  const fe a = vm_operand<false, R>(oa, wa, r, s_prev, s_pow);
+  fe t;
+  if (op == ZKHIP_OP_MUL || op == ZKHIP_OP_SQR || op == ZKHIP_OP_MAD) {
+    const fe b32 = op == ZKHIP_OP_SQR ? vm_times32(a) : vm_operand<true, R>(ob, wb, r, s_prev, s_pow);
+    t = fe_mul<Fr, true>(a, b32);      // single-chain product columns (fp29.hpp): -2 % on the wrapper quotient, same box
+    if (op == ZKHIP_OP_MAD) {
+      uint32_t wc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (vm_is_mem(oc)) vm_load_words(L, oc, row, wc);
+      t = vm_add(t, vm_operand<false, R>(oc, wc, r, s_prev, s_pow));
+    }
+  } else if (op == ZKHIP_OP_ADD) {
+    t = vm_add(a, vm_operand<false, R>(ob, wb, r, s_prev, s_pow));
+  } else if (op == ZKHIP_OP_SUB) {
+    t = vm_sub(a, vm_operand<false, R>(ob, wb, r, s_prev, s_pow));
+  } else if (op == ZKHIP_OP_NEG) {
+    t = vm_sub(fe_zero(), a);
+  } else if (op == ZKHIP_OP_DBL) {
+    t = vm_add(a, a);
+  } else {
+    t = a;   // MOV
+  }
+  vm_reg_set(r, dst, t);
+}
+
+// One instruction as the kernel reads it: the 16-byte instruction of the ABI plus, for its operands a and b, everything the address of their
+// words needs -- base (a column's pointer, a constant's address, or a dummy for operands that are not in memory), rotation offset in rows and
+// a row mask (all ones for a column, zero otherwise).  Resolved on the host (row_vm_device), so a fetch is ONE scalar load of 64 bytes and the
+// operand loads depend on nothing else; the loop fetches two instructions ahead and loads operands one instruction ahead.
+struct vm_uop {
+  uint32_t head, oa, ob, oc;
+  uint64_t base_a, base_b;
+  uint32_t off_a, off_b, mask_a, mask_b;
+  uint32_t pad[4];
+};
+static_assert(sizeof(vm_uop) == 64, "micro-op layout");
+struct vm_decoded { uint32_t head, oa, ob, oc; uint64_t base_a, base_b; uint32_t off_a, off_b, mask_a, mask_b; };
+__device__ __forceinline__ vm_decoded vm_decode(const vm_launch& L, uint32_t pc) {
+  const vm_c128 q = (vm_c128)L.prog + (size_t)pc * 4;          // same instruction for every lane: scalar loads, decoded on the scalar unit
+  const vm_u128 q0 = q[0], q1 = q[1], q2 = q[2];
+  vm_decoded d;
+  d.head = q0.x; d.oa = q0.y; d.ob = q0.z; d.oc = q0.w;
+  d.base_a = (uint64_t)q1.x | ((uint64_t)q1.y << 32); d.base_b = (uint64_t)q1.z | ((uint64_t)q1.w << 32);
+  d.off_a = q2.x; d.off_b = q2.y; d.mask_a = q2.z; d.mask_b = q2.w;
+  return d;
+}
+__device__ __forceinline__ void vm_load_resolved(uint64_t base, uint32_t off, uint32_t mask, uint64_t row, uint64_t rows, uint32_t (&w)[8]) {
+  const uint64_t rr = (row + off) & (rows - 1) & (uint64_t)(int64_t)(int32_t)mask;      // mask = 0: the base itself (a constant / a dummy)
+  const vm_g128 p = (vm_g128)(base + rr * 32);
+  const vm_u128 lo = p[0], hi = p[1];
+  w[0] = lo.x; w[1] = lo.y; w[2] = lo.z; w[3] = lo.w; w[4] = hi.x; w[5] = hi.y; w[6] = hi.z; w[7] = hi.w;
+}
+// issue the loads of an instruction's operands a / b -- unconditionally (see vm_load_words)
+__device__ __forceinline__ void vm_prefetch(const vm_launch& L, const vm_decoded& d, uint64_t row, uint32_t (&wa)[8], uint32_t (&wb)[8]) {
+  vm_load_resolved(d.base_a, d.off_a, d.mask_a, row, L.rows, wa);
+  vm_load_resolved(d.base_b, d.off_b, d.mask_b, row, L.rows, wb);
+}
+
+template <int R>
+__global__ void __launch_bounds__(VM_THREADS) k_row_vm(const vm_launch L) {
+  __shared__ uint32_t s_prev[NL * VM_THREADS], s_pow[NL * VM_THREADS];
   const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= L.rows) return;
   fe r[R];
 #pragma unroll
   for (int i = 0; i < R; i++) r[i] = fe_zero();
-  fe prev = fe_zero(), xpow = fe_zero();
-  if (L.accumulate) prev = load_ext(L.out, row);
+  vm_lds_put(s_prev, L.accumulate ? load_ext(L.out, row) : fe_zero());      // (a lane reads back only what it wrote: no barrier)
   if (L.pow_lo) {
     uint32_t w[8];
     load_words(L.pow_lo + (row & ((1u << POW_LO_BITS) - 1)) * 8, w);
-    xpow = fe_mul<Fr>(load_ext(L.pow_hi, row >> POW_LO_BITS), fe_unpack<5>(w));
+    vm_lds_put(s_pow, fe_mul<Fr>(load_ext(L.pow_hi, row >> POW_LO_BITS), fe_unpack<5>(w)));
+  } else {
+    vm_lds_put(s_pow, fe_zero());
   }
+  if constexpr (R > 12) {
+    // the 16-register file leaves no room for a second buffer pair at 2 waves per SIMD: operands are loaded when the instruction runs
+    uint32_t wa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll 1
-  for (uint32_t pc = 0; pc < L.n_insns; pc++) {
-    const uint4 q = L.prog[pc];
-    // same instruction for every lane: keep the decode on the scalar unit
-    const uint32_t head = __builtin_amdgcn_readfirstlane(q.x), oa = __builtin_amdgcn_readfirstlane(q.y),
-                   ob = __builtin_amdgcn_readfirstlane(q.z), oc = __builtin_amdgcn_readfirstlane(q.w);
-    const uint32_t op = head & 0xff, dst = (head >> 8) & 0xff;
-    const fe a = vm_fetch<false, R>(L, oa, row, r, prev, xpow);
-    fe t;
-    if (op == ZKHIP_OP_MUL || op == ZKHIP_OP_SQR || op == ZKHIP_OP_MAD) {
-      const fe b32 = op == ZKHIP_OP_SQR ? vm_times32(a) : vm_fetch<true, R>(L, ob, row, r, prev, xpow);
-      t = fe_mul<Fr, true>(a, b32);      // single-chain product columns (fp29.hpp): -2 % on the wrapper quotient, same box
-      if (op == ZKHIP_OP_MAD) t = vm_add(t, vm_fetch<false, R>(L, oc, row, r, prev, xpow));
-    } else if (op == ZKHIP_OP_ADD) {
-      t = vm_add(a, vm_fetch<false, R>(L, ob, row, r, prev, xpow));
-    } else if (op == ZKHIP_OP_SUB) {
-      t = vm_sub(a, vm_fetch<false, R>(L, ob, row, r, prev, xpow));
-    } else if (op == ZKHIP_OP_NEG) {
-      t = vm_sub(fe_zero(), a);
-    } else if (op == ZKHIP_OP_DBL) {
-      t = vm_add(a, a);
-    } else {
-      t = a;   // MOV
+    for (uint32_t pc = 0; pc < L.n_insns; pc++) {
+      const vm_decoded d = vm_decode(L, pc);
+      vm_prefetch(L, d, row, wa, wb);
+      vm_execute<R>(L, d.head, d.oa, d.ob, d.oc, wa, wb, row, r, s_prev, s_pow);
     }
-    vm_reg_set(r, dst, t);
+    uint32_t w[8];
+    fe_pack(fe_canon_lt2p<Fr>(vm_reg_get(r, L.result_reg)), w);
+    store_words(L.out + row * 8, w);
+    return;
+  }
+  // Software pipeline, two word-buffer pairs alternated by a loop unrolled twice (no register copies):
+  //     [fetch instruction pc + 2]  ->  [issue the operand loads of pc + 1]  ->  [execute pc]
+  // The program is padded with no-op micro-ops (row_vm_device), so the fetches and loads past the end are harmless and the loop body has no
+  // conditions besides its exit.  (Loads two instructions ahead -- a third buffer pair, 127 VGPRs -- measured equal: 13.24-13.34 vs
+  // 13.33-13.65 ms on the wrapper quotient; the cycles still parked, 19 %, are not operand loads.)
+  uint32_t wa0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wb0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wa1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wb1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  vm_decoded cur = vm_decode(L, 0), nxt = vm_decode(L, 1);
+  vm_prefetch(L, cur, row, wa0, wb0);
+#pragma unroll 1
+  for (uint32_t pc = 0; pc < L.n_insns; pc += 2) {
+    const vm_decoded nn = vm_decode(L, pc + 2);
+    vm_prefetch(L, nxt, row, wa1, wb1);
+    vm_execute<R>(L, cur.head, cur.oa, cur.ob, cur.oc, wa0, wb0, row, r, s_prev, s_pow);
+    if (pc + 1 >= L.n_insns) break;
+    cur = nn;
+    const vm_decoded n3 = vm_decode(L, pc + 3);
+    vm_prefetch(L, cur, row, wa0, wb0);
+    vm_execute<R>(L, nxt.head, nxt.oa, nxt.ob, nxt.oc, wa1, wb1, row, r, s_prev, s_pow);
+    nxt = n3;
   }
   uint32_t w[8];
   fe_pack(fe_canon_lt2p<Fr>(vm_reg_get(r, L.result_reg)), w);
@@ -270,50 +388,94 @@ int row_vm_validate(const zkhip_vm_program* p, uint32_t n_columns, uint32_t log_
 
 size_t row_vm_workspace_bytes(const zkhip_vm_program* p, uint32_t n_columns, uint32_t log_rows) {
   const size_t rows = (size_t)1 << log_rows;
-  return align256((size_t)p->n_insns * 16) + align256((size_t)p->n_constants * 32 + 32) + align256((size_t)p->n_rotations * 4 + 4) +
+  return align256(((size_t)p->n_insns + 4) * sizeof(vm_uop)) + align256((size_t)p->n_constants * 32 + 32) + align256((size_t)p->n_rotations * 4 + 4) +
          align256((size_t)n_columns * 8 + 8) + 256 + align256(((size_t)1 << POW_LO_BITS) * 32) + align256(((rows >> POW_LO_BITS) + 1) * 32);
 }
 
 // the program, its tables and the column pointers are staged into `ws` (device), then one launch
+void vm_staging::release() {
+  for (int i = 0; i < 2; i++) {
+    if (copied[i]) { (void)hipEventSynchronize(copied[i]); (void)hipEventDestroy(copied[i]); copied[i] = nullptr; }
+    if (host[i]) { (void)hipHostFree(host[i]); host[i] = nullptr; cap[i] = 0; }
+  }
+}
+
 int row_vm_device(const zkhip_vm_program* p, const void* const* d_columns, uint32_t n_columns, uint32_t log_rows, int accumulate,
-                  uint32_t* d_out, void* ws, size_t ws_bytes, hipStream_t stream) {
+                  uint32_t* d_out, void* ws, size_t ws_bytes, hipStream_t stream, vm_staging* staging) {
   const uint64_t rows = (uint64_t)1 << log_rows;
   if (ws_bytes < row_vm_workspace_bytes(p, n_columns, log_rows)) { set_error("eval_rows: workspace too small"); return ZKHIP_EINVAL; }
   // one host blob, one copy
   const size_t o_prog = 0;
-  const size_t o_const = o_prog + align256((size_t)p->n_insns * 16);
+  const size_t o_const = o_prog + align256(((size_t)p->n_insns + 4) * sizeof(vm_uop));
   const size_t o_rot = o_const + align256((size_t)p->n_constants * 32 + 32);
   const size_t o_cols = o_rot + align256((size_t)p->n_rotations * 4 + 4);
   const size_t o_omega = o_cols + align256((size_t)n_columns * 8 + 8);
   const size_t o_lo = o_omega + 256;
   const size_t o_hi = o_lo + align256(((size_t)1 << POW_LO_BITS) * 32);
-  std::vector<unsigned char> blob(o_lo, 0);
-  static_assert(sizeof(zkhip_vm_insn) == 16, "instruction layout");
-  std::memcpy(blob.data() + o_prog, p->insns, (size_t)p->n_insns * 16);
-  // a product's second factor is fetched scaled by 2^5: free for a column / constant (the other unpacking shift), a repack for a
-  // register -- so put the memory operand second where the host did not
-  for (uint32_t pc = 0; pc < p->n_insns; pc++) {
-    zkhip_vm_insn* in = (zkhip_vm_insn*)(blob.data() + o_prog) + pc;
-    const bool a_mem = in->a.kind == ZKHIP_SRC_COLUMN || in->a.kind == ZKHIP_SRC_CONST;
-    const bool b_mem = in->b.kind == ZKHIP_SRC_COLUMN || in->b.kind == ZKHIP_SRC_CONST;
-    if ((in->op == ZKHIP_OP_MUL || in->op == ZKHIP_OP_MAD) && a_mem && !b_mem) { const zkhip_vm_operand t = in->a; in->a = in->b; in->b = t; }
+  // the blob: pinned staging of the caller's scratch set (no wait for the stream), or a local vector (then the stream is synchronised below)
+  std::vector<unsigned char> local;
+  unsigned char* blob_p = nullptr;
+  int slot = -1;
+  if (staging) {
+    slot = staging->turn;
+    staging->turn ^= 1;
+    if (staging->copied[slot]) HIPCHK(hipEventSynchronize(staging->copied[slot]));          // the copy that last read this buffer is done
+    else HIPCHK(hipEventCreateWithFlags(&staging->copied[slot], hipEventDisableTiming));
+    if (staging->cap[slot] < o_lo) {
+      if (staging->host[slot]) (void)hipHostFree(staging->host[slot]);
+      staging->host[slot] = nullptr; staging->cap[slot] = 0;
+      const size_t want = align256(o_lo + o_lo / 2 + 4096);
+      if (hipHostMalloc(&staging->host[slot], want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); set_error("eval_rows: hipHostMalloc(%zu) failed", want); return ZKHIP_ENOMEM; }
+      staging->cap[slot] = want;
+    }
+    blob_p = (unsigned char*)staging->host[slot];
+    std::memset(blob_p, 0, o_lo);
+  } else {
+    local.assign(o_lo, 0);
+    blob_p = local.data();
   }
-  if (p->n_constants) std::memcpy(blob.data() + o_const, p->constants, (size_t)p->n_constants * 32);
+  struct { unsigned char* p; unsigned char* data() const { return p; } } blob{blob_p};
+  static_assert(sizeof(zkhip_vm_insn) == 16, "instruction layout");
+  std::vector<uint32_t> rot_rows(p->n_rotations ? p->n_rotations : 1, 0u);
   for (uint32_t i = 0; i < p->n_rotations; i++) {
     const int64_t off = ((int64_t)p->rotations[i] * (int64_t)p->rot_scale) % (int64_t)rows;
-    const uint32_t v = (uint32_t)(off < 0 ? off + (int64_t)rows : off);
-    std::memcpy(blob.data() + o_rot + (size_t)i * 4, &v, 4);
+    rot_rows[i] = (uint32_t)(off < 0 ? off + (int64_t)rows : off);
   }
-  for (uint32_t i = 0; i < n_columns; i++) {
+  const uint64_t d_consts = (uint64_t)((char*)ws + o_const);
+  for (uint32_t i = 0; i < n_columns; i++)
     if (!d_columns[i]) { set_error("eval_rows: column %u is null", i); return ZKHIP_EINVAL; }
-    std::memcpy(blob.data() + o_cols + (size_t)i * 8, &d_columns[i], 8);
+  // micro-ops: the instruction + its operands' resolved addresses; a product's second factor is fetched scaled by 2^5 -- free for a column /
+  // constant (the other unpacking shift), a repack for a register -- so the memory operand goes second where the host did not put it there
+  vm_uop* uops = (vm_uop*)(blob.data() + o_prog);
+  for (uint32_t pc = 0; pc < p->n_insns + 4; pc++) {
+    vm_uop& u = uops[pc];
+    std::memset(&u, 0, sizeof(u));
+    u.base_a = u.base_b = d_consts;                      // dummy address for operands that are not in memory (and for the padding no-ops)
+    if (pc >= p->n_insns) { u.head = ZKHIP_OP_MOV | ((uint32_t)0 << 8); u.oa = ZKHIP_SRC_REG; continue; }   // MOV r0 <- r0 (never executed)
+    zkhip_vm_insn in = p->insns[pc];
+    const bool a_mem = in.a.kind == ZKHIP_SRC_COLUMN || in.a.kind == ZKHIP_SRC_CONST;
+    const bool b_mem = in.b.kind == ZKHIP_SRC_COLUMN || in.b.kind == ZKHIP_SRC_CONST;
+    if ((in.op == ZKHIP_OP_MUL || in.op == ZKHIP_OP_MAD) && a_mem && !b_mem) { const zkhip_vm_operand t = in.a; in.a = in.b; in.b = t; }
+    std::memcpy(&u, &in, 16);
+    const bool uses_b = in.op == ZKHIP_OP_MUL || in.op == ZKHIP_OP_MAD || in.op == ZKHIP_OP_ADD || in.op == ZKHIP_OP_SUB;
+    auto resolve = [&](const zkhip_vm_operand& o, bool used, uint64_t* base, uint32_t* off, uint32_t* mask) {
+      if (!used) return;
+      if (o.kind == ZKHIP_SRC_COLUMN) { *base = (uint64_t)d_columns[o.index]; *off = rot_rows[o.rot]; *mask = 0xffffffffu; }
+      else if (o.kind == ZKHIP_SRC_CONST) { *base = d_consts + (uint64_t)o.index * 32; }
+    };
+    resolve(in.a, true, &u.base_a, &u.off_a, &u.mask_a);
+    resolve(in.b, uses_b, &u.base_b, &u.off_b, &u.mask_b);
   }
+  if (p->n_constants) std::memcpy(blob.data() + o_const, p->constants, (size_t)p->n_constants * 32);
+  for (uint32_t i = 0; i < p->n_rotations; i++) std::memcpy(blob.data() + o_rot + (size_t)i * 4, &rot_rows[i], 4);      // (a MAD's column addend still goes through the tables)
+  for (uint32_t i = 0; i < n_columns; i++) std::memcpy(blob.data() + o_cols + (size_t)i * 8, &d_columns[i], 8);
   if (p->omega) std::memcpy(blob.data() + o_omega, p->omega, 32);
   char* d = (char*)ws;
-  HIPCHK(hipMemcpyAsync(d, blob.data(), blob.size(), hipMemcpyHostToDevice, stream));
-  HIPCHK(hipStreamSynchronize(stream));   // the blob is a local
+  HIPCHK(hipMemcpyAsync(d, blob.data(), o_lo, hipMemcpyHostToDevice, stream));
+  if (staging) HIPCHK(hipEventRecord(staging->copied[slot], stream));
+  else HIPCHK(hipStreamSynchronize(stream));   // the blob is a local
   vm_launch L;
-  L.prog = (const uint4*)(d + o_prog);
+  L.prog = (const void*)(d + o_prog);
   L.n_insns = p->n_insns;
   L.result_reg = p->result_reg;
   L.cols = (const uint32_t* const*)(d + o_cols);
@@ -339,11 +501,11 @@ int row_vm_device(const zkhip_vm_program* p, const void* const* d_columns, uint3
     const zkhip_vm_operand* o[3] = {&in.a, &in.b, &in.c};
     for (int k = 0; k < 3; k++) if (o[k]->kind == ZKHIP_SRC_REG && o[k]->index < (uint32_t)VM_MAX_REGS && o[k]->index > top) top = o[k]->index;
   }
-  const dim3 grid((unsigned)((rows + 255) / 256));
-  if (top < 6) hipLaunchKernelGGL(k_row_vm<6>, grid, dim3(256), 0, stream, L);
-  else if (top < 8) hipLaunchKernelGGL(k_row_vm<8>, grid, dim3(256), 0, stream, L);
-  else if (top < 12) hipLaunchKernelGGL(k_row_vm<12>, grid, dim3(256), 0, stream, L);
-  else hipLaunchKernelGGL(k_row_vm<16>, grid, dim3(256), 0, stream, L);
+  const dim3 grid((unsigned)((rows + VM_THREADS - 1) / VM_THREADS));
+  if (top < 6) hipLaunchKernelGGL(k_row_vm<6>, grid, dim3(VM_THREADS), 0, stream, L);
+  else if (top < 8) hipLaunchKernelGGL(k_row_vm<8>, grid, dim3(VM_THREADS), 0, stream, L);
+  else if (top < 12) hipLaunchKernelGGL(k_row_vm<12>, grid, dim3(VM_THREADS), 0, stream, L);
+  else hipLaunchKernelGGL(k_row_vm<16>, grid, dim3(VM_THREADS), 0, stream, L);
   HIPCHK(hipGetLastError());
   return ZKHIP_OK;
 }

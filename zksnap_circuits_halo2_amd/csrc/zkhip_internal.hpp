@@ -91,8 +91,18 @@ int fr_batch_invert_device(uint32_t* d_a, size_t n, void* ws, size_t ws_bytes, h
 // rowvm.hip
 int row_vm_validate(const zkhip_vm_program* p, uint32_t n_columns, uint32_t log_rows, int accumulate);
 size_t row_vm_workspace_bytes(const zkhip_vm_program* p, uint32_t n_columns, uint32_t log_rows);
+// Pinned host staging for the program blob of a row program (two buffers, used alternately; an event per buffer says when the copy that read
+// it has completed).  With it row_vm_device never waits for the stream: the host builds program i + 1 while program i runs.  Owned by the
+// caller's scratch set (one user at a time); nullptr = build the blob in a local buffer and synchronise the stream after the copy.
+struct vm_staging {
+  void* host[2] = {nullptr, nullptr};
+  size_t cap[2] = {0, 0};
+  hipEvent_t copied[2] = {nullptr, nullptr};
+  int turn = 0;
+  void release();
+};
 int row_vm_device(const zkhip_vm_program* p, const void* const* d_columns, uint32_t n_columns, uint32_t log_rows, int accumulate,
-                  uint32_t* d_out, void* ws, size_t ws_bytes, hipStream_t stream);
+                  uint32_t* d_out, void* ws, size_t ws_bytes, hipStream_t stream, vm_staging* staging = nullptr);
 int fr_pointwise_mul_device(const uint32_t* d_a, const uint32_t* d_b, size_t n, uint32_t* d_out, hipStream_t stream);
 int fr_gather_mul_device(const uint32_t* d_a, uint32_t a_len, const uint32_t* d_ia, const uint32_t* d_b, uint32_t b_len, const uint32_t* d_ib, size_t n,
                          uint32_t* d_out, hipStream_t stream);
