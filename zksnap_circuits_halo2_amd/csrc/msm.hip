@@ -27,6 +27,7 @@
 #include <cstring>
 #include <cstdlib>
 #include "ec_quad.hpp"
+#include "fe_inverse.hpp"
 #include "zkhip_internal.hpp"
 
 namespace zkhip {
@@ -1741,16 +1742,9 @@ __device__ __forceinline__ xyzz scalar_mul_affine(const uint32_t (&kw)[8], const
   return acc;
 }
 
-__device__ __forceinline__ fe fq_inverse(const fe& a) {   // a^(q-2), a reduced (< 2p), result < 2p
-  // exponent q - 2 as 8 x u32 (little endian)
-  const uint32_t e[8] = {0xd87cfd45u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
-  fe acc = fe_one<Fq>();
-  for (int bit = 253; bit >= 0; bit--) {
-    acc = fe_sqr<Fq>(acc);
-    if ((e[bit >> 5] >> (bit & 31)) & 1) acc = fe_mul<Fq>(acc, a);
-  }
-  return acc;
-}
+// a^-1 in Fq: a reduced (< 2p), result < 2p.  Division steps instead of the Fermat chain a^(q-2) (fe_inverse.hpp): ~11 k instead of
+// ~82 k instructions of one thread, under every batched affine conversion below.
+__device__ __forceinline__ fe fq_inverse(const fe& a) { return fe_inverse<Fq>(a); }
 
 __global__ void __launch_bounds__(64) k_gen_walk(const uint32_t* __restrict__ t0_d /* 16 words: t0, d (Montgomery-256) */,
                                                  uint32_t n, uint32_t* __restrict__ out, uint32_t* __restrict__ tmp_pts,

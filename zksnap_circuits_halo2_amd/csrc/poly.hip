@@ -8,12 +8,14 @@
 // incoming carry.  2 multiplies per element, O(log_CH n) launches.
 //   suffix Horner scan  out[i] = a[i] + b * out[i+1]           (kate_division; eval_polynomial is out[0])
 //   prefix product      out[0] = 1, out[i+1] = out[i] * v[i]
-//   batch inversion     Montgomery's trick per chunk with one Fermat inversion per thread
+//   batch inversion     Montgomery's trick per chunk with one inversion (division steps, fe_inverse.hpp) per thread
 // Values are kept in the external Montgomery-256 domain throughout: x*2^256 is the radix-2^261 form of x*2^-5 and the
 // recurrences are linear in the data, so only the constant multiplier is converted (fp29.hpp).
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstdlib>
 #include "fp29.hpp"
+#include "fe_inverse.hpp"
 #include "fr_vec.hpp"
 #include "zkhip_internal.hpp"
 
@@ -122,21 +124,14 @@ __global__ void __launch_bounds__(256) k_prod_apply(const uint32_t* __restrict__
 }
 
 // ---- batch inversion (zeros stay zero, like ff::BatchInvert) ------------------------------------------
-__device__ __forceinline__ fe fr_inverse(const fe& a) {   // a^(r-2); a internal & reduced
-  const uint32_t e[8] = {0xefffffffu, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
-  fe acc = fe_one<Fr>();
-  for (int bit = 253; bit >= 0; bit--) {
-    acc = fe_sqr<Fr>(acc);
-    if ((e[bit >> 5] >> (bit & 31)) & 1) acc = fe_mul<Fr>(acc, a);
-  }
-  return acc;
-}
+// a^-1 in Fr, a internal & reduced: division steps instead of the Fermat chain a^(r-2) (fe_inverse.hpp)
+__device__ __forceinline__ fe fr_inverse(const fe& a) { return fe_inverse<Fr>(a); }
 
-__global__ void __launch_bounds__(128) k_batch_invert(uint32_t* __restrict__ a, size_t n, uint32_t* __restrict__ scratch) {
+__global__ void __launch_bounds__(64) k_batch_invert(uint32_t* __restrict__ a, size_t n, uint32_t* __restrict__ scratch, uint32_t ch) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t lo = t * POLY_CH;
+  const size_t lo = t * ch;
   if (lo >= n) return;
-  const size_t hi = lo + POLY_CH < n ? lo + POLY_CH : n;
+  const size_t hi = lo + ch < n ? lo + ch : n;
   // x*2^256 read as the internal form of x' = x*2^-5.  prefix products of the non-zero x' (internal form), parked in scratch
   const fe one = fe_one<Fr>();
   fe pref = one;
@@ -313,7 +308,13 @@ static int prefix_product_rec(const uint32_t* d_v, size_t n, const uint32_t* car
 int fr_batch_invert_device(uint32_t* d_a, size_t n, void* ws, size_t ws_bytes, hipStream_t stream) {
   if (n == 0) return ZKHIP_OK;
   if (ws_bytes < poly_workspace_bytes(n)) { set_error("batch_invert: workspace too small"); return ZKHIP_EINVAL; }
-  hipLaunchKernelGGL(k_batch_invert, grid_for(chunks_of(n), 128), dim3(128), 0, stream, d_a, n, (uint32_t*)ws);
+  // elements per thread: 3 multiplications each + one inversion (~50 multiplications' worth since it is division steps, fe_inverse.hpp).
+  // Full chunks when there are enough of them to fill the chip; shorter ones below that, where the call is the latency of one thread.
+  uint32_t ch = POLY_CH;
+  while (ch > 4 && n / ch < 65536) ch >>= 1;
+  // one wavefront per workgroup: with few waves per CU, 128-thread workgroups land pairwise on the same two SIMDs (measured: 1024 waves take
+  // 0.098 ms as 512 workgroups of 128 threads, 0.063 ms as 1024 of 64 or 256 of 256 -- profiles/r03_batch_invert_ab.txt)
+  hipLaunchKernelGGL(k_batch_invert, grid_for((n + ch - 1) / ch, 64), dim3(64), 0, stream, d_a, n, (uint32_t*)ws, ch);
   HIPCHK(hipGetLastError());
   return ZKHIP_OK;
 }
