@@ -154,8 +154,14 @@ def main() -> None:
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cpu_group = None
-    if world > 1:
+    # ZKHIP_BENCH_FORCE_DIST=1: the rendezvous, barriers, all_gather and all_reduce of the N > 1 path run on RCCL even with ONE rank (a rehearsal of
+    # the multi-GPU control flow on a one-GPU box: tests/test_gpu_multi_shard.py); the line says so ("rccl_rehearsal")
+    use_dist = world > 1 or os.environ.get("ZKHIP_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         dist.init_process_group("nccl", device_id=dev)
         cpu_group = dist.new_group(backend="gloo")      # host-side waits that must not occupy the GPUs (the single-process leg at the end)
 
@@ -185,7 +191,7 @@ def main() -> None:
     # Exchange per step: one 96-byte all_gather + a fold of the N partials, enqueued behind the MSM on the same stream.  (Running it on a
     # side stream under the next step's MSM was measured at N = 1 with the gather degenerated to a copy -- ZKHIP_BENCH_FORCE_EXCHANGE=1
     # -- and is slower: 599 vs 612 Mpoints/s, against 616 without any exchange; the cross-stream events cost more than the fold.)
-    exchange = world > 1 or os.environ.get("ZKHIP_BENCH_FORCE_EXCHANGE") == "1"
+    exchange = use_dist or os.environ.get("ZKHIP_BENCH_FORCE_EXCHANGE") == "1"
     d_gather = torch.zeros(12 * world, dtype=torch.int64, device=dev)
     d_final = torch.zeros(12, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
@@ -198,18 +204,18 @@ def main() -> None:
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -370,8 +376,10 @@ def main() -> None:
         result["cpu_baseline"] = cpu_baseline(args.log_n, d_scalars, d_bases, d_out, n)
 
     if rank == 0:
+        if use_dist and world == 1:
+            result["rccl_rehearsal"] = True
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <vector>
 #include "ec.hpp"
+#include "fe_inverse.hpp"
 
 using namespace zkhip;
 typedef unsigned __int128 u128;
@@ -104,6 +105,28 @@ template <class P> static void field_tests(const char* name) {
     CHECK(big_cmp(to_int<P>(in, rinv), x) == 0, name);
     fe_to_ext<P>(in, w2);
     CHECK(memcmp(w, w2, 32) == 0, name);
+  }
+  // inversion by division steps (fe_inverse.hpp) against the big-integer a^(p-2): plain integers and Montgomery-261 values, edge values,
+  // and lazily reduced inputs (0 -> 0)
+  const big one_b = [] { big o = big_zero(); o.w[0] = 1; return o; }();
+  for (int it = 0; it < 600; it++) {
+    big x = rnd_below(p);
+    if (it == 0) x = big_zero();
+    if (it == 1) x = one_b;
+    if (it == 2) x = big_sub(p, one_b);
+    if (it == 3) { x = big_zero(); x.w[0] = 2; }
+    if (it == 4) x = big_sub(p, big_add(one_b, one_b));
+    if (it >= 5 && it < 40) { x = big_zero(); x.w[(it - 5) / 9] = 1ULL << (7 * ((it - 5) % 9)); x = big_mod(x, p); }      // single bits
+    if (it >= 40 && it < 60) { x = rnd_below(p); x.w[3] = 0; x.w[2] = 0; if (it & 1) x.w[1] = 0; }                       // short values
+    const big want = big_cmp(x, big_zero()) == 0 ? big_zero() : invmod(x, p);
+    const fe plain = fe_inverse_plain<P>(fe_from_big(x));
+    CHECK(is_N(plain) && below(plain, 1, p) && big_cmp(fe_value(plain), want) == 0, name);
+    const fe a = to_fe<P>(x);
+    const fe inv = fe_inverse<P>(a);
+    CHECK(is_N(inv) && below(inv, 2, p) && big_cmp(to_int<P>(inv, rinv), want) == 0, name);
+    fe k; for (int i = 0; i < NL; i++) k.l[i] = P::P8_S1[i];
+    const fe inv_lazy = fe_inverse<P>(fe_add(fe_add(a, k), k));          // the same element + 16p, limbs up to 2^31
+    CHECK(big_cmp(to_int<P>(inv_lazy, rinv), want) == 0, name);
   }
 }
 

@@ -495,3 +495,29 @@ def test_bench_config4_leg_four_ranks_on_one_gpu():
         assert p.exitcode == 0
     assert sorted(r[:2] for r in res) == [(r, True) for r in range(world)]
     assert "2^22 points per GPU x 4" in res[0][3]
+
+
+def test_bench_multi_gpu_control_flow_on_rccl_with_one_rank():
+    """bench.py's N > 1 control flow -- init_process_group("nccl", device_id=...), the gloo side group, dist.barrier(), the all_gather_into_tensor
+    of the 96-byte partial on device tensors inside the timed step, the device-side all_reduce(MAX) of the elapsed time, destroy_process_group --
+    on RCCL itself with ONE rank (ZKHIP_BENCH_FORCE_DIST=1): everything of the multi-GPU bench path that a one-GPU box can execute.  (The
+    world-size-4 rehearsal above substitutes gloo, because RCCL refuses several ranks on one device.)"""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ZKHIP_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        env["MASTER_PORT"] = str(sk.getsockname()[1])
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "5", "--warmup", "1", "--no-extras", "--no-cpu-baseline", "--no-general-path"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert run.returncode == 0, run.stderr[-2000:]
+    line = [l for l in run.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["rccl_rehearsal"] is True and rec["n_gpus"] == 1 and rec["value"] > 100.0
+    assert "all_gather" in rec["config"]["parallelism"]
