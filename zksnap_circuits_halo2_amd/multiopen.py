@@ -196,26 +196,18 @@ class RotationSet:
 
 def construct_rotation_sets(queries: Sequence[ProverQuery]) -> Tuple[List[RotationSet], List[int]]:
     """`construct_intermediate_sets` of shplonk.rs -> (rotation sets, super point set ascending)"""
-    by_poly: List[Tuple[int, set]] = []
+    by_poly: dict = {}                                  # poly -> its points, in order of first appearance (dicts keep insertion order)
+    evals: dict = {}
     for q in queries:
-        for poly, pts in by_poly:
-            if poly == q.poly:
-                pts.add(q.point % R_MOD)
-                break
-        else:
-            by_poly.append((q.poly, {q.point % R_MOD}))
-    sets: List[Tuple[frozenset, List[int]]] = []
-    for poly, pts in by_poly:
-        key = frozenset(pts)
-        for k2, polys in sets:
-            if k2 == key:
-                polys.append(poly)
-                break
-        else:
-            sets.append((key, [poly]))
+        by_poly.setdefault(q.poly, set()).add(q.point % R_MOD)
+        evals.setdefault((q.poly, q.point % R_MOD), q.eval)          # the first query of a (poly, point) pair gives the evaluation
+    sets_by_key: dict = {}                              # point set -> its polynomials, in order of first appearance
+    for poly, pts in by_poly.items():
+        sets_by_key.setdefault(frozenset(pts), []).append(poly)
+    sets = list(sets_by_key.items())
 
     def get_eval(poly, point):
-        return next(q.eval for q in queries if q.poly == poly and q.point % R_MOD == point)
+        return evals[(poly, point)]
 
     out = []
     for key, polys in sets:
