@@ -1048,13 +1048,18 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))
       }
       j = 1;
     }
+    // The reference of point j + 1 is loaded during iteration j - 1, so that the gather of point j + 1 (issued at the top of iteration j, under the
+    // current addition) does not start with a dependent load: with `ref = refs[j + 1]` inside the iteration every trip began with that load and an
+    // s_waitcnt vmcnt(0) before the gather's address existed.
+    uint32_t nref = j + 1 < tk.len ? refs[j + 1] : 0u;
     for (; j < tk.len; j++) {
       affine_words cur = pt;
       uint32_t cref = ref;
       if (j + 1 < tk.len) {            // prefetch the next point under the current addition
-        ref = refs[j + 1];
+        ref = nref;
         pt = point(ref & 0x7fffffffu);
       }
+      if (j + 2 < tk.len) nref = refs[j + 2];
       if (affine_is_identity(cur)) continue;
       fe x2, y2;
       if constexpr (TABLE) {

@@ -220,7 +220,13 @@ __global__ void __launch_bounds__(2048 / E) __attribute__((amdgpu_waves_per_eu(E
       constexpr int e = decltype(ec)::value;
       x[e] = ntt_fetch<CH>(a, src, __brev(pos[e]) >> (32 - B), j0 + jj, NR, Ns);
     });
-    if (v == (uint32_t)VM) {
+    if (E == 4 && v == (uint32_t)VM && a.first && a.in_len <= (NR << (B - 2))) {
+      // zero-padded input of at most N / 4 elements (coeff_to_extended: n coefficients on the 4n-point coset): only source rows below R / 4
+      // are non-zero, and those are the thread's element 0 (rows bitrev(4 m + e): e = 1, 2, 3 select the upper three quarters).  Both
+      // stages of the round then add or subtract zeros: all four outputs equal x[0] (the general code below would compute x[0] + 3p,
+      // x[0] + 6p and x[0] + 3p - w4 * 0 with one multiplication); the three fetches above returned zero without touching memory.
+      x[1] = x[0]; x[2] = x[0]; x[3] = x[0];
+    } else if (v == (uint32_t)VM) {
       // v == VM, lo == 0: twiddles depend only on the register index and 7 of the 12 (E = 4: 3 of the 4) are w^0 = 1, so
       // those butterflies need no multiply.  Inputs are N-form < 2p.  Bounds (value / limb) are noted per stage.
       const fe w4 = load_fe9(a.tw_local, 1u << (B - 2));
