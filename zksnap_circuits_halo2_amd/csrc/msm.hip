@@ -36,6 +36,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 
 constexpr int FINE_BITS = 12;           // wide windows: a bucket id = (coarse group, 12-bit fine id); MAX_GROUPS = 2^(20 - 1 - 12) groups at c = 20
 constexpr int MAX_GROUPS = 128;
+constexpr int MAX_WIDE_W = 16;          // windows of the wide path (c >= 17: at most 16): the coarse groups are counted and reserved per (window, group)
 constexpr int MAX_TASK_LEN = 128;       // tasks are 2^task_shift entries, task_shift <= 7 (length histograms hold MAX_TASK_LEN + 1 counters)
 constexpr int TASK_SHIFT = 6;           // 64 entries per accumulate task: short tasks keep the tail of the launch balanced
                                         // (measured at 2^22: 5.9 ms with 64-entry tasks, 6.9 ms with 256, 8.1 ms with 512)
@@ -142,8 +143,8 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ sca
 // 256-thread workgroup per 256 scalars, 0.5 M atomics -- was measured in round 1: +39 us in this kernel for the -33 us it saved).
 __global__ void __launch_bounds__(1024) k_digits_wide(const uint32_t* __restrict__ scalars, int32_t* __restrict__ digits, uint32_t n, uint32_t n_pad,
                                                        int c, int W, uint32_t* __restrict__ gcount) {
-  __shared__ uint32_t cnt[MAX_GROUPS];
-  if (threadIdx.x < MAX_GROUPS) cnt[threadIdx.x] = 0;
+  __shared__ uint32_t cnt[MAX_WIDE_W * MAX_GROUPS];          // [window][group]
+  for (uint32_t t = threadIdx.x; t < (uint32_t)W * MAX_GROUPS; t += blockDim.x) cnt[t] = 0;
   __syncthreads();
   const uint32_t half = 1u << (c - 1), mask = (1u << c) - 1;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += gridDim.x * blockDim.x) {
@@ -172,11 +173,12 @@ __global__ void __launch_bounds__(1024) k_digits_wide(const uint32_t* __restrict
       int32_t d;
       if (v >= half) { d = (int32_t)v - (int32_t)(1u << c); carry = 1; } else { d = (int32_t)v; carry = 0; }
       digits[(size_t)win * n_pad + i] = d;
-      if (d != 0) atomicAdd(&cnt[((uint32_t)(d < 0 ? -d : d) - 1) >> FINE_BITS], 1u);
+      if (d != 0) atomicAdd(&cnt[win * MAX_GROUPS + (((uint32_t)(d < 0 ? -d : d) - 1) >> FINE_BITS)], 1u);
     }
   }
   __syncthreads();
-  if (threadIdx.x < MAX_GROUPS && cnt[threadIdx.x]) atomicAdd(&gcount[threadIdx.x], cnt[threadIdx.x]);
+  for (uint32_t t = threadIdx.x; t < (uint32_t)W * MAX_GROUPS; t += blockDim.x)
+    if (cnt[t]) atomicAdd(&gcount[t], cnt[t]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -428,7 +430,7 @@ __global__ void __launch_bounds__(1024) k_coarse_count(const int32_t* __restrict
     }
   }
   __syncthreads();
-  if (threadIdx.x < MAX_GROUPS && cnt[threadIdx.x]) atomicAdd(&gcount[threadIdx.x], cnt[threadIdx.x]);
+  if (threadIdx.x < MAX_GROUPS && cnt[threadIdx.x]) atomicAdd(&gcount[win * MAX_GROUPS + threadIdx.x], cnt[threadIdx.x]);
 }
 
 // Coarse placement with the chunk sorted by group in LDS first (same reasoning as k_fine_sorted below): a workgroup takes
@@ -471,7 +473,12 @@ __global__ void __launch_bounds__(1024) k_coarse_sorted(const int32_t* __restric
       if ((int)threadIdx.x >= off) x += y;
     }
     const uint32_t l0 = x - s, l1 = l0 + c0;
-    const uint32_t g0 = c0 ? atomicAdd(&gcursor[2 * threadIdx.x], c0) : 0u, g1 = c1 ? atomicAdd(&gcursor[2 * threadIdx.x + 1], c1) : 0u;
+    // The reservation cursors are per (window, group): a group's staging region is laid out window after window (k_group_offsets).  With one
+    // cursor per group every workgroup of every window hit the same 128 words -- 6656 workgroups at 2^22 -- and the kernel's time WAS those
+    // atomics: it scaled with the number of workgroups, not with the bytes (0.27 / 0.50 / 0.97 ms at 2^22 with 8 Ki / 4 Ki / 2 Ki-digit chunks:
+    // ~40 ns per same-address atomic, profiles/r03_msm_experiments_ab.txt J).
+    uint32_t* const wcur = gcursor + (uint32_t)win * MAX_GROUPS;
+    const uint32_t g0 = c0 ? atomicAdd(&wcur[2 * threadIdx.x], c0) : 0u, g1 = c1 ? atomicAdd(&wcur[2 * threadIdx.x + 1], c1) : 0u;
     cur[2 * threadIdx.x] = l0; cur[2 * threadIdx.x + 1] = l1;
     // the way out without a search (as in k_fine_sorted): run-start bits, word prefixes, and delta indexed by a run's rank among the
     // non-empty groups
@@ -527,13 +534,18 @@ constexpr uint32_t SORT_CHUNK = 28672;   // entries per workgroup of the sorted 
 
 // goff[g] = start of group g in the staging array (exclusive scan of the group counts), gcursor = copy; cstart[g] = index of the
 // group's first SORT_CHUNK-sized chunk in the numbering of k_fine_sorted's workgroups
-__global__ void __launch_bounds__(64) k_group_offsets(const uint32_t* __restrict__ gcount, int G, uint32_t* __restrict__ goff, uint32_t* __restrict__ gcursor,
+__global__ void __launch_bounds__(64) k_group_offsets(const uint32_t* __restrict__ wcount, int W, int G, uint32_t* __restrict__ goff, uint32_t* __restrict__ wcursor,
                                                        uint32_t* __restrict__ cstart, uint32_t chunk) {
   // one wavefront, groups 2 lane and 2 lane + 1 per lane (G <= MAX_GROUPS = 128): two exclusive scans by shuffles (the serial loop
-  // this replaces took 12 us: 128 dependent global loads)
+  // this replaces took 12 us: 128 dependent global loads).  wcount[w][g] = entries of window w in group g; a group's region holds its
+  // windows one after the other and wcursor[w][g] is where window w's workgroups start to reserve.
   if (blockIdx.x != 0 || threadIdx.x >= 64) return;
   const int lane = threadIdx.x;
-  const uint32_t c0 = 2 * lane < G ? gcount[2 * lane] : 0u, c1 = 2 * lane + 1 < G ? gcount[2 * lane + 1] : 0u;
+  uint32_t c0 = 0, c1 = 0;
+  for (int w = 0; w < W; w++) {
+    if (2 * lane < G) c0 += wcount[w * MAX_GROUPS + 2 * lane];
+    if (2 * lane + 1 < G) c1 += wcount[w * MAX_GROUPS + 2 * lane + 1];
+  }
   const uint32_t k0 = (c0 + chunk - 1) / chunk, k1 = (c1 + chunk - 1) / chunk;
   uint32_t x = c0 + c1, y = k0 + k1;
 #pragma unroll
@@ -542,8 +554,13 @@ __global__ void __launch_bounds__(64) k_group_offsets(const uint32_t* __restrict
     if (lane >= off) { x += xs; y += ys; }
   }
   const uint32_t ex = x - (c0 + c1), ey = y - (k0 + k1);
-  if (2 * lane < G) { goff[2 * lane] = ex; gcursor[2 * lane] = ex; cstart[2 * lane] = ey; }
-  if (2 * lane + 1 < G) { goff[2 * lane + 1] = ex + c0; gcursor[2 * lane + 1] = ex + c0; cstart[2 * lane + 1] = ey + k0; }
+  if (2 * lane < G) { goff[2 * lane] = ex; cstart[2 * lane] = ey; }
+  if (2 * lane + 1 < G) { goff[2 * lane + 1] = ex + c0; cstart[2 * lane + 1] = ey + k0; }
+  uint32_t r0 = ex, r1 = ex + c0;
+  for (int w = 0; w < W; w++) {
+    if (2 * lane < G) { wcursor[w * MAX_GROUPS + 2 * lane] = r0; r0 += wcount[w * MAX_GROUPS + 2 * lane]; }
+    if (2 * lane + 1 < G) { wcursor[w * MAX_GROUPS + 2 * lane + 1] = r1; r1 += wcount[w * MAX_GROUPS + 2 * lane + 1]; }
+  }
   if (lane == 63) { goff[G] = x; cstart[G] = y; }
 }
 
@@ -1464,7 +1481,7 @@ static msm_layout msm_lay_out(char* base, size_t n_in, size_t K, int c, bool pre
   L.stage_ref = wide ? (uint32_t*)carve(entries * sizeof(uint32_t)) : nullptr;
   L.stage_fine = wide ? (uint16_t*)carve(entries * sizeof(uint16_t)) : nullptr;
   L.zero_lo = p;
-  L.gcounters = wide ? (uint32_t*)carve(4096) : nullptr;   // [0..128) group counts, [128..257) group offsets, [384..512) group cursors, [512..641) chunk starts
+  L.gcounters = wide ? (uint32_t*)carve(32768) : nullptr;  // words: [128..257) group offsets, [512..641) chunk starts, [1024..3072) counts [window][group], [3072..5120) cursors [window][group]
   L.counters = (uint32_t*)carve(2048);                     // [0] total entries, [1] total tasks, [2] max task partials of one bucket, [3] heavy buckets,
                                                            // [32..161) task-length histogram (MAX_TASK_LEN + 1), [192..321) its cursors
   L.count = (uint32_t*)carve((NB + 1) * sizeof(uint32_t));
@@ -1513,6 +1530,7 @@ int msm_build_tasks(const uint32_t* d_scalars, size_t n_in, size_t batch, size_t
   const uint32_t NB = (uint32_t)WB * B;
   if ((size_t)W * n * K >= (1ull << 32) || (size_t)WB * B >= (1ull << 31)) { set_error("msm: W*n*batch overflows 32-bit slot index"); return ZKHIP_EINVAL; }
   if (wide && (!shared_buckets || K != 1)) { set_error("msm: windows above 16 bits need one shared bucket set"); return ZKHIP_EINVAL; }
+  if (wide && W > MAX_WIDE_W) { set_error("msm: %d windows of %d bits exceed the wide path's %d", W, c, MAX_WIDE_W); return ZKHIP_EINVAL; }
   const msm_layout lay = msm_lay_out((char*)ws, n_in, K, c, shared_buckets, xyzz_bytes, glv);
   if (ws_bytes < lay.total) { set_error("msm: workspace too small (%zu < %zu bytes)", ws_bytes, lay.total); return ZKHIP_EINVAL; }
   const uint32_t task_shift = lay.task_shift;
@@ -1541,7 +1559,7 @@ int msm_build_tasks(const uint32_t* d_scalars, size_t n_in, size_t batch, size_t
       static const unsigned wg_knob = [] { const char* e = getenv("ZKHIP_DIGIT_WGS"); const int v = e ? atoi(e) : 0; return v >= 64 && v <= 4096 ? (unsigned)v : 0u; }();   // A/B knob
       const unsigned wg_cap = wg_knob ? wg_knob : (n_pad > (1u << 21) ? 1024u : 512u);
       const unsigned wblocks = (unsigned)std::min<size_t>(((size_t)n_pad + 1023) / 1024, wg_cap);
-      hipLaunchKernelGGL(k_digits_wide, dim3(wblocks), dim3(1024), 0, stream, d_scalars, (int32_t*)digits, (uint32_t)n, n_pad, c, W, gcounters);
+      hipLaunchKernelGGL(k_digits_wide, dim3(wblocks), dim3(1024), 0, stream, d_scalars, (int32_t*)digits, (uint32_t)n, n_pad, c, W, gcounters + 1024);
     } else {
       hipLaunchKernelGGL(k_digits<int32_t>, dim3(dblocks), dim3(256), 0, stream, d_scalars, (int32_t*)digits, (uint32_t)n, n_pad, c, W, K, sstride);
     }
@@ -1573,10 +1591,10 @@ int msm_build_tasks(const uint32_t* d_scalars, size_t n_in, size_t batch, size_t
   if (wide) {
     static const bool fused_count2 = getenv("ZKHIP_NO_FUSED_COUNT") == nullptr;
     if (!fused_count2)        // (otherwise k_digits_wide has counted the groups)
-      hipLaunchKernelGGL(k_coarse_count, dim3(chunks, W), dim3(1024), 0, stream, (const int32_t*)digits, n_pad, chunk, gcounters);
-    hipLaunchKernelGGL(k_group_offsets, dim3(1), dim3(64), 0, stream, gcounters, G, gcounters + 128, gcounters + 384, gcounters + 512, sort_chunk);
+      hipLaunchKernelGGL(k_coarse_count, dim3(chunks, W), dim3(1024), 0, stream, (const int32_t*)digits, n_pad, chunk, gcounters + 1024);
+    hipLaunchKernelGGL(k_group_offsets, dim3(1), dim3(64), 0, stream, gcounters + 1024, W, G, gcounters + 128, gcounters + 3072, gcounters + 512, sort_chunk);
     static_assert(MAX_GROUPS == 128, "k_coarse_sorted scans two groups per lane of one wavefront");
-    hipLaunchKernelGGL(k_coarse_sorted, dim3((n_pad + COARSE_CHUNK - 1) / COARSE_CHUNK, W), dim3(1024), 0, stream, (const int32_t*)digits, n_pad, gcounters + 384,
+    hipLaunchKernelGGL(k_coarse_sorted, dim3((n_pad + COARSE_CHUNK - 1) / COARSE_CHUNK, W), dim3(1024), 0, stream, (const int32_t*)digits, n_pad, gcounters + 3072,
                        stage_ref, stage_fine, ref_base, ref_stride);
     prof_mark(stream, "coarse");
     hipLaunchKernelGGL(k_fine_count, dim3(sort_chunks), dim3(1024), 0, stream, stage_fine, gcounters + 128, gcounters + 512, G, count, sort_chunk);
