@@ -1444,9 +1444,10 @@ static uint32_t msm_task_shift(size_t entries /* W n K */, size_t NB) {
   uint32_t task_shift = TASK_SHIFT;
   // 128-entry tasks halve the partials the combine step has to add, and pay once the launch is many rounds of waves deep even
   // so: measured (6 / 7) 2^24 21.40 / 21.00 ms (combine 0.71 -> 0.27), but 2^22 6.00 / 6.07 and 2^20 1.72 / 1.85 (too few tasks).
+  // Round 3 (W = 13): 2^22 4.78 / 4.89, 2^23 9.24 / 9.02, 2^24 17.99 / 17.70 ms -- the switch sits between 2^22 and 2^23 points.
   static const int knob = [] { const char* e = getenv("ZKHIP_TASK_SHIFT"); return e ? atoi(e) : 0; }();
   if (knob >= 2 && knob <= 7) task_shift = (uint32_t)knob;
-  else if ((entries >> 7) >= ((size_t)1 << 20)) task_shift = 7;
+  else if ((entries >> 7) >= ((size_t)3 << 18)) task_shift = 7;
   if ((entries >> TASK_SHIFT) < ((size_t)1 << 17)) {
     const double occ = (double)entries / (double)NB;
     double best = 1e300;
@@ -1621,7 +1622,8 @@ int msm_build_tasks(const uint32_t* d_scalars, size_t n_in, size_t batch, size_t
   else hipLaunchKernelGGL(k_sort_pass<true>, dim3(chunks, W, K), dim3(1024), lds, stream, (const int16_t*)digits, n_pad, chunk, c, cursor, sorted, wb_stride, ref_base, ref_stride);
   prof_mark(stream, "scatter");
   // 5. tasks
-  const unsigned task_blocks = (unsigned)std::min<size_t>((NB + 255) / 256, 256);
+  static const unsigned task_wg_cap = getenv("ZKHIP_TASK_WGS") ? (unsigned)atoi(getenv("ZKHIP_TASK_WGS")) : 256u;      // A/B knob
+  const unsigned task_blocks = (unsigned)std::min<size_t>((NB + 255) / 256, task_wg_cap);
   if (scan_single) {
     hipLaunchKernelGGL(k_scan_single<1>, dim3(1), dim3(1024), 0, stream, count, (uint32_t)NB, counters + 1, task_off, (uint32_t*)nullptr, task_shift, counters + 192);
     hipLaunchKernelGGL(k_make_tasks, dim3(task_blocks), dim3(256), 0, stream, offset, task_off, NB, tasks, task_shift, counters + 2, (uint32_t*)nullptr, lay.seq_parts,
