@@ -543,6 +543,29 @@ def test_row_a7_vs_reference_algorithm(cref, n):
     assert np.array_equal(A.eval_polynomial(z, x), np.zeros(4, dtype=np.uint64))
 
 
+@pytest.mark.parametrize("n", [4 * 65536 - 1, 4 * 65536 + 1, (1 << 19) + 3, 16 * 65536 + 7, (1 << 21) + 5])
+def test_batch_invert_at_the_chunk_length_switches(cref, n):
+    """`zkhip_fr_batch_invert` picks 4 ... 32 elements per thread from n (so that n / ch <= 65536) and inverts one chunk product per thread by
+    division steps (csrc/fe_inverse.hpp): sizes on both sides of every switch, with zeros, +-1, 2 and small values sprinkled in, against the C
+    restatement of `BatchInvert::batch_invert` (zeros stay zero) -- and x * x^-1 = 1 on a sample through Python integers."""
+    from zksnap_circuits_halo2_amd import arithmetic as A
+
+    a = cref.gen_scalars(9100 + n % 1000, n, 0)
+    rng = np.random.default_rng(n)
+    special = F.fr_encode([0, 1, F.R_MOD - 1, 2, F.R_MOD - 2, 3, (F.R_MOD + 1) // 2, 1 << 128, (1 << 253) + 12345])
+    idx = rng.integers(0, n, size=4096)
+    a[idx] = special[rng.integers(0, special.shape[0], size=idx.shape[0])]
+    a[:9] = special                                      # every special value at least once, inside one chunk
+    a[n - 1] = special[1]
+    b, ref = a.copy(), a.copy()
+    A.batch_invert(b)
+    cref.batch_invert(ref)
+    assert np.array_equal(b, ref)
+    sample = np.concatenate([np.arange(9), idx[:40], [n - 1]])
+    for x, y in zip(F.fr_decode(a[sample]), F.fr_decode(b[sample])):
+        assert (x * y) % F.R_MOD == (1 if x else 0) and (x != 0 or y == 0)
+
+
 def test_row_a7_golden_small():
     from zksnap_circuits_halo2_amd import arithmetic as A
 
