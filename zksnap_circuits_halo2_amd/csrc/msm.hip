@@ -270,7 +270,8 @@ __device__ __forceinline__ void decompose(const uint32_t (&k)[8], uint32_t (&m1)
 }  // namespace glv
 
 // digits of both halves: point i (k1, base P_i) in column i, point n + i (k2, base phi(P_i)) in column n + i of the [W][n2_pad] array
-__global__ void __launch_bounds__(256) k_digits_glv(const uint32_t* __restrict__ scalars, int16_t* __restrict__ digits, uint32_t n, uint32_t n2_pad, int c, int W) {
+template <typename DIGIT>   // int16_t; int32_t when the two-level sort takes over (msm_two_level)
+__global__ void __launch_bounds__(256) k_digits_glv(const uint32_t* __restrict__ scalars, DIGIT* __restrict__ digits, uint32_t n, uint32_t n2_pad, int c, int W) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n2_pad - 2 * n) {                         // padding columns: digit 0 = "no entry"
     for (int win = 0; win < W; win++) digits[(size_t)win * n2_pad + 2 * n + i] = 0;
@@ -290,7 +291,7 @@ __global__ void __launch_bounds__(256) k_digits_glv(const uint32_t* __restrict__
 #pragma unroll
   for (int h = 0; h < 2; h++) {
     uint32_t carry = 0;
-    int16_t* col = digits + (size_t)h * n + i;
+    DIGIT* col = digits + (size_t)h * n + i;
     for (int win = 0; win < W; win++) {
       const int bit = win * c;
       uint32_t v = 0;
@@ -305,7 +306,7 @@ __global__ void __launch_bounds__(256) k_digits_glv(const uint32_t* __restrict__
       // (at c = 16 the digit +2^15 does not exist in int16: -(-2^15) would wrap)
       int32_t d;
       if (neg[h] ? (v > half) : (v >= half)) { d = (int32_t)v - (int32_t)(1u << c); carry = 1; } else { d = (int32_t)v; carry = 0; }
-      col[(size_t)win * n2_pad] = (int16_t)(neg[h] ? -d : d);
+      col[(size_t)win * n2_pad] = (DIGIT)(neg[h] ? -d : d);
     }
   }
 }
@@ -407,7 +408,7 @@ __global__ void __launch_bounds__(1024) k_sort_pass(const int16_t* __restrict__ 
 // 0.139 vs 0.117 ms at 2^20, 1.75 vs 1.3 ms at 2^24.)
 // The group counts as a pass of their own over the stored digits: what the pipeline ran until round 3, when the counts moved into the digit
 // kernel (k_digits_wide); kept as the A/B reference (ZKHIP_NO_FUSED_COUNT=1).
-__global__ void __launch_bounds__(1024) k_coarse_count(const int32_t* __restrict__ digits, uint32_t n_pad, uint32_t chunk, uint32_t* __restrict__ gcount) {
+__global__ void __launch_bounds__(1024) k_coarse_count(const int32_t* __restrict__ digits, uint32_t n_pad, uint32_t chunk, uint32_t* __restrict__ gcount, uint32_t gstride) {
   __shared__ uint32_t cnt[MAX_GROUPS];
   const int win = blockIdx.y;
   const uint32_t lo = blockIdx.x * chunk, hi = min(n_pad, lo + chunk);   // multiples of 8
@@ -425,7 +426,7 @@ __global__ void __launch_bounds__(1024) k_coarse_count(const int32_t* __restrict
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const int32_t d = d4[k];
-        if (d != 0) atomicAdd(&cnt[((uint32_t)(d < 0 ? -d : d) - 1) >> FINE_BITS], 1u);
+        if (d != 0) atomicAdd(&cnt[(uint32_t)win * gstride + (((uint32_t)(d < 0 ? -d : d) - 1) >> FINE_BITS)], 1u);
       }
     }
   }
@@ -439,12 +440,15 @@ __global__ void __launch_bounds__(1024) k_coarse_count(const int32_t* __restrict
 constexpr uint32_t COARSE_CHUNK = 8192;
 __global__ void __launch_bounds__(1024) k_coarse_sorted(const int32_t* __restrict__ digits, uint32_t n_pad, uint32_t* __restrict__ gcursor,
                                                         uint32_t* __restrict__ stage_ref, uint16_t* __restrict__ stage_fine,
-                                                        uint32_t ref_base, uint32_t ref_stride) {
+                                                        uint32_t ref_base, uint32_t ref_stride, uint32_t gstride) {
   __shared__ uint32_t cur[MAX_GROUPS], delta[MAX_GROUPS];
   __shared__ uint32_t refs[COARSE_CHUNK];
   __shared__ uint16_t fines[COARSE_CHUNK];
   __shared__ uint32_t mask[COARSE_CHUNK / 32], wpre[COARSE_CHUNK / 32];      // run-start bits of the sorted chunk and their word prefixes
   const int win = blockIdx.y;
+  // gstride = 0: one bucket set shared by all windows (prepared tables), group = bucket >> 12.  gstride = B >> 12: a bucket set per window
+  // (general path), group = window * gstride + (bucket >> 12) -- the groups of a window are contiguous, as its buckets are
+  const uint32_t gbase = (uint32_t)win * gstride;
   const uint32_t lo = blockIdx.x * COARSE_CHUNK, hi = min(n_pad, lo + COARSE_CHUNK);   // multiples of 8
   if (lo >= hi) return;
   if (threadIdx.x < MAX_GROUPS) cur[threadIdx.x] = 0;
@@ -461,7 +465,7 @@ __global__ void __launch_bounds__(1024) k_coarse_sorted(const int32_t* __restric
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     const int32_t d = d8[k];
-    if (d != 0) atomicAdd(&cur[((uint32_t)(d < 0 ? -d : d) - 1) >> FINE_BITS], 1u);
+    if (d != 0) atomicAdd(&cur[gbase + (((uint32_t)(d < 0 ? -d : d) - 1) >> FINE_BITS)], 1u);
   }
   __syncthreads();
   if (threadIdx.x < 64) {            // one wavefront: exclusive scan of the MAX_GROUPS = 128 counts (two per lane), then the reservations
@@ -515,7 +519,7 @@ __global__ void __launch_bounds__(1024) k_coarse_sorted(const int32_t* __restric
     const int32_t d = d8[k];
     if (d != 0) {
       const uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1;
-      const uint32_t pos = atomicAdd(&cur[b >> FINE_BITS], 1u);
+      const uint32_t pos = atomicAdd(&cur[gbase + (b >> FINE_BITS)], 1u);
       refs[pos] = (rbase + (k < 4 ? vi : vj) * 4 + (k & 3)) | (d < 0 ? 0x80000000u : 0u);
       fines[pos] = (uint16_t)(b & ((1u << FINE_BITS) - 1));
     }
@@ -1460,12 +1464,25 @@ static uint32_t msm_task_shift(size_t entries /* W n K */, size_t NB) {
   return task_shift;
 }
 
+// The two-level sort (coarse groups of 4096 buckets, then bucket runs sorted inside LDS) serves the wide windows of the prepared path and, since
+// round 3, the general path's GLV MSMs at c = 16: there a window has its own 2^15 buckets = 8 groups, 8 windows = 64 groups.  The one-level
+// scatter it replaces stores every reference with its own 4-byte write (PMC: 8.7 bytes reach memory per byte of payload).
+// The same holds for prepared tables with 16-bit windows (2^16 <= n < 2^20: one shared set of 2^15 buckets = 8 groups).
+static bool msm_two_level(int c, bool glv, size_t n_in, bool shared_buckets, size_t K) {
+  if (c > 16) return true;
+  static const long thr_glv = [] { const char* e = getenv("ZKHIP_GLV_TWO_LEVEL_MIN"); return e ? atol(e) : (1L << 18); }();      // A/B knobs (0 = never)
+  static const long thr_prep = [] { const char* e = getenv("ZKHIP_PREP_TWO_LEVEL_MIN"); return e ? atol(e) : (1L << 16); }();
+  if (c != 16 || K != 1) return false;
+  if (glv) return thr_glv > 0 && n_in >= (size_t)thr_glv;
+  return shared_buckets && thr_prep > 0 && n_in >= (size_t)thr_prep;
+}
+
 // n_in: scalars per vector.  glv: the sort sees 2 n_in points (a point and its endomorphism image) and ceil(128 / c) windows.
 static msm_layout msm_lay_out(char* base, size_t n_in, size_t K, int c, bool prepared, size_t xyzz_bytes = 144, bool glv = false) {
   msm_layout L;
   const size_t n = glv ? 2 * n_in : n_in;
   const size_t W = (size_t)msm_windows(c, glv), B = (size_t)1 << (c - 1), WB = prepared ? K : W, NB = WB * B;
-  const bool wide = c > 16;
+  const bool wide = msm_two_level(c, glv, n_in, prepared, K);
   const size_t nk = n * K, entries = W * nk;
   const size_t n_pad = (n + 7) & ~(size_t)7;
   L.task_shift = msm_task_shift(entries, NB);
@@ -1522,15 +1539,16 @@ size_t msm_workspace_bytes(size_t n_one, int c, bool prepared, size_t batch, siz
 int msm_build_tasks(const uint32_t* d_scalars, size_t n_in, size_t batch, size_t scalar_stride, int c, bool shared_buckets, uint32_t ref_base, uint32_t ref_stride,
                     size_t xyzz_bytes, void* ws, size_t ws_bytes, hipStream_t stream, msm_tasks_view* out, bool glv) {
   const uint32_t K = (uint32_t)batch;
-  const bool wide = c > 16;                         // two-level bucket sort, int32 digits
+  const bool wide = msm_two_level(c, glv, n_in, shared_buckets, batch);     // two-level bucket sort, int32 digits
   const int W = msm_windows(c, glv);
-  if (glv && (K != 1 || wide || shared_buckets)) { set_error("msm: GLV digits are for one vector of the general path"); return ZKHIP_EINVAL; }
+  if (glv && (K != 1 || c > 16 || shared_buckets)) { set_error("msm: GLV digits are for one vector of the general path"); return ZKHIP_EINVAL; }
   const size_t n = glv ? 2 * n_in : n_in;           // points the sort sees
   const uint32_t B = 1u << (c - 1);
   const int WB = shared_buckets ? (int)K : W;      // number of bucket sets
   const uint32_t NB = (uint32_t)WB * B;
   if ((size_t)W * n * K >= (1ull << 32) || (size_t)WB * B >= (1ull << 31)) { set_error("msm: W*n*batch overflows 32-bit slot index"); return ZKHIP_EINVAL; }
-  if (wide && (!shared_buckets || K != 1)) { set_error("msm: windows above 16 bits need one shared bucket set"); return ZKHIP_EINVAL; }
+  if (c > 16 && (!shared_buckets || K != 1)) { set_error("msm: windows above 16 bits need one shared bucket set"); return ZKHIP_EINVAL; }
+  if (wide && !shared_buckets && (size_t)W * (B >> FINE_BITS) > (size_t)MAX_GROUPS) { set_error("msm: two-level sort: %d windows x %u groups exceed %d", W, B >> FINE_BITS, MAX_GROUPS); return ZKHIP_EINVAL; }
   if (wide && W > MAX_WIDE_W) { set_error("msm: %d windows of %d bits exceed the wide path's %d", W, c, MAX_WIDE_W); return ZKHIP_EINVAL; }
   const msm_layout lay = msm_lay_out((char*)ws, n_in, K, c, shared_buckets, xyzz_bytes, glv);
   if (ws_bytes < lay.total) { set_error("msm: workspace too small (%zu < %zu bytes)", ws_bytes, lay.total); return ZKHIP_EINVAL; }
@@ -1551,7 +1569,8 @@ int msm_build_tasks(const uint32_t* d_scalars, size_t n_in, size_t batch, size_t
   const size_t nk = n * K, max_tasks = lay.max_tasks;
   (void)nk; (void)max_tasks;
   const unsigned dblocks = (unsigned)(((size_t)K * n_pad + 255) / 256);
-  if (glv) hipLaunchKernelGGL(k_digits_glv, dim3((unsigned)((std::max<size_t>(n_in, 8) + 255) / 256)), dim3(256), 0, stream, d_scalars, (int16_t*)digits, (uint32_t)n_in, n_pad, c, W);
+  if (glv && wide) hipLaunchKernelGGL(k_digits_glv<int32_t>, dim3((unsigned)((std::max<size_t>(n_in, 8) + 255) / 256)), dim3(256), 0, stream, d_scalars, (int32_t*)digits, (uint32_t)n_in, n_pad, c, W);
+  else if (glv) hipLaunchKernelGGL(k_digits_glv<int16_t>, dim3((unsigned)((std::max<size_t>(n_in, 8) + 255) / 256)), dim3(256), 0, stream, d_scalars, (int16_t*)digits, (uint32_t)n_in, n_pad, c, W);
   else if (wide) {
     static const bool fused_count = getenv("ZKHIP_NO_FUSED_COUNT") == nullptr;      // A/B knob
     if (fused_count) {
@@ -1585,18 +1604,20 @@ int msm_build_tasks(const uint32_t* d_scalars, size_t n_in, size_t batch, size_t
     HIPCHK(hipFuncSetAttribute((const void*)k_fine_sorted, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * (1 << FINE_BITS) + SORT_CHUNK + SORT_CHUNK / 16) * 4));
     attr_set = true;
   }
-  const int G = wide ? (int)(B >> FINE_BITS) : 1;                      // coarse groups
+  const uint32_t gstride = (wide && !shared_buckets) ? (B >> FINE_BITS) : 0u;       // groups per window when every window has its own bucket set
+  const int G = wide ? (int)(gstride ? (uint32_t)W * gstride : (B >> FINE_BITS)) : 1;                      // coarse groups
   const uint32_t sort_chunk = SORT_CHUNK;
   const uint32_t sort_chunks = (uint32_t)(((size_t)W * n + sort_chunk - 1) / sort_chunk) + (uint32_t)G;     // upper bound of the fine passes' chunks; surplus workgroups return at once
   const uint32_t wb_stride = shared_buckets ? 0u : B;
   if (wide) {
     static const bool fused_count2 = getenv("ZKHIP_NO_FUSED_COUNT") == nullptr;
-    if (!fused_count2)        // (otherwise k_digits_wide has counted the groups)
-      hipLaunchKernelGGL(k_coarse_count, dim3(chunks, W), dim3(1024), 0, stream, (const int32_t*)digits, n_pad, chunk, gcounters + 1024);
+    if (!fused_count2 || glv)        // (otherwise k_digits_wide has counted the groups; the GLV digit kernel -- one scalar per thread, thousands of
+                                     // workgroups -- leaves the counting to this pass: its merges would be that many same-address atomics)
+      hipLaunchKernelGGL(k_coarse_count, dim3(chunks, W), dim3(1024), 0, stream, (const int32_t*)digits, n_pad, chunk, gcounters + 1024, gstride);
     hipLaunchKernelGGL(k_group_offsets, dim3(1), dim3(64), 0, stream, gcounters + 1024, W, G, gcounters + 128, gcounters + 3072, gcounters + 512, sort_chunk);
     static_assert(MAX_GROUPS == 128, "k_coarse_sorted scans two groups per lane of one wavefront");
     hipLaunchKernelGGL(k_coarse_sorted, dim3((n_pad + COARSE_CHUNK - 1) / COARSE_CHUNK, W), dim3(1024), 0, stream, (const int32_t*)digits, n_pad, gcounters + 3072,
-                       stage_ref, stage_fine, ref_base, ref_stride);
+                       stage_ref, stage_fine, ref_base, ref_stride, gstride);
     prof_mark(stream, "coarse");
     hipLaunchKernelGGL(k_fine_count, dim3(sort_chunks), dim3(1024), 0, stream, stage_fine, gcounters + 128, gcounters + 512, G, count, sort_chunk);
   } else {
