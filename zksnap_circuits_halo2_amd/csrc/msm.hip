@@ -396,10 +396,13 @@ __global__ void __launch_bounds__(1024) k_sort_pass(const int16_t* __restrict__ 
 
 
 // ------------------------------------------------------------------------------------------------
-// 2'/4'. wide windows (16 < c <= 21, prepared path only).  Fewer windows = fewer additions (c = 20: 13 instead of 16),
-//     but 2^(c-1) buckets no longer fit an LDS histogram.  Two levels:
-//       coarse  bucket >> 12 selects one of G = 2^(c-13) groups (128 at c = 20); a (window, chunk) workgroup counts / places its
-//               entries per group (G LDS counters, one ranged global atomic per group) into a staging array (ref u32 + fine u16);
+// 2'/4'. the two-level sort: wide windows (16 < c <= 21, prepared path only) and, since round 3, 16-bit windows with enough entries per
+//     group (msm_two_level: the general path's GLV MSMs, prepared tables of 2^16 ... 2^19 points).  Fewer windows = fewer additions
+//     (c = 20: 13 instead of 16), but 2^(c-1) buckets no longer fit an LDS histogram -- and at any window size the one-level scatter of
+//     step 4 stores every reference with its own 4-byte write.  Two levels:
+//       coarse  bucket >> 12 selects one of G = 2^(c-13) groups (128 at c = 20; with a bucket set per window: window * 8 + (bucket >> 12));
+//               a (window, chunk) workgroup counts / places its entries per group (G LDS counters, one ranged global atomic per group on
+//               the cursor of ITS window) into a staging array (ref u32 + fine u16) -- a group's region holds its windows one after the other;
 //       fine    per group, the 2^12 "fine" buckets: LDS histogram, atomics into the global counts (k_fine_count), scan, then
 //               k_fine_sorted: reservation and a counting sort of the chunk inside LDS, so that bucket runs leave as runs.
 // ------------------------------------------------------------------------------------------------
