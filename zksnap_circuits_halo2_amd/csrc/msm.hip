@@ -731,7 +731,8 @@ __global__ void __launch_bounds__(1024) k_fine_count(const uint16_t* __restrict_
 // ------------------------------------------------------------------------------------------------
 // 3. exclusive scans of the bucket counts (three small kernels).  MODE 0: identity, MODE 1: ceil(x / 2^task_shift)
 // ------------------------------------------------------------------------------------------------
-constexpr int SCAN_BLOCK = 256, SCAN_PER_THREAD = 16, SCAN_TILE = SCAN_BLOCK * SCAN_PER_THREAD;
+constexpr int SCAN_BLOCK = 256, SCAN_PER_THREAD = 4,     // (16 -> 4: 4 x the workgroups and 16-byte lane strides: scan phase 0.024 -> 0.0155 ms at 2^20)
+          SCAN_TILE = SCAN_BLOCK * SCAN_PER_THREAD;
 
 template <int MODE>
 __device__ __forceinline__ uint32_t scan_xform(uint32_t v, uint32_t task_shift) {
