@@ -21,7 +21,11 @@
 
 namespace zkhip {
 
-constexpr uint32_t POLY_CH = 32;   // elements per thread
+// elements per thread of the scans.  16, not 32 (round 3, same-box A/B in profiles/r03_batch_invert_ab.txt): 2^15 eval / kate / prefix 0.099 / 0.170 /
+// 0.111 -> 0.086 / 0.139 / 0.078 ms, 2^20 0.130 / 0.231 / 0.160 -> 0.117 / 0.196 / 0.120, 2^24 0.367 / 0.980 / 0.854 -> 0.361 / 0.942 / 0.805 (8: the large
+// sizes lose).  The batch inversion picks its own chunk length (INV_CH_MAX).
+constexpr uint32_t POLY_CH = 16;
+constexpr uint32_t INV_CH_MAX = 32;
 
 // ---- suffix Horner scan ---------------------------------------------------------------------------
 // pass A: agg[t] = sum_{i in chunk t} a[i] b^(i - lo)          (the chunk's scan value at its first element, carry-in 0)
@@ -310,7 +314,7 @@ int fr_batch_invert_device(uint32_t* d_a, size_t n, void* ws, size_t ws_bytes, h
   if (ws_bytes < poly_workspace_bytes(n)) { set_error("batch_invert: workspace too small"); return ZKHIP_EINVAL; }
   // elements per thread: 3 multiplications each + one inversion (~50 multiplications' worth since it is division steps, fe_inverse.hpp).
   // Full chunks when there are enough of them to fill the chip; shorter ones below that, where the call is the latency of one thread.
-  uint32_t ch = POLY_CH;
+  uint32_t ch = INV_CH_MAX;
   while (ch > 4 && n / ch < 65536) ch >>= 1;
   // one wavefront per workgroup: with few waves per CU, 128-thread workgroups land pairwise on the same two SIMDs (measured: 1024 waves take
   // 0.098 ms as 512 workgroups of 128 threads, 0.063 ms as 1024 of 64 or 256 of 256 -- profiles/r03_batch_invert_ab.txt)
