@@ -2183,12 +2183,16 @@ __global__ void __launch_bounds__(64) k_g1fft_store_jacobian(const uint32_t* __r
 }
 
 // XYZZ work array -> affine points, one inversion per thread chunk (as k_fixed_base_mul)
+// points per thread (one shared inversion each): 32 when there are enough points to fill the chip, fewer below that -- a commitment batch of a
+// few hundred points is then one inversion + ten multiplications deep instead of 32 x that (the inversion is ~50 multiplications' worth since
+// it is division steps, fe_inverse.hpp)
 constexpr int AFFINE_CHUNK = 32;
+static inline uint32_t affine_chunk(size_t n) { uint32_t ch = AFFINE_CHUNK; while (ch > 1 && n / ch < 65536) ch >>= 1; return ch; }
 __global__ void __launch_bounds__(64) k_xyzz_to_affine(const uint32_t* __restrict__ work, uint32_t n, uint32_t* __restrict__ out,
-                                                       uint32_t* __restrict__ tmp_pref) {
-  const uint32_t lo = (blockIdx.x * blockDim.x + threadIdx.x) * AFFINE_CHUNK;
+                                                       uint32_t* __restrict__ tmp_pref, uint32_t ch) {
+  const uint32_t lo = (blockIdx.x * blockDim.x + threadIdx.x) * ch;
   if (lo >= n) return;
-  const uint32_t cnt = min((uint32_t)AFFINE_CHUNK, n - lo);
+  const uint32_t cnt = min(ch, n - lo);
   fe pref = fe_one<Fq>();
   for (uint32_t i = 0; i < cnt; i++) {
     const xyzz Q = load_xyzz(work, lo + i);
@@ -2233,7 +2237,7 @@ int g1_batch_normalize_device(const uint32_t* d_in, size_t n, uint32_t* d_out, v
   uint32_t* work = (uint32_t*)ws;
   uint32_t* pref = (uint32_t*)((char*)ws + align_up(n * 144, 256));
   hipLaunchKernelGGL(k_jacobian_to_xyzz, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_in, (uint32_t)n, work);
-  hipLaunchKernelGGL(k_xyzz_to_affine, dim3((unsigned)(((n + AFFINE_CHUNK - 1) / AFFINE_CHUNK + 63) / 64)), dim3(64), 0, stream, work, (uint32_t)n, d_out, pref);
+  { const uint32_t ach = affine_chunk(n); hipLaunchKernelGGL(k_xyzz_to_affine, dim3((unsigned)(((n + ach - 1) / ach + 63) / 64)), dim3(64), 0, stream, work, (uint32_t)n, d_out, pref, ach); }
   HIPCHK(hipGetLastError());
   return ZKHIP_OK;
 }
@@ -2256,7 +2260,7 @@ int g1_fft_device(const uint32_t* d_in, int in_format, uint32_t* d_out, int out_
   for (uint32_t s = 1; s <= log_n; s++)
     hipLaunchKernelGGL(k_g1fft_level, dim3((unsigned)((n / 2 + 63) / 64)), dim3(64), 0, stream, work, (uint32_t)n, (int)s, (int)log_n, om);
   if (out_format == 1) hipLaunchKernelGGL(k_g1fft_store_jacobian, dim3(gb), dim3(64), 0, stream, work, (uint32_t)n, d_out);
-  else hipLaunchKernelGGL(k_xyzz_to_affine, dim3((unsigned)(((n + AFFINE_CHUNK - 1) / AFFINE_CHUNK + 63) / 64)), dim3(64), 0, stream, work, (uint32_t)n, d_out, pref);
+  else { const uint32_t ach = affine_chunk(n); hipLaunchKernelGGL(k_xyzz_to_affine, dim3((unsigned)(((n + ach - 1) / ach + 63) / 64)), dim3(64), 0, stream, work, (uint32_t)n, d_out, pref, ach); }
   HIPCHK(hipGetLastError());
   return ZKHIP_OK;
 }
