@@ -949,9 +949,21 @@ __global__ void __launch_bounds__(256) k_make_tasks(const uint32_t* __restrict__
 // Execution order of the tasks: longest first, so that the 64 tasks of a wave have equal length (a wave runs as long as its
 // longest task) and the launch tail consists of short tasks.  len_cursor[L] = first slot of length L.
 __global__ void k_order_offsets(const uint32_t* __restrict__ len_count, uint32_t* __restrict__ len_cursor) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  uint32_t run = 0;
-  for (int L = MAX_TASK_LEN; L >= 1; L--) { len_cursor[L] = run; run += len_count[L]; }
+  // one wavefront: lengths MAX_TASK_LEN - 2 lane and MAX_TASK_LEN - 2 lane - 1 per lane, an exclusive scan by shuffles (longest first).  (The
+  // single-thread loop this replaces was 128 dependent loads and stores: 5 us.)
+  static_assert(MAX_TASK_LEN == 128, "two lengths per lane of one wavefront");
+  if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+  const int lane = threadIdx.x, L0 = MAX_TASK_LEN - 2 * lane, L1 = L0 - 1;         // L0 = 128 ... 2, L1 = 127 ... 1
+  const uint32_t c0 = len_count[L0], c1 = len_count[L1];
+  uint32_t x = c0 + c1;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t y = __shfl_up(x, off, 64);
+    if (lane >= off) x += y;
+  }
+  const uint32_t ex = x - (c0 + c1);
+  len_cursor[L0] = ex;
+  len_cursor[L1] = ex + c0;
 }
 
 // Within the class of full-length tasks the order is j-major per workgroup (j = the task's index inside its
