@@ -614,9 +614,29 @@ def extras(lib, _lib, F, torch, dev, stream) -> dict:
         sc2 = sc.clone()       # the MSMs read a copy: the transforms run in place on `sc`
         ms_msm_beside_ntt = timed(replay3, 2)
         del sc2
+        # the same mix with the 13 extended transforms issued the way the device-resident prover issues them: `coeff_to_extended` as ONE fused
+        # call (coset scale + zero padding + transform: the first pass reads n coefficients, not 4n) instead of a full in-place 2^24 transform
+        try:
+            from zksnap_circuits_halo2_amd.domain import EvaluationDomain
+            dom22 = EvaluationDomain(4, 22)
+
+            def replay4():
+                for _ in range(18):
+                    _lib.check(lib.zkhip_msm_g1_prepared_device(h22, 0, sc.data_ptr(), n, res.data_ptr(), stream))
+                for _ in range(13):
+                    _lib.check(lib.zkhip_ifft_scaled_device(sc.data_ptr(), om22i.ctypes.data, 22, div22.ctypes.data, stream))
+                for _ in range(13):
+                    _lib.check(lib.zkhip_coeff_to_extended_device(sc.data_ptr(), n, 22, ext.data_ptr(), 1 << 24, 24, 1, dom22.extended_omega.ctypes.data,
+                                                                  dom22.g_coset.ctypes.data, stream))
+                _lib.check(lib.zkhip_ifft_scaled_device(ext.data_ptr(), om24i.ctypes.data, 24, div24.ctypes.data, stream))
+
+            ms_fused_ext = timed(replay4, 2)
+        except Exception as exc:
+            ms_fused_ext = repr(exc)
     except Exception as exc:   # an extra: never fail the bench line
         ms_two_streams = repr(exc)
         ms_msm_beside_ntt = None
+        ms_fused_ext = None
     # the same 2^22 MSM under scalar distributions that real columns have: buckets that hold a large share of all entries must not
     # serialise anything (profiles/r02_scalar_distributions.txt, tools/skew_probe.py)
     try:
@@ -740,6 +760,7 @@ def extras(lib, _lib, F, torch, dev, stream) -> dict:
                              "note": "MSM+NTT portion only; the Rust host (witness, transcript) cannot run here"}
     out["wrapper_replay"]["ms_commits_on_two_streams"] = round(ms_two_streams, 2) if isinstance(ms_two_streams, float) else ms_two_streams
     out["wrapper_replay"]["ms_commits_beside_transforms"] = round(ms_msm_beside_ntt, 2) if isinstance(ms_msm_beside_ntt, float) else ms_msm_beside_ntt
+    out["wrapper_replay"]["ms_with_fused_coeff_to_extended"] = round(ms_fused_ext, 2) if isinstance(ms_fused_ext, float) else ms_fused_ext   # 13 x zkhip_coeff_to_extended_device (2^22 -> 2^24) in place of 13 full 2^24 transforms
     out["wrapper_replay"]["host_buffers_ms"] = round(ms_host, 1)              # PCIe-inclusive: never `value`
     out["wrapper_replay"]["proofs_per_s_host_buffers"] = round(1e3 / ms_host, 3)
     out["wrapper_replay"]["host_buffers_two_caller_threads_ms"] = round(ms_host2, 1)
