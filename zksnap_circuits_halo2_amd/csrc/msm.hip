@@ -37,6 +37,20 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 constexpr int FINE_BITS = 12;           // wide windows: a bucket id = (coarse group, 12-bit fine id); MAX_GROUPS = 2^(20 - 1 - 12) groups at c = 20
 constexpr int MAX_GROUPS = 128;
 constexpr int MAX_WIDE_W = 16;          // windows of the wide path (c >= 17: at most 16): the coarse groups are counted and reserved per (window, group)
+// Balanced windows of the wide prepared path.  W = ceil(256 / c) windows of c bits cover W c >= 256 bits, and with uniform widths the surplus sits
+// in the top window: at c = 20 it holds 15 bits, so its 2^20 digits fall into the lowest 2^14 buckets, which then hold ~90 entries = two tasks
+// (a combining addition each, and the longest chains of the accumulation) while every other bucket holds ~26.  Here the last `narrow` = W c - 256
+// windows are c - 1 bits wide instead (c = 20: nine windows of 20 bits, four of 19): every window fills at least half of the bucket range.  The top
+// window still ends at bit 256, two bits above any scalar, so the signed recoding never carries out of it.  Offsets: win_off(w).
+struct win_layout { int c, W, narrow; };
+__host__ __device__ __forceinline__ int win_bits(const win_layout& L, int w) { return w < L.W - L.narrow ? L.c : L.c - 1; }
+__host__ __device__ __forceinline__ int win_off(const win_layout& L, int w) { const int full = L.W - L.narrow; return w <= full ? w * L.c : full * L.c + (w - full) * (L.c - 1); }
+static int msm_narrow_windows(int c, int W) {
+  static const bool uniform = getenv("ZKHIP_UNIFORM_WINDOWS") != nullptr;      // A/B knob (read once: tables and digits of a process agree)
+  if (c <= 16 || uniform) return 0;
+  const int narrow = W * c - 256;
+  return narrow > 0 && narrow <= W ? narrow : 0;
+}
 constexpr int MAX_TASK_LEN = 128;       // tasks are 2^task_shift entries, task_shift <= 7 (length histograms hold MAX_TASK_LEN + 1 counters)
 constexpr int TASK_SHIFT = 6;           // 64 entries per accumulate task: short tasks keep the tail of the launch balanced
                                         // (measured at 2^22: 5.9 ms with 64-entry tasks, 6.9 ms with 256, 8.1 ms with 512)
@@ -99,7 +113,7 @@ __device__ __forceinline__ void store_fe9_generic(uint32_t* p, size_t idx, const
 // ------------------------------------------------------------------------------------------------
 template <typename DIGIT>   // int16_t for c <= 16, int32_t for the wide windows of the prepared path
 __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, DIGIT* __restrict__ digits,
-                                                uint32_t n, uint32_t n_pad, int c, int W, uint32_t K, size_t scalar_stride) {
+                                                uint32_t n, uint32_t n_pad, int c, int W, uint32_t K, size_t scalar_stride, int narrow) {
   // batch: K scalar vectors (vector k at scalars + k * scalar_stride elements); digits are laid out [W][K][n_pad]
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)K * n_pad) return;
@@ -118,10 +132,11 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ sca
   for (int k = 0; k < NL; k++) c32.l[k] = FrParams::FROM_EXT_CANON[k];
   fe s = fe_canon_lt2p<FrParams>(fe_mul<FrParams>(c32, fe_unpack<0>(w)));
   fe_pack(s, w);
-  const uint32_t half = 1u << (c - 1), mask = (1u << c) - 1;
+  const win_layout lay{c, W, narrow};
   uint32_t carry = 0;
   for (int win = 0; win < W; win++) {
-    int bit = win * c;
+    const int bit = win_off(lay, win), cw = win_bits(lay, win);
+    const uint32_t half = 1u << (cw - 1), mask = (1u << cw) - 1;
     uint32_t v = 0;
     if (bit < 256) {
       int wi = bit >> 5, sh = bit & 31;
@@ -131,7 +146,7 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ sca
     }
     v += carry;
     int32_t d;
-    if (v >= half) { d = (int32_t)v - (int32_t)(1u << c); carry = 1; } else { d = (int32_t)v; carry = 0; }
+    if (v >= half) { d = (int32_t)v - (int32_t)(1u << cw); carry = 1; } else { d = (int32_t)v; carry = 0; }
     digits[(size_t)win * row + i] = (DIGIT)d;
   }
 }
@@ -142,11 +157,11 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ sca
 // with one global atomic each at the end: 512 - 1024 workgroups, so at most 128 K atomics on the 128 words (the naive form -- one
 // 256-thread workgroup per 256 scalars, 0.5 M atomics -- was measured in round 1: +39 us in this kernel for the -33 us it saved).
 __global__ void __launch_bounds__(1024) k_digits_wide(const uint32_t* __restrict__ scalars, int32_t* __restrict__ digits, uint32_t n, uint32_t n_pad,
-                                                       int c, int W, uint32_t* __restrict__ gcount) {
+                                                       int c, int W, uint32_t* __restrict__ gcount, int narrow) {
   __shared__ uint32_t cnt[MAX_WIDE_W * MAX_GROUPS];          // [window][group]
   for (uint32_t t = threadIdx.x; t < (uint32_t)W * MAX_GROUPS; t += blockDim.x) cnt[t] = 0;
   __syncthreads();
-  const uint32_t half = 1u << (c - 1), mask = (1u << c) - 1;
+  const win_layout lay{c, W, narrow};
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += gridDim.x * blockDim.x) {
     if (i >= n) {                                   // padding entries: digit 0 = "no entry"
       for (int win = 0; win < W; win++) digits[(size_t)win * n_pad + i] = 0;
@@ -161,7 +176,8 @@ __global__ void __launch_bounds__(1024) k_digits_wide(const uint32_t* __restrict
     fe_pack(sv, w);
     uint32_t carry = 0;
     for (int win = 0; win < W; win++) {
-      const int bit = win * c;
+      const int bit = win_off(lay, win), cw = win_bits(lay, win);
+      const uint32_t half = 1u << (cw - 1), mask = (1u << cw) - 1;
       uint32_t v = 0;
       if (bit < 256) {
         const int wi = bit >> 5, sh = bit & 31;
@@ -171,7 +187,7 @@ __global__ void __launch_bounds__(1024) k_digits_wide(const uint32_t* __restrict
       }
       v += carry;
       int32_t d;
-      if (v >= half) { d = (int32_t)v - (int32_t)(1u << c); carry = 1; } else { d = (int32_t)v; carry = 0; }
+      if (v >= half) { d = (int32_t)v - (int32_t)(1u << cw); carry = 1; } else { d = (int32_t)v; carry = 0; }
       digits[(size_t)win * n_pad + i] = d;
       if (d != 0) atomicAdd(&cnt[win * MAX_GROUPS + (((uint32_t)(d < 0 ? -d : d) - 1) >> FINE_BITS)], 1u);
     }
@@ -1585,6 +1601,7 @@ int msm_build_tasks(const uint32_t* d_scalars, size_t n_in, size_t batch, size_t
   const size_t nk = n * K, max_tasks = lay.max_tasks;
   (void)nk; (void)max_tasks;
   const unsigned dblocks = (unsigned)(((size_t)K * n_pad + 255) / 256);
+  const int narrow = (shared_buckets && !glv) ? msm_narrow_windows(c, W) : 0;       // balanced windows of the wide prepared tables (k_build_table agrees)
   if (glv && wide) hipLaunchKernelGGL(k_digits_glv<int32_t>, dim3((unsigned)((std::max<size_t>(n_in, 8) + 255) / 256)), dim3(256), 0, stream, d_scalars, (int32_t*)digits, (uint32_t)n_in, n_pad, c, W);
   else if (glv) hipLaunchKernelGGL(k_digits_glv<int16_t>, dim3((unsigned)((std::max<size_t>(n_in, 8) + 255) / 256)), dim3(256), 0, stream, d_scalars, (int16_t*)digits, (uint32_t)n_in, n_pad, c, W);
   else if (wide) {
@@ -1595,12 +1612,12 @@ int msm_build_tasks(const uint32_t* d_scalars, size_t n_in, size_t batch, size_t
       static const unsigned wg_knob = [] { const char* e = getenv("ZKHIP_DIGIT_WGS"); const int v = e ? atoi(e) : 0; return v >= 64 && v <= 4096 ? (unsigned)v : 0u; }();   // A/B knob
       const unsigned wg_cap = wg_knob ? wg_knob : (n_pad > (1u << 21) ? 1024u : 512u);
       const unsigned wblocks = (unsigned)std::min<size_t>(((size_t)n_pad + 1023) / 1024, wg_cap);
-      hipLaunchKernelGGL(k_digits_wide, dim3(wblocks), dim3(1024), 0, stream, d_scalars, (int32_t*)digits, (uint32_t)n, n_pad, c, W, gcounters + 1024);
+      hipLaunchKernelGGL(k_digits_wide, dim3(wblocks), dim3(1024), 0, stream, d_scalars, (int32_t*)digits, (uint32_t)n, n_pad, c, W, gcounters + 1024, narrow);
     } else {
-      hipLaunchKernelGGL(k_digits<int32_t>, dim3(dblocks), dim3(256), 0, stream, d_scalars, (int32_t*)digits, (uint32_t)n, n_pad, c, W, K, sstride);
+      hipLaunchKernelGGL(k_digits<int32_t>, dim3(dblocks), dim3(256), 0, stream, d_scalars, (int32_t*)digits, (uint32_t)n, n_pad, c, W, K, sstride, narrow);
     }
   }
-  else hipLaunchKernelGGL(k_digits<int16_t>, dim3(dblocks), dim3(256), 0, stream, d_scalars, (int16_t*)digits, (uint32_t)n, n_pad, c, W, K, sstride);
+  else hipLaunchKernelGGL(k_digits<int16_t>, dim3(dblocks), dim3(256), 0, stream, d_scalars, (int16_t*)digits, (uint32_t)n, n_pad, c, W, K, sstride, 0);
   prof_mark(stream, "digits");
   // 2. count
   uint32_t chunks = (uint32_t)((n + 65535) / 65536);
@@ -2028,7 +2045,8 @@ __device__ __forceinline__ void store_table_point(uint32_t* table, size_t idx, c
 
 __global__ void __launch_bounds__(64) k_build_table(const uint32_t* __restrict__ bases, uint32_t n, int c, int W,
                                                     uint32_t* __restrict__ table, uint32_t* __restrict__ tmp_pts,
-                                                    uint32_t* __restrict__ tmp_pref) {
+                                                    uint32_t* __restrict__ tmp_pref, int narrow) {
+  const win_layout lay{c, W, narrow};             // table[w] = 2^(win_off(w)) P: window w - 1 is win_bits(w - 1) doublings below window w
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   affine_words pt = load_affine(bases, i);
@@ -2044,7 +2062,7 @@ __global__ void __launch_bounds__(64) k_build_table(const uint32_t* __restrict__
   store_table_point(table, i, P.X, P.Y);
   fe pref = fe_one<Fq>();
   for (int w = 1; w < W; w++) {
-    for (int k = 0; k < c; k++) P = xyzz_dbl(P);
+    for (int k = 0, nd = win_bits(lay, w - 1); k < nd; k++) P = xyzz_dbl(P);
     store_xyzz(tmp_pts, (size_t)(w - 1) * n + i, P);
     store_fe9_generic(tmp_pref, (size_t)(w - 1) * n + i, pref);
     pref = fe_mul<Fq>(pref, fe_mul<Fq>(P.ZZ, P.ZZZ));     // never zero: the group has odd prime order
@@ -2074,7 +2092,7 @@ int prepare_bases_device(const uint32_t* d_bases, size_t n, hipStream_t stream, 
   if (hipMalloc(&table, tbytes) != hipSuccess) { delete pb; set_error("prepare_bases: hipMalloc(%zu) failed", tbytes); return ZKHIP_ENOMEM; }
   if (hipMalloc(&tmp, tmp_pts + tmp_pref) != hipSuccess) { (void)hipFree(table); delete pb; set_error("prepare_bases: hipMalloc(%zu) failed", tmp_pts + tmp_pref); return ZKHIP_ENOMEM; }
   hipLaunchKernelGGL(k_build_table, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_bases, (uint32_t)n, c, W, (uint32_t*)table,
-                     (uint32_t*)tmp, (uint32_t*)((char*)tmp + tmp_pts));
+                     (uint32_t*)tmp, (uint32_t*)((char*)tmp + tmp_pts), msm_narrow_windows(c, W));
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(stream);
   (void)hipFree(tmp);

@@ -50,7 +50,7 @@ int msm_build_tasks(const uint32_t* d_scalars, size_t n, size_t batch, size_t sc
 size_t msm_g2_workspace_bytes(size_t n);
 int msm_g2_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, uint32_t* d_out, void* ws, size_t ws_bytes, hipStream_t stream);
 int test_g2_op(int op, const uint32_t* d_a, const uint32_t* d_b, uint32_t* d_out, size_t n, hipStream_t stream);
-struct prepared_bases {   // table[w * n + i] = 2^(c w) * P_i, affine external format
+struct prepared_bases {   // table[w * n + i] = 2^(o_w) * P_i with o_w the bit offset of window w (c w; balanced widths above 16 bits: msm.hip win_off)
   uint32_t* table;
   size_t n;
   int c, W;
