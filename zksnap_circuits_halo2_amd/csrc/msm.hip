@@ -1483,7 +1483,7 @@ static uint32_t msm_task_shift(size_t entries /* W n K */, size_t NB) {
   // Round 3 (W = 13): 2^22 4.78 / 4.89, 2^23 9.24 / 9.02, 2^24 17.99 / 17.70 ms -- the switch sits between 2^22 and 2^23 points.
   static const int knob = [] { const char* e = getenv("ZKHIP_TASK_SHIFT"); return e ? atoi(e) : 0; }();
   if (knob >= 2 && knob <= 7) task_shift = (uint32_t)knob;
-  else if ((entries >> 7) >= ((size_t)3 << 18)) task_shift = 7;
+  else if ((entries >> 7) >= ((size_t)3 << 16)) task_shift = 7;      // (with the balanced windows: 2^21 2.397 / 2.380 ms, 2^22 4.812 / 4.815 -- from 2^21 points on)
   if ((entries >> TASK_SHIFT) < ((size_t)1 << 17)) {
     const double occ = (double)entries / (double)NB;
     double best = 1e300;
