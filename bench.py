@@ -225,7 +225,12 @@ def main() -> None:
         step()
     torch.cuda.synchronize()
     # the W warm-up steps of the contract, then untimed steps until the card has been busy for PREWARM_MS (see prewarm): W = 5 steps are 7 ms
-    extra_warm = prewarm(step, torch, 0) if os.environ.get("ZKHIP_BENCH_NO_PREWARM") != "1" else 0
+    # (the MSM alone, not step(): the count is time-based and differs from rank to rank, and step() holds a collective)
+    def msm_only():
+        _lib.check(lib.zkhip_msm_g1_prepared_device(handle, 0, d_scalars.data_ptr(), n, d_out.data_ptr(), stream))
+
+    extra_warm = prewarm(msm_only, torch, 0) if os.environ.get("ZKHIP_BENCH_NO_PREWARM") != "1" else 0
+    torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
