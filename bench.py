@@ -91,23 +91,119 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+def structured_point(lib, _lib, F, torch, d_scalars, n, t0: int, d: int, stream, dev):
+    """[sum_i a_i (t0 + i d)] G as affine Montgomery words (8 x u64) -- what an MSM of the scalars a against the walk bases (t0 + i d) G must be.
+    Computed WITHOUT the MSM kernels and without the oracle: sum a_i = p(1) (zkhip_fr_eval_polynomial_device), sum i a_i = p'(1) = q(1) for
+    q = (p - p(1)) / (X - 1) (zkhip_fr_kate_division_device + one more evaluation), the two 256-bit results combined on the host, and one
+    fixed-base multiplication of the generator (zkhip_g1_fixed_base_mul_device)."""
+    one = F.fr_encode([1])[0]
+    d_q = torch.empty(max(n - 1, 1) * 4, dtype=torch.int64, device=dev)
+    d_ev = torch.zeros(8, dtype=torch.int64, device=dev)
+    _lib.check(lib.zkhip_fr_eval_polynomial_device(d_scalars.data_ptr(), n, one.ctypes.data, d_ev.data_ptr(), stream))
+    if n > 1:
+        _lib.check(lib.zkhip_fr_kate_division_device(d_scalars.data_ptr(), n, one.ctypes.data, d_q.data_ptr(), stream))
+        _lib.check(lib.zkhip_fr_eval_polynomial_device(d_q.data_ptr(), n - 1, one.ctypes.data, d_ev.data_ptr() + 32, stream))
+    _lib.check(lib.zkhip_stream_sync(stream))
+    p1, dp1 = F.fr_decode(d_ev.cpu().numpy().view(np.uint64).reshape(2, 4))
+    k = (t0 * p1 + d * dp1) % F.R_MOD
+    d_k = torch.from_numpy(F.fr_encode([k]).view(np.int64)).to(dev)
+    d_pt = torch.zeros(8, dtype=torch.int64, device=dev)
+    _lib.check(lib.zkhip_g1_fixed_base_mul_device(d_k.data_ptr(), 1, d_pt.data_ptr(), stream))
+    _lib.check(lib.zkhip_stream_sync(stream))
+    return d_pt.cpu().numpy().view(np.uint64).copy()
+
+
+def affine_words(lib, _lib, jac_words: np.ndarray) -> np.ndarray:
+    """(m, 12) Jacobian Montgomery words -> (m, 8) affine (zkhip_g1_batch_normalize: canonical words, identity = zeros)"""
+    jac = np.ascontiguousarray(jac_words, dtype=np.uint64).reshape(-1, 12)
+    out = np.zeros((jac.shape[0], 8), dtype=np.uint64)
+    _lib.check(lib.zkhip_g1_batch_normalize(jac.ctypes.data, jac.shape[0], out.ctypes.data))
+    return out
+
+
+def verify_exchange(lib, _lib, F, torch, dist, dev, stream, cpu_group, world, d_scalars, n, t0: int, d: int, d_partial, d_gather, d_final,
+                    check_devices: bool = True) -> dict:
+    """Evidence that an N-rank line is what it says, computed after the timed region from the buffers of its last step:
+      ranks_seen      device-side all_reduce(SUM) of ones over the data-path backend (RCCL at N > 1)
+      devices         every rank's device (name, PCI bus id, uuid), gathered on the host group; two ranks on one device are refused unless
+                      ZKHIP_BENCH_ALLOW_SHARED_DEVICE=1 (rehearsals on a one-card box)
+      result_checked  every rank: its partial sum == the structured identity of ITS walk and scalars (structured_point: no MSM kernel involved);
+                      rank 0: the gathered slots hold exactly the ranks' partials (compared with what each rank reports over the host group) and
+                      the fold equals zkhip_g1_sum of the gathered partials recomputed on the host path"""
+    rank = dist.get_rank()
+    ones = torch.ones(1, dtype=torch.int64, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(ones)
+    props = torch.cuda.get_device_properties(dev)
+    me = {"rank": rank, "device_index": dev.index, "name": props.name,
+          "pci": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0)),
+          "uuid": str(getattr(props, "uuid", ""))}
+    want = structured_point(lib, _lib, F, torch, d_scalars, n, t0, d, stream, dev)
+    part = d_partial.cpu().numpy().view(np.uint64)[:12].copy()
+    me["partial_ok"] = bool(np.array_equal(affine_words(lib, _lib, part)[0], want))
+    me["partial"] = part.tolist()
+    everyone = [None] * world
+    dist.all_gather_object(everyone, me, group=cpu_group)
+    out = {"ranks_seen": int(ones.item()), "backend": dist.get_backend(),
+           "devices": [{k: e[k] for k in ("rank", "device_index", "name", "pci", "uuid")} for e in everyone]}
+    ids = [(e["pci"], e["uuid"], e["device_index"]) for e in everyone]
+    out["distinct_devices"] = len(set(ids)) == world
+    if check_devices and not out["distinct_devices"] and os.environ.get("ZKHIP_BENCH_ALLOW_SHARED_DEVICE") != "1":
+        fail(f"{world} ranks but only {len(set(ids))} distinct device(s) {sorted(set(ids))}: refusing to report an n_gpus = {world} line", 4)
+    partial_ok = all(e["partial_ok"] for e in everyone)
+    if rank == 0:
+        width = d_partial.numel()
+        gathered = d_gather.cpu().numpy().view(np.uint64).reshape(world, width)[:, :12]
+        slots_ok = all(np.array_equal(gathered[r], np.array(everyone[r]["partial"], dtype=np.uint64)) for r in range(world))
+        refold = np.zeros(12, dtype=np.uint64)
+        g = np.ascontiguousarray(gathered)
+        _lib.check(lib.zkhip_g1_sum(g.ctypes.data, world, refold.ctypes.data))
+        fold_ok = bool(np.array_equal(affine_words(lib, _lib, refold)[0], affine_words(lib, _lib, d_final.cpu().numpy().view(np.uint64)[:12])[0]))
+        out["result_checked"] = {"every_rank_partial_equals_its_structured_identity": bool(partial_ok), "gathered_slots_are_the_ranks_partials": bool(slots_ok),
+                                 "fold_equals_sum_of_gathered_partials": fold_ok, "ok": bool(partial_ok and slots_ok and fold_ok)}
+        if not out["result_checked"]["ok"]:
+            fail(f"N = {world} result check failed: {out['result_checked']}", 5)
+    return out
+
+
 def fail(msg: str, code: int = 2):
     print("bench.py: " + msg, file=sys.stderr, flush=True)
     sys.exit(code)
 
 
+def visible_gpus_without_hip():
+    """AMD GPUs this process could open, counted WITHOUT initialising the HIP / HSA runtime (the launcher parent must stay clean of it: on ROCm
+    wheels `torch.cuda.device_count()` may fall through to hipGetDeviceCount and open /dev/kfd): the KFD topology in sysfs lists one node per
+    agent, GPUs are the nodes with simd_count > 0; *_VISIBLE_DEVICES lists cap the count.  None when the topology cannot be read (the per-rank
+    check in main() still refuses a rank without its device)."""
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    if not os.path.isdir(root):
+        return 0                                      # no KFD driver: no AMD GPU
+    count = 0
+    try:
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                count += 1
+    except (OSError, ValueError):
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            count = min(count, len([x for x in v.split(",") if x.strip() != ""]))
+    return count
+
+
 def launch_ranks(args, argv) -> int:
     """`python bench.py --gpus N` outside a torchrun environment: start the N ranks ourselves (one process per GPU) and return the job's exit
-    status.  This process has not touched HIP (nothing below initialises a device; the device COUNT does not), it starts the ranks as child
+    status.  This process never touches HIP (the device count comes from sysfs, torch is not even imported), it starts the ranks as child
     processes -- never a re-exec -- and rank 0's JSON line reaches stdout through the inherited descriptor."""
     import socket
     import subprocess
 
     if not args.launcher_selftest:
-        import torch
-
-        have = torch.cuda.device_count()
-        if have < args.gpus:
+        have = visible_gpus_without_hip()
+        if have is not None and have < args.gpus:
             fail(f"--gpus {args.gpus} asked for, {have} HIP device(s) visible: refusing to run a {args.gpus}-GPU measurement on fewer GPUs", 3)
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -229,10 +325,24 @@ def main() -> None:
     def msm_only():
         _lib.check(lib.zkhip_msm_g1_prepared_device(handle, 0, d_scalars.data_ptr(), n, d_out.data_ptr(), stream))
 
-    extra_warm = prewarm(msm_only, torch, 0) if os.environ.get("ZKHIP_BENCH_NO_PREWARM") != "1" else 0
+    # (round 4, advisor) first the figure WITHOUT the pre-warm, for comparison with the lines of rounds 1-2: K steps straight after the W warm-up
+    # steps, bracketed the same way -- reported as value_cold, never as value
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_cold = time.perf_counter()
+    for _ in range(args.steps):
+        step()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
+    torch.cuda.synchronize()
+    elapsed_cold = time.perf_counter() - t_cold
+    # the rendezvous comes BEFORE the pre-warm so that no host-side idle gap separates the pre-warm from the timed region (each rank pre-warms
+    # for the same wall time, then starts its K steps; the closing barrier and the max over ranks absorb the skew)
+    if use_dist:
+        dist.barrier()
+    extra_warm = prewarm(msm_only, torch, 0) if os.environ.get("ZKHIP_BENCH_NO_PREWARM") != "1" else 0
     torch.cuda.synchronize()
     t_start = time.perf_counter()
     for _ in range(args.steps):
@@ -243,9 +353,9 @@ def main() -> None:
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, elapsed_cold], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, elapsed_cold = float(t[0].item()), float(t[1].item())
 
     ms_per_step = elapsed / args.steps * 1e3
     mpoints = world * n * args.steps / elapsed / 1e6
@@ -259,7 +369,8 @@ def main() -> None:
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "clock_prewarm": {"untimed_steps_after_the_warmup": extra_warm, "ms": PREWARM_MS,
+        "value_cold": round(world * n * args.steps / elapsed_cold / 1e6, 3),
+        "clock_prewarm": {"untimed_steps_after_the_warmup": extra_warm + args.steps, "ms": PREWARM_MS, "value_cold_is": "the K steps straight after the W warm-up steps (no pre-warm), same bracketing",
                           "why": "the card needs 30-40 ms of continuous work to reach its clocks after idling; steady-state throughput is the metric (DESIGN.md section 7)"},
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True,
@@ -273,6 +384,19 @@ def main() -> None:
                    "points_per_gpu": n, "prepare_bases_ms_one_time": round(t_prep * 1e3, 2),
                    "parallelism": f"point-range shard x{world} + all_gather(96 B) + fold"},
     }
+
+    if use_dist:
+        # the N-rank line carries its own evidence (ranks, devices, results): see verify_exchange
+        ver = verify_exchange(lib, _lib, F, torch, dist, dev, stream, cpu_group, world, d_scalars, n, 0x5A4B534E41500002 + 7919 * rank,
+                              0x9E3779B97F4A7C15F39CC0605CEDC835, d_out, d_gather, d_final)
+        result.update({k: ver[k] for k in ("ranks_seen", "devices", "distinct_devices", "result_checked") if k in ver})
+        result["exchange_backend"] = ver["backend"]
+    elif world == 1:
+        want = structured_point(lib, _lib, F, torch, d_scalars, n, 0x5A4B534E41500002, 0x9E3779B97F4A7C15F39CC0605CEDC835, stream, dev)
+        ok = bool(np.array_equal(affine_words(lib, _lib, d_out.cpu().numpy().view(np.uint64)[:12])[0], want))
+        result["result_checked"] = {"msm_equals_structured_identity": ok, "ok": ok}
+        if not ok:
+            fail("the timed MSM's result is not [sum a_i (t0 + i d)] G", 5)
 
     if rank == 0:
         # ---- roofline of the dominant kernel (bucket accumulation), HIP events on the launch stream ---------
@@ -367,7 +491,7 @@ def main() -> None:
     # N = 1: the same 2^24-point MSM through the C ABI's own multi-GPU path with 8 virtual shards of 2^21 points on the one card.
     if not args.no_extras:
         try:
-            c4 = config4_leg(lib, _lib, F, torch, dist, dev, stream, rank, world, gather_fold_device)
+            c4 = config4_leg(lib, _lib, F, torch, dist, dev, stream, rank, world, gather_fold_device, cpu_group=cpu_group)
             if rank == 0:
                 result["config4_wrapper_k24_msm"] = c4
         except Exception as exc:   # an extra: never fail the bench line
@@ -415,7 +539,7 @@ def main() -> None:
 CONFIG4_T0, CONFIG4_D = 0x5A4B534E41500002 + 424242, 0x9E3779B97F4A7C15F39CC0605CEDC835
 
 
-def config4_leg(lib, _lib, F, torch, dist, dev, stream, rank, world, gather_fold_device, debug: dict = None) -> dict:
+def config4_leg(lib, _lib, F, torch, dist, dev, stream, rank, world, gather_fold_device, debug: dict = None, cpu_group=None) -> dict:
     """BASELINE configs[4] (wrapper_circuit at bench-k + 2: one 2^24-point MSM over the node's GPUs, partial sums exchanged and folded).
     world > 1: strong-scaling leg -- rank g holds points [g n / N, (g + 1) n / N) of the 2^24 (device-resident, prepared), the step is its
     MSM + the all_gather(96 B) + fold, timed like the headline (barrier + synchronize on both sides, max over ranks).
@@ -457,11 +581,15 @@ def config4_leg(lib, _lib, F, torch, dist, dev, stream, rank, world, gather_fold
         el = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         ms = float(el.item()) / steps * 1e3
+        # every rank's partial against the identity of its slice of the walk, the gathered slots and the fold (see verify_exchange); the devices
+        # were checked by the headline leg
+        ver = verify_exchange(lib, _lib, F, torch, dist, dev, stream, cpu_group, world, sc, per, (T0 + rank * per * D) % F.R_MOD, D, part, gat, fin, check_devices=False)
         lib.zkhip_release_bases(h)
         if debug is not None:       # the rehearsal test checks the folded point against the structured identity
             debug.update(final=fin.cpu().numpy().view(np.uint64)[:12].copy(), scalars=h_sc, t0=(T0 + rank * per * D) % F.R_MOD, d=D)
         return {"workload": f"BASELINE configs[4]: 2^24-point MSM, 2^{per.bit_length() - 1} points per GPU x {world} GPUs, all_gather(96 B) + fold, device-resident",
-                "scaling": "strong", "ms_per_msm": round(ms, 4), "Mpoints_per_s": round(total / ms / 1e3, 1), "steps": steps}
+                "scaling": "strong", "ms_per_msm": round(ms, 4), "Mpoints_per_s": round(total / ms / 1e3, 1), "steps": steps,
+                "ranks_seen": ver["ranks_seen"], "result_checked": ver.get("result_checked")}
     # one card: 8 virtual shards through the C ABI
     return c_abi_config4(lib, _lib, F, torch, dev, stream, devices=[dev.index or 0], shards=8)
 

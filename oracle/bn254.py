@@ -567,6 +567,29 @@ def permute_expression_pair(input_expression: Sequence[int], table_expression: S
     return permuted_input, permuted_table
 
 
+def permute_expression_pair_np(input_values, table_values, usable_rows: int):
+    """The same statement sequence for values below 2^63 (range-check lookups: inputs below 2^lookup_bits, table = the range), vectorised
+    with numpy so that the wrapper's size (2^22 rows, /root/reference/aggregator/benches/wrapper_circuit.rs:21,66) is checked in seconds:
+    sorted input; the first row of every run takes its own value out of the table's multiset; the leftovers, ascending, go to the repeated
+    rows from the LAST one backwards (BTreeMap iteration + Vec::pop).  tests/test_oracle.py pins it to permute_expression_pair above."""
+    import numpy as np
+
+    pin = np.sort(np.asarray(input_values[:usable_rows], dtype=np.int64))
+    ts = np.sort(np.asarray(table_values[:usable_rows], dtype=np.int64))
+    first = np.ones(usable_rows, dtype=bool)
+    first[1:] = pin[1:] != pin[:-1]
+    distinct = pin[first]
+    at = np.searchsorted(ts, distinct, side="left")              # first instance of every distinct input value in the sorted table
+    if np.any(at >= usable_rows) or np.any(ts[np.minimum(at, usable_rows - 1)] != distinct):
+        raise ValueError("ConstraintSystemFailure: lookup input value not in table")
+    keep = np.ones(usable_rows, dtype=bool)
+    keep[at] = False
+    ptab = np.empty(usable_rows, dtype=np.int64)
+    ptab[first] = distinct
+    ptab[~first] = ts[keep][::-1]                                 # ascending leftovers, handed out from the last repeated row backwards
+    return pin, ptab
+
+
 # ----------------------------------------------------------------------------------------------
 # SURVEY.md section 8(f) row 1: the quotient numerator ([DEP] halo2-axiom plonk/evaluation.rs, reached from
 # /root/reference/aggregator/src/wrapper.rs:129).  Two independent restatements:

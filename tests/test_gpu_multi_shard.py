@@ -465,7 +465,7 @@ def _config4_worker(rank, world, port, q):
     dist.all_gather_object(parts, mine)
     exp = Cr.jac_to_affine(Cr.scalar_mul(sum(parts) % FF.R_MOD, Cr.generator()))
     got = Cr.jac_to_affine(np.ascontiguousarray(dbg["final"]))
-    q.put((rank, bool(np.array_equal(got, exp)), res["Mpoints_per_s"], res["workload"]))
+    q.put((rank, bool(np.array_equal(got, exp)), res["Mpoints_per_s"], res["workload"], res["ranks_seen"], res["result_checked"]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -495,6 +495,11 @@ def test_bench_config4_leg_four_ranks_on_one_gpu():
         assert p.exitcode == 0
     assert sorted(r[:2] for r in res) == [(r, True) for r in range(world)]
     assert "2^22 points per GPU x 4" in res[0][3]
+    # the leg's own evidence (round 4): the rank count seen by the collective, and on rank 0 the three result checks -- every rank's partial
+    # against the structured identity of its slice, the gathered slots, the fold
+    assert all(r[4] == world for r in res)
+    checked = [r[5] for r in res if r[0] == 0][0]
+    assert checked["ok"] and checked["every_rank_partial_equals_its_structured_identity"] and checked["gathered_slots_are_the_ranks_partials"] and checked["fold_equals_sum_of_gathered_partials"]
 
 
 def test_bench_multi_gpu_control_flow_on_rccl_with_one_rank():
@@ -521,3 +526,8 @@ def test_bench_multi_gpu_control_flow_on_rccl_with_one_rank():
     rec = json.loads(line)
     assert rec["rccl_rehearsal"] is True and rec["n_gpus"] == 1 and rec["value"] > 100.0
     assert "all_gather" in rec["config"]["parallelism"]
+    # the self-verification keys of an N-rank line (round 4), here with N = 1 on RCCL
+    assert rec["ranks_seen"] == 1 and rec["exchange_backend"] == "nccl" and rec["distinct_devices"] is True
+    assert len(rec["devices"]) == 1 and rec["devices"][0]["rank"] == 0 and rec["devices"][0]["name"]
+    assert rec["result_checked"]["ok"] and rec["result_checked"]["fold_equals_sum_of_gathered_partials"]
+    assert rec["value_cold"] > 100.0

@@ -250,3 +250,28 @@ def test_glv_parameters_of_the_general_path_msm():
     # floors of the APPROXIMATE quotients: c = floor(x + e) with |e| <= k / 2^257 < 1/8, so |k_i| < (1 + 1/8) (a1 + a2) -- which must leave room for the
     # signed recoding's carry in the top window when the windows cover exactly 128 bits (8-bit windows: top value <= 125, + 1 < 128)
     assert worst < (a1 + a2) * 9 // 8 + (1 << 64) < (1 << 127) - (1 << 120)
+
+
+@pytest.mark.parametrize("n,bits,seed", [(1, 3, 1), (64, 3, 2), (1000, 6, 3), (5000, 10, 4), (1 << 14, 12, 5), (3000, 40, 6)])
+def test_numpy_permute_expression_pair_is_the_statement_by_statement_one(n, bits, seed):
+    """oracle.permute_expression_pair_np (the vectorised form the 2^22-row GPU test uses) against the statement-by-statement restatement of
+    `permute_expression_pair` [DEP halo2-axiom plonk/lookup/prover.rs], incl. the missing-value error"""
+    import random
+
+    rng = random.Random(seed)
+    usable = max(1, n - 6) if n > 8 else n
+    table = [i % (1 << bits) for i in range(n)] if bits < 20 else [rng.randrange(1 << bits) for _ in range(n)]
+    inputs = [rng.choice(table[:usable]) for _ in range(n)]
+    head = table[:usable]
+    rng.shuffle(head)
+    table[:usable] = head
+    exp_in, exp_tab = O.permute_expression_pair(inputs, table, usable)
+    got_in, got_tab = O.permute_expression_pair_np(inputs, table, usable)
+    assert got_in.tolist() == exp_in and got_tab.tolist() == exp_tab
+    if n > 8:
+        bad = list(inputs)
+        bad[3] = (1 << 62) + 5
+        with pytest.raises(ValueError):
+            O.permute_expression_pair_np(bad, table, usable)
+        with pytest.raises(ValueError):
+            O.permute_expression_pair(bad, table, usable)

@@ -20,9 +20,11 @@ echo "pmc hbm done"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $O/${TAG}_pmc_sq_a -- python3 $R/tools/prof_msm.py 20 3 24 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVES -d $O/${TAG}_pmc_sq_b -- python3 $R/tools/prof_msm.py 20 3 24 > /dev/null 2>&1
 echo "pmc sq done"
-# roctx ranges of the C ABI (one per call): marker trace + kernel trace of a short MSM / NTT workload
+# roctx ranges of the C ABI (one per call; opt-in since round 4: ZKHIP_ROCTX=1): marker trace + kernel trace of a short MSM / NTT workload
+export ZKHIP_ROCTX=1
 rocprofv3 --marker-trace --kernel-trace --stats -d $O/${TAG}_marker -- python3 $R/tools/prof_msm.py 20 2 22 > $O/${TAG}_marker.log 2>&1 || true
 python3 $R/tools/marker_summary.py $O/${TAG}_marker $O/${TAG}_marker_trace.txt || true
+unset ZKHIP_ROCTX
 echo "marker done"
 cd $R
 python3 tools/summarize_prof.py stats $O/${TAG}_prof_msm $O/${TAG}_kernel_stats_bench_msm2p20.csv

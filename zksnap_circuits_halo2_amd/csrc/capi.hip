@@ -70,8 +70,10 @@ void prof_mark(hipStream_t stream, const char* name) {
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s failed: %s", #x, hipGetErrorString(e_)); return ZKHIP_EHIP; } } while (0)
 
 // roctx ranges, one per C-ABI call, so that `rocprofv3 --marker-trace --kernel-trace` attributes kernels to entry points (the tracing
-// counterpart of the reference's per-phase `start_timer!` lines).  The marker library is looked up at run time
-// (rocprofiler-sdk's roctx, else roctracer's): no link dependency, and plain no-ops where neither is installed or ZKHIP_NO_ROCTX is set.
+// counterpart of the reference's per-phase `start_timer!` lines).  OPT-IN: the ranges are live when a marker library is
+// ALREADY loaded in the process (a profiler brought it: found with RTLD_NOLOAD, nothing is loaded on the library's own initiative) or when
+// ZKHIP_ROCTX=1 asks for it (then rocprofiler-sdk's roctx, else roctracer's, is dlopen'ed); otherwise -- every production host -- the macro
+// costs one branch on a cached null pointer.  ZKHIP_NO_ROCTX=1 turns them off under a profiler too.  No link dependency either way.
 struct roctx_api {
   int (*push)(const char*) = nullptr;
   int (*pop)() = nullptr;
@@ -80,10 +82,12 @@ static const roctx_api& roctx() {
   static const roctx_api api = [] {
     roctx_api a;
     if (getenv("ZKHIP_NO_ROCTX")) return a;
-    void* h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_LAZY | RTLD_LOCAL);
-    if (!h) h = dlopen("librocprofiler-sdk-roctx.so", RTLD_LAZY | RTLD_LOCAL);
-    if (!h) h = dlopen("libroctx64.so.4", RTLD_LAZY | RTLD_LOCAL);
-    if (!h) h = dlopen("libroctx64.so", RTLD_LAZY | RTLD_LOCAL);
+    static const char* const names[] = {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"};
+    void* h = nullptr;
+    for (const char* nm : names) if (!h) h = dlopen(nm, RTLD_LAZY | RTLD_LOCAL | RTLD_NOLOAD);
+    const char* want = getenv("ZKHIP_ROCTX");
+    if (!h && want && want[0] == '1')
+      for (const char* nm : names) if (!h) h = dlopen(nm, RTLD_LAZY | RTLD_LOCAL);
     if (h) {
       a.push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
       a.pop = (int (*)())dlsym(h, "roctxRangePop");

@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <mutex>
 #include "ec_quad.hpp"
 #include "fe_inverse.hpp"
 #include "zkhip_internal.hpp"
@@ -1434,15 +1435,34 @@ int msm_pick_window(size_t n) {
 constexpr int MAX_WINDOW_PREPARED = 20;   // 2^19 buckets = 128 groups of 2^12
 
 int msm_pick_window_prepared(size_t n) {
-  // one shared bucket set: W * 10 n multiplications of accumulation + 2 * 14 * 2^(c-1) of bucket reduction.  Windows above
-  // 16 bits add a partition pass over the entries (~1 multiplication-equivalent each) and are only worth it for large n.
+  // one shared bucket set: W * 10 n multiplications of accumulation + the bucket reduction.
+  // Below 2^20 points (windows <= 16 bits): the reduction priced at 2 * 14 * 2^(c-1) multiplications; the choice was measured end to end under every
+  // window size (tools/small_window_probe.py) and is the fastest or within 1 % of it, with the one exception handled below.
+  // From 2^20 points (round 4): the reduction tail priced as MEASURED (tools/window_sweep.py, profiles/r04_window_sweep.txt; same box, alternating,
+  // c = 16 / 18 / 19 / 20 at 2^20 .. 2^23), in units of one field multiplication of the accumulation kernel (6.1 ps: 61 ps per mixed addition):
+  //   pyramid  = 0.24 ns per bucket (39 units; the single-lane levels) + 6.7 us per level (1.1 M units; c - 2 dependent quad steps)
+  //              measured 0.094 / 0.141 / 0.173 / 0.247 ms at c = 16 / 18 / 19 / 20, the fit gives 0.094 / 0.139 / 0.177 / 0.247
+  //   weighted sum + combine ~ 0.08 ms (13 M units), nearly independent of c
+  //   sort     ~ 1 unit per entry (W n entries)
+  //   accumulation per addition relative to c = 20: 1.07 (c = 16), 1.06 (c = 18), 1.13 (c = 19) -- the balanced layout of W = 14 / 15 windows
+  //              fills the lower half of the bucket range with all windows and the upper half with 4 / 1 of them (96 against 16 entries per
+  //              bucket at 2^20), which costs the task list its uniformity; measured 64.9 / 64.3 / 68.4 / 60.6 ps per addition at 2^20
+  // The tail's latency part is why wider windows lose below 2^20 points and why c = 19 never wins on uniform scalars (2^20: 1.521 vs 1.385 ms,
+  // 2^23: 9.78 vs 9.08): halving the buckets returns 0.07 ms of pyramid and costs 7.7 % + 13 % of the accumulation.
+  const bool large = n >= ((size_t)1 << 20);
   int best = 2;
   double best_cost = 1e300;
   for (int c = 2; c <= MAX_WINDOW_PREPARED; c++) {
-    double W = (256 + c - 1) / c;
-    double cost = W * 10.0 * (double)n + 28.0 * (double)(1u << (c - 1)) + (c > 16 ? W * 1.0 * (double)n : 0.0);
-    if (msm_top_window_is_degenerate(c)) continue;
-    if (c > 16 && n < ((size_t)1 << 20)) continue;   // measured (median of 60, c = 16 / c = 20): 2^20 1.83 / 1.67 ms, 2^21 3.32 / 2.95 on one box; the crossover was at 2^22 before the wide sort wrote bucket runs
+    const double W = (256 + c - 1) / c, buckets = (double)(1u << (c - 1));
+    if (msm_top_window_is_degenerate(c) && c <= 16) continue;     // (windows above 16 bits are balanced: no short top window)
+    if (c > 16 && !large) continue;   // measured (median of 60, c = 16 / c = 20): 2^20 1.83 / 1.67 ms, 2^21 3.32 / 2.95 on one box; the crossover was at 2^22 before the wide sort wrote bucket runs
+    if (c == 17) continue;            // 16 balanced windows of 16 bits in a 2^16-bucket range: c = 16 with half the buckets empty
+    double cost;
+    if (!large) cost = W * 10.0 * (double)n + 28.0 * buckets;
+    else {
+      const double eff = c == 20 ? 1.0 : (c == 19 ? 1.13 : (c == 18 ? 1.06 : 1.07));
+      cost = W * (10.0 * eff + 1.0) * (double)n + 39.0 * buckets + 1.1e6 * (double)(c - 2) + 13.0e6;
+    }
     if (cost < best_cost) { best_cost = cost; best = c; }
   }
   // small MSMs are latency-bound (their cost is the depth of the reduction tail and the task chains, which the multiplication count above
@@ -1625,18 +1645,20 @@ int msm_build_tasks(const uint32_t* d_scalars, size_t n_in, size_t batch, size_t
   if (chunks == 0) chunks = 1;
   const uint32_t chunk = (uint32_t)((((n + chunks - 1) / chunks) + 7) & ~(size_t)7);   // multiple of 8 (vector loads)
   const size_t lds = wide ? ((size_t)4 << FINE_BITS) : (size_t)B * sizeof(uint32_t);
-  // function attributes belong to the device's copy of the kernel: once per device (callers serialise the enqueue: capi.hip g_mu;
-  // the worker threads of a sharded MSM touch distinct devices)
-  static bool attr_set_dev[64] = {};
+  // function attributes belong to the device's copy of the kernel: once per device.  The enqueue for one device may come from the caller's
+  // thread (device-resident fan-out, under capi.hip's g_mu) AND from that device's worker thread (host-buffer fan-out, without it), so the
+  // one-time setup is guarded per device rather than left to the callers' serialisation.
+  static std::once_flag attr_once[64];
+  static hipError_t attr_err[64];
   int cur_dev = 0;
   HIPCHK(hipGetDevice(&cur_dev));
-  bool& attr_set = attr_set_dev[cur_dev & 63];
-  if (!attr_set) {
-    HIPCHK(hipFuncSetAttribute((const void*)k_sort_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void*)k_sort_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void*)k_fine_sorted, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * (1 << FINE_BITS) + SORT_CHUNK + SORT_CHUNK / 16) * 4));
-    attr_set = true;
-  }
+  std::call_once(attr_once[cur_dev & 63], [&] {
+    hipError_t e = hipFuncSetAttribute((const void*)k_sort_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_sort_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_fine_sorted, hipFuncAttributeMaxDynamicSharedMemorySize, (2 * (1 << FINE_BITS) + SORT_CHUNK + SORT_CHUNK / 16) * 4);
+    attr_err[cur_dev & 63] = e;
+  });
+  HIPCHK(attr_err[cur_dev & 63]);
   const uint32_t gstride = (wide && !shared_buckets) ? (B >> FINE_BITS) : 0u;       // groups per window when every window has its own bucket set
   const int G = wide ? (int)(gstride ? (uint32_t)W * gstride : (B >> FINE_BITS)) : 1;                      // coarse groups
   const uint32_t sort_chunk = SORT_CHUNK;
@@ -1676,7 +1698,7 @@ int msm_build_tasks(const uint32_t* d_scalars, size_t n_in, size_t batch, size_t
   else hipLaunchKernelGGL(k_sort_pass<true>, dim3(chunks, W, K), dim3(1024), lds, stream, (const int16_t*)digits, n_pad, chunk, c, cursor, sorted, wb_stride, ref_base, ref_stride);
   prof_mark(stream, "scatter");
   // 5. tasks
-  static const unsigned task_wg_cap = getenv("ZKHIP_TASK_WGS") ? (unsigned)atoi(getenv("ZKHIP_TASK_WGS")) : 256u;      // A/B knob
+  static const unsigned task_wg_cap = [] { const char* e = getenv("ZKHIP_TASK_WGS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 4096 ? (unsigned)v : 256u; }();   // A/B knob (anything else: the default)
   const unsigned task_blocks = (unsigned)std::min<size_t>((NB + 255) / 256, task_wg_cap);
   if (scan_single) {
     hipLaunchKernelGGL(k_scan_single<1>, dim3(1), dim3(1024), 0, stream, count, (uint32_t)NB, counters + 1, task_off, (uint32_t*)nullptr, task_shift, counters + 192);
