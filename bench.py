@@ -456,15 +456,22 @@ def main() -> None:
         t_acc = acc.get("accumulate", float("nan"))
         alg_bytes = 96.0 * n                                       # 64 B affine base + 32 B scalar per point
         achieved = alg_bytes / (t_acc * 1e-3) / 1e9
-        traffic, traffic_source = None, None
+        traffic, traffic_source, whole_msm_traffic = None, None, None
         try:   # PMC-measured HBM bytes of this kernel at this size: NOT measured by this run -- collected in separate rocprofv3 --pmc passes of
                # this same command (tools/collect_profiles.sh) and committed; the file names the commit it was collected at
             if args.log_n == 20:
-                for cand in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+                for cand in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
                     path = os.path.join(ROOT, "profiles", cand)
                     if os.path.exists(path):
                         rec = json.load(open(path))
                         traffic = rec["k_accumulate"]["hbm_bytes_per_launch"]
+                        whole = rec.get("whole_msm")      # round 4: every kernel of the MSM, launches per MSM x bytes per launch, summed
+                        if whole:
+                            whole_msm_traffic = {"hbm_bytes_raw_fetch": whole["hbm_bytes_raw_fetch"], "hbm_bytes_x2_fetch": whole["hbm_bytes_x2_fetch"],
+                                                 "over_algorithmic_raw": round(whole["hbm_bytes_raw_fetch"] / (96.0 * n), 2),
+                                                 "per_kernel_x2": {k.replace("zkhip::", ""): v["hbm_bytes_per_msm_x2_fetch"] for k, v in rec.get("kernels_per_msm", {}).items()
+                                                                   if v["hbm_bytes_per_msm_x2_fetch"] >= 1 << 20},
+                                                 "source": f"profiles/{cand} (same passes as `traffic`)"}
                         traffic_source = f"profiles/{cand}@{rec.get('commit', 'round-1 head')} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch -- the x2 is the guide's gfx950 correction for coalesced streams, an assumption for 64-byte gathers: the file also holds the raw counter; a committed constant, not a live counter)"
                         break
         except Exception:
@@ -474,6 +481,7 @@ def main() -> None:
                               "avg_launch_ms": round(t_acc, 4), "avg_launch_how": "median of 8 launches by in-library HIP events on the launch stream",
                               "algorithmic_bytes_per_launch": alg_bytes,
                               "whole_msm_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / 8000.0, 5),
+                              "whole_msm_traffic": whole_msm_traffic,
                               "note": "256-bit modular-integer work: ALU-bound, not HBM-bound (DESIGN.md)"}
         # issue-rate view of the same kernel: 8M + 2S mixed addition with Y3's two products under one reduction
         # = 6*162 + (2*81 + 81) + 2*126 = 1467 v_mad_u64_u32 (ISA count of the loop body),
@@ -696,12 +704,25 @@ def extras(lib, _lib, F, torch, dev, stream) -> dict:
     # roofline object of the NTT's kernel (64 B per element per transform, one 32-byte read and one 32-byte write;
     # a pass moves N x 32 B in and N x 32 B out, PMC-confirmed, so a transform of p passes has p x 64 B per element of traffic)
     p24 = ntt["2^24"]["passes_ms"]
+    ntt_traffic, ntt_traffic_source = None, None
+    try:   # PMC bytes per k_ntt_pass launch at 2^24: separate rocprofv3 --pmc passes (tools/collect_profiles.sh), a committed constant like roofline.traffic
+        path = os.path.join(ROOT, "profiles", "r04_pmc_traffic_ntt.json")
+        if os.path.exists(path):
+            rec = json.load(open(path))
+            rows = [v for k_, v in rec["ntt"]["2^24"].items() if "k_ntt_pass" in k_]
+            if rows:
+                tot_d = sum(v["dispatches"] for v in rows)
+                ntt_traffic = round(sum(v["hbm_bytes_per_launch"] * v["dispatches"] for v in rows) / tot_d)
+                ntt_traffic_source = f"profiles/r04_pmc_traffic_ntt.json@{rec.get('commit', '?')}: average over the k_ntt_pass launches of the 2^24 transform (FETCH_SIZE x2 + WRITE_SIZE)"
+    except Exception:
+        ntt_traffic, ntt_traffic_source = None, None
     if p24:
         avg_pass = sum(p24.values()) / len(p24)
         out["roofline_ntt"] = {"bound": "hbm", "kernel": "k_ntt_pass", "workload": "NTT 2^24 (three passes)", "avg_pass_ms": round(avg_pass, 4),
                                "algorithmic_bytes_per_launch": 64.0 * (1 << 24), "achieved": round(64.0 * (1 << 24) / (avg_pass * 1e-3) / 1e9, 1),
                                "peak": 8000.0, "unit": "GB/s", "frac": round(64.0 * (1 << 24) / (avg_pass * 1e-3) / 1e9 / 8000.0, 4),
                                "whole_transform_frac": ntt["2^24"]["hbm_frac_algorithmic"],
+                               "traffic": ntt_traffic, "traffic_source": ntt_traffic_source,
                                "note": "per launch = one pass over the 2^24 elements (N x 32 B read + N x 32 B written); the kernel is bound by VALU issue (254-bit modular multiplies), DESIGN.md section 4"}
 
     k = 22

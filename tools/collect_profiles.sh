@@ -4,7 +4,7 @@
 # rocprofv3 passes: kernel stats of the bench command, kernel stats of the full bench, FETCH_SIZE / WRITE_SIZE (separate passes),
 # SQ issue/wait counters of the MSM + NTT workload (separate passes, --kernel-trace only).
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
@@ -17,6 +17,12 @@ echo "stats full done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/${TAG}_pmc_fetch -- $BENCH_PMC > $O/${TAG}_pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/${TAG}_pmc_write -- $BENCH_PMC > $O/${TAG}_pmc_write.log 2>&1
 echo "pmc hbm done"
+# NTT passes (round 4): FETCH / WRITE per k_ntt_pass launch at 2^22 and 2^24, one size per pass so that the per-kernel averages are per size
+for L in 22 24; do
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/${TAG}_pmc_ntt${L}_fetch -- python3 $R/tools/ntt_prof.py $L > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/${TAG}_pmc_ntt${L}_write -- python3 $R/tools/ntt_prof.py $L > /dev/null 2>&1
+done
+echo "pmc ntt done"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $O/${TAG}_pmc_sq_a -- python3 $R/tools/prof_msm.py 20 3 24 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVES -d $O/${TAG}_pmc_sq_b -- python3 $R/tools/prof_msm.py 20 3 24 > /dev/null 2>&1
 echo "pmc sq done"
@@ -30,6 +36,8 @@ cd $R
 python3 tools/summarize_prof.py stats $O/${TAG}_prof_msm $O/${TAG}_kernel_stats_bench_msm2p20.csv
 python3 tools/summarize_prof.py stats $O/${TAG}_prof_full $O/${TAG}_kernel_stats_bench_full.csv
 python3 tools/summarize_prof.py pmc $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write $O/${TAG}_pmc_hbm_bytes_bench.txt $O/${TAG}_pmc_traffic.json
+python3 tools/summarize_prof.py pmc_ntt $O/${TAG}_pmc_traffic_ntt.json 22 $O/${TAG}_pmc_ntt22_fetch $O/${TAG}_pmc_ntt22_write 24 $O/${TAG}_pmc_ntt24_fetch $O/${TAG}_pmc_ntt24_write
 python3 tools/summarize_prof.py sq $O/${TAG}_pmc_sq_a $O/${TAG}_pmc_sq_b $O/${TAG}_pmc_sq_issue.txt
+rm -rf $O/${TAG}_pmc_ntt22_fetch $O/${TAG}_pmc_ntt22_write $O/${TAG}_pmc_ntt24_fetch $O/${TAG}_pmc_ntt24_write
 rm -rf $O/${TAG}_prof_msm $O/${TAG}_prof_full $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write $O/${TAG}_pmc_sq_a $O/${TAG}_pmc_sq_b $O/${TAG}_marker
 echo "summaries written"

@@ -132,10 +132,16 @@ struct scratch {       // one user at a time: the calls of one stream
   void release() { ws.release(); scalars.release(); bases.release(); poly.release(); poly2.release(); small.release(); ntt_tmp.release(); vm.release(); gather.release(); vm_stage.release(); }
 };
 
+constexpr int STREAM_PIECES_MAX = 64;      // pieces of one chunked host-buffer MSM
 struct lane {          // host-buffer calls: a library-owned stream + (through the stream) a scratch set + a pinned result buffer
   hipStream_t stream = nullptr;
   void* pinned = nullptr;              // LANE_PINNED bytes, hipHostMalloc
   bool busy = false;
+  // chunked host-buffer MSM (msm_shard_enqueue): the scalar pieces cross PCIe on `copy` while the pieces before them are sorted and
+  // accumulated on `stream`; one event per piece in flight.  Created on first use.
+  hipStream_t copy = nullptr;
+  hipEvent_t copied[STREAM_PIECES_MAX] = {};
+  hipEvent_t drained = nullptr;        // recorded on `stream` before a chunked MSM's first upload: the scalar buffer's previous readers are done
 };
 constexpr size_t LANE_PINNED = 64 * 1024;
 constexpr size_t MAX_STREAM_SCRATCH = 8;   // scratch sets kept per device (least recently used caller streams are dropped beyond that)
@@ -351,6 +357,9 @@ static void destroy_device_ctx(device_ctx* d) {
   for (auto& L : d->lanes) {
     if (L.pinned) (void)hipHostFree(L.pinned);
     if (L.stream) (void)hipStreamDestroy(L.stream);
+    if (L.copy) (void)hipStreamDestroy(L.copy);
+    for (auto& e : L.copied) if (e) (void)hipEventDestroy(e);
+    if (L.drained) (void)hipEventDestroy(L.drained);
   }
   for (auto e : d->shard_events) (void)hipEventDestroy(e);
   if (d->side_fork) (void)hipEventDestroy(d->side_fork);
@@ -518,10 +527,52 @@ namespace zkhip {
 // One shard's share of a host-buffer MSM on device `d` (current device = d.device, stream / scratch of its lane 0 or the borrowed
 // lane): uploads the scalar slice (and the base slice when there is no prepared table), runs the MSM, leaves the 96-byte partial at
 // d_partial (memory of device d).
+// Chunked upload (round 4).  A host-buffer MSM used to upload all its scalars with one copy and only then start its first kernel (2^22 points:
+// 2.4 ms of PCIe + 4.9 ms of kernels, nothing overlapped).  With a prepared table of wide windows and at least two pieces of 2^20 scalars the
+// upload is cut into J even pieces on the lane's copy stream; piece j is sorted and accumulated into the shared bucket set (msm.hip:
+// msm_chunk_add) while piece j + 1 crosses PCIe, and one reduction tail ends the call.  Only the first piece's upload is exposed.
+// ZKHIP_STREAM_PIECE_LOG: log2 of the target piece size (default 20; 0 = never chunk).
+static size_t msm_stream_pieces(size_t n, const prepared_bases* pb) {
+  static const int piece_log = [] { const char* e = getenv("ZKHIP_STREAM_PIECE_LOG"); const int v = e ? atoi(e) : 20; return (v == 0 || (v >= 16 && v <= 26)) ? v : 20; }();
+  if (!pb || pb->c <= 16 || piece_log == 0) return 1;
+  const size_t J = n >> piece_log;
+  return J < 2 ? 1 : std::min<size_t>(J, (size_t)STREAM_PIECES_MAX);
+}
+
+static int msm_shard_enqueue_chunked(lane* L, scratch* sc, hipStream_t s, const uint64_t* scalars, size_t n, const prepared_bases* pb, size_t pb_off,
+                                     uint32_t* d_partial, size_t J) {
+  int rc;
+  if (!L->copy) HIPCHK(hipStreamCreateWithFlags(&L->copy, hipStreamNonBlocking));
+  if (!L->drained) HIPCHK(hipEventCreateWithFlags(&L->drained, hipEventDisableTiming));
+  const size_t cap = (n + J - 1) / J;
+  const size_t ws_bytes = msm_chunk_workspace_bytes(cap, pb->c);
+  if ((rc = sc->scalars.reserve(n * 32)) != ZKHIP_OK) return rc;
+  if ((rc = sc->ws.reserve(ws_bytes)) != ZKHIP_OK) return rc;
+  // the uploads overwrite the lane's scalar buffer: an earlier piece of the same call (virtual shards run back to back on this lane) may still
+  // be reading it on `s`
+  HIPCHK(hipEventRecord(L->drained, s));
+  HIPCHK(hipStreamWaitEvent(L->copy, L->drained, 0));
+  size_t lo = 0;
+  for (size_t j = 0; j < J; j++) {
+    const size_t len = n / J + (j < n % J ? 1 : 0);          // cap or cap - 1
+    if (!L->copied[j]) HIPCHK(hipEventCreateWithFlags(&L->copied[j], hipEventDisableTiming));
+    HIPCHK(hipMemcpyAsync((char*)sc->scalars.p + lo * 32, scalars + lo * 4, len * 32, hipMemcpyHostToDevice, L->copy));
+    HIPCHK(hipEventRecord(L->copied[j], L->copy));
+    HIPCHK(hipStreamWaitEvent(s, L->copied[j], 0));
+    if ((rc = msm_chunk_add((const uint32_t*)((char*)sc->scalars.p + lo * 32), len, pb, pb_off + lo, cap, j == 0, sc->ws.p, sc->ws.cap, s)) != ZKHIP_OK) return rc;
+    lo += len;
+  }
+  return msm_chunk_finish(pb, cap, d_partial, sc->ws.p, sc->ws.cap, s);
+}
+
 static int msm_shard_enqueue(scratch* sc, hipStream_t s, const uint64_t* scalars, const uint64_t* bases, size_t n, const prepared_bases* pb,
-                             size_t pb_off, uint32_t* d_partial) {
+                             size_t pb_off, uint32_t* d_partial, lane* L = nullptr) {
   int rc;
   if (n == 0) return msm_g1_device(nullptr, nullptr, 0, d_partial, nullptr, 0, 0, s);
+  if (L) {
+    const size_t J = msm_stream_pieces(n, pb);
+    if (J > 1) return msm_shard_enqueue_chunked(L, sc, s, scalars, n, pb, pb_off, d_partial, J);
+  }
   if ((rc = sc->scalars.reserve(n * 32)) != ZKHIP_OK) return rc;
   HIPCHK(hipMemcpyAsync(sc->scalars.p, scalars, n * 32, hipMemcpyHostToDevice, s));
   if (pb) {
@@ -546,7 +597,9 @@ static int reserve_for_pieces(scratch* sc, const std::vector<piece_t>& pieces, c
     if (p.n == 0) continue;
     sc_bytes = std::max(sc_bytes, p.n * 32);
     if (!p.pb) bs_bytes = std::max(bs_bytes, p.n * 64);
-    ws_bytes = std::max(ws_bytes, p.pb ? msm_workspace_bytes(p.n, p.pb->c, true) : msm_workspace_bytes(p.n, msm_pick_window(p.n)));
+    const size_t J = msm_stream_pieces(p.n, p.pb);
+    if (J > 1) ws_bytes = std::max(ws_bytes, msm_chunk_workspace_bytes((p.n + J - 1) / J, p.pb->c));
+    else ws_bytes = std::max(ws_bytes, p.pb ? msm_workspace_bytes(p.n, p.pb->c, true) : msm_workspace_bytes(p.n, msm_pick_window(p.n)));
   }
   int rc;
   if ((rc = sc->scalars.reserve(sc_bytes)) != ZKHIP_OK) return rc;
@@ -580,7 +633,7 @@ static int host_msm(lane_hold& H, const uint64_t* scalars, const uint64_t* bases
   if ((rc = sc->small.reserve(4096)) != ZKHIP_OK) return rc;
   if (pieces.size() == 1 && pieces[0].dev == 0) {
     const piece_t& p = pieces[0];
-    if ((rc = msm_shard_enqueue(sc, s, scalars + p.lo * 4, bases + p.lo * 8, p.n, p.pb, p.pb_off, (uint32_t*)sc->small.p)) != ZKHIP_OK) return rc;
+    if ((rc = msm_shard_enqueue(sc, s, scalars + p.lo * 4, bases + p.lo * 8, p.n, p.pb, p.pb_off, (uint32_t*)sc->small.p, H.L)) != ZKHIP_OK) return rc;
   } else {
     // fan out: the primary device's pieces run on this thread's lane, one after another (virtual shards) -- the other devices'
     // pieces on their worker threads, each device over its own PCIe link
@@ -610,7 +663,7 @@ static int host_msm(lane_hold& H, const uint64_t* scalars, const uint64_t* bases
         for (size_t k = 0; k < mine.size(); k++) {
           const piece_t& p = pieces[mine[k]];
           uint32_t* part = (uint32_t*)((char*)dsc->small.p + 4096 + k * 96);
-          if ((r = msm_shard_enqueue(dsc, ds, scalars + p.lo * 4, bases + p.lo * 8, p.n, p.pb, p.pb_off, part)) != ZKHIP_OK) return r;
+          if ((r = msm_shard_enqueue(dsc, ds, scalars + p.lo * 4, bases + p.lo * 8, p.n, p.pb, p.pb_off, part, &D->lanes[0])) != ZKHIP_OK) return r;
           HIPCHK(hipMemcpyPeerAsync(gather + mine[k] * 24, primary_dev, part, D->device, 96, ds));
         }
         HIPCHK(hipStreamSynchronize(ds));                 // the partials have landed on the primary device
@@ -620,7 +673,7 @@ static int host_msm(lane_hold& H, const uint64_t* scalars, const uint64_t* bases
     int rc_local = ZKHIP_OK;
     for (size_t i : by_dev[0]) {
       const piece_t& p = pieces[i];
-      if ((rc_local = msm_shard_enqueue(sc, s, scalars + p.lo * 4, bases + p.lo * 8, p.n, p.pb, p.pb_off, gather + i * 24)) != ZKHIP_OK) break;
+      if ((rc_local = msm_shard_enqueue(sc, s, scalars + p.lo * 4, bases + p.lo * 8, p.n, p.pb, p.pb_off, gather + i * 24, H.L)) != ZKHIP_OK) break;
     }
     int rc_remote = ZKHIP_OK;
     for (size_t d = 1; d < g_ctx.devs.size(); d++) {

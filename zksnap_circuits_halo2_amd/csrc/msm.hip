@@ -1721,6 +1721,85 @@ int msm_build_tasks(const uint32_t* d_scalars, size_t n_in, size_t batch, size_t
   return ZKHIP_OK;
 }
 
+// Steps 6 - 7 for one task list: bucket accumulation + per-bucket combine; leaves the dense bucket array (NB XYZZ points, empty buckets = identity)
+// at `buckets`.  d_bases: the caller's points or the prepared table.
+static int msm_accumulate_combine(const msm_tasks_view& tv, const uint32_t* d_bases, bool prepared, bool glv, size_t n, uint32_t* buckets, hipStream_t stream) {
+  const uint32_t NB = tv.NB;
+  const size_t max_tasks = tv.max_tasks;
+  const task_t* const tasks = (const task_t*)tv.tasks;
+  uint32_t* const counters = tv.ntasks - 1;
+  const uint4* const order = tv.order;
+  const uint32_t *const sorted = tv.sorted, *const task_off = tv.task_off;
+  uint32_t* const partials = tv.partials;
+  // 6. accumulate (grid-stride over the device-side task count)
+  {
+    uint32_t blocks = (uint32_t)((max_tasks + 127) / 128);
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    if (prepared) hipLaunchKernelGGL(k_accumulate<true>, dim3(blocks), dim3(128), 0, stream, tasks, counters + 1, order, sorted, d_bases, partials, buckets, (const uint32_t*)nullptr, 0xffffffffu);
+    else hipLaunchKernelGGL(k_accumulate<false>, dim3(blocks), dim3(128), 0, stream, tasks, counters + 1, order, sorted, d_bases, partials, buckets, (const uint32_t*)tv.endo,
+                            glv ? (uint32_t)n : 0xffffffffu);
+  }
+  prof_mark(stream, "accumulate");
+  // 7. combine: one launch (per-bucket sums + the heavy-bucket workgroups)
+  {
+    const int combine_lanes = tv.combine_lanes;
+    const uint32_t seq_parts = tv.seq_parts;
+    const size_t lanes_total = (size_t)NB * combine_lanes;
+    const bool quad = lanes_total * 4 <= 131072;        // far below the chip's lane count: the additions' latency is the step time
+    const unsigned blocks = (unsigned)((lanes_total * (quad ? 4 : 1) + 127) / 128);
+#define ZK_LAUNCH_COMBINE(L)                                                                                                                        \
+    do {                                                                                                                                              \
+      if (quad) hipLaunchKernelGGL(k_combine_seq_quad<L>, dim3(blocks + HEAVY_WGS), dim3(128), 0, stream, task_off, NB, partials, buckets, seq_parts, blocks,   \
+                                   tv.heavy_count, (const uint2*)tv.heavy, tv.heavy_cap, tv.heavy_done);                                              \
+      else hipLaunchKernelGGL(k_combine_seq<L>, dim3(blocks + HEAVY_WGS), dim3(128), 0, stream, task_off, NB, partials, buckets, seq_parts, blocks,             \
+                              tv.heavy_count, (const uint2*)tv.heavy, tv.heavy_cap, tv.heavy_done);                                                   \
+    } while (0)
+    if (combine_lanes == 1) ZK_LAUNCH_COMBINE(1);
+    else if (combine_lanes == 2) ZK_LAUNCH_COMBINE(2);
+    else if (combine_lanes == 4) ZK_LAUNCH_COMBINE(4);
+    else ZK_LAUNCH_COMBINE(8);
+#undef ZK_LAUNCH_COMBINE
+  }
+  prof_mark(stream, "combine");
+  return ZKHIP_OK;
+}
+
+// Steps 8 - 9: dense buckets (WB sets of B, at `cur`; `nxt` = a second array of the same size, both are overwritten) -> the MSM's result(s) at d_out.
+// prepared: every bucket set's weighted sum is a result (K = WB of them); otherwise the WB window sums are folded into one.
+static int msm_reduce_buckets(int WB, uint32_t B, int c, uint32_t K, bool prepared, uint32_t* cur, uint32_t* nxt, uint32_t* winsum, uint32_t* d_out, hipStream_t stream) {
+  // 8. pyramid: buckets were written with window stride B (dense).  Steps 1 .. c-2 leave X with 2 elements.
+  uint32_t in_stride = B;
+  int nz = 0;
+  {
+    uint32_t N = B;
+    int s = 1;
+    while (N > 2) {
+      uint32_t per_win = N / 2 + (uint32_t)s * (N / 4);
+      uint32_t out_stride = per_win;
+      // below ~1/4 of the chip's lanes an addition's latency is the step time: four lanes per addition
+      if ((size_t)per_win * WB <= 65536) hipLaunchKernelGGL(k_pyramid_step_quad, dim3((4 * per_win + 127) / 128, WB), dim3(128), 0, stream, cur, nxt, N, s, in_stride, out_stride);
+      else hipLaunchKernelGGL(k_pyramid_step, dim3((per_win + 127) / 128, WB), dim3(128), 0, stream, cur, nxt, N, s, in_stride, out_stride);
+      uint32_t* t = cur; cur = nxt; nxt = t;
+      in_stride = out_stride;
+      N >>= 1;
+      s++;
+    }
+    nz = s - 1;   // number of Z rows, one element each (B == 2: none)
+  }
+  prof_mark(stream, "pyramid");
+  // 9. Horner + fold
+  if (B == 1) { set_error("msm: internal: B == 1"); return ZKHIP_EINVAL; }     // (c >= 2, so B >= 2 always)
+  const bool direct = prepared && WB <= 2048;     // the weighted-sum kernel writes the results itself (one launch less)
+  if (WB <= 2048) hipLaunchKernelGGL(k_window_horner_quad, dim3(WB), dim3(128), 0, stream, cur, in_stride, nz, winsum, direct ? d_out : (uint32_t*)nullptr);
+  else hipLaunchKernelGGL(k_window_horner, dim3((WB * 32 + 63) / 64), dim3(64), 0, stream, cur, in_stride, nz, winsum, WB);
+  prof_mark(stream, "horner");
+  if (prepared) { if (!direct) hipLaunchKernelGGL(k_store_results, dim3((K + 63) / 64), dim3(64), 0, stream, winsum, K, d_out); }   // one result per bucket set
+  else hipLaunchKernelGGL(k_fold, dim3(1), dim3(64), 0, stream, winsum, WB, c, d_out);
+  prof_mark(stream, "fold");
+  HIPCHK(hipGetLastError());
+  return ZKHIP_OK;
+}
+
 // d_scalars: n x 8 words, d_bases: n x 16 words, d_out: 24 words (device).  ws: workspace of msm_workspace_bytes.
 // prepared != nullptr: d_bases is ignored, points come from the table (window w of point i at table[w * stride + off + i]).
 // batch > 1 (prepared path, c <= 16 only): `batch` scalar vectors of n elements, vector k at d_scalars + k * scalar_stride
@@ -1750,81 +1829,57 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
                            144, ws, ws_bytes, stream, &tv, glv);
   if (rc != ZKHIP_OK) return rc;
   if (glv) hipLaunchKernelGGL(k_endo_bases, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_bases, (uint32_t)n, tv.endo);
-  const int WB = tv.WB;
-  const uint32_t B = tv.B, NB = tv.NB;
-  const size_t max_tasks = tv.max_tasks;
-  const task_t* const tasks = (const task_t*)tv.tasks;
-  uint32_t* const counters = tv.ntasks - 1;
-  const uint4* const order = tv.order;
-  const uint32_t *const sorted = tv.sorted, *const task_off = tv.task_off;
-  uint32_t *const partials = tv.partials, *const pyrA = tv.pyrA, *const pyrB = tv.pyrB, *const winsum = tv.winsum;
-  // 6. accumulate (grid-stride over the device-side task count)
-  {
-    uint32_t blocks = (uint32_t)((max_tasks + 127) / 128);
-    if (blocks > 256 * 64) blocks = 256 * 64;
-    if (prepared) hipLaunchKernelGGL(k_accumulate<true>, dim3(blocks), dim3(128), 0, stream, tasks, counters + 1, order, sorted, d_bases, partials, pyrA, (const uint32_t*)nullptr, 0xffffffffu);
-    else hipLaunchKernelGGL(k_accumulate<false>, dim3(blocks), dim3(128), 0, stream, tasks, counters + 1, order, sorted, d_bases, partials, pyrA, (const uint32_t*)tv.endo,
-                            glv ? (uint32_t)n : 0xffffffffu);
-  }
-  prof_mark(stream, "accumulate");
-  // 7. combine: one launch (per-bucket sums + the heavy-bucket workgroups)
-  {
-    const int combine_lanes = tv.combine_lanes;
-    const uint32_t seq_parts = tv.seq_parts;
-    const size_t lanes_total = (size_t)NB * combine_lanes;
-    const bool quad = lanes_total * 4 <= 131072;        // far below the chip's lane count: the additions' latency is the step time
-    const unsigned blocks = (unsigned)((lanes_total * (quad ? 4 : 1) + 127) / 128);
-#define ZK_LAUNCH_COMBINE(L)                                                                                                                        \
-    do {                                                                                                                                              \
-      if (quad) hipLaunchKernelGGL(k_combine_seq_quad<L>, dim3(blocks + HEAVY_WGS), dim3(128), 0, stream, task_off, NB, partials, pyrA, seq_parts, blocks,   \
-                                   tv.heavy_count, (const uint2*)tv.heavy, tv.heavy_cap, tv.heavy_done);                                              \
-      else hipLaunchKernelGGL(k_combine_seq<L>, dim3(blocks + HEAVY_WGS), dim3(128), 0, stream, task_off, NB, partials, pyrA, seq_parts, blocks,             \
-                              tv.heavy_count, (const uint2*)tv.heavy, tv.heavy_cap, tv.heavy_done);                                                   \
-    } while (0)
-    if (combine_lanes == 1) ZK_LAUNCH_COMBINE(1);
-    else if (combine_lanes == 2) ZK_LAUNCH_COMBINE(2);
-    else if (combine_lanes == 4) ZK_LAUNCH_COMBINE(4);
-    else ZK_LAUNCH_COMBINE(8);
-#undef ZK_LAUNCH_COMBINE
-  }
-  prof_mark(stream, "combine");
-  // 8. pyramid: buckets were written with window stride B (dense).  Steps 1 .. c-2 leave X with 2 elements.
-  uint32_t* cur = pyrA;
-  uint32_t* nxt = pyrB;
-  uint32_t in_stride = B;
-  int nz = 0;
-  {
-    uint32_t N = B;
-    int s = 1;
-    while (N > 2) {
-      uint32_t per_win = N / 2 + (uint32_t)s * (N / 4);
-      uint32_t out_stride = per_win;
-      // below ~1/4 of the chip's lanes an addition's latency is the step time: four lanes per addition
-      if ((size_t)per_win * WB <= 65536) hipLaunchKernelGGL(k_pyramid_step_quad, dim3((4 * per_win + 127) / 128, WB), dim3(128), 0, stream, cur, nxt, N, s, in_stride, out_stride);
-      else hipLaunchKernelGGL(k_pyramid_step, dim3((per_win + 127) / 128, WB), dim3(128), 0, stream, cur, nxt, N, s, in_stride, out_stride);
-      uint32_t* t = cur; cur = nxt; nxt = t;
-      in_stride = out_stride;
-      N >>= 1;
-      s++;
-    }
-    nz = s - 1;   // number of Z rows, one element each (B == 2: none; B == 1 handled below)
-  }
-  prof_mark(stream, "pyramid");
-  // 9. Horner + fold
-  if (B == 1) {
-    // c == 1 is excluded (c >= 2), so B >= 2 always; keep the guard for clarity
-    set_error("msm: internal: B == 1");
-    return ZKHIP_EINVAL;
-  }
-  const bool direct = prepared && WB <= 2048;     // the weighted-sum kernel writes the results itself (one launch less)
-  if (WB <= 2048) hipLaunchKernelGGL(k_window_horner_quad, dim3(WB), dim3(128), 0, stream, cur, in_stride, nz, winsum, direct ? d_out : (uint32_t*)nullptr);
-  else hipLaunchKernelGGL(k_window_horner, dim3((WB * 32 + 63) / 64), dim3(64), 0, stream, cur, in_stride, nz, winsum, WB);
-  prof_mark(stream, "horner");
-  if (prepared) { if (!direct) hipLaunchKernelGGL(k_store_results, dim3((K + 63) / 64), dim3(64), 0, stream, winsum, K, d_out); }   // one result per bucket set
-  else hipLaunchKernelGGL(k_fold, dim3(1), dim3(64), 0, stream, winsum, WB, c, d_out);
-  prof_mark(stream, "fold");
+  if ((rc = msm_accumulate_combine(tv, d_bases, prepared != nullptr, glv, n, tv.pyrA, stream)) != ZKHIP_OK) return rc;
+  return msm_reduce_buckets(tv.WB, tv.B, c, K, prepared != nullptr, tv.pyrA, tv.pyrB, tv.winsum, d_out, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Chunked prepared MSM (round 4): the scalars arrive in pieces -- a host buffer crossing PCIe chunk by chunk (capi.hip: host_msm) -- and every
+// piece is sorted and accumulated as soon as it has landed, INTO THE SAME BUCKET SET: the bucket sums of piece j are added, bucket by bucket, to
+// those of the pieces before it (a sum over points is a sum over pieces of sums), and the reduction tail runs once at the end.  Against cutting the
+// MSM into independent shards this pays one elementwise pass of 2^(c-1) general additions per extra piece (~0.05 ms at c = 20) instead of a whole
+// tail (0.34 ms), and the table, the window size and the bucket set are those of the unchunked MSM: the result is the same group element.
+//   msm_chunk_workspace_bytes(chunk, c)   workspace for pieces of at most `chunk` scalars
+//   msm_chunk_begin / msm_chunk_add (x pieces, any sizes <= chunk, in any order) / msm_chunk_finish
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(128) k_bucket_sets_add(uint32_t* __restrict__ acc, const uint32_t* __restrict__ add, uint32_t nb) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nb) return;
+  store_xyzz(acc, k, xyzz_add(load_xyzz(acc, k), load_xyzz(add, k)));
+}
+
+// bytes of the per-piece layout: pieces are chunk_cap or chunk_cap - 1 scalars (an even split), and the layout is not monotone in n where the
+// task length switches, so both are covered; any other piece size is checked against this bound by msm_build_tasks (an error, never an overrun)
+static size_t msm_chunk_lay_bytes(size_t chunk_cap, int c) {
+  size_t b = msm_lay_out(nullptr, chunk_cap, 1, c, true).total;
+  if (chunk_cap > 1) b = std::max(b, msm_lay_out(nullptr, chunk_cap - 1, 1, c, true).total);
+  return align_up(b, 256);
+}
+
+size_t msm_chunk_workspace_bytes(size_t chunk_cap, int c) {
+  if (chunk_cap == 0) return 0;
+  return msm_chunk_lay_bytes(chunk_cap, c) + align_up(((size_t)1 << (c - 1)) * 144, 256);
+}
+
+int msm_chunk_add(const uint32_t* d_scalars, size_t n, const prepared_bases* pb, size_t pb_off, size_t chunk_cap, bool first, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (!pb || n == 0 || n > chunk_cap || pb_off + n > pb->n) { set_error("msm_chunk_add: bad piece (n = %zu, capacity %zu)", n, chunk_cap); return ZKHIP_EINVAL; }
+  const size_t lay_bytes = msm_chunk_lay_bytes(chunk_cap, pb->c);
+  if (ws_bytes < msm_chunk_workspace_bytes(chunk_cap, pb->c)) { set_error("msm_chunk_add: workspace too small"); return ZKHIP_EINVAL; }
+  uint32_t* const acc = (uint32_t*)((char*)ws + lay_bytes);
+  msm_tasks_view tv;
+  int rc = msm_build_tasks(d_scalars, n, 1, 0, pb->c, true, (uint32_t)pb_off, (uint32_t)pb->n, 144, ws, lay_bytes, stream, &tv, false);
+  if (rc != ZKHIP_OK) return rc;
+  if ((rc = msm_accumulate_combine(tv, pb->table, true, false, n, first ? acc : tv.pyrA, stream)) != ZKHIP_OK) return rc;
+  if (!first) hipLaunchKernelGGL(k_bucket_sets_add, dim3((tv.NB + 127) / 128), dim3(128), 0, stream, acc, (const uint32_t*)tv.pyrA, tv.NB);
   HIPCHK(hipGetLastError());
   return ZKHIP_OK;
+}
+
+int msm_chunk_finish(const prepared_bases* pb, size_t chunk_cap, uint32_t* d_out, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (!pb || ws_bytes < msm_chunk_workspace_bytes(chunk_cap, pb->c)) { set_error("msm_chunk_finish: workspace too small"); return ZKHIP_EINVAL; }
+  const msm_layout lay = msm_lay_out((char*)ws, chunk_cap, 1, pb->c, true);
+  uint32_t* const acc = (uint32_t*)((char*)ws + msm_chunk_lay_bytes(chunk_cap, pb->c));
+  return msm_reduce_buckets(1, 1u << (pb->c - 1), pb->c, 1, true, acc, lay.pyrA, lay.winsum, d_out, stream);
 }
 
 

@@ -59,6 +59,10 @@ int msm_pick_window_prepared(size_t n);
 int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, uint32_t* d_out, void* ws, size_t ws_bytes,
                   int c_override, hipStream_t stream, const prepared_bases* prepared = nullptr, size_t prepared_off = 0, size_t batch = 1,
                   size_t scalar_stride = 0);
+// chunked prepared MSM: pieces of at most chunk_cap scalars, sorted and accumulated one by one into one bucket set, one reduction at the end
+size_t msm_chunk_workspace_bytes(size_t chunk_cap, int c);
+int msm_chunk_add(const uint32_t* d_scalars, size_t n, const prepared_bases* pb, size_t pb_off, size_t chunk_cap, bool first, void* ws, size_t ws_bytes, hipStream_t stream);
+int msm_chunk_finish(const prepared_bases* pb, size_t chunk_cap, uint32_t* d_out, void* ws, size_t ws_bytes, hipStream_t stream);
 int prepare_bases_device(const uint32_t* d_bases, size_t n, hipStream_t stream, prepared_bases** out, int c_override = 0);
 void release_prepared(prepared_bases* pb);
 // d_out[b] = sum over i < m of d_in[i * count + b], b < count (count = 1: the plain fold of m points)
