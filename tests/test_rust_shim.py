@@ -158,3 +158,10 @@ def test_rust_files_are_lexically_balanced(name):
         elif ch in ")]}":
             assert stack and stack.pop() == pairs[ch], f"{name}: unbalanced {ch}"
     assert not stack, f"{name}: unclosed {stack}"
+
+
+def test_integration_md_reproduces_the_shim_files_verbatim():
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for name in ("Cargo.patch.toml", "build.rs", "zkhip_ffi.rs", "arithmetic_patch.rs", "commitment_patch.rs", "domain_patch.rs"):
+        body = open(os.path.join(SHIM, name)).read().rstrip()
+        assert body in doc, f"INTEGRATION.md section 2 is out of date with rust-shim/{name}"

@@ -1578,9 +1578,18 @@ static msm_layout msm_lay_out(char* base, size_t n_in, size_t K, int c, bool pre
 // GLV applies to the G1 general path: arbitrary bases, one scalar vector (the prepared path has its doublings in the table already)
 static inline bool msm_uses_glv(bool prepared, size_t batch, size_t xyzz_bytes) { return !prepared && batch == 1 && xyzz_bytes == 144 && msm_glv_enabled(); }
 
+// Direct tables (below: "Direct tables") serve single MSMs over prepared sets of at most 2^ZKHIP_DIRECT_MAX_LOG points (default 15; 0 = never; at most 18)
+int msm_direct_max_log() {
+  static const int v = [] { const char* e = getenv("ZKHIP_DIRECT_MAX_LOG"); const int x = e ? atoi(e) : 15; return (x >= 0 && x <= 18) ? x : 15; }();
+  return v;
+}
+static inline bool msm_direct_wanted(size_t n) { const int L = msm_direct_max_log(); return L > 0 && n >= 2 && n <= ((size_t)1 << L); }
+
 size_t msm_workspace_bytes(size_t n_one, int c, bool prepared, size_t batch, size_t xyzz_bytes) {
   if (n_one == 0 || batch == 0) return 0;
-  return msm_lay_out(nullptr, n_one, batch, c, prepared, xyzz_bytes, msm_uses_glv(prepared, batch, xyzz_bytes)).total;
+  size_t b = msm_lay_out(nullptr, n_one, batch, c, prepared, xyzz_bytes, msm_uses_glv(prepared, batch, xyzz_bytes)).total;
+  if (prepared && batch == 1 && xyzz_bytes == 144 && msm_direct_wanted(n_one)) b = std::max(b, msm_direct_workspace_bytes(n_one));   // the same call may take the direct path
+  return b;
 }
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s failed: %s", #x, hipGetErrorString(e_)); return ZKHIP_EHIP; } } while (0)
@@ -1822,6 +1831,7 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
     if (prepared_off + n > prepared->n) { set_error("msm: range exceeds the prepared bases"); return ZKHIP_EINVAL; }
     if ((size_t)((256 + c - 1) / c) * prepared->n >= (1ull << 31)) { set_error("msm: prepared table too large for 31-bit point references"); return ZKHIP_EINVAL; }
     d_bases = prepared->table;
+    if (prepared->direct && batch == 1) return msm_g1_direct(d_scalars, n, prepared, prepared_off, d_out, ws, ws_bytes, stream);     // small fixed base set: no buckets
   }
   msm_tasks_view tv;
   const bool glv = msm_uses_glv(prepared != nullptr, batch, 144);
@@ -2163,7 +2173,7 @@ int prepare_bases_device(const uint32_t* d_bases, size_t n, hipStream_t stream, 
   if (c < 2 || c > MAX_WINDOW_PREPARED) { set_error("prepare_bases: window bits %d out of range [2,%d]", c, MAX_WINDOW_PREPARED); return ZKHIP_EINVAL; }
   const int W = (256 + c - 1) / c;
   prepared_bases* pb = new prepared_bases();
-  pb->n = n; pb->c = c; pb->W = W; pb->table = nullptr;
+  pb->n = n; pb->c = c; pb->W = W; pb->table = nullptr; pb->direct = nullptr;
   void *table = nullptr, *tmp = nullptr;
   const size_t tbytes = (size_t)W * n * 64, tmp_pts = align_up((size_t)(W - 1) * n * 144, 256), tmp_pref = align_up((size_t)(W - 1) * n * 36, 256);
   if (hipMalloc(&table, tbytes) != hipSuccess) { delete pb; set_error("prepare_bases: hipMalloc(%zu) failed", tbytes); return ZKHIP_ENOMEM; }
@@ -2175,6 +2185,8 @@ int prepare_bases_device(const uint32_t* d_bases, size_t n, hipStream_t stream, 
   (void)hipFree(tmp);
   if (e != hipSuccess) { (void)hipFree(table); delete pb; set_error("prepare_bases: %s", hipGetErrorString(e)); return ZKHIP_EHIP; }
   pb->table = (uint32_t*)table;
+  // small sets with an automatic window also get the direct table (a failed allocation leaves the bucket path, which needs nothing more)
+  if (c_override <= 0 && msm_direct_wanted(n) && prepare_direct_table(pb, d_bases, stream) != ZKHIP_OK) pb->direct = nullptr;
   *out = pb;
   return ZKHIP_OK;
 }
@@ -2182,7 +2194,209 @@ int prepare_bases_device(const uint32_t* d_bases, size_t n, hipStream_t stream, 
 void release_prepared(prepared_bases* pb) {
   if (!pb) return;
   if (pb->table) (void)hipFree(pb->table);
+  if (pb->direct) (void)hipFree(pb->direct);
   delete pb;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Direct tables: bucket-free MSM for the small circuits' SRS (round 4).
+//
+// An unmodified `create_proof` commits column by column (`params.commit_lagrange(&column)` in a loop: [DEP] halo2-axiom plonk/prover.rs, reached from
+// /root/reference/aggregator/src/wrapper.rs:129 and the voter / state-transition benches, /root/reference/voter/benches/voter_circuit.rs:80,
+// /root/reference/aggregator/benches/state_transition_circuit.rs:84), so at k = 13 .. 15 it sees ONE small MSM at a time -- and a Pippenger run of 2^13
+// points is 0.23 ms of pure latency on this machine: ~36 dependent launches, of which the bucket reduction (pyramid + weighted sum + combine) is 63 %.
+// For a FIXED base set that small, HBM buys the buckets off entirely: with 8-bit signed windows the table holds every multiple a digit can ask for,
+//     direct[i][w][m - 1] = m * 2^(8 w) * P_i,    i < n, w < 32, m = 1 .. 128     (n * 256 KiB: 2 GiB at 2^13 points, 8 GiB at 2^15)
+// and the MSM is a PLAIN sum of 32 n table points: no sort, no buckets, no weights, no doublings.  Two kernel shapes:
+//     k_direct_accumulate   thread (i, g): the 4 digits of window group g of scalar i (recoded from the scalar itself: one Montgomery multiplication and a
+//                           byte scan), 4 gathers, first point copied, 3 mixed additions -> 8 n partial sums
+//     k_points_sum_quad     512-thread workgroups, one quad per addition: 4 partials per quad, then a shuffle tree over the wavefront's 16 quads and an LDS
+//                           tree over the 8 wavefronts: 512 -> 1 in 10 dependent quad additions; two launches take 2^18 partials to the result
+// Depth: 3 mixed + ~20 quad additions, against 11 + 11 pyramid / doubling steps, the combine and the sort chain of the bucket method.
+// Signed recoding: digit_w = byte_w + carry in [-128, 127] u {128 -> -128 + carry}; the scalar is < 2^254, so the top window's byte is < 64: no carry out.
+// ------------------------------------------------------------------------------------------------
+constexpr int DIRECT_W = 32, DIRECT_M = 128, DIRECT_GROUPS = 8, DIRECT_WPT = DIRECT_W / DIRECT_GROUPS;   // windows, multiples per window, threads per scalar
+
+__global__ void __launch_bounds__(64) k_direct_build(const uint32_t* __restrict__ wtable /* [32][n_all] reduced internal affine: 2^(8 w) P_i */, uint32_t n_all,
+                                                     uint32_t i0, uint32_t cnt, uint32_t* __restrict__ direct, uint32_t* __restrict__ tmp_pts,
+                                                     uint32_t* __restrict__ tmp_pref) {
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, T = cnt * DIRECT_W;
+  if (tid >= T) return;
+  const uint32_t i = i0 + tid / DIRECT_W, w = tid % DIRECT_W;
+  const affine_words pt = load_affine(wtable, (size_t)w * n_all + i);
+  uint4* const slot = reinterpret_cast<uint4*>(direct + ((size_t)i * DIRECT_W + w) * DIRECT_M * 16);
+  if (affine_is_identity(pt)) {
+    for (int k = 0; k < DIRECT_M * 4; k++) slot[k] = make_uint4(0, 0, 0, 0);
+    return;
+  }
+  slot[0] = make_uint4(pt.x[0], pt.x[1], pt.x[2], pt.x[3]); slot[1] = make_uint4(pt.x[4], pt.x[5], pt.x[6], pt.x[7]);     // 1 * Q: the window table's own entry
+  slot[2] = make_uint4(pt.y[0], pt.y[1], pt.y[2], pt.y[3]); slot[3] = make_uint4(pt.y[4], pt.y[5], pt.y[6], pt.y[7]);
+  const fe x = fe_unpack<0>(pt.x), y = fe_unpack<0>(pt.y);
+  xyzz acc = xyzz_identity();
+  xyzz_madd(acc, x, y);
+  fe pref = fe_one<Fq>();
+  for (int k = 2; k <= DIRECT_M; k++) {             // k Q by repeated mixed addition (k = 2 takes the doubling branch); never the identity: k < r
+    xyzz_madd(acc, x, y);
+    store_xyzz(tmp_pts, (size_t)(k - 2) * T + tid, acc);
+    store_fe9_generic(tmp_pref, (size_t)(k - 2) * T + tid, pref);
+    pref = fe_mul<Fq>(pref, fe_mul<Fq>(acc.ZZ, acc.ZZZ));
+  }
+  fe inv = fq_inverse(pref);
+  for (int k = DIRECT_M; k >= 2; k--) {
+    const xyzz Q = load_xyzz(tmp_pts, (size_t)(k - 2) * T + tid);
+    const fe pre = load_fe9_generic(tmp_pref, (size_t)(k - 2) * T + tid);
+    const fe winv = fe_mul<Fq>(inv, pre);
+    inv = fe_mul<Fq>(inv, fe_mul<Fq>(Q.ZZ, Q.ZZZ));
+    store_table_point(direct, ((size_t)i * DIRECT_W + w) * DIRECT_M + (k - 1), fe_mul<Fq>(fe_mul<Fq>(winv, Q.ZZZ), Q.X), fe_mul<Fq>(fe_mul<Fq>(winv, Q.ZZ), Q.Y));
+  }
+}
+
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) k_direct_accumulate(const uint32_t* __restrict__ scalars, uint32_t n, uint32_t off,
+                                                    const uint32_t* __restrict__ direct, uint32_t* __restrict__ partials) {
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= n * DIRECT_GROUPS) return;
+  const uint32_t i = tid / DIRECT_GROUPS, g = tid % DIRECT_GROUPS;
+  uint32_t w[8];
+  load_words(scalars + (size_t)i * 8, w);
+  fe c32;
+#pragma unroll
+  for (int k = 0; k < NL; k++) c32.l[k] = FrParams::FROM_EXT_CANON[k];
+  fe sv = fe_canon_lt2p<FrParams>(fe_mul<FrParams>(c32, fe_unpack<0>(w)));       // Montgomery words -> the canonical integer (k_digits does the same)
+  fe_pack(sv, w);
+  // carry into this thread's first window: a byte scan from the bottom (carry_out = byte + carry_in >= 128)
+  uint32_t carry = 0;
+  const uint32_t first = g * DIRECT_WPT;
+  // (the scan is written over the 8 words with a uniform trip count per word so that w[] stays in registers)
+#pragma unroll
+  for (int wi = 0; wi < 8; wi++) {
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const uint32_t win = (uint32_t)(wi * 4 + b);
+      const uint32_t v = ((w[wi] >> (8 * b)) & 255u) + carry;
+      if (win < first) carry = v >= 128u ? 1u : 0u;
+    }
+  }
+  int32_t dg[DIRECT_WPT];
+  {
+    // the thread's own word: DIRECT_WPT = 4 windows = exactly word g
+    uint32_t own = 0;
+#pragma unroll
+    for (int wi = 0; wi < 8; wi++) own = ((uint32_t)wi == g) ? w[wi] : own;
+#pragma unroll
+    for (int b = 0; b < DIRECT_WPT; b++) {
+      const uint32_t v = ((own >> (8 * b)) & 255u) + carry;
+      if (v >= 128u) { dg[b] = (int32_t)v - 256; carry = 1; } else { dg[b] = (int32_t)v; carry = 0; }
+    }
+  }
+  // (compile-time loops: under `#pragma unroll` the compiler keeps a loop whose body holds the asm-block multiplications rolled, which indexes
+  // the point array dynamically and puts it into scratch)
+  affine_words pts[DIRECT_WPT];
+  static_for<0, DIRECT_WPT>([&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    const uint32_t mag = (uint32_t)(dg[b] < 0 ? -dg[b] : dg[b]);
+    const size_t idx = (((size_t)(off + i) * DIRECT_W + first + b) * DIRECT_M) + (mag ? mag - 1 : 0);
+    pts[b] = load_affine(direct, idx);
+  });
+  xyzz acc = xyzz_identity();
+  static_for<0, DIRECT_WPT>([&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    if (dg[b] != 0 && !affine_is_identity(pts[b])) {
+      fe x2 = fe_unpack<0>(pts[b].x), y2 = fe_unpack<0>(pts[b].y);
+      if (dg[b] < 0) y2 = fe_neg_red(y2, Fq::P2_S1);        // limbs < 2^30, < 2p
+      if (xyzz_is_identity(acc)) { acc.X = x2; acc.Y = dg[b] < 0 ? fe_norm(y2) : y2; acc.ZZ = acc.ZZZ = fe_one<Fq>(); }
+      else xyzz_madd_nz<true>(acc, x2, y2);
+    }
+  });
+  store_xyzz(partials, tid, acc);
+}
+
+// out[b] = sum of in[b * 128 S .. ): 128 quads per workgroup, quad t adds the S points t, t + 128, ... of the workgroup's slice (coalesced rows), a
+// shuffle tree adds the 16 quads of a wavefront, an LDS tree the 8 wavefronts.  jac_out != nullptr (single workgroup): the Jacobian result.
+__global__ void __launch_bounds__(512) k_points_sum_quad(const uint32_t* __restrict__ in, uint32_t m, uint32_t S, uint32_t* __restrict__ out,
+                                                         uint32_t* __restrict__ jac_out) {
+  __shared__ __attribute__((aligned(16))) uint32_t xch[8 * 36];
+  const uint32_t q = threadIdx.x & 3, quad = threadIdx.x >> 2, wave = threadIdx.x >> 6;
+  const uint32_t base = blockIdx.x * 128u * S;
+  xyzz acc = xyzz_identity();
+#pragma unroll 1
+  for (uint32_t s_ = 0; s_ < S; s_++) {
+    const uint32_t idx = base + s_ * 128u + quad;
+    if (idx < m) acc = xyzz_add_quad(acc, load_xyzz(in, idx), q);          // uniform over the quad
+  }
+#pragma unroll 1
+  for (int mask = 4; mask < 64; mask <<= 1) acc = xyzz_add_quad(acc, xyzz_shfl_xor(acc, mask), q);   // every quad of the wavefront ends with its sum
+  if ((threadIdx.x & 63) == 0) store_xyzz(xch, wave, acc);
+  __syncthreads();
+  if (wave == 0) {
+    acc = (quad < 8) ? load_xyzz(xch, quad) : xyzz_identity();
+#pragma unroll 1
+    for (int mask = 4; mask < 32; mask <<= 1) acc = xyzz_add_quad(acc, xyzz_shfl_xor(acc, mask), q);
+    if (threadIdx.x == 0) {
+      if (jac_out) store_jacobian(acc, jac_out);
+      else store_xyzz(out, blockIdx.x, acc);
+    }
+  }
+}
+
+size_t direct_table_bytes(size_t n) { return n * (size_t)DIRECT_W * DIRECT_M * 64; }
+size_t msm_direct_workspace_bytes(size_t n) { return align_up(n * DIRECT_GROUPS * 144, 256) + align_up(((n * DIRECT_GROUPS + 511) / 512 + 1) * 144, 256); }
+
+// builds pb->direct from the points (device-resident affine bases); returns ZKHIP_ENOMEM when the table does not fit (the caller keeps the bucket path)
+int prepare_direct_table(prepared_bases* pb, const uint32_t* d_bases, hipStream_t stream) {
+  const size_t n = pb->n;
+  void *direct = nullptr, *wt = nullptr, *tmp = nullptr;
+  const size_t slice = std::min<size_t>(n, 4096), T = slice * DIRECT_W;
+  const size_t wt_bytes = (size_t)DIRECT_W * n * 64, wtmp_pts = align_up((size_t)(DIRECT_W - 1) * n * 144, 256), wtmp_pref = align_up((size_t)(DIRECT_W - 1) * n * 36, 256);
+  const size_t tmp_pts = align_up((size_t)(DIRECT_M - 1) * T * 144, 256), tmp_pref = align_up((size_t)(DIRECT_M - 1) * T * 36, 256);
+  const size_t tmp_bytes = std::max(wtmp_pts + wtmp_pref, tmp_pts + tmp_pref);
+  if (hipMalloc(&direct, direct_table_bytes(n)) != hipSuccess) { (void)hipGetLastError(); set_error("direct table: hipMalloc(%zu) failed", direct_table_bytes(n)); return ZKHIP_ENOMEM; }
+  if (hipMalloc(&wt, wt_bytes) != hipSuccess || hipMalloc(&tmp, tmp_bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(direct); if (wt) (void)hipFree(wt);
+    set_error("direct table: temporary allocation failed");
+    return ZKHIP_ENOMEM;
+  }
+  // the 32 window points 2^(8 w) P_i of every base: the prepared-table builder with 8-bit windows
+  hipLaunchKernelGGL(k_build_table, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_bases, (uint32_t)n, 8, DIRECT_W, (uint32_t*)wt, (uint32_t*)tmp,
+                     (uint32_t*)((char*)tmp + wtmp_pts), 0);
+  for (size_t i0 = 0; i0 < n; i0 += slice) {
+    const size_t cnt = std::min(slice, n - i0);
+    hipLaunchKernelGGL(k_direct_build, dim3((unsigned)((cnt * DIRECT_W + 63) / 64)), dim3(64), 0, stream, (const uint32_t*)wt, (uint32_t)n, (uint32_t)i0, (uint32_t)cnt,
+                       (uint32_t*)direct, (uint32_t*)tmp, (uint32_t*)((char*)tmp + tmp_pts));
+  }
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  (void)hipFree(wt); (void)hipFree(tmp);
+  if (e != hipSuccess) { (void)hipFree(direct); set_error("direct table: %s", hipGetErrorString(e)); return ZKHIP_EHIP; }
+  pb->direct = (uint32_t*)direct;
+  return ZKHIP_OK;
+}
+
+// d_scalars: n x 8 words; points [off, off + n) of the prepared set; d_out: 24 words.  ws: msm_direct_workspace_bytes(n).
+int msm_g1_direct(const uint32_t* d_scalars, size_t n, const prepared_bases* pb, size_t off, uint32_t* d_out, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (!pb || !pb->direct || off + n > pb->n) { set_error("msm_direct: bad range"); return ZKHIP_EINVAL; }
+  if (n == 0) { hipLaunchKernelGGL(k_sum_jacobian, dim3(1), dim3(64), 0, stream, (const uint32_t*)nullptr, 0, d_out, 1u); HIPCHK(hipGetLastError()); return ZKHIP_OK; }
+  if (ws_bytes < msm_direct_workspace_bytes(n)) { set_error("msm_direct: workspace too small"); return ZKHIP_EINVAL; }
+  uint32_t* const partials = (uint32_t*)ws;
+  uint32_t* const level1 = (uint32_t*)((char*)ws + align_up(n * DIRECT_GROUPS * 144, 256));
+  prof_begin(stream);
+  uint32_t m = (uint32_t)(n * DIRECT_GROUPS);
+  hipLaunchKernelGGL(k_direct_accumulate, dim3((m + 127) / 128), dim3(128), 0, stream, d_scalars, (uint32_t)n, (uint32_t)off, (const uint32_t*)pb->direct, partials);
+  prof_mark(stream, "direct_accumulate");
+  const uint32_t* cur = partials;
+  uint32_t* nxt = level1;
+  // 512 -> 1 per workgroup (S = 4) while more than 512 points remain; the last launch is one workgroup with S = ceil(m / 128)
+  while (m > 512) {
+    const uint32_t outs = (m + 511) / 512;
+    hipLaunchKernelGGL(k_points_sum_quad, dim3(outs), dim3(512), 0, stream, cur, m, 4u, nxt, (uint32_t*)nullptr);
+    // ping-pong inside the workspace: level 1 writes behind the partials, level 2 (<= 512 points) overwrites the head of the partials
+    const uint32_t* t = cur; cur = nxt; nxt = (uint32_t*)t;
+    m = outs;
+  }
+  hipLaunchKernelGGL(k_points_sum_quad, dim3(1), dim3(512), 0, stream, cur, m, (m + 127) / 128, (uint32_t*)nullptr, d_out);
+  prof_mark(stream, "direct_sum");
+  HIPCHK(hipGetLastError());
+  return ZKHIP_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -54,7 +54,13 @@ struct prepared_bases {   // table[w * n + i] = 2^(o_w) * P_i with o_w the bit o
   uint32_t* table;
   size_t n;
   int c, W;
+  uint32_t* direct = nullptr;   // small sets only (msm.hip "Direct tables"): [i][w < 32][m - 1 < 128] = m 2^(8 w) P_i, or null
 };
+// bucket-free MSM over a direct table (single vector, n <= 2^15 by default)
+size_t direct_table_bytes(size_t n);
+size_t msm_direct_workspace_bytes(size_t n);
+int prepare_direct_table(prepared_bases* pb, const uint32_t* d_bases, hipStream_t stream);
+int msm_g1_direct(const uint32_t* d_scalars, size_t n, const prepared_bases* pb, size_t off, uint32_t* d_out, void* ws, size_t ws_bytes, hipStream_t stream);
 int msm_pick_window_prepared(size_t n);
 int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, uint32_t* d_out, void* ws, size_t ws_bytes,
                   int c_override, hipStream_t stream, const prepared_bases* prepared = nullptr, size_t prepared_off = 0, size_t batch = 1,
