@@ -172,9 +172,10 @@ def fail(msg: str, code: int = 2):
 
 def visible_gpus_without_hip():
     """AMD GPUs this process could open, counted WITHOUT initialising the HIP / HSA runtime (the launcher parent must stay clean of it: on ROCm
-    wheels `torch.cuda.device_count()` may fall through to hipGetDeviceCount and open /dev/kfd): the KFD topology in sysfs lists one node per
-    agent, GPUs are the nodes with simd_count > 0; *_VISIBLE_DEVICES lists cap the count.  None when the topology cannot be read (the per-rank
-    check in main() still refuses a rank without its device)."""
+    wheels `torch.cuda.device_count()` may fall through to hipGetDeviceCount and open /dev/kfd).  The KFD topology in sysfs lists one node per
+    agent of the HOST (GPUs: simd_count > 0) whatever the container may use, so a GPU counts only if its DRM render node can actually be opened
+    (a device cgroup refuses the open of the cards that are not this container's); *_VISIBLE_DEVICES lists cap the count.  None when the
+    topology cannot be read (the per-rank check in main() still refuses a rank without its device)."""
     root = "/sys/class/kfd/kfd/topology/nodes"
     if not os.path.isdir(root):
         return 0                                      # no KFD driver: no AMD GPU
@@ -183,8 +184,17 @@ def visible_gpus_without_hip():
         for node in os.listdir(root):
             with open(os.path.join(root, node, "properties")) as f:
                 props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
-            if int(props.get("simd_count", "0")) > 0:
+            if int(props.get("simd_count", "0")) <= 0:
+                continue
+            minor = int(props.get("drm_render_minor", "-1"))
+            if minor < 0:
+                continue
+            try:
+                fd = os.open(f"/dev/dri/renderD{minor}", os.O_RDWR)      # opening the render node starts nothing: no KFD process, no queues
+                os.close(fd)
                 count += 1
+            except OSError:
+                pass
     except (OSError, ValueError):
         return None
     for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
@@ -266,7 +276,8 @@ def main() -> None:
     import torch.distributed as dist
 
     if torch.cuda.device_count() <= local_rank or torch.cuda.device_count() < world:
-        fail(f"rank {rank}: local rank {local_rank} of {world} needs {world} visible HIP devices, {torch.cuda.device_count()} found", 3)
+        fail(f"rank {rank}: local rank {local_rank} of {world} needs {world} visible HIP devices, {torch.cuda.device_count()} found: refusing to run a "
+             f"{world}-GPU measurement on fewer GPUs", 3)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cpu_group = None

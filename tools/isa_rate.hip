@@ -165,7 +165,7 @@ static int mfma_probe(uint32_t* out, int cus, hipEvent_t e0, hipEvent_t e1) {
       wi++;
     }
   }
-  return mfma_probe(out, cus, e0, e1);
+  return 0;
 }
 
 int main() {
