@@ -2215,7 +2215,7 @@ void release_prepared(prepared_bases* pb) {
 // Depth: 3 mixed + ~20 quad additions, against 11 + 11 pyramid / doubling steps, the combine and the sort chain of the bucket method.
 // Signed recoding: digit_w = byte_w + carry in [-128, 127] u {128 -> -128 + carry}; the scalar is < 2^254, so the top window's byte is < 64: no carry out.
 // ------------------------------------------------------------------------------------------------
-constexpr int DIRECT_W = 32, DIRECT_M = 128, DIRECT_GROUPS = 8, DIRECT_WPT = DIRECT_W / DIRECT_GROUPS;   // windows, multiples per window, threads per scalar
+constexpr int DIRECT_W = 32, DIRECT_M = 128, DIRECT_GROUPS = 8;   // windows, multiples per window, threads per scalar at most (k_direct_accumulate<4>)
 
 __global__ void __launch_bounds__(64) k_direct_build(const uint32_t* __restrict__ wtable /* [32][n_all] reduced internal affine: 2^(8 w) P_i */, uint32_t n_all,
                                                      uint32_t i0, uint32_t cnt, uint32_t* __restrict__ direct, uint32_t* __restrict__ tmp_pts,
@@ -2251,11 +2251,13 @@ __global__ void __launch_bounds__(64) k_direct_build(const uint32_t* __restrict_
   }
 }
 
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) k_direct_accumulate(const uint32_t* __restrict__ scalars, uint32_t n, uint32_t off,
-                                                    const uint32_t* __restrict__ direct, uint32_t* __restrict__ partials) {
+template <int WPT>      // windows per thread: 4 (8 threads per scalar) or 8 (4 threads per scalar)
+__device__ __forceinline__ void direct_accumulate_body(const uint32_t* __restrict__ scalars, uint32_t n, uint32_t off,
+                                                       const uint32_t* __restrict__ direct, uint32_t* __restrict__ partials) {
+  constexpr uint32_t GROUPS = DIRECT_W / WPT;
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid >= n * DIRECT_GROUPS) return;
-  const uint32_t i = tid / DIRECT_GROUPS, g = tid % DIRECT_GROUPS;
+  if (tid >= n * GROUPS) return;
+  const uint32_t i = tid / GROUPS, g = tid % GROUPS;
   uint32_t w[8];
   load_words(scalars + (size_t)i * 8, w);
   fe c32;
@@ -2263,10 +2265,10 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))
   for (int k = 0; k < NL; k++) c32.l[k] = FrParams::FROM_EXT_CANON[k];
   fe sv = fe_canon_lt2p<FrParams>(fe_mul<FrParams>(c32, fe_unpack<0>(w)));       // Montgomery words -> the canonical integer (k_digits does the same)
   fe_pack(sv, w);
-  // carry into this thread's first window: a byte scan from the bottom (carry_out = byte + carry_in >= 128)
+  // carry into this thread's first window: a byte scan from the bottom (carry_out = byte + carry_in >= 128), written over all 8 words with
+  // compile-time indices so that w[] stays in registers
   uint32_t carry = 0;
-  const uint32_t first = g * DIRECT_WPT;
-  // (the scan is written over the 8 words with a uniform trip count per word so that w[] stays in registers)
+  const uint32_t first = g * WPT;
 #pragma unroll
   for (int wi = 0; wi < 8; wi++) {
 #pragma unroll
@@ -2276,39 +2278,46 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))
       if (win < first) carry = v >= 128u ? 1u : 0u;
     }
   }
-  int32_t dg[DIRECT_WPT];
-  {
-    // the thread's own word: DIRECT_WPT = 4 windows = exactly word g
+  xyzz acc = xyzz_identity();
+  // 4 windows = one scalar word at a time: digits, 4 gathers in flight, then the additions (the first point of a thread is a copy).
+  // (compile-time loops: under `#pragma unroll` the compiler keeps a loop whose body holds the asm-block multiplications rolled, which indexes
+  // the point array dynamically and puts it into scratch)
+  static_for<0, WPT / 4>([&](auto hc) {
+    constexpr int h = decltype(hc)::value;
     uint32_t own = 0;
 #pragma unroll
-    for (int wi = 0; wi < 8; wi++) own = ((uint32_t)wi == g) ? w[wi] : own;
+    for (int wi = 0; wi < 8; wi++) own = ((uint32_t)wi == g * (WPT / 4) + h) ? w[wi] : own;
+    int32_t dg[4];
 #pragma unroll
-    for (int b = 0; b < DIRECT_WPT; b++) {
+    for (int b = 0; b < 4; b++) {
       const uint32_t v = ((own >> (8 * b)) & 255u) + carry;
       if (v >= 128u) { dg[b] = (int32_t)v - 256; carry = 1; } else { dg[b] = (int32_t)v; carry = 0; }
     }
-  }
-  // (compile-time loops: under `#pragma unroll` the compiler keeps a loop whose body holds the asm-block multiplications rolled, which indexes
-  // the point array dynamically and puts it into scratch)
-  affine_words pts[DIRECT_WPT];
-  static_for<0, DIRECT_WPT>([&](auto bc) {
-    constexpr int b = decltype(bc)::value;
-    const uint32_t mag = (uint32_t)(dg[b] < 0 ? -dg[b] : dg[b]);
-    const size_t idx = (((size_t)(off + i) * DIRECT_W + first + b) * DIRECT_M) + (mag ? mag - 1 : 0);
-    pts[b] = load_affine(direct, idx);
-  });
-  xyzz acc = xyzz_identity();
-  static_for<0, DIRECT_WPT>([&](auto bc) {
-    constexpr int b = decltype(bc)::value;
-    if (dg[b] != 0 && !affine_is_identity(pts[b])) {
-      fe x2 = fe_unpack<0>(pts[b].x), y2 = fe_unpack<0>(pts[b].y);
-      if (dg[b] < 0) y2 = fe_neg_red(y2, Fq::P2_S1);        // limbs < 2^30, < 2p
-      if (xyzz_is_identity(acc)) { acc.X = x2; acc.Y = dg[b] < 0 ? fe_norm(y2) : y2; acc.ZZ = acc.ZZZ = fe_one<Fq>(); }
-      else xyzz_madd_nz<true>(acc, x2, y2);
-    }
+    affine_words pts[4];
+    static_for<0, 4>([&](auto bc) {
+      constexpr int b = decltype(bc)::value;
+      const uint32_t mag = (uint32_t)(dg[b] < 0 ? -dg[b] : dg[b]);
+      const size_t idx = (((size_t)(off + i) * DIRECT_W + first + 4 * h + b) * DIRECT_M) + (mag ? mag - 1 : 0);
+      pts[b] = load_affine(direct, idx);
+    });
+    static_for<0, 4>([&](auto bc) {
+      constexpr int b = decltype(bc)::value;
+      if (dg[b] != 0 && !affine_is_identity(pts[b])) {
+        fe x2 = fe_unpack<0>(pts[b].x), y2 = fe_unpack<0>(pts[b].y);
+        if (dg[b] < 0) y2 = fe_neg_red(y2, Fq::P2_S1);        // limbs < 2^30, < 2p
+        if (xyzz_is_identity(acc)) { acc.X = x2; acc.Y = dg[b] < 0 ? fe_norm(y2) : y2; acc.ZZ = acc.ZZZ = fe_one<Fq>(); }
+        else xyzz_madd_nz<true>(acc, x2, y2);
+      }
+    });
   });
   store_xyzz(partials, tid, acc);
 }
+// 4 windows per thread: launches of up to 2^17 threads, sized for 4 waves per SIMD (128 VGPRs, no scratch); 8 windows per thread: the scalar's
+// words stay live across two rounds of gathers -- 2 waves per SIMD at the sizes it runs at, so it may take the registers it needs
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) k_direct_accumulate4(const uint32_t* __restrict__ scalars, uint32_t n, uint32_t off,
+                                                    const uint32_t* __restrict__ direct, uint32_t* __restrict__ partials) { direct_accumulate_body<4>(scalars, n, off, direct, partials); }
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 3))) k_direct_accumulate8(const uint32_t* __restrict__ scalars, uint32_t n, uint32_t off,
+                                                    const uint32_t* __restrict__ direct, uint32_t* __restrict__ partials) { direct_accumulate_body<8>(scalars, n, off, direct, partials); }
 
 // out[b] = sum of in[b * 128 S .. ): 128 quads per workgroup, quad t adds the S points t, t + 128, ... of the workgroup's slice (coalesced rows), a
 // shuffle tree adds the 16 quads of a wavefront, an LDS tree the 8 wavefronts.  jac_out != nullptr (single workgroup): the Jacobian result.
@@ -2380,8 +2389,12 @@ int msm_g1_direct(const uint32_t* d_scalars, size_t n, const prepared_bases* pb,
   uint32_t* const partials = (uint32_t*)ws;
   uint32_t* const level1 = (uint32_t*)((char*)ws + align_up(n * DIRECT_GROUPS * 144, 256));
   prof_begin(stream);
-  uint32_t m = (uint32_t)(n * DIRECT_GROUPS);
-  hipLaunchKernelGGL(k_direct_accumulate, dim3((m + 127) / 128), dim3(128), 0, stream, d_scalars, (uint32_t)n, (uint32_t)off, (const uint32_t*)pb->direct, partials);
+  // 8 threads per scalar (3 dependent mixed additions) while that is at most one round of waves; above 2^14 scalars 4 threads per scalar: the
+  // launch is throughput-bound either way and half as many partial sums enter the tree (2^15: 0.226 -> see profiles/r04_small_msm_direct_ab.txt)
+  const bool wide = n > ((size_t)1 << 14);
+  uint32_t m = (uint32_t)(n * (wide ? 4 : 8));
+  if (wide) hipLaunchKernelGGL(k_direct_accumulate8, dim3((m + 127) / 128), dim3(128), 0, stream, d_scalars, (uint32_t)n, (uint32_t)off, (const uint32_t*)pb->direct, partials);
+  else hipLaunchKernelGGL(k_direct_accumulate4, dim3((m + 127) / 128), dim3(128), 0, stream, d_scalars, (uint32_t)n, (uint32_t)off, (const uint32_t*)pb->direct, partials);
   prof_mark(stream, "direct_accumulate");
   const uint32_t* cur = partials;
   uint32_t* nxt = level1;
