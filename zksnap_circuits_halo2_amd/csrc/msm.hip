@@ -1777,6 +1777,7 @@ static int msm_accumulate_combine(const msm_tasks_view& tv, const uint32_t* d_ba
 // prepared: every bucket set's weighted sum is a result (K = WB of them); otherwise the WB window sums are folded into one.
 static int msm_reduce_buckets(int WB, uint32_t B, int c, uint32_t K, bool prepared, uint32_t* cur, uint32_t* nxt, uint32_t* winsum, uint32_t* d_out, hipStream_t stream) {
   // 8. pyramid: buckets were written with window stride B (dense).  Steps 1 .. c-2 leave X with 2 elements.
+  static const size_t quad_max = [] { const char* e = getenv("ZKHIP_PYR_QUAD_MAX"); const long v = e ? atol(e) : 0; return v >= 256 && v <= (1 << 20) ? (size_t)v : (size_t)65536; }();   // A/B knob
   uint32_t in_stride = B;
   int nz = 0;
   {
@@ -1786,7 +1787,7 @@ static int msm_reduce_buckets(int WB, uint32_t B, int c, uint32_t K, bool prepar
       uint32_t per_win = N / 2 + (uint32_t)s * (N / 4);
       uint32_t out_stride = per_win;
       // below ~1/4 of the chip's lanes an addition's latency is the step time: four lanes per addition
-      if ((size_t)per_win * WB <= 65536) hipLaunchKernelGGL(k_pyramid_step_quad, dim3((4 * per_win + 127) / 128, WB), dim3(128), 0, stream, cur, nxt, N, s, in_stride, out_stride);
+      if ((size_t)per_win * WB <= quad_max) hipLaunchKernelGGL(k_pyramid_step_quad, dim3((4 * per_win + 127) / 128, WB), dim3(128), 0, stream, cur, nxt, N, s, in_stride, out_stride);
       else hipLaunchKernelGGL(k_pyramid_step, dim3((per_win + 127) / 128, WB), dim3(128), 0, stream, cur, nxt, N, s, in_stride, out_stride);
       uint32_t* t = cur; cur = nxt; nxt = t;
       in_stride = out_stride;
