@@ -21,7 +21,14 @@ counts = {}
 def aff(x): return Cr.jac_to_affine(np.ascontiguousarray(x))
 
 def scalars(n, seed):
-    kind = rng.randrange(5)
+    kind = rng.randrange(6)
+    if kind == 5:                                      # bytes on the edges of the 8-bit signed recoding of the direct tables (carry ripples)
+        pick = np.random.default_rng(seed)
+        raw = pick.choice(np.array([0x00, 0x7f, 0x80, 0x81, 0xff, 0x01], dtype=np.uint8), size=(n, 32), p=[0.15, 0.25, 0.25, 0.1, 0.2, 0.05])
+        raw[:, 31] &= 0x1f                             # below 2^253 < r: canonical integers
+        vals = [int.from_bytes(bytes(r_), "little") for r_ in raw[: min(n, 4096)]]
+        enc = F.fr_encode(vals)
+        return np.ascontiguousarray(enc[np.arange(n) % enc.shape[0]])
     if kind < 2: return Cr.gen_scalars(seed, n, kind)
     if kind == 4:                                      # what real columns look like: uniform values with clusters of 1, -1, small constants
         s = Cr.gen_scalars(seed, n, 0)
@@ -206,6 +213,30 @@ def fuzz_sharded(seed):
         lib.zkhip_unregister_bases(hb.ctypes.data)
         lib.zkhip_set_msm_shards(0)
 
+def fuzz_host_chunked(seed):
+    """large only: the host-buffer MSM over a registered array of 2^21 .. 5 * 2^20 points -- the chunked upload (pieces accumulated into one bucket
+    set) -- on a random sub-range, with 1 .. 3 shards"""
+    n = rng.randint(1 << 21, 5 << 20)
+    bases = torch.empty(n * 8, dtype=torch.int64, device="cuda")
+    _lib.check(lib.zkhip_g1_gen_walk_device(t0m.ctypes.data, dm.ctypes.data, n, bases.data_ptr(), None))
+    torch.cuda.synchronize()
+    hb = np.ascontiguousarray(bases.cpu().numpy().view(np.uint64).reshape(n, 8))
+    del bases
+    sc = scalars(n, seed)
+    S = rng.choice([1, 1, 2, 3])
+    _lib.check(lib.zkhip_set_msm_shards(S))
+    _lib.check(lib.zkhip_register_bases(hb.ctypes.data, n))
+    try:
+        for off, m in ((0, n), (rng.randrange(0, n // 4), rng.randint(n // 2, n - n // 4))):
+            sub = np.ascontiguousarray(sc[off:off + m])
+            out = np.zeros(12, dtype=np.uint64)
+            _lib.check(lib.zkhip_msm_g1(sub.ctypes.data, hb[off:].ctypes.data, m, out.ctypes.data))
+            exp = aff(Cr.scalar_mul(Cr.expected_scalar(sub, (T0 + off * D) % R, D), Cr.generator()))
+            assert np.array_equal(aff(out), exp), f"chunked host msm n={n} S={S} off={off} m={m}"
+    finally:
+        lib.zkhip_unregister_bases(hb.ctypes.data)
+        lib.zkhip_set_msm_shards(0)
+
 _g2_walk = {}
 def fuzz_g2(seed):
     """G2 MSM on a prefix of a fixed walk of G2 points (the oracle builds the walk once: big-integer Fq2 arithmetic)"""
@@ -220,7 +251,7 @@ def fuzz_g2(seed):
     got = O.g2_jac_from_limbs([int(x) for x in A.best_multiexp_g2(sc, _g2_walk["enc"][:n])])
     assert got == O.g2_scalar_mul(Cr.expected_scalar(sc, T0, D), O.G2_GEN), f"g2 msm n={n}"
 
-fns = [fuzz_msm] if LARGE else [fuzz_msm, fuzz_ntt, fuzz_poly, fuzz_rows, fuzz_lookup, fuzz_batched, fuzz_sharded, fuzz_g2]
+fns = [fuzz_msm, fuzz_host_chunked] if LARGE else [fuzz_msm, fuzz_ntt, fuzz_poly, fuzz_rows, fuzz_lookup, fuzz_batched, fuzz_sharded, fuzz_g2]
 t_end = time.time() + budget
 it = 0
 while time.time() < t_end:
