@@ -1146,6 +1146,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))
 //        ~4.7 us even when no bucket needed it.)
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t HEAVY_WGS = 256;
+constexpr uint32_t HEAVY_QUAD_MAX = 256;     // heavy buckets of at most this many partials are summed by 32 quads instead of 128 lanes
 
 // sum of the 128 threads' points: LDS tree, result in thread 0 (xch: 64 x 36 words)
 __device__ __forceinline__ xyzz workgroup_sum_128(xyzz acc, uint32_t* __restrict__ xch) {
@@ -1165,13 +1166,34 @@ __device__ __forceinline__ xyzz workgroup_sum_128(xyzz acc, uint32_t* __restrict
 __device__ __forceinline__ void combine_heavy_buckets(uint32_t wg, const uint32_t* __restrict__ task_off, uint32_t* __restrict__ partials,
                                                       uint32_t* __restrict__ buckets, const uint32_t* __restrict__ heavy_count,
                                                       const uint2* __restrict__ heavy, uint32_t heavy_cap, uint32_t* __restrict__ heavy_done,
-                                                      uint32_t* __restrict__ xch /* 64 x 36 words of LDS */) {
+                                                      uint32_t* __restrict__ xch /* 64 x 36 words of LDS */, uint32_t quad_max) {
   __shared__ uint32_t is_last;
   const uint32_t nh = min(*heavy_count, heavy_cap);
   for (uint32_t i = wg; i < nh; i += HEAVY_WGS) {          // uniform over the workgroup
     const uint2 e = heavy[i];
     const uint32_t k = e.x, sl = e.y, t = task_off[k], m = task_off[k + 1] - t;
     const uint32_t P = (m + HEAVY_SLICE - 1) / HEAVY_SLICE, lo = sl * HEAVY_SLICE, hi = min(m, lo + HEAVY_SLICE);
+    if (m <= quad_max) {
+      // a mildly heavy bucket (round 4): up to 256 partials -- e.g. the 2^8 buckets that a column of 88-bit limbs fills in window 4 of the
+      // c = 20 layout, ~19 partials each.  The 128-lane slice sum below would spend one single-lane addition plus a 7-level LDS tree of
+      // single-lane additions on it (~13 us each at a lone wavefront's issue rate); here the workgroup is 32 quads: quad t adds partials t,
+      // t + 32, ... on the quad formulas, a shuffle tree adds the 16 quads of each wavefront, one LDS step the two wavefronts: <= 8 + 4 + 1
+      // quad additions of ~5 us (combine 0.118 -> see profiles/r04_heavy_quad_ab.txt on the witness-like mix at 2^20)
+      const uint32_t q = threadIdx.x & 3, quad = threadIdx.x >> 2;
+      xyzz acc = xyzz_identity();
+#pragma unroll 1
+      for (uint32_t j = quad; j < m; j += 32) acc = xyzz_add_quad(acc, load_xyzz(partials, t + j), q);
+#pragma unroll 1
+      for (int mask = 4; mask < 64; mask <<= 1) acc = xyzz_add_quad(acc, xyzz_shfl_xor(acc, mask), q);
+      __syncthreads();                                     // (xch may still be read by the previous list entry's tree)
+      if (threadIdx.x == 64) store_xyzz(xch, 0, acc);
+      __syncthreads();
+      if (threadIdx.x < 4) {
+        acc = xyzz_add_quad(acc, load_xyzz(xch, 0), q);
+        if (q == 0) store_xyzz(buckets, k, acc);
+      }
+      continue;
+    }
     xyzz acc = xyzz_identity();
 #pragma unroll 1
     for (uint32_t j = lo + threadIdx.x; j < hi; j += 128) acc = xyzz_add(acc, load_xyzz(partials, t + j));
@@ -1200,9 +1222,9 @@ template <int COMBINE_LANES>
 __global__ void __launch_bounds__(128) k_combine_seq(const uint32_t* __restrict__ task_off, uint32_t nbuckets,
                                                      uint32_t* __restrict__ partials, uint32_t* __restrict__ buckets,
                                                      uint32_t seq_parts, uint32_t blocks, const uint32_t* __restrict__ heavy_count,
-                                                     const uint2* __restrict__ heavy, uint32_t heavy_cap, uint32_t* __restrict__ heavy_done) {
+                                                     const uint2* __restrict__ heavy, uint32_t heavy_cap, uint32_t* __restrict__ heavy_done, uint32_t quad_max) {
   __shared__ __attribute__((aligned(16))) uint32_t xch[64 * 36];
-  if (blockIdx.x >= blocks) { combine_heavy_buckets(blockIdx.x - blocks, task_off, partials, buckets, heavy_count, heavy, heavy_cap, heavy_done, xch); return; }
+  if (blockIdx.x >= blocks) { combine_heavy_buckets(blockIdx.x - blocks, task_off, partials, buckets, heavy_count, heavy, heavy_cap, heavy_done, xch, quad_max); return; }
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t k = gid / COMBINE_LANES, q = gid % COMBINE_LANES;
   const bool live = k < nbuckets;                  // whole lane groups are live or dead together (128 % 8 == 0)
@@ -1226,9 +1248,9 @@ template <int COMBINE_LANES>
 __global__ void __launch_bounds__(128) k_combine_seq_quad(const uint32_t* __restrict__ task_off, uint32_t nbuckets,
                                                           uint32_t* __restrict__ partials, uint32_t* __restrict__ buckets,
                                                           uint32_t seq_parts, uint32_t blocks, const uint32_t* __restrict__ heavy_count,
-                                                          const uint2* __restrict__ heavy, uint32_t heavy_cap, uint32_t* __restrict__ heavy_done) {
+                                                          const uint2* __restrict__ heavy, uint32_t heavy_cap, uint32_t* __restrict__ heavy_done, uint32_t quad_max) {
   __shared__ __attribute__((aligned(16))) uint32_t xch[64 * 36];
-  if (blockIdx.x >= blocks) { combine_heavy_buckets(blockIdx.x - blocks, task_off, partials, buckets, heavy_count, heavy, heavy_cap, heavy_done, xch); return; }
+  if (blockIdx.x >= blocks) { combine_heavy_buckets(blockIdx.x - blocks, task_off, partials, buckets, heavy_count, heavy, heavy_cap, heavy_done, xch, quad_max); return; }
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t q = gid & 3, lane = (gid >> 2) % COMBINE_LANES, k = (gid >> 2) / COMBINE_LANES;
   const bool live = k < nbuckets;                  // whole groups of 4 * COMBINE_LANES lanes are live or dead together
@@ -1755,13 +1777,14 @@ static int msm_accumulate_combine(const msm_tasks_view& tv, const uint32_t* d_ba
     const uint32_t seq_parts = tv.seq_parts;
     const size_t lanes_total = (size_t)NB * combine_lanes;
     const bool quad = lanes_total * 4 <= 131072;        // far below the chip's lane count: the additions' latency is the step time
+    static const uint32_t heavy_quad_max = [] { const char* e = getenv("ZKHIP_HEAVY_QUAD_MAX"); const long v = e ? atol(e) : -1; return v >= 0 && v <= 2048 ? (uint32_t)v : HEAVY_QUAD_MAX; }();   // A/B knob (0 = the 128-lane slice sums only)
     const unsigned blocks = (unsigned)((lanes_total * (quad ? 4 : 1) + 127) / 128);
 #define ZK_LAUNCH_COMBINE(L)                                                                                                                        \
     do {                                                                                                                                              \
       if (quad) hipLaunchKernelGGL(k_combine_seq_quad<L>, dim3(blocks + HEAVY_WGS), dim3(128), 0, stream, task_off, NB, partials, buckets, seq_parts, blocks,   \
-                                   tv.heavy_count, (const uint2*)tv.heavy, tv.heavy_cap, tv.heavy_done);                                              \
+                                   tv.heavy_count, (const uint2*)tv.heavy, tv.heavy_cap, tv.heavy_done, heavy_quad_max);                              \
       else hipLaunchKernelGGL(k_combine_seq<L>, dim3(blocks + HEAVY_WGS), dim3(128), 0, stream, task_off, NB, partials, buckets, seq_parts, blocks,             \
-                              tv.heavy_count, (const uint2*)tv.heavy, tv.heavy_cap, tv.heavy_done);                                                   \
+                              tv.heavy_count, (const uint2*)tv.heavy, tv.heavy_cap, tv.heavy_done, heavy_quad_max);                                   \
     } while (0)
     if (combine_lanes == 1) ZK_LAUNCH_COMBINE(1);
     else if (combine_lanes == 2) ZK_LAUNCH_COMBINE(2);
