@@ -77,7 +77,9 @@ int zkhip_msm_g1_batch(const uint64_t *scalars, const uint64_t *bases, size_t n,
 int zkhip_msm_g2(const uint64_t *scalars, const uint64_t *bases, size_t n, uint64_t out_xyz[24]);
 
 /* Residency for `ParamsKZG::{g, g_lagrange}` (static per params object): upload once and build the prepared table
- * (2^(c w) * P_i for every window w: W * 64 bytes per point of HBM, one-time ~25 ms per 2^20 points) on every shard's device;
+ * (2^(c w) * P_i for every window w: W * 64 bytes per point of HBM, one-time ~25 ms per 2^20 points; arrays of at most 2^15 points
+ * -- $ZKHIP_DIRECT_MAX_LOG -- also get every multiple of every 8-bit window point, 256 KiB per point, and their single MSMs need no
+ * buckets: DESIGN.md section 3c) on every shard's device;
  * zkhip_msm_g1 recognises `bases` pointers inside a registered range (any sub-range), skips the upload and runs the prepared
  * path: one shared bucket set per shard, no window fold, one gather + fold of the shards' partial sums.
  * Contract: the caller keeps [bases, bases + 8 n) alive AND UNCHANGED until zkhip_unregister_bases -- the table is built from the
