@@ -110,7 +110,7 @@ pub(crate) fn try_ntt_fr<S: 'static, G: 'static>(a: &mut [G], omega: &S, log_n: 
     // SAFETY: &mut [G] = &mut [Fr], 2^log_n elements of 4 limbs, transformed in place; omega: 4 limbs, read only
     let rc = unsafe { zkhip_ntt_fr(a.as_mut_ptr() as *mut u64, omega as *const S as *const u64, log_n) };
     if rc != 0 {
-        // `a` is written only by the final device-to-host copy of a successful transform (capi.hip: host_ntt), so the CPU body below
+        // `a` is written only by the final device-to-host copy of a successful transform (capi.hip: host_transform), so the CPU body below
         // still sees the caller's input
         warn_once("zkhip_ntt_fr", rc);
         return false;
