@@ -559,7 +559,10 @@ static int msm_shard_enqueue_chunked(lane* L, scratch* sc, hipStream_t s, const 
     HIPCHK(hipMemcpyAsync((char*)sc->scalars.p + lo * 32, scalars + lo * 4, len * 32, hipMemcpyHostToDevice, L->copy));
     HIPCHK(hipEventRecord(L->copied[j], L->copy));
     HIPCHK(hipStreamWaitEvent(s, L->copied[j], 0));
-    if ((rc = msm_chunk_add((const uint32_t*)((char*)sc->scalars.p + lo * 32), len, pb, pb_off + lo, cap, j == 0, sc->ws.p, sc->ws.cap, s)) != ZKHIP_OK) return rc;
+    if ((rc = msm_chunk_add((const uint32_t*)((char*)sc->scalars.p + lo * 32), len, pb, pb_off + lo, cap, j == 0, sc->ws.p, sc->ws.cap, s)) != ZKHIP_OK) {
+      (void)hipStreamSynchronize(L->copy);     // no upload of a failed call may still be writing the lane's scalar buffer when the lane is handed on
+      return rc;
+    }
     lo += len;
   }
   return msm_chunk_finish(pb, cap, d_partial, sc->ws.p, sc->ws.cap, s);
@@ -788,7 +791,7 @@ int zkhip_register_bases(const uint64_t* bases, size_t n) {
     sh.dev = di; sh.lo = lo; sh.n = hi - lo;
     if ((rc = dsc->bases.reserve(sh.n * 64)) == ZKHIP_OK) {
       if (hipMemcpyAsync(dsc->bases.p, bases + lo * 8, sh.n * 64, hipMemcpyHostToDevice, ds) != hipSuccess) { set_error("register_bases: upload failed"); rc = ZKHIP_EHIP; }
-      else rc = prepare_bases_device((const uint32_t*)dsc->bases.p, sh.n, ds, &sh.pb);
+      else rc = prepare_bases_device((const uint32_t*)dsc->bases.p, sh.n, ds, &sh.pb, 0, /* direct table only for arrays that are small as a whole: */ n);
     }
     if (rc == ZKHIP_OK) reg->shards.push_back(sh);
   }

@@ -2191,7 +2191,7 @@ __global__ void __launch_bounds__(64) k_build_table(const uint32_t* __restrict__
 }
 
 // d_bases: n affine points on the device.  Allocates the table (W * n * 64 B) and a temporary (freed before returning).
-int prepare_bases_device(const uint32_t* d_bases, size_t n, hipStream_t stream, prepared_bases** out, int c_override) {
+int prepare_bases_device(const uint32_t* d_bases, size_t n, hipStream_t stream, prepared_bases** out, int c_override, size_t n_whole) {
   if (n == 0 || n >= (1ull << 27)) { set_error("prepare_bases: n = %zu out of range", n); return ZKHIP_EINVAL; }
   const int c = c_override > 0 ? c_override : msm_pick_window_prepared(n);
   if (c < 2 || c > MAX_WINDOW_PREPARED) { set_error("prepare_bases: window bits %d out of range [2,%d]", c, MAX_WINDOW_PREPARED); return ZKHIP_EINVAL; }
@@ -2210,7 +2210,7 @@ int prepare_bases_device(const uint32_t* d_bases, size_t n, hipStream_t stream, 
   if (e != hipSuccess) { (void)hipFree(table); delete pb; set_error("prepare_bases: %s", hipGetErrorString(e)); return ZKHIP_EHIP; }
   pb->table = (uint32_t*)table;
   // small sets with an automatic window also get the direct table (a failed allocation leaves the bucket path, which needs nothing more)
-  if (c_override <= 0 && msm_direct_wanted(n) && prepare_direct_table(pb, d_bases, stream) != ZKHIP_OK) pb->direct = nullptr;
+  if (c_override <= 0 && msm_direct_wanted(std::max(n, n_whole)) && prepare_direct_table(pb, d_bases, stream) != ZKHIP_OK) pb->direct = nullptr;
   *out = pb;
   return ZKHIP_OK;
 }

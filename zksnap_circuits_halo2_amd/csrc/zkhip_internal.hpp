@@ -69,7 +69,8 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
 size_t msm_chunk_workspace_bytes(size_t chunk_cap, int c);
 int msm_chunk_add(const uint32_t* d_scalars, size_t n, const prepared_bases* pb, size_t pb_off, size_t chunk_cap, bool first, void* ws, size_t ws_bytes, hipStream_t stream);
 int msm_chunk_finish(const prepared_bases* pb, size_t chunk_cap, uint32_t* d_out, void* ws, size_t ws_bytes, hipStream_t stream);
-int prepare_bases_device(const uint32_t* d_bases, size_t n, hipStream_t stream, prepared_bases** out, int c_override = 0);
+// n_whole: size of the array this set is a shard of (0 = n): the direct table is meant for SMALL base sets, not for the shards of a large one
+int prepare_bases_device(const uint32_t* d_bases, size_t n, hipStream_t stream, prepared_bases** out, int c_override = 0, size_t n_whole = 0);
 void release_prepared(prepared_bases* pb);
 // d_out[b] = sum over i < m of d_in[i * count + b], b < count (count = 1: the plain fold of m points)
 int sum_jacobian_device(const uint32_t* d_in, int m, uint32_t* d_out, hipStream_t stream, size_t count = 1);
