@@ -71,8 +71,8 @@ def test_chunked_commit_with_skewed_columns(lib, cref, srs):
 
 
 def test_chunked_pieces_on_virtual_shards(lib, cref):
-    """two shards of 2^21 + 1 points on the one card: each shard's MSM is chunked, and the second shard's uploads reuse the lane's scalar buffer
-    while the first shard's kernels may still be reading it (the copy stream waits for the lane stream: `drained`)"""
+    """two shards of 2^21 + 1 points on the one card: each shard's MSM is chunked, and the second shard's pieces cross PCIe (into their own region of
+    the lane's scalar buffer) while the first shard is still being accumulated"""
     n = (1 << 22) + 2
     bases = walk_host(lib, n)
     sc = cref.gen_scalars(7200, n, 0)

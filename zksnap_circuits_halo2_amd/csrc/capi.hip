@@ -141,7 +141,6 @@ struct lane {          // host-buffer calls: a library-owned stream + (through t
   // accumulated on `stream`; one event per piece in flight.  Created on first use.
   hipStream_t copy = nullptr;
   hipEvent_t copied[STREAM_PIECES_MAX] = {};
-  hipEvent_t drained = nullptr;        // recorded on `stream` before a chunked MSM's first upload: the scalar buffer's previous readers are done
 };
 constexpr size_t LANE_PINNED = 64 * 1024;
 constexpr size_t MAX_STREAM_SCRATCH = 8;   // scratch sets kept per device (least recently used caller streams are dropped beyond that)
@@ -359,7 +358,6 @@ static void destroy_device_ctx(device_ctx* d) {
     if (L.stream) (void)hipStreamDestroy(L.stream);
     if (L.copy) (void)hipStreamDestroy(L.copy);
     for (auto& e : L.copied) if (e) (void)hipEventDestroy(e);
-    if (L.drained) (void)hipEventDestroy(L.drained);
   }
   for (auto e : d->shard_events) (void)hipEventDestroy(e);
   if (d->side_fork) (void)hipEventDestroy(d->side_fork);
@@ -540,26 +538,25 @@ static size_t msm_stream_pieces(size_t n, const prepared_bases* pb) {
 }
 
 static int msm_shard_enqueue_chunked(lane* L, scratch* sc, hipStream_t s, const uint64_t* scalars, size_t n, const prepared_bases* pb, size_t pb_off,
-                                     uint32_t* d_partial, size_t J) {
+                                     uint32_t* d_partial, size_t J, size_t region) {
   int rc;
   if (!L->copy) HIPCHK(hipStreamCreateWithFlags(&L->copy, hipStreamNonBlocking));
-  if (!L->drained) HIPCHK(hipEventCreateWithFlags(&L->drained, hipEventDisableTiming));
   const size_t cap = (n + J - 1) / J;
   const size_t ws_bytes = msm_chunk_workspace_bytes(cap, pb->c);
-  if ((rc = sc->scalars.reserve(n * 32)) != ZKHIP_OK) return rc;
+  if ((rc = sc->scalars.reserve((region + n) * 32)) != ZKHIP_OK) return rc;      // (a no-op inside a fan-out: reserve_for_pieces sized the buffer for all pieces)
   if ((rc = sc->ws.reserve(ws_bytes)) != ZKHIP_OK) return rc;
-  // the uploads overwrite the lane's scalar buffer: an earlier piece of the same call (virtual shards run back to back on this lane) may still
-  // be reading it on `s`
-  HIPCHK(hipEventRecord(L->drained, s));
-  HIPCHK(hipStreamWaitEvent(L->copy, L->drained, 0));
+  // Every piece of a call has its own region of the lane's scalar buffer (`region`, in scalars), so the copy stream may run ahead of the kernels:
+  // while shard k is being accumulated on `s`, the pieces of shard k + 1 are already crossing PCIe (virtual shards on one lane).  A call ends with
+  // hipStreamSynchronize(s), and `s` waits for every copy it used, so nothing of an earlier call is in flight here.
+  char* const dst = (char*)sc->scalars.p + region * 32;
   size_t lo = 0;
   for (size_t j = 0; j < J; j++) {
     const size_t len = n / J + (j < n % J ? 1 : 0);          // cap or cap - 1
     if (!L->copied[j]) HIPCHK(hipEventCreateWithFlags(&L->copied[j], hipEventDisableTiming));
-    HIPCHK(hipMemcpyAsync((char*)sc->scalars.p + lo * 32, scalars + lo * 4, len * 32, hipMemcpyHostToDevice, L->copy));
+    HIPCHK(hipMemcpyAsync(dst + lo * 32, scalars + lo * 4, len * 32, hipMemcpyHostToDevice, L->copy));
     HIPCHK(hipEventRecord(L->copied[j], L->copy));
     HIPCHK(hipStreamWaitEvent(s, L->copied[j], 0));
-    if ((rc = msm_chunk_add((const uint32_t*)((char*)sc->scalars.p + lo * 32), len, pb, pb_off + lo, cap, j == 0, sc->ws.p, sc->ws.cap, s)) != ZKHIP_OK) {
+    if ((rc = msm_chunk_add((const uint32_t*)(dst + lo * 32), len, pb, pb_off + lo, cap, j == 0, sc->ws.p, sc->ws.cap, s)) != ZKHIP_OK) {
       (void)hipStreamSynchronize(L->copy);     // no upload of a failed call may still be writing the lane's scalar buffer when the lane is handed on
       return rc;
     }
@@ -568,37 +565,40 @@ static int msm_shard_enqueue_chunked(lane* L, scratch* sc, hipStream_t s, const 
   return msm_chunk_finish(pb, cap, d_partial, sc->ws.p, sc->ws.cap, s);
 }
 
+// region: offset (in scalars) of this piece inside the lane's scalar buffer -- the pieces one lane runs back to back (virtual shards) do not share
+// upload space, so one piece's upload never waits for the previous piece's kernels
 static int msm_shard_enqueue(scratch* sc, hipStream_t s, const uint64_t* scalars, const uint64_t* bases, size_t n, const prepared_bases* pb,
-                             size_t pb_off, uint32_t* d_partial, lane* L = nullptr) {
+                             size_t pb_off, uint32_t* d_partial, lane* L = nullptr, size_t region = 0) {
   int rc;
   if (n == 0) return msm_g1_device(nullptr, nullptr, 0, d_partial, nullptr, 0, 0, s);
   if (L) {
     const size_t J = msm_stream_pieces(n, pb);
-    if (J > 1) return msm_shard_enqueue_chunked(L, sc, s, scalars, n, pb, pb_off, d_partial, J);
+    if (J > 1) return msm_shard_enqueue_chunked(L, sc, s, scalars, n, pb, pb_off, d_partial, J, region);
   }
-  if ((rc = sc->scalars.reserve(n * 32)) != ZKHIP_OK) return rc;
-  HIPCHK(hipMemcpyAsync(sc->scalars.p, scalars, n * 32, hipMemcpyHostToDevice, s));
+  if ((rc = sc->scalars.reserve((region + n) * 32)) != ZKHIP_OK) return rc;
+  char* const d_sc = (char*)sc->scalars.p + region * 32;
+  HIPCHK(hipMemcpyAsync(d_sc, scalars, n * 32, hipMemcpyHostToDevice, s));
   if (pb) {
     if ((rc = sc->ws.reserve(msm_workspace_bytes(n, pb->c, true))) != ZKHIP_OK) return rc;
-    return msm_g1_device((const uint32_t*)sc->scalars.p, nullptr, n, d_partial, sc->ws.p, sc->ws.cap, 0, s, pb, pb_off);
+    return msm_g1_device((const uint32_t*)d_sc, nullptr, n, d_partial, sc->ws.p, sc->ws.cap, 0, s, pb, pb_off);
   }
   if ((rc = sc->bases.reserve(n * 64)) != ZKHIP_OK) return rc;
   HIPCHK(hipMemcpyAsync(sc->bases.p, bases, n * 64, hipMemcpyHostToDevice, s));
   const int c = msm_pick_window(n);
   if ((rc = sc->ws.reserve(msm_workspace_bytes(n, c))) != ZKHIP_OK) return rc;
-  return msm_g1_device((const uint32_t*)sc->scalars.p, (const uint32_t*)sc->bases.p, n, d_partial, sc->ws.p, sc->ws.cap, c, s);
+  return msm_g1_device((const uint32_t*)d_sc, (const uint32_t*)sc->bases.p, n, d_partial, sc->ws.p, sc->ws.cap, c, s);
 }
 
 struct piece_t { int dev; size_t lo, n; const prepared_bases* pb; size_t pb_off; };   // points [lo, lo + n) of the call's range
 
-// Size the scratch for the largest of the pieces one device will run back to back: growing a buffer between two pieces would
-// free it (a device-wide wait) under the previous piece's kernels.
+// Size the scratch for the pieces one device will run back to back (scalars: the sum, one region per piece; bases and workspace: the largest):
+// growing a buffer between two pieces would free it (a device-wide wait) under the previous piece's kernels.
 static int reserve_for_pieces(scratch* sc, const std::vector<piece_t>& pieces, const std::vector<size_t>& mine) {
   size_t sc_bytes = 0, bs_bytes = 0, ws_bytes = 0;
   for (size_t i : mine) {
     const piece_t& p = pieces[i];
     if (p.n == 0) continue;
-    sc_bytes = std::max(sc_bytes, p.n * 32);
+    sc_bytes += p.n * 32;                           // one region per piece (msm_shard_enqueue)
     if (!p.pb) bs_bytes = std::max(bs_bytes, p.n * 64);
     const size_t J = msm_stream_pieces(p.n, p.pb);
     if (J > 1) ws_bytes = std::max(ws_bytes, msm_chunk_workspace_bytes((p.n + J - 1) / J, p.pb->c));
@@ -663,10 +663,12 @@ static int host_msm(lane_hold& H, const uint64_t* scalars, const uint64_t* bases
         int r;
         if ((r = dsc->small.reserve(4096 + mine.size() * 96)) != ZKHIP_OK) return r;
         if ((r = reserve_for_pieces(dsc, pieces, mine)) != ZKHIP_OK) return r;
+        size_t region = 0;
         for (size_t k = 0; k < mine.size(); k++) {
           const piece_t& p = pieces[mine[k]];
           uint32_t* part = (uint32_t*)((char*)dsc->small.p + 4096 + k * 96);
-          if ((r = msm_shard_enqueue(dsc, ds, scalars + p.lo * 4, bases + p.lo * 8, p.n, p.pb, p.pb_off, part, &D->lanes[0])) != ZKHIP_OK) return r;
+          if ((r = msm_shard_enqueue(dsc, ds, scalars + p.lo * 4, bases + p.lo * 8, p.n, p.pb, p.pb_off, part, &D->lanes[0], region)) != ZKHIP_OK) return r;
+          region += p.n;
           HIPCHK(hipMemcpyPeerAsync(gather + mine[k] * 24, primary_dev, part, D->device, 96, ds));
         }
         HIPCHK(hipStreamSynchronize(ds));                 // the partials have landed on the primary device
@@ -674,9 +676,11 @@ static int host_msm(lane_hold& H, const uint64_t* scalars, const uint64_t* bases
       });
     }
     int rc_local = ZKHIP_OK;
+    size_t region0 = 0;
     for (size_t i : by_dev[0]) {
       const piece_t& p = pieces[i];
-      if ((rc_local = msm_shard_enqueue(sc, s, scalars + p.lo * 4, bases + p.lo * 8, p.n, p.pb, p.pb_off, gather + i * 24, H.L)) != ZKHIP_OK) break;
+      if ((rc_local = msm_shard_enqueue(sc, s, scalars + p.lo * 4, bases + p.lo * 8, p.n, p.pb, p.pb_off, gather + i * 24, H.L, region0)) != ZKHIP_OK) break;
+      region0 += p.n;
     }
     int rc_remote = ZKHIP_OK;
     for (size_t d = 1; d < g_ctx.devs.size(); d++) {
