@@ -1281,21 +1281,24 @@ __global__ void __launch_bounds__(128) k_combine_seq_quad(const uint32_t* __rest
 __global__ void __launch_bounds__(128) k_pyramid_step(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                       uint32_t N, int s, uint32_t in_stride, uint32_t out_stride) {
   const uint32_t per_win = N / 2 + (uint32_t)s * (N / 4);
-  uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid >= per_win) return;
   const int win = blockIdx.y;
   const uint32_t* wi = in + (size_t)win * in_stride * 36;
   uint32_t* wo = out + (size_t)win * out_stride * 36;
-  uint32_t ia, ib;
-  if (tid < N / 2) {
-    ia = 2 * tid; ib = 2 * tid + 1;
-  } else {
-    uint32_t r = tid - N / 2;
-    uint32_t l = r / (N / 4), u = r % (N / 4);
-    if ((int)l == s - 1) { ia = 4 * u + 1; ib = 4 * u + 3; }
-    else { ia = N + l * (N / 2) + 2 * u; ib = ia + 1; }
+  // grid stride: the host may launch fewer threads than additions (ZKHIP_PYR_PERSIST: one resident round of waves that loop, instead of
+  // several rounds of one-addition waves that all start with their loads at the same moment)
+#pragma unroll 1
+  for (uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x; tid < per_win; tid += gridDim.x * blockDim.x) {
+    uint32_t ia, ib;
+    if (tid < N / 2) {
+      ia = 2 * tid; ib = 2 * tid + 1;
+    } else {
+      uint32_t r = tid - N / 2;
+      uint32_t l = r / (N / 4), u = r % (N / 4);
+      if ((int)l == s - 1) { ia = 4 * u + 1; ib = 4 * u + 3; }
+      else { ia = N + l * (N / 2) + 2 * u; ib = ia + 1; }
+    }
+    store_xyzz(wo, tid, xyzz_add(load_xyzz(wi, ia), load_xyzz(wi, ib)));
   }
-  store_xyzz(wo, tid, xyzz_add(load_xyzz(wi, ia), load_xyzz(wi, ib)));
 }
 
 // the same step with the 4 lanes of a quad per addition (ec_quad.hpp): every pyramid level is far smaller than the chip, so the
@@ -1801,6 +1804,7 @@ static int msm_accumulate_combine(const msm_tasks_view& tv, const uint32_t* d_ba
 static int msm_reduce_buckets(int WB, uint32_t B, int c, uint32_t K, bool prepared, uint32_t* cur, uint32_t* nxt, uint32_t* winsum, uint32_t* d_out, hipStream_t stream) {
   // 8. pyramid: buckets were written with window stride B (dense).  Steps 1 .. c-2 leave X with 2 elements.
   static const size_t quad_max = [] { const char* e = getenv("ZKHIP_PYR_QUAD_MAX"); const long v = e ? atol(e) : 0; return v >= 256 && v <= (1 << 20) ? (size_t)v : (size_t)65536; }();   // A/B knob
+  static const long pyr_persist = [] { const char* e = getenv("ZKHIP_PYR_PERSIST"); const long v = e ? atol(e) : 0; return v >= 64 && v <= 65536 ? v : 0L; }();   // A/B knob: workgroup cap of the single-lane steps (0 = one addition per thread)
   uint32_t in_stride = B;
   int nz = 0;
   {
@@ -1811,7 +1815,11 @@ static int msm_reduce_buckets(int WB, uint32_t B, int c, uint32_t K, bool prepar
       uint32_t out_stride = per_win;
       // below ~1/4 of the chip's lanes an addition's latency is the step time: four lanes per addition
       if ((size_t)per_win * WB <= quad_max) hipLaunchKernelGGL(k_pyramid_step_quad, dim3((4 * per_win + 127) / 128, WB), dim3(128), 0, stream, cur, nxt, N, s, in_stride, out_stride);
-      else hipLaunchKernelGGL(k_pyramid_step, dim3((per_win + 127) / 128, WB), dim3(128), 0, stream, cur, nxt, N, s, in_stride, out_stride);
+      else {
+        unsigned blocks = (per_win + 127) / 128;
+        if (pyr_persist > 0 && WB == 1) blocks = std::min<unsigned>(blocks, (unsigned)pyr_persist);
+        hipLaunchKernelGGL(k_pyramid_step, dim3(blocks, WB), dim3(128), 0, stream, cur, nxt, N, s, in_stride, out_stride);
+      }
       uint32_t* t = cur; cur = nxt; nxt = t;
       in_stride = out_stride;
       N >>= 1;
