@@ -276,6 +276,9 @@ int zkhip_g1_fft_device(void *d_points_xyz, const uint64_t omega[4], uint32_t lo
 /* `g_to_lagrange(g, k)` [DEP poly/kzg/commitment.rs, used by ParamsKZG::setup / from_parts for an SRS whose trapdoor is not known]:
  * d_g_lagrange[i] = (1/n) sum_j omega_k^(-i j) d_g[j], both arrays 2^k G1Affine points (64 B); may not alias. */
 int zkhip_g_to_lagrange_device(const void *d_g, uint32_t k, void *d_g_lagrange, void *stream);
+/* host-buffer form with the memory of the reference's function: g_xyz = 2^k Jacobian points (`Vec<G1>`, 12 limbs each), g_lagrange = 2^k affine
+ * points (`Vec<G1Affine>`, 8 limbs each); the inverse FFT over the points, the 1/n scaling and the batch normalisation in one call */
+int zkhip_g_to_lagrange(const uint64_t *g_xyz, uint32_t k, uint64_t *g_lagrange);
 /* `Curve::batch_normalize` [DEP group / halo2curves; create_proof normalises its commitments before they enter the transcript, and
  * keygen stores `to_affine()` of the fixed / permutation commitments in the verifying key]: n Jacobian points (12 limbs each) -> n
  * affine points (8 limbs each, canonical Montgomery limbs; the identity becomes (0, 0)). */

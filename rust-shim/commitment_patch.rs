@@ -14,6 +14,9 @@
 //!        `from_parts`   :  `Self { k, n: 1 << k, g_lagrange: ..., g, g2, s_g2 }.zkhip_pinned()`
 //!        `read_custom`  :  `Ok(Self { k, n: n as u64, g, g_lagrange, g2, s_g2 }.zkhip_pinned())`     (`read` forwards to it)
 //!   4. `Params::downsize` (it truncates `g` and replaces `g_lagrange`): first statement `self.zkhip_unpin();`, last statement `self.zkhip_pin();`.
+//!   5. `g_to_lagrange<C: CurveAffine>(g_projective: Vec<C::Curve>, k: u32) -> Vec<C>` -- first statement:
+//!        `if let Some(v) = zkhip_ffi::try_g_to_lagrange::<C, C::Curve>(&g_projective, k, C::identity()) { return v; }`
+//!      (the upstream body -- best_fft over the points, `*g *= n_inv`, batch_normalize -- stays below it for every other curve and as the fall-back).
 //! A struct with a `Drop` impl cannot be destructured by move; the crate never does that with `ParamsKZG` (it is only read through
 //! `&self`: `get_g`, `g2`, `s_g2`, `commit*`, `verifier_params`).
 

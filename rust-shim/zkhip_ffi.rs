@@ -34,9 +34,16 @@ extern "C" {
     fn zkhip_extended_to_coeff(a: *mut u64, ext_k: u32, ext_omega_inv: *const u64, ext_divisor: *const u64, zeta: *const u64,
                                out: *mut u64, out_len: usize) -> c_int;
     fn zkhip_mul_periodic(a: *mut u64, n: usize, table: *const u64, period: u32) -> c_int;
+    fn zkhip_g_to_lagrange(g_xyz: *const u64, k: u32, g_lagrange: *mut u64) -> c_int;
     fn zkhip_register_bases(bases: *const u64, n: usize) -> c_int;
     fn zkhip_unregister_bases(bases: *const u64) -> c_int;
 }
+
+/// Below these sizes a call is answered by the crate's CPU body: a GPU call costs ~0.1 ms of launch chain and PCIe latency whatever its size, and the
+/// verifier / accumulation side of the reference (`verify_proof`, `AccumulatorStrategy`, /root/reference/aggregator/src/wrapper.rs:145) issues
+/// multi-exponentiations of a handful of points.  (A 2^10-point MSM is ~0.1 ms on one CPU core; the smallest circuit of the reference commits 2^13.)
+const MIN_GPU_MSM: usize = 1 << 10;
+const MIN_GPU_NTT_LOG: u32 = 11;
 
 /// 0 = not probed, 1 = GPU path usable, 2 = disabled (no device, layout self-test failed, or ZKHIP_DISABLE=1)
 static STATE: AtomicU8 = AtomicU8::new(0);
@@ -88,7 +95,7 @@ fn is<T: 'static, U: 'static>() -> bool {
 /// `C`, `S` (= C::Scalar) and `P` (= C::Curve) are type parameters so that this module does not need the crate's trait imports; all three
 /// carry `'static` through `CurveAffine` / `ff::Field` / `group::Group` [DEP halo2curves, ff, group].
 pub(crate) fn try_msm_g1<C: 'static, S: 'static, P: 'static>(coeffs: &[S], bases: &[C], identity: P) -> Option<P> {
-    if !(is::<C, G1Affine>() && is::<S, Fr>() && is::<P, G1>()) || coeffs.len() != bases.len() || !usable() {
+    if !(is::<C, G1Affine>() && is::<S, Fr>() && is::<P, G1>()) || coeffs.len() != bases.len() || coeffs.len() < MIN_GPU_MSM || !usable() {
         return None;
     }
     let mut out = identity;
@@ -104,7 +111,7 @@ pub(crate) fn try_msm_g1<C: 'static, S: 'static, P: 'static>(coeffs: &[S], bases
 
 /// `best_fft::<Scalar, G>`: true when G = Scalar = bn256::Fr and the transform was done in place on the GPU.
 pub(crate) fn try_ntt_fr<S: 'static, G: 'static>(a: &mut [G], omega: &S, log_n: u32) -> bool {
-    if !(is::<G, Fr>() && is::<S, Fr>()) || log_n > 28 || a.len() != 1usize << log_n || !usable() {
+    if !(is::<G, Fr>() && is::<S, Fr>()) || log_n < MIN_GPU_NTT_LOG || log_n > 28 || a.len() != 1usize << log_n || !usable() {
         return false;
     }
     // SAFETY: &mut [G] = &mut [Fr], 2^log_n elements of 4 limbs, transformed in place; omega: 4 limbs, read only
@@ -132,6 +139,23 @@ pub(crate) fn pin<C: 'static>(bases: &[C]) {
     }
 }
 
+/// `g_to_lagrange::<C>(g_projective, k)` [DEP poly/kzg/commitment.rs; `ParamsKZG::{setup, from_parts, downsize}`, reached from `gen_srs`,
+/// /root/reference/aggregator/benches/wrapper_circuit.rs:35,49,69]: the inverse FFT over the 2^k points, the 1/n scaling and the batch normalisation
+/// in one call (1.2 s at k = 22, where the CPU body runs 2^22 scalar multiplications).  Some(g_lagrange) for C = bn256::G1Affine, None otherwise.
+pub(crate) fn try_g_to_lagrange<C: 'static + Clone, P: 'static>(g_projective: &[P], k: u32, identity: C) -> Option<Vec<C>> {
+    if !(is::<C, G1Affine>() && is::<P, G1>()) || k > 26 || k < MIN_GPU_NTT_LOG || g_projective.len() != 1usize << k || !usable() {
+        return None;
+    }
+    let mut out = vec![identity; 1usize << k];
+    // SAFETY: &[P] = &[G1] (96-byte Jacobian points, read only), out = Vec<G1Affine> of 2^k elements (64 bytes each), written in full on success
+    let rc = unsafe { zkhip_g_to_lagrange(g_projective.as_ptr() as *const u64, k, out.as_mut_ptr() as *mut u64) };
+    if rc != 0 {
+        warn_once("zkhip_g_to_lagrange", rc);
+        return None;
+    }
+    Some(out)
+}
+
 /// Undo `pin`; must run before the memory is freed or rewritten (`Drop for ParamsKZG`, `downsize`).
 pub(crate) fn unpin<C: 'static>(bases: &[C]) {
     if !is::<C, G1Affine>() || bases.is_empty() || STATE.load(Ordering::Acquire) != 1 {
@@ -143,7 +167,7 @@ pub(crate) fn unpin<C: 'static>(bases: &[C]) {
 
 /// `EvaluationDomain::ifft` for F = bn256::Fr: inverse transform and the 1/n scale in one call.
 pub(crate) fn try_ifft_scaled<F: 'static>(a: &mut [F], omega_inv: &F, log_n: u32, divisor: &F) -> bool {
-    if !is::<F, Fr>() || log_n > 28 || a.len() != 1usize << log_n || !usable() {
+    if !is::<F, Fr>() || log_n < MIN_GPU_NTT_LOG || log_n > 28 || a.len() != 1usize << log_n || !usable() {
         return false;
     }
     // SAFETY: as try_ntt_fr

@@ -10,6 +10,7 @@
  *   ParamsKZG::setup / read     register(g), register(g_lagrange)                       (commitment_patch.rs: zkhip_pinned)
  *   commit / commit_lagrange    msm(scalars, &g[..n']) for n' <= len                     (arithmetic_patch.rs: best_multiexp)
  *   EvaluationDomain            ntt, ifft_scaled, coeff_to_extended, extended_to_coeff, mul_periodic   (best_fft, domain_patch.rs)
+ *   g_to_lagrange               zkhip_g_to_lagrange (setup / from_parts / downsize)
  *   Drop                        unregister(g), unregister(g_lagrange)
  *   a second ParamsKZG whose Vecs land on the SAME addresses, other points: register again, commit
  *
@@ -145,6 +146,23 @@ int main(void) {
     for (j = (size_t)4 << K_NTT; j < (size_t)12 << K_NTT; j++) tail_zero &= (back[j] == 0);
     CHECK(tail_zero, "coefficients n .. 3n of a degree < n polynomial are zero");
     free(back);
+  }
+
+  /* ---- g_to_lagrange (ParamsKZG::setup / from_parts / downsize; commitment_patch.rs item 5): 2^11 Jacobian points in, affine Lagrange basis out.
+   * g_lagrange[i] = (1/n) sum_j omega^(-i j) g[j], hence sum_i g_lagrange[i] = g[0]: checked with an MSM of ones over the result ---- */
+  {
+    const uint32_t kk = 11;
+    const size_t m = (size_t)1 << kk;
+    uint64_t *jac = malloc(m * 96), *lag = malloc(m * 64), *ones = malloc(m * 32), sum[12], first[12];
+    size_t j;
+    if (!jac || !lag || !ones) return 2;
+    for (j = 0; j < m; j++) { memcpy(jac + 12 * j, g + 8 * j, 64); memcpy(jac + 12 * j + 8, FQ_ONE, 32); memcpy(ones + 4 * j, FR_ONE, 32); }   /* z = 1 */
+    OK(zkhip_g_to_lagrange(jac, kk, lag));
+    OK(zkhip_msm_g1(ones, lag, m, sum));
+    memcpy(first, jac, 96);
+    CHECK(same_point(sum, first), "sum of the Lagrange-basis points == g[0]");
+    CHECK(memcmp(lag, g, 64) != 0, "the Lagrange basis differs from the monomial one");
+    free(jac); free(lag); free(ones);
   }
 
   /* ---- Drop for ParamsKZG: unregister BEFORE the Vecs are freed ---- */

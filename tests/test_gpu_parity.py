@@ -935,6 +935,20 @@ def test_g_to_lagrange_agrees_with_the_trapdoor_formula(lib, cref, k):
     params = Z.ParamsKZG.setup(k, s)
     try:
         assert np.array_equal(kzg.g_to_lagrange(params.g, k), params.g_lagrange)
+        # the host-buffer entry point with the reference function's memory (`Vec<G1>` in, `Vec<G1Affine>` out: rust-shim/commitment_patch.rs item 5):
+        # Jacobian input with z = 1 and, for every third point, another representative of the same point (x z^2, y z^3, z)
+        n = 1 << k
+        one_q = np.array(O.limbs4(O.to_mont(1, O.Q_MOD)), dtype=np.uint64)
+        jac = np.concatenate([params.g, np.broadcast_to(one_q, (n, 4))], axis=1)
+        for i in range(0, n, 3):
+            pt = O.affine_from_limbs([int(v) for v in params.g[i]])
+            z = 0x1234567 + i
+            jac[i] = np.array(O.limbs4(O.to_mont(pt[0] * z * z % O.Q_MOD, O.Q_MOD)) + O.limbs4(O.to_mont(pt[1] * z * z * z % O.Q_MOD, O.Q_MOD))
+                              + O.limbs4(O.to_mont(z, O.Q_MOD)), dtype=np.uint64)
+        jac = np.ascontiguousarray(jac)
+        out = np.zeros((n, 8), dtype=np.uint64)
+        _lib.check(lib.zkhip_g_to_lagrange(jac.ctypes.data, k, out.ctypes.data))
+        assert np.array_equal(out, params.g_lagrange)
         evals = cref.gen_scalars(4242 + k, 1 << k, 0)
         expected = aff(cref, params.commit_lagrange(evals))
     finally:

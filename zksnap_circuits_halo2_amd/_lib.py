@@ -55,6 +55,7 @@ _SIGS = {
     "zkhip_prepare_bases_device": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]),
     "zkhip_g1_fft_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "zkhip_g_to_lagrange_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "zkhip_g_to_lagrange": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     "zkhip_prepare_bases_device_c": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint64)]),
     "zkhip_release_bases": (C.c_int, [C.c_uint64]),
     "zkhip_prepared_window_bits": (C.c_int, [C.c_uint64]),

@@ -1707,6 +1707,32 @@ int zkhip_g_to_lagrange_device(const void* d_g, uint32_t k, void* d_g_lagrange, 
   return g1_fft_device((const uint32_t*)d_g, 0, (uint32_t*)d_g_lagrange, 0, k, (const uint32_t*)omega_inv.l, (const uint32_t*)n_inv.l, sc->ws.p, sc->ws.cap, s);
 }
 
+// host-buffer form, with the memory of the reference's `g_to_lagrange(g_projective: Vec<C::Curve>, k) -> Vec<C>`: 2^k Jacobian points in, 2^k affine
+// points out (the whole function: inverse FFT over the points, the 1/n scaling and Curve::batch_normalize in one call)
+int zkhip_g_to_lagrange(const uint64_t* g_xyz, uint32_t k, uint64_t* g_lagrange) {
+  ZK_API_RANGE();
+  if (!g_xyz || !g_lagrange) { set_error("g_to_lagrange: null pointer"); return ZKHIP_EINVAL; }
+  if (k > 26) { set_error("g_to_lagrange: k = %u out of range", k); return ZKHIP_EINVAL; }
+  lane_hold H;
+  if (H.rc != ZKHIP_OK) return H.rc;
+  int rc;
+  const size_t n = (size_t)1 << k;
+  hipStream_t s = H.s;
+  scratch* sc = H.sc;
+  if ((rc = sc->bases.reserve(n * 96)) != ZKHIP_OK) return rc;
+  if ((rc = sc->poly.reserve(n * 64)) != ZKHIP_OK) return rc;
+  if ((rc = sc->ws.reserve(g1_fft_workspace(n))) != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(sc->bases.p, g_xyz, n * 96, hipMemcpyHostToDevice, s));
+  namespace Hh = zkhip::halo2;
+  Hh::Fr omega = Hh::fr_root_of_unity();
+  for (uint32_t i = k; i < 28; i++) omega = Hh::detail::mul(omega, omega);
+  const Hh::Fr omega_inv = Hh::detail::invert(omega), n_inv = Hh::detail::invert(Hh::detail::from_u64((uint64_t)n));
+  if ((rc = g1_fft_device((const uint32_t*)sc->bases.p, 1, (uint32_t*)sc->poly.p, 0, k, (const uint32_t*)omega_inv.l, (const uint32_t*)n_inv.l, sc->ws.p, sc->ws.cap, s)) != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(g_lagrange, sc->poly.p, n * 64, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return ZKHIP_OK;
+}
+
 int zkhip_g1_gen_walk_device(const uint64_t t0[4], const uint64_t d[4], size_t n, void* d_out, void* stream) {
   ZK_API_RANGE();
   guard_t g(g_mu);
