@@ -2247,7 +2247,7 @@ void release_prepared(prepared_bases* pb) {
 // Depth: 3 mixed + ~20 quad additions, against 11 + 11 pyramid / doubling steps, the combine and the sort chain of the bucket method.
 // Signed recoding: digit_w = byte_w + carry in [-128, 127] u {128 -> -128 + carry}; the scalar is < 2^254, so the top window's byte is < 64: no carry out.
 // ------------------------------------------------------------------------------------------------
-constexpr int DIRECT_W = 32, DIRECT_M = 128, DIRECT_GROUPS = 8;   // windows, multiples per window, threads per scalar at most (k_direct_accumulate<4>)
+constexpr int DIRECT_W = 32, DIRECT_M = 128;   // windows, multiples per window
 
 __global__ void __launch_bounds__(64) k_direct_build(const uint32_t* __restrict__ wtable /* [32][n_all] reduced internal affine: 2^(8 w) P_i */, uint32_t n_all,
                                                      uint32_t i0, uint32_t cnt, uint32_t* __restrict__ direct, uint32_t* __restrict__ tmp_pts,
@@ -2283,10 +2283,12 @@ __global__ void __launch_bounds__(64) k_direct_build(const uint32_t* __restrict_
   }
 }
 
-template <int WPT>      // windows per thread: 4 (8 threads per scalar) or 8 (4 threads per scalar)
+template <int WPT>      // windows per thread: 1, 2, 4 or 8 (32 / WPT threads per scalar)
 __device__ __forceinline__ void direct_accumulate_body(const uint32_t* __restrict__ scalars, uint32_t n, uint32_t off,
                                                        const uint32_t* __restrict__ direct, uint32_t* __restrict__ partials) {
   constexpr uint32_t GROUPS = DIRECT_W / WPT;
+  constexpr int WORDS = WPT >= 4 ? WPT / 4 : 1;      // scalar words a thread reads its digits from
+  constexpr int PER = WPT >= 4 ? 4 : WPT;            // windows per word
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= n * GROUPS) return;
   const uint32_t i = tid / GROUPS, g = tid % GROUPS;
@@ -2311,28 +2313,29 @@ __device__ __forceinline__ void direct_accumulate_body(const uint32_t* __restric
     }
   }
   xyzz acc = xyzz_identity();
-  // 4 windows = one scalar word at a time: digits, 4 gathers in flight, then the additions (the first point of a thread is a copy).
+  // one scalar word (up to 4 windows) at a time: digits, the gathers in flight together, then the additions (the first point of a thread is a copy).
   // (compile-time loops: under `#pragma unroll` the compiler keeps a loop whose body holds the asm-block multiplications rolled, which indexes
   // the point array dynamically and puts it into scratch)
-  static_for<0, WPT / 4>([&](auto hc) {
+  static_for<0, WORDS>([&](auto hc) {
     constexpr int h = decltype(hc)::value;
+    const uint32_t word = first / 4 + h, byte0 = WPT >= 4 ? 0u : first % 4;
     uint32_t own = 0;
 #pragma unroll
-    for (int wi = 0; wi < 8; wi++) own = ((uint32_t)wi == g * (WPT / 4) + h) ? w[wi] : own;
-    int32_t dg[4];
+    for (int wi = 0; wi < 8; wi++) own = ((uint32_t)wi == word) ? w[wi] : own;
+    int32_t dg[PER];
 #pragma unroll
-    for (int b = 0; b < 4; b++) {
-      const uint32_t v = ((own >> (8 * b)) & 255u) + carry;
+    for (int b = 0; b < PER; b++) {
+      const uint32_t v = ((own >> (8 * (byte0 + b))) & 255u) + carry;
       if (v >= 128u) { dg[b] = (int32_t)v - 256; carry = 1; } else { dg[b] = (int32_t)v; carry = 0; }
     }
-    affine_words pts[4];
-    static_for<0, 4>([&](auto bc) {
+    affine_words pts[PER];
+    static_for<0, PER>([&](auto bc) {
       constexpr int b = decltype(bc)::value;
       const uint32_t mag = (uint32_t)(dg[b] < 0 ? -dg[b] : dg[b]);
-      const size_t idx = (((size_t)(off + i) * DIRECT_W + first + 4 * h + b) * DIRECT_M) + (mag ? mag - 1 : 0);
+      const size_t idx = (((size_t)(off + i) * DIRECT_W + first + PER * h + b) * DIRECT_M) + (mag ? mag - 1 : 0);
       pts[b] = load_affine(direct, idx);
     });
-    static_for<0, 4>([&](auto bc) {
+    static_for<0, PER>([&](auto bc) {
       constexpr int b = decltype(bc)::value;
       if (dg[b] != 0 && !affine_is_identity(pts[b])) {
         fe x2 = fe_unpack<0>(pts[b].x), y2 = fe_unpack<0>(pts[b].y);
@@ -2344,12 +2347,21 @@ __device__ __forceinline__ void direct_accumulate_body(const uint32_t* __restric
   });
   store_xyzz(partials, tid, acc);
 }
-// 4 windows per thread: launches of up to 2^17 threads, sized for 4 waves per SIMD (128 VGPRs, no scratch); 8 windows per thread: the scalar's
-// words stay live across two rounds of gathers -- 2 waves per SIMD at the sizes it runs at, so it may take the registers it needs
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) k_direct_accumulate4(const uint32_t* __restrict__ scalars, uint32_t n, uint32_t off,
-                                                    const uint32_t* __restrict__ direct, uint32_t* __restrict__ partials) { direct_accumulate_body<4>(scalars, n, off, direct, partials); }
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 3))) k_direct_accumulate8(const uint32_t* __restrict__ scalars, uint32_t n, uint32_t off,
-                                                    const uint32_t* __restrict__ direct, uint32_t* __restrict__ partials) { direct_accumulate_body<8>(scalars, n, off, direct, partials); }
+// Windows per thread.  Everything here is latency: a thread's k - 1 dependent mixed additions cost ~8 us each, a level of the quad tree ~5 us, so FEWER
+// windows per thread win as long as the first tree launch stays one round of workgroups (256 x 512 inputs = 2^17 partial sums): 1 window per thread up to
+// 2^12 scalars, 2 at 2^13, 4 at 2^14, 8 above.  1 .. 4 windows: launches of up to 2^17 threads sized for 4 waves per SIMD (128 VGPRs, no scratch);
+// 8 windows: the scalar's words stay live across two rounds of gathers, it may take the registers it needs.
+static inline int direct_wpt(size_t n) { int wpt = 1; while (wpt < 8 && n * (size_t)DIRECT_W / (size_t)wpt > ((size_t)1 << 17)) wpt <<= 1; return wpt; }
+#define ZK_DIRECT_KERNEL(W, OCC_LO, OCC_HI)                                                                                                          \
+  __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(OCC_LO, OCC_HI))) k_direct_accumulate##W(                                 \
+      const uint32_t* __restrict__ scalars, uint32_t n, uint32_t off, const uint32_t* __restrict__ direct, uint32_t* __restrict__ partials) {         \
+    direct_accumulate_body<W>(scalars, n, off, direct, partials);                                                                                     \
+  }
+ZK_DIRECT_KERNEL(1, 4, 4)
+ZK_DIRECT_KERNEL(2, 4, 4)
+ZK_DIRECT_KERNEL(4, 4, 4)
+ZK_DIRECT_KERNEL(8, 2, 3)
+#undef ZK_DIRECT_KERNEL
 
 // out[b] = sum of in[b * 128 S .. ): 128 quads per workgroup, quad t adds the S points t, t + 128, ... of the workgroup's slice (coalesced rows), a
 // shuffle tree adds the 16 quads of a wavefront, an LDS tree the 8 wavefronts.  jac_out != nullptr (single workgroup): the Jacobian result.
@@ -2380,7 +2392,8 @@ __global__ void __launch_bounds__(512) k_points_sum_quad(const uint32_t* __restr
 }
 
 size_t direct_table_bytes(size_t n) { return n * (size_t)DIRECT_W * DIRECT_M * 64; }
-size_t msm_direct_workspace_bytes(size_t n) { return align_up(n * DIRECT_GROUPS * 144, 256) + align_up(((n * DIRECT_GROUPS + 511) / 512 + 1) * 144, 256); }
+static inline size_t direct_partials(size_t n) { return n * (size_t)DIRECT_W / (size_t)direct_wpt(n); }
+size_t msm_direct_workspace_bytes(size_t n) { return align_up(direct_partials(n) * 144, 256) + align_up(((direct_partials(n) + 511) / 512 + 1) * 144, 256); }
 
 // builds pb->direct from the points (device-resident affine bases); returns ZKHIP_ENOMEM when the table does not fit (the caller keeps the bucket path)
 int prepare_direct_table(prepared_bases* pb, const uint32_t* d_bases, hipStream_t stream) {
@@ -2419,14 +2432,16 @@ int msm_g1_direct(const uint32_t* d_scalars, size_t n, const prepared_bases* pb,
   if (n == 0) { hipLaunchKernelGGL(k_sum_jacobian, dim3(1), dim3(64), 0, stream, (const uint32_t*)nullptr, 0, d_out, 1u); HIPCHK(hipGetLastError()); return ZKHIP_OK; }
   if (ws_bytes < msm_direct_workspace_bytes(n)) { set_error("msm_direct: workspace too small"); return ZKHIP_EINVAL; }
   uint32_t* const partials = (uint32_t*)ws;
-  uint32_t* const level1 = (uint32_t*)((char*)ws + align_up(n * DIRECT_GROUPS * 144, 256));
+  uint32_t* const level1 = (uint32_t*)((char*)ws + align_up(direct_partials(n) * 144, 256));
   prof_begin(stream);
-  // 8 threads per scalar (3 dependent mixed additions) while that is at most one round of waves; above 2^14 scalars 4 threads per scalar: the
-  // launch is throughput-bound either way and half as many partial sums enter the tree (2^15: 0.226 -> see profiles/r04_small_msm_direct_ab.txt)
-  const bool wide = n > ((size_t)1 << 14);
-  uint32_t m = (uint32_t)(n * (wide ? 4 : 8));
-  if (wide) hipLaunchKernelGGL(k_direct_accumulate8, dim3((m + 127) / 128), dim3(128), 0, stream, d_scalars, (uint32_t)n, (uint32_t)off, (const uint32_t*)pb->direct, partials);
-  else hipLaunchKernelGGL(k_direct_accumulate4, dim3((m + 127) / 128), dim3(128), 0, stream, d_scalars, (uint32_t)n, (uint32_t)off, (const uint32_t*)pb->direct, partials);
+  const int wpt = direct_wpt(n);
+  uint32_t m = (uint32_t)direct_partials(n);
+  const dim3 grid((m + 127) / 128), block(128);
+  const uint32_t* const tab = (const uint32_t*)pb->direct;
+  if (wpt == 1) hipLaunchKernelGGL(k_direct_accumulate1, grid, block, 0, stream, d_scalars, (uint32_t)n, (uint32_t)off, tab, partials);
+  else if (wpt == 2) hipLaunchKernelGGL(k_direct_accumulate2, grid, block, 0, stream, d_scalars, (uint32_t)n, (uint32_t)off, tab, partials);
+  else if (wpt == 4) hipLaunchKernelGGL(k_direct_accumulate4, grid, block, 0, stream, d_scalars, (uint32_t)n, (uint32_t)off, tab, partials);
+  else hipLaunchKernelGGL(k_direct_accumulate8, grid, block, 0, stream, d_scalars, (uint32_t)n, (uint32_t)off, tab, partials);
   prof_mark(stream, "direct_accumulate");
   const uint32_t* cur = partials;
   uint32_t* nxt = level1;
