@@ -48,7 +48,7 @@ def edge_scalars(rng, n):
     return F.fr_encode([v % R for v in vals[:n]])
 
 
-@pytest.mark.parametrize("n", [2, 3, 17, 100, 1000, 1 << 13, (1 << 13) + 5, (1 << 14) + 1, 1 << 15])
+@pytest.mark.parametrize("n", [2, 3, 17, 100, 1000, 1025, 2049, 4097, 1 << 13, (1 << 13) + 5, (1 << 14) + 1, 1 << 15])
 def test_direct_msm_vs_oracle_and_bucket_path(lib, cref, n):
     import random
 

@@ -2347,11 +2347,18 @@ __device__ __forceinline__ void direct_accumulate_body(const uint32_t* __restric
   });
   store_xyzz(partials, tid, acc);
 }
-// Windows per thread.  Everything here is latency: a thread's k - 1 dependent mixed additions cost ~8 us each, a level of the quad tree ~5 us, so FEWER
-// windows per thread win as long as the first tree launch stays one round of workgroups (256 x 512 inputs = 2^17 partial sums): 1 window per thread up to
-// 2^12 scalars, 2 at 2^13, 4 at 2^14, 8 above.  1 .. 4 windows: launches of up to 2^17 threads sized for 4 waves per SIMD (128 VGPRs, no scratch);
-// 8 windows: the scalar's words stay live across two rounds of gathers, it may take the registers it needs.
-static inline int direct_wpt(size_t n) { int wpt = 1; while (wpt < 8 && n * (size_t)DIRECT_W / (size_t)wpt > ((size_t)1 << 17)) wpt <<= 1; return wpt; }
+// Windows per thread.  Everything here is latency: a thread's k - 1 dependent mixed additions cost ~8 us each, the quad tree 80 / 89 / 102 / 111 us for
+// 2^13 / 2^15 / 2^16 / 2^17 partial sums (measured, profiles/r04_small_msm_direct_ab.txt).  Up to 2^15 partial sums fewer windows per thread win
+// (2^10 scalars: 1 window 0.094 ms, 4 windows 0.099); beyond that the tree's growth costs more than the additions saved (2^12: 1 window 0.121, 4 windows
+// 0.110), and past 2^17 partial sums the first tree launch would need a second round of workgroups: 1 window per thread up to 2^10 scalars, 2 at 2^11,
+// 4 from 2^12 to 2^14, 8 above.  1 .. 4 windows: launches sized for 4 waves per SIMD (<= 128 VGPRs, no scratch); 8 windows: the scalar's words stay
+// live across two rounds of gathers, it may take the registers it needs.
+static inline int direct_wpt(size_t n) {
+  int wpt = 1;
+  while (wpt < 4 && n * (size_t)DIRECT_W / (size_t)wpt > ((size_t)1 << 15)) wpt <<= 1;
+  while (wpt < 8 && n * (size_t)DIRECT_W / (size_t)wpt > ((size_t)1 << 17)) wpt <<= 1;
+  return wpt;
+}
 #define ZK_DIRECT_KERNEL(W, OCC_LO, OCC_HI)                                                                                                          \
   __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(OCC_LO, OCC_HI))) k_direct_accumulate##W(                                 \
       const uint32_t* __restrict__ scalars, uint32_t n, uint32_t off, const uint32_t* __restrict__ direct, uint32_t* __restrict__ partials) {         \
