@@ -2351,13 +2351,16 @@ __device__ __forceinline__ void direct_accumulate_body(const uint32_t* __restric
 // 2^13 / 2^15 / 2^16 / 2^17 partial sums (measured, profiles/r04_small_msm_direct_ab.txt).  Up to 2^15 partial sums fewer windows per thread win
 // (2^10 scalars: 1 window 0.094 ms, 4 windows 0.099); beyond that the tree's growth costs more than the additions saved (2^12: 1 window 0.121, 4 windows
 // 0.110), and past 2^17 partial sums the first tree launch would need a second round of workgroups: 1 window per thread up to 2^10 scalars, 2 at 2^11,
-// 4 from 2^12 to 2^14, 8 above.  1 .. 4 windows: launches sized for 4 waves per SIMD (<= 128 VGPRs, no scratch); 8 windows: the scalar's words stay
+// 4 at 2^12, 2 at 2^13, 4 at 2^14, 8 above (the measured optimum at every size; it is not monotone because both costs are step functions).  1 .. 4 windows: launches sized for 4 waves per SIMD (<= 128 VGPRs, no scratch); 8 windows: the scalar's words stay
 // live across two rounds of gathers, it may take the registers it needs.
+// (2^13 scalars, measured both ways on one box: 2 windows per thread 0.1275 ms, 4 windows 0.1333.)
 static inline int direct_wpt(size_t n) {
-  int wpt = 1;
-  while (wpt < 4 && n * (size_t)DIRECT_W / (size_t)wpt > ((size_t)1 << 15)) wpt <<= 1;
-  while (wpt < 8 && n * (size_t)DIRECT_W / (size_t)wpt > ((size_t)1 << 17)) wpt <<= 1;
-  return wpt;
+  if (n <= 1024) return 1;
+  if (n <= 2048) return 2;
+  if (n <= 4096) return 4;
+  if (n <= 8192) return 2;       // 2^17 partial sums: still one round of tree workgroups, and two dependent additions less per thread
+  if (n <= 16384) return 4;
+  return 8;
 }
 #define ZK_DIRECT_KERNEL(W, OCC_LO, OCC_HI)                                                                                                          \
   __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(OCC_LO, OCC_HI))) k_direct_accumulate##W(                                 \
