@@ -176,7 +176,8 @@ def visible_gpus_without_hip():
     agent of the HOST (GPUs: simd_count > 0) whatever the container may use, so a GPU counts only if its DRM render node can actually be opened
     (a device cgroup refuses the open of the cards that are not this container's); *_VISIBLE_DEVICES lists cap the count.  None when the
     topology cannot be read (the per-rank check in main() still refuses a rank without its device)."""
-    root = "/sys/class/kfd/kfd/topology/nodes"
+    root = os.environ.get("ZKHIP_BENCH_KFD_NODES", "/sys/class/kfd/kfd/topology/nodes")      # (the overrides exist for tests/test_bench_launcher.py)
+    dri = os.environ.get("ZKHIP_BENCH_DRI_DIR", "/dev/dri")
     if not os.path.isdir(root):
         return 0                                      # no KFD driver: no AMD GPU
     count = 0
@@ -190,7 +191,7 @@ def visible_gpus_without_hip():
             if minor < 0:
                 continue
             try:
-                fd = os.open(f"/dev/dri/renderD{minor}", os.O_RDWR)      # opening the render node starts nothing: no KFD process, no queues
+                fd = os.open(os.path.join(dri, f"renderD{minor}"), os.O_RDWR)      # opening the render node starts nothing: no KFD process, no queues
                 os.close(fd)
                 count += 1
             except OSError:

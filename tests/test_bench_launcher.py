@@ -72,3 +72,28 @@ def test_gpus_2_on_a_one_gpu_box_exits_nonzero():
         pytest.skip("box has two or more GPUs: --gpus 2 is a legitimate run here")
     r = run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-extras", "--no-cpu-baseline"])
     assert r.returncode != 0 and "refusing" in r.stderr and "n_gpus" not in r.stdout
+
+
+def test_gpu_count_comes_from_sysfs_and_openable_render_nodes(tmp_path, monkeypatch):
+    """the launcher parent counts GPUs without HIP: KFD topology nodes with simd_count > 0 whose DRM render node can be opened, capped by
+    *_VISIBLE_DEVICES (advisor, round 3: torch.cuda.device_count() in the parent may initialise the runtime)"""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    nodes, dri = tmp_path / "nodes", tmp_path / "dri"
+    nodes.mkdir(); dri.mkdir()
+    for idx, (simd, minor) in enumerate([(0, -1), (1024, 128), (1024, 129), (1024, 130)]):     # a CPU node and three GPUs
+        d = nodes / str(idx); d.mkdir()
+        (d / "properties").write_text(f"cpu_cores_count {64 if simd == 0 else 0}\nsimd_count {simd}\ndrm_render_minor {minor}\n")
+    (dri / "renderD128").write_text(""); (dri / "renderD129").write_text("")                     # the third card's node is not this container's
+    monkeypatch.setenv("ZKHIP_BENCH_KFD_NODES", str(nodes)); monkeypatch.setenv("ZKHIP_BENCH_DRI_DIR", str(dri))
+    for v in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(v, raising=False)
+    assert bench.visible_gpus_without_hip() == 2
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0")
+    assert bench.visible_gpus_without_hip() == 1
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.setenv("ZKHIP_BENCH_KFD_NODES", str(tmp_path / "missing"))
+    assert bench.visible_gpus_without_hip() == 0                                               # no KFD driver: no AMD GPU
