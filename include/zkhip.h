@@ -306,6 +306,10 @@ int zkhip_g1_decompress_device(const void *d_in32, size_t n, void *d_points, int
  * `max` durations (milliseconds) and names (63 chars + NUL each). */
 int zkhip_profile_enable(int on);
 int zkhip_profile_read(double *ms, char (*names)[64], int max);
+/* enable(2): every following call APPENDS its phases (no read-back between calls: a loop of calls runs back to back as it does
+ * unprofiled); zkhip_profile_read_calls then synchronises and returns all recorded phases in call order, call_of[i] = index of the
+ * call phase i belongs to.  The pool holds 2048 events (about 100 MSM calls); calls beyond it record nothing. */
+int zkhip_profile_read_calls(double *ms, char (*names)[64], int *call_of, int max);
 
 /* ---- parity hooks for the field / curve layer (rows a1/a2 of SURVEY.md section 8) ------------------ */
 /* field: 0 = Fq, 1 = Fr.  op: 0 mul, 1 add, 2 sub, 3 square (b ignored).  Elementwise on n elements. */

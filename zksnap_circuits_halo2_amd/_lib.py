@@ -87,6 +87,7 @@ _SIGS = {
     "zkhip_g1_decompress_device": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.c_void_p]),
     "zkhip_profile_enable": (C.c_int, [C.c_int]),
     "zkhip_profile_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "zkhip_profile_read_calls": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "zkhip_test_field_op": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "zkhip_test_g1_op": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
 }

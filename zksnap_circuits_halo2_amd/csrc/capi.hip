@@ -41,29 +41,53 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-// ---- profiler (one profiled call at a time: a debugging aid, not part of the concurrent surface) --------------------
-static bool g_prof_on = false;
+// ---- profiler (one profiling caller at a time: a debugging aid, not part of the concurrent surface) --------------------
+// mode 1: the events of the LAST call are kept (read after every call: a host read-back between calls).
+// mode 2: every call appends its events to a pool and zkhip_profile_read_calls reads them all at the end, so a loop of calls runs
+//         back to back as it does unprofiled (bench.py's roofline figure; round 4 read back after every call and interleaved other work,
+//         which put the phase sum above the step time).
+static int g_prof_mode = 0;
 static const int PROF_MAX = 32;
-static hipEvent_t g_prof_ev[PROF_MAX + 1];
+static const int PROF_POOL = 2048;           // mode 2: events of up to PROF_POOL / 16 typical calls
+static hipEvent_t g_prof_ev[PROF_POOL];
 static bool g_prof_ev_ready = false;
-static int g_prof_n = 0;   // number of marks recorded after the begin event
-static char g_prof_names[PROF_MAX][64];
+static int g_prof_base = 0;                  // first event of the current call
+static int g_prof_n = 0;                     // number of marks recorded after the current call's begin event
+static char g_prof_names[PROF_POOL][24];
+static int g_prof_calls[PROF_POOL / 2][2];   // mode 2: (base, marks) per recorded call
+static int g_prof_ncalls = 0;
+static bool g_prof_full = false;             // mode 2: the pool ran out, the current call records nothing
 
 void prof_begin(hipStream_t stream) {
-  if (!g_prof_on) return;
+  if (!g_prof_mode) return;
   if (!g_prof_ev_ready) {
-    for (int i = 0; i <= PROF_MAX; i++) (void)hipEventCreate(&g_prof_ev[i]);
+    for (int i = 0; i < PROF_POOL; i++) (void)hipEventCreate(&g_prof_ev[i]);
     g_prof_ev_ready = true;
   }
+  if (g_prof_mode == 2) {
+    if (g_prof_full) return;
+    int base = 0;
+    if (g_prof_ncalls > 0) {                 // close the previous call
+      g_prof_calls[g_prof_ncalls - 1][1] = g_prof_n;
+      base = g_prof_calls[g_prof_ncalls - 1][0] + g_prof_n + 1;
+    }
+    if (base + PROF_MAX + 1 > PROF_POOL || g_prof_ncalls >= PROF_POOL / 2) { g_prof_full = true; g_prof_n = PROF_MAX; return; }
+    g_prof_base = base;
+    g_prof_calls[g_prof_ncalls][0] = base;
+    g_prof_calls[g_prof_ncalls][1] = 0;
+    g_prof_ncalls++;
+  } else {
+    g_prof_base = 0;
+  }
   g_prof_n = 0;
-  (void)hipEventRecord(g_prof_ev[0], stream);
+  (void)hipEventRecord(g_prof_ev[g_prof_base], stream);
 }
 
 void prof_mark(hipStream_t stream, const char* name) {
-  if (!g_prof_on || !g_prof_ev_ready || g_prof_n >= PROF_MAX) return;
-  snprintf(g_prof_names[g_prof_n], 64, "%s", name);
+  if (!g_prof_mode || !g_prof_ev_ready || g_prof_n >= PROF_MAX) return;
+  snprintf(g_prof_names[g_prof_base + g_prof_n], sizeof(g_prof_names[0]), "%s", name);
   g_prof_n++;
-  (void)hipEventRecord(g_prof_ev[g_prof_n], stream);
+  (void)hipEventRecord(g_prof_ev[g_prof_base + g_prof_n], stream);
 }
 
 
@@ -1635,15 +1659,18 @@ int zkhip_fr_grand_product(const uint64_t* num, const uint64_t* den, size_t n, u
 
 int zkhip_profile_enable(int on) {
   guard_t g(g_mu);
-  g_prof_on = on != 0;
+  g_prof_mode = on == 2 ? 2 : (on != 0 ? 1 : 0);
   g_prof_n = 0;
+  g_prof_base = 0;
+  g_prof_ncalls = 0;
+  g_prof_full = false;
   return ZKHIP_OK;
 }
 
 int zkhip_profile_read(double* ms, char (*names)[64], int max) {
   ZK_API_RANGE();
   guard_t g(g_mu);
-  if (!g_prof_ev_ready || g_prof_n == 0) return 0;
+  if (!g_prof_ev_ready || g_prof_n == 0 || g_prof_mode == 2) return 0;
   if (hipEventSynchronize(g_prof_ev[g_prof_n]) != hipSuccess) { set_error("profile_read: event sync failed"); return ZKHIP_EHIP; }
   for (int i = 0; i < g_prof_n && i < max; i++) {
     float t = 0;
@@ -1652,6 +1679,27 @@ int zkhip_profile_read(double* ms, char (*names)[64], int max) {
     if (names) snprintf(names[i], 64, "%s", g_prof_names[i]);
   }
   return g_prof_n;
+}
+
+int zkhip_profile_read_calls(double* ms, char (*names)[64], int* call_of, int max) {
+  ZK_API_RANGE();
+  guard_t g(g_mu);
+  if (!g_prof_ev_ready || g_prof_mode != 2 || g_prof_ncalls == 0) return 0;
+  if (!g_prof_full) g_prof_calls[g_prof_ncalls - 1][1] = g_prof_n;
+  int out = 0;
+  for (int c = 0; c < g_prof_ncalls; c++) {
+    const int base = g_prof_calls[c][0], n = g_prof_calls[c][1];
+    if (n == 0) continue;
+    if (hipEventSynchronize(g_prof_ev[base + n]) != hipSuccess) { set_error("profile_read_calls: event sync failed"); return ZKHIP_EHIP; }
+    for (int i = 0; i < n && out < max; i++, out++) {
+      float t = 0;
+      (void)hipEventElapsedTime(&t, g_prof_ev[base + i], g_prof_ev[base + i + 1]);
+      if (ms) ms[out] = t;
+      if (names) snprintf(names[out], 64, "%s", g_prof_names[base + i]);
+      if (call_of) call_of[out] = c;
+    }
+  }
+  return out;
 }
 
 int zkhip_g1_fixed_base_mul_device(const void* d_scalars, size_t n, void* d_out, void* stream) {
