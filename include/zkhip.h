@@ -93,16 +93,30 @@ int zkhip_unregister_bases(const uint64_t *bases);
 /* In place, natural order in and out: a[i] <- sum_j a[j] * omega^(i j).  log_n <= 28. */
 int zkhip_ntt_fr(uint64_t *a, const uint64_t omega[4], uint32_t log_n);
 
-/* `batch` contiguous polynomials, each transformed in place, one launch set */
+/* `batch` contiguous polynomials, each transformed in place, one launch set per device.  With several devices (zkhip_init) the batch is
+ * cut into contiguous shares, one per device: every transform runs on ONE device (independent polynomials are
+ * independent units), every device moves its share over its own PCIe link; results do not depend on the device count. */
 int zkhip_ntt_fr_batch(uint64_t *a, const uint64_t omega[4], uint32_t log_n, uint32_t batch);
+/* Which batched transforms are spread over the devices: 0 none, 1 (default) the host-buffer forms (zkhip_ntt_fr_batch,
+ * zkhip_ifft_scaled_batch, zkhip_coeff_to_extended_batch), 2 also the `_device` batch forms (zkhip_ntt_fr_batch_device,
+ * zkhip_ifft_scaled_batch_device, zkhip_coeff_to_extended_device, zkhip_extended_to_coeff_device: a secondary device pulls its
+ * polynomials from the primary's HBM over xGMI, transforms them with its own twiddle plan and pushes the results back -- off by
+ * default).  $ZKHIP_NTT_FANOUT sets the initial mode. */
+int zkhip_set_ntt_fanout(int mode);
+int zkhip_ntt_fanout(void);
 
 /* ---- EvaluationDomain pieces ([DEP] halo2_proofs/src/poly/domain.rs), host buffers ----------------- */
 /* `EvaluationDomain::ifft`: best_fft with omega_inv, then every element times `divisor`. */
 int zkhip_ifft_scaled(uint64_t *a, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4]);
+/* the same for `batch` contiguous polynomials (`lagrange_to_coeff` of every advice column of a phase in one call) */
+int zkhip_ifft_scaled_batch(uint64_t *a, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4], uint32_t batch);
 /* `coeff_to_extended`: a (2^k coeffs) -> out (2^ext_k evaluations on the coset zeta * <ext_omega>):
  * distribute_powers_zeta(into_coset) (a[i] *= {1, zeta, zeta^2}[i % 3]), zero-pad, best_fft. */
 int zkhip_coeff_to_extended(const uint64_t *a, uint32_t k, uint64_t *out, uint32_t ext_k, const uint64_t ext_omega[4],
                             const uint64_t zeta[4]);
+/* `batch` polynomials: a[b * 2^k ..] -> out[b * 2^ext_k ..] (the per-column loop of the quotient phase in one call) */
+int zkhip_coeff_to_extended_batch(const uint64_t *a, uint32_t k, uint64_t *out, uint32_t ext_k, uint32_t batch, const uint64_t ext_omega[4],
+                                  const uint64_t zeta[4]);
 /* `extended_to_coeff`: ifft on the extended domain, distribute_powers_zeta(out of coset), truncate to
  * out_len elements (= n * quotient_poly_degree).  `a` is consumed (overwritten). */
 int zkhip_extended_to_coeff(uint64_t *a, uint32_t ext_k, const uint64_t ext_omega_inv[4], const uint64_t ext_divisor[4],

@@ -248,6 +248,7 @@ struct context {
   bool ready = false;
   std::vector<device_ctx*> devs;       // devs[0] = primary
   int shards = 1;                      // MSM shards a registered array is cut into (default: one per device)
+  int ntt_fanout = 1;                  // batched transforms over the devices: 0 never, 1 host-buffer forms, 2 `_device` forms too (zkhip_set_ntt_fanout)
   std::map<const void*, std::shared_ptr<registered_t>> registered;
   std::map<uint64_t, prepared_bases*> handles;          // zkhip_prepare_bases_device handles (primary device)
   uint64_t next_handle = 1;
@@ -461,6 +462,8 @@ int zkhip_init(const int* devices, int ndev) {
   (void)hipSetDevice(want[0]);
   g_ctx.shards = (int)want.size();
   if (const char* e = getenv("ZKHIP_SHARDS")) { const int v = atoi(e); if (v >= 1 && v <= 64) g_ctx.shards = v; }
+  g_ctx.ntt_fanout = 1;
+  if (const char* e = getenv("ZKHIP_NTT_FANOUT")) { const int v = atoi(e); if (v >= 0 && v <= 2) g_ctx.ntt_fanout = v; }
   g_ctx.ready = true;
   return ZKHIP_OK;
 }
@@ -1149,11 +1152,71 @@ static int run_transform(scratch* sc, const uint32_t* d_in, uint32_t in_len, uin
 }
 
 // a `_device` transform on the caller's stream (g_mu held by the caller)
+static int device_transform_one(const void* d_in, uint32_t in_len, size_t in_stride, void* d_out, uint32_t out_len, size_t out_stride, uint32_t batch, uint32_t L,
+                                const uint64_t* omega, const uint32_t* in_scale, uint32_t in_period, const uint32_t* out_scale, uint32_t out_period, hipStream_t s) {
+  return run_transform(scratch_for(primary(), s), (const uint32_t*)d_in, in_len, (uint32_t)in_stride, (uint32_t*)d_out, out_len, (uint32_t)out_stride, batch, L,
+                       (const uint32_t*)omega, in_scale, in_period, out_scale, out_period, s);
+}
+
+// Round 5 (second split): the polynomials of a batch are independent units, so a batched transform may be spread over the
+// devices of zkhip_init -- every transform still runs on ONE device.  Polynomials [lo_d, hi_d) (shard_range over the batch) go to device d.
+// `_device` form (this function, fan-out mode 2 only): device d > 0 waits for the caller's stream (fan_ready), pulls its polynomials from the
+// primary's HBM over xGMI (hipMemcpyPeerAsync) into its own scratch, transforms them on its `fan` stream with its own twiddle plan, pushes the
+// results back into d_out and records fan_done, which the caller's stream waits for.  Asynchronous like every `_device` call.
+// Off by default: a 2^24 result is 512 MiB over one xGMI link (about 8 ms at 65 GB/s) against a 1.8 ms transform, so copying out and back
+// only pays where the links are idle and the batch is deep; the host-buffer forms below (mode 1, default) are the ones that win outright --
+// each device moves its own polynomials over its own PCIe link.  Results are identical either way (one device per transform).
 static int device_transform(const void* d_in, uint32_t in_len, size_t in_stride, void* d_out, uint32_t out_len, size_t out_stride, uint32_t batch, uint32_t L,
                             const uint64_t* omega, const uint32_t* in_scale, uint32_t in_period, const uint32_t* out_scale, uint32_t out_period, void* stream) {
   hipStream_t s = caller_stream(stream);
-  return run_transform(scratch_for(primary(), s), (const uint32_t*)d_in, in_len, (uint32_t)in_stride, (uint32_t*)d_out, out_len, (uint32_t)out_stride, batch, L,
-                       (const uint32_t*)omega, in_scale, in_period, out_scale, out_period, s);
+  const int S = (int)g_ctx.devs.size();
+  if (g_ctx.ntt_fanout < 2 || S < 2 || batch < 2 || L < 12)
+    return device_transform_one(d_in, in_len, in_stride, d_out, out_len, out_stride, batch, L, omega, in_scale, in_period, out_scale, out_period, s);
+  device_ctx& P = primary();
+  const size_t N = (size_t)1 << L;
+  if (!P.fan_ready) HIPCHK(hipEventCreateWithFlags(&P.fan_ready, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(P.fan_ready, s));
+  int rc_remote = ZKHIP_OK;
+  std::vector<int> waited;
+  for (int d = 1; d < S && rc_remote == ZKHIP_OK; d++) {
+    size_t lo, hi;
+    shard_range(batch, d, S, &lo, &hi);
+    if (lo >= hi) continue;
+    device_ctx* D = g_ctx.devs[(size_t)d];
+    if (hipSetDevice(D->device) != hipSuccess) { set_error("hipSetDevice(%d) failed", D->device); rc_remote = ZKHIP_ENODEV; break; }
+    auto body = [&]() -> int {
+      if (!D->fan) {
+        HIPCHK(hipStreamCreateWithFlags(&D->fan, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&D->fan_done, hipEventDisableTiming));
+      }
+      scratch* dsc = scratch_for(*D, D->fan);
+      const size_t cnt = hi - lo;
+      int r;
+      if ((r = dsc->poly.reserve(cnt * N * 32)) != ZKHIP_OK) return r;
+      HIPCHK(hipStreamWaitEvent(D->fan, P.fan_ready, 0));
+      uint32_t* buf = (uint32_t*)dsc->poly.p;                 // polynomial b of this device at buf + b * N elements, transformed in place
+      for (size_t b = 0; b < cnt; b++)
+        HIPCHK(hipMemcpyPeerAsync(buf + b * N * 8, D->device, (const uint32_t*)d_in + (lo + b) * in_stride * 8, P.device, (size_t)in_len * 32, D->fan));
+      if ((r = run_transform(dsc, buf, in_len, (uint32_t)N, buf, out_len, (uint32_t)N, (uint32_t)cnt, L, (const uint32_t*)omega, in_scale, in_period,
+                             out_scale, out_period, D->fan)) != ZKHIP_OK) return r;
+      for (size_t b = 0; b < cnt; b++)
+        HIPCHK(hipMemcpyPeerAsync((uint32_t*)d_out + (lo + b) * out_stride * 8, P.device, buf + b * N * 8, D->device, (size_t)out_len * 32, D->fan));
+      return ZKHIP_OK;
+    };
+    rc_remote = body();
+    if (D->fan_done && D->fan) { (void)hipEventRecord(D->fan_done, D->fan); waited.push_back(d); }   // also after an error: s must not run ahead of work already queued
+  }
+  if (hipSetDevice(P.device) != hipSuccess) { set_error("hipSetDevice(%d) failed", P.device); return ZKHIP_ENODEV; }
+  int rc_local = ZKHIP_OK;
+  {
+    size_t lo, hi;
+    shard_range(batch, 0, S, &lo, &hi);
+    if (lo < hi && rc_remote == ZKHIP_OK)
+      rc_local = device_transform_one((const uint32_t*)d_in + lo * in_stride * 8, in_len, in_stride, (uint32_t*)d_out + lo * out_stride * 8, out_len, out_stride,
+                                      (uint32_t)(hi - lo), L, omega, in_scale, in_period, out_scale, out_period, s);
+  }
+  for (int d : waited) HIPCHK(hipStreamWaitEvent(s, g_ctx.devs[(size_t)d]->fan_done, 0));
+  return rc_remote != ZKHIP_OK ? rc_remote : rc_local;
 }
 
 }  // namespace zkhip
@@ -1216,61 +1279,122 @@ int zkhip_mul_periodic_device(void* d_a, size_t n, const void* d_table, uint32_t
 
 namespace zkhip {
 
-static int host_transform(const uint64_t* in, size_t in_len, uint64_t* out, size_t out_len, uint32_t log_n, const uint64_t* omega,
-                          const uint32_t* in_scale, uint32_t in_period, const uint32_t* out_scale, uint32_t out_period) {
+// One device's share of a host-buffer batch: `cnt` polynomials (polynomial b at in + b * in_stride elements) cross this device's PCIe link
+// into its scratch, are transformed in place (polynomial b at b * N elements) and go back to out + b * out_stride.  Runs on the calling
+// thread for the primary device and on the device's worker thread for a secondary (the current device is per host thread).
+static int host_transform_share(scratch* sc, hipStream_t s, const uint64_t* in, size_t in_len, size_t in_stride, uint64_t* out, size_t out_len, size_t out_stride,
+                                size_t cnt, uint32_t log_n, const uint64_t* omega, const uint32_t* in_scale, uint32_t in_period, const uint32_t* out_scale,
+                                uint32_t out_period) {
+  int rc;
+  const size_t N = (size_t)1 << log_n;
+  if ((rc = sc->poly.reserve(cnt * N * 32)) != ZKHIP_OK) return rc;
+  if (cnt == 1) HIPCHK(hipMemcpyAsync(sc->poly.p, in, in_len * 32, hipMemcpyHostToDevice, s));
+  else if (in_len == N && in_stride == N) HIPCHK(hipMemcpyAsync(sc->poly.p, in, cnt * N * 32, hipMemcpyHostToDevice, s));
+  else HIPCHK(hipMemcpy2DAsync(sc->poly.p, N * 32, in, in_stride * 32, in_len * 32, cnt, hipMemcpyHostToDevice, s));
+  rc = run_transform(sc, (const uint32_t*)sc->poly.p, (uint32_t)in_len, (uint32_t)N, (uint32_t*)sc->poly.p, (uint32_t)out_len, (uint32_t)N, (uint32_t)cnt, log_n,
+                     (const uint32_t*)omega, in_scale, in_period, out_scale, out_period, s);
+  if (rc != ZKHIP_OK) return rc;
+  if (cnt == 1) HIPCHK(hipMemcpyAsync(out, sc->poly.p, out_len * 32, hipMemcpyDeviceToHost, s));
+  else if (out_len == N && out_stride == N) HIPCHK(hipMemcpyAsync(out, sc->poly.p, cnt * N * 32, hipMemcpyDeviceToHost, s));
+  else HIPCHK(hipMemcpy2DAsync(out, out_stride * 32, sc->poly.p, N * 32, out_len * 32, cnt, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return ZKHIP_OK;
+}
+
+// Host-buffer transforms, `batch` polynomials.  With several devices (fan-out mode >= 1) the batch is cut by shard_range: the primary's share
+// runs on this thread's lane, every other device's share on its worker thread -- N PCIe links carry the batch instead of one (a 2^24
+// transform through ONE link is 21 ms around a 1.8 ms kernel).  Each transform runs on one device: the results do not depend on the split.
+static int host_transform(const uint64_t* in, size_t in_len, size_t in_stride, uint64_t* out, size_t out_len, size_t out_stride, uint32_t batch, uint32_t log_n,
+                          const uint64_t* omega, const uint32_t* in_scale, uint32_t in_period, const uint32_t* out_scale, uint32_t out_period) {
   if (log_n > 28) { set_error("ntt: log_n = %u > 28", log_n); return ZKHIP_EINVAL; }
   if (!in || !out || !omega) { set_error("ntt: null pointer"); return ZKHIP_EINVAL; }
   const size_t N = (size_t)1 << log_n;
-  if (in_len > N || out_len > N) { set_error("ntt: length exceeds domain"); return ZKHIP_EINVAL; }
+  if (in_len > N || out_len > N || (batch > 1 && (in_stride < in_len || out_stride < out_len))) { set_error("ntt: length exceeds domain or stride"); return ZKHIP_EINVAL; }
+  if (batch == 0) return ZKHIP_OK;
   lane_hold H;
   if (H.rc != ZKHIP_OK) return H.rc;
-  int rc;
-  hipStream_t s = H.s;
-  if ((rc = H.sc->poly.reserve(N * 32)) != ZKHIP_OK) return rc;
-  HIPCHK(hipMemcpyAsync(H.sc->poly.p, in, in_len * 32, hipMemcpyHostToDevice, s));
-  rc = run_transform(H.sc, (const uint32_t*)H.sc->poly.p, (uint32_t)in_len, (uint32_t)N, (uint32_t*)H.sc->poly.p, (uint32_t)out_len, (uint32_t)N, 1, log_n,
-                     (const uint32_t*)omega, in_scale, in_period, out_scale, out_period, s);
-  if (rc != ZKHIP_OK) return rc;
-  HIPCHK(hipMemcpyAsync(out, H.sc->poly.p, out_len * 32, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
-  return ZKHIP_OK;
+  int S, mode;
+  { guard_t g(g_mu); S = (int)g_ctx.devs.size(); mode = g_ctx.ntt_fanout; }
+  if (S < 2 || batch < 2 || mode < 1)
+    return host_transform_share(H.sc, H.s, in, in_len, in_stride, out, out_len, out_stride, batch, log_n, omega, in_scale, in_period, out_scale, out_period);
+  std::unique_lock<std::mutex> fan(g_fanout_mu);              // the secondary devices have one lane each
+  for (int d = 1; d < S; d++) {
+    size_t lo, hi;
+    shard_range(batch, d, S, &lo, &hi);
+    if (lo >= hi) continue;
+    device_ctx* D = g_ctx.devs[(size_t)d];
+    D->w->submit([=]() -> int {
+      hipStream_t ds = D->lanes[0].stream;
+      scratch* dsc;
+      { guard_t g(g_mu); dsc = scratch_for(*D, ds); }
+      return host_transform_share(dsc, ds, in + lo * in_stride * 4, in_len, in_stride, out + lo * out_stride * 4, out_len, out_stride, hi - lo, log_n, omega,
+                                  in_scale, in_period, out_scale, out_period);
+    });
+  }
+  int rc_local = ZKHIP_OK;
+  {
+    size_t lo, hi;
+    shard_range(batch, 0, S, &lo, &hi);
+    if (lo < hi)
+      rc_local = host_transform_share(H.sc, H.s, in + lo * in_stride * 4, in_len, in_stride, out + lo * out_stride * 4, out_len, out_stride, hi - lo, log_n, omega,
+                                      in_scale, in_period, out_scale, out_period);
+  }
+  int rc_remote = ZKHIP_OK;
+  for (int d = 1; d < S; d++) {
+    size_t lo, hi;
+    shard_range(batch, d, S, &lo, &hi);
+    if (lo >= hi) continue;
+    const int r = g_ctx.devs[(size_t)d]->w->wait();
+    if (r != ZKHIP_OK) rc_remote = r;
+  }
+  return rc_local != ZKHIP_OK ? rc_local : rc_remote;
 }
 
 }  // namespace zkhip
 
 extern "C" {
 
-// `batch` contiguous polynomials of 2^log_n elements, transformed in place in one launch set
+int zkhip_set_ntt_fanout(int mode) {
+  ZK_API_RANGE();
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if (mode < 0 || mode > 2) { set_error("set_ntt_fanout: mode %d not in 0..2", mode); return ZKHIP_EINVAL; }
+  g_ctx.ntt_fanout = mode;
+  return ZKHIP_OK;
+}
+
+int zkhip_ntt_fanout(void) {
+  guard_t g(g_mu);
+  return g_ctx.ready ? g_ctx.ntt_fanout : 1;
+}
+
+// `batch` contiguous polynomials of 2^log_n elements, transformed in place (one launch set per device)
 int zkhip_ntt_fr_batch(uint64_t* a, const uint64_t omega[4], uint32_t log_n, uint32_t batch) {
   ZK_API_RANGE();
   if (!a || !omega || log_n > 28) { set_error("ntt_batch: bad argument"); return ZKHIP_EINVAL; }
-  if (batch == 0) return ZKHIP_OK;
-  lane_hold H;
-  if (H.rc != ZKHIP_OK) return H.rc;
-  int rc;
-  const size_t N = (size_t)1 << log_n, total = N * batch;
-  if (N >= ((size_t)1 << 32)) { set_error("ntt_batch: bad argument"); return ZKHIP_EINVAL; }
-  hipStream_t s = H.s;
-  if ((rc = H.sc->poly.reserve(total * 32)) != ZKHIP_OK) return rc;
-  HIPCHK(hipMemcpyAsync(H.sc->poly.p, a, total * 32, hipMemcpyHostToDevice, s));
-  if ((rc = run_transform(H.sc, (const uint32_t*)H.sc->poly.p, (uint32_t)N, (uint32_t)N, (uint32_t*)H.sc->poly.p, (uint32_t)N, (uint32_t)N, batch, log_n,
-                          (const uint32_t*)omega, nullptr, 0, nullptr, 0, s)) != ZKHIP_OK) return rc;
-  HIPCHK(hipMemcpyAsync(a, H.sc->poly.p, total * 32, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
-  return ZKHIP_OK;
+  const size_t N = (size_t)1 << log_n;
+  return host_transform(a, N, N, a, N, N, batch, log_n, omega, nullptr, 0, nullptr, 0);
+}
+
+int zkhip_ifft_scaled_batch(uint64_t* a, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4], uint32_t batch) {
+  ZK_API_RANGE();
+  if (!a || !omega_inv || !divisor || log_n > 28) { set_error("ifft_batch: bad argument"); return ZKHIP_EINVAL; }
+  const size_t N = (size_t)1 << log_n;
+  return host_transform(a, N, N, a, N, N, batch, log_n, omega_inv, nullptr, 0, (const uint32_t*)divisor, 1);
 }
 
 int zkhip_ntt_fr(uint64_t* a, const uint64_t omega[4], uint32_t log_n) {
   ZK_API_RANGE();
   const size_t N = (size_t)1 << (log_n > 28 ? 0 : log_n);
-  return host_transform(a, N, a, N, log_n, omega, nullptr, 0, nullptr, 0);
+  return host_transform(a, N, N, a, N, N, 1, log_n, omega, nullptr, 0, nullptr, 0);
 }
 
 int zkhip_ifft_scaled(uint64_t* a, const uint64_t omega_inv[4], uint32_t log_n, const uint64_t divisor[4]) {
   ZK_API_RANGE();
   if (!divisor) { set_error("ifft: null divisor"); return ZKHIP_EINVAL; }
   const size_t N = (size_t)1 << (log_n > 28 ? 0 : log_n);
-  return host_transform(a, N, a, N, log_n, omega_inv, nullptr, 0, (const uint32_t*)divisor, 1);
+  return host_transform(a, N, N, a, N, N, 1, log_n, omega_inv, nullptr, 0, (const uint32_t*)divisor, 1);
 }
 
 }  // extern "C"
@@ -1302,7 +1426,18 @@ int zkhip_coeff_to_extended(const uint64_t* a, uint32_t k, uint64_t* out, uint32
   if (!a || !out || !ext_omega || !zeta || k > ext_k || ext_k > 28) { set_error("coeff_to_extended: bad argument"); return ZKHIP_EINVAL; }
   uint32_t sc[24];
   coset_scales(zeta, nullptr, sc);
-  return host_transform(a, (size_t)1 << k, out, (size_t)1 << ext_k, ext_k, ext_omega, sc, 3, nullptr, 0);
+  return host_transform(a, (size_t)1 << k, (size_t)1 << k, out, (size_t)1 << ext_k, (size_t)1 << ext_k, 1, ext_k, ext_omega, sc, 3, nullptr, 0);
+}
+
+// `batch` polynomials: polynomial b = a[b * 2^k ..], its extended-coset evaluations = out[b * 2^ext_k ..] (the per-column loop of the
+// quotient phase in one call; with several devices each takes its share of the columns over its own PCIe link)
+int zkhip_coeff_to_extended_batch(const uint64_t* a, uint32_t k, uint64_t* out, uint32_t ext_k, uint32_t batch, const uint64_t ext_omega[4],
+                                  const uint64_t zeta[4]) {
+  ZK_API_RANGE();
+  if (!a || !out || !ext_omega || !zeta || k > ext_k || ext_k > 28) { set_error("coeff_to_extended_batch: bad argument"); return ZKHIP_EINVAL; }
+  uint32_t sc[24];
+  coset_scales(zeta, nullptr, sc);
+  return host_transform(a, (size_t)1 << k, (size_t)1 << k, out, (size_t)1 << ext_k, (size_t)1 << ext_k, batch, ext_k, ext_omega, sc, 3, nullptr, 0);
 }
 
 int zkhip_extended_to_coeff(uint64_t* a, uint32_t ext_k, const uint64_t ext_omega_inv[4], const uint64_t ext_divisor[4],
@@ -1311,7 +1446,7 @@ int zkhip_extended_to_coeff(uint64_t* a, uint32_t ext_k, const uint64_t ext_omeg
   if (!a || !out || !ext_omega_inv || !ext_divisor || !zeta || ext_k > 28) { set_error("extended_to_coeff: bad argument"); return ZKHIP_EINVAL; }
   uint32_t sc[24];
   coset_scales(zeta, ext_divisor, sc);
-  return host_transform(a, (size_t)1 << ext_k, out, out_len, ext_k, ext_omega_inv, nullptr, 0, sc, 3);
+  return host_transform(a, (size_t)1 << ext_k, (size_t)1 << ext_k, out, out_len, out_len, 1, ext_k, ext_omega_inv, nullptr, 0, sc, 3);
 }
 
 // device-resident forms, `batch` polynomials per launch set (polynomial b at base + b * stride elements)

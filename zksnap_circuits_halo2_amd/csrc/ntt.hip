@@ -381,9 +381,11 @@ __global__ void __launch_bounds__(256) k_mul_periodic(uint32_t* a, size_t n, con
 }
 
 // ------------------------------------------------------------------------------------------------
-// plans: pass split + twiddle tables, cached per (omega, log_n)
+// plans: pass split + twiddle tables, cached per (device, omega, log_n) -- the tables live in the HBM of the device that runs the
+// transform (round 5: independent transforms of a batch are spread over the devices of zkhip_init, capi.hip transform fan-out)
 // ------------------------------------------------------------------------------------------------
 struct ntt_plan {
+  int device = 0;
   uint32_t L = 0;
   int npass = 0;
   uint32_t B[4] = {0, 0, 0, 0}, S[4] = {0, 0, 0, 0}, h[4] = {0, 0, 0, 0}, rk[4] = {0, 0, 0, 0};
@@ -395,13 +397,18 @@ struct ntt_plan {
   size_t bytes = 0;          // device memory held by the tables
   uint64_t last_use = 0;
   ~ntt_plan() {              // a transform queued on some stream may still read the tables
-    if (!allocs.empty()) (void)hipDeviceSynchronize();
+    if (allocs.empty()) return;
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != device) (void)hipSetDevice(device);
+    (void)hipDeviceSynchronize();
     for (void* d : allocs) (void)hipFree(d);
+    if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
   }
 };
 
 static std::mutex g_plan_mu;
-static std::map<std::array<uint32_t, 9>, std::shared_ptr<ntt_plan>> g_plans;   // a transform in flight keeps its plan alive past an eviction
+static std::map<std::array<uint32_t, 10>, std::shared_ptr<ntt_plan>> g_plans;   // a transform in flight keeps its plan alive past an eviction
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s failed: %s", #x, hipGetErrorString(e_)); return ZKHIP_EHIP; } } while (0)
 
@@ -418,6 +425,7 @@ static int build_plan(const uint32_t omega_ext[8], uint32_t L, hipStream_t strea
   ntt_plan* p = new ntt_plan();
   *out = p;                  // the caller frees a partly built plan on any error return below
   p->L = L;
+  HIPCHK(hipGetDevice(&p->device));
   int rc;
   uint32_t* d_omega = nullptr;
   if ((rc = plan_alloc(p, &d_omega, 32)) != ZKHIP_OK) return rc;
@@ -462,9 +470,12 @@ static int build_plan(const uint32_t omega_ext[8], uint32_t L, hipStream_t strea
 }
 
 static int get_plan(const uint32_t omega_ext[8], uint32_t L, hipStream_t stream, std::shared_ptr<ntt_plan>* out) {
-  std::array<uint32_t, 9> key;
+  std::array<uint32_t, 10> key;
   for (int i = 0; i < 8; i++) key[i] = omega_ext[i];
   key[8] = L;
+  int cur_dev = 0;
+  HIPCHK(hipGetDevice(&cur_dev));
+  key[9] = (uint32_t)cur_dev;
   std::lock_guard<std::mutex> g(g_plan_mu);
   static uint64_t clock = 0;
   auto it = g_plans.find(key);
@@ -474,13 +485,15 @@ static int get_plan(const uint32_t omega_ext[8], uint32_t L, hipStream_t stream,
   // freed when the last transform holding them has been enqueued, after a device synchronisation: ~ntt_plan).
   constexpr size_t PLAN_CACHE_BYTES = (size_t)12 << 30;
   constexpr size_t PLAN_CACHE_ENTRIES = 48;
-  size_t held = 0;
-  for (auto& kv : g_plans) held += kv.second->bytes;
+  size_t held = 0;                              // the byte cap is per device (each has its own 288 GB)
+  for (auto& kv : g_plans) if (kv.first[9] == key[9]) held += kv.second->bytes;
   const size_t incoming = (size_t)36 << (L > 2 ? L : 2);
   while (!g_plans.empty() && (g_plans.size() >= PLAN_CACHE_ENTRIES || held + incoming > PLAN_CACHE_BYTES)) {
-    auto victim = g_plans.begin();
-    for (auto jt = g_plans.begin(); jt != g_plans.end(); ++jt) if (jt->second->last_use < victim->second->last_use) victim = jt;
-    held -= victim->second->bytes;
+    auto victim = g_plans.end();
+    for (auto jt = g_plans.begin(); jt != g_plans.end(); ++jt)
+      if ((g_plans.size() >= PLAN_CACHE_ENTRIES || jt->first[9] == key[9]) && (victim == g_plans.end() || jt->second->last_use < victim->second->last_use)) victim = jt;
+    if (victim == g_plans.end()) break;
+    if (victim->first[9] == key[9]) held -= victim->second->bytes;
     g_plans.erase(victim);
   }
   ntt_plan* raw = nullptr;
