@@ -1098,23 +1098,44 @@ def wrapper_replay_k24(lib, _lib, F, torch, dev, stream, c4: dict) -> dict:
         ms_ntt = timed(ntts, 1)
         ms_all = timed(lambda: (msms(), ntts()), 1)
         one_ntt26 = timed(lambda: _lib.check(lib.zkhip_ntt_fr_device(ext.data_ptr(), om_e.ctypes.data, ek, stream)), 2)
+        one_intt24 = timed(lambda: _lib.check(lib.zkhip_ifft_scaled_device(sc.data_ptr(), om_i.ctypes.data, k, div.ctypes.data, stream)), 4)
     finally:
         lib.zkhip_release_bases(h)
         del sc, ext
         torch.cuda.empty_cache()
     out = {"workload": "k=24: 18 MSM 2^24 + 13 iNTT 2^24 + 13 NTT 2^26 + 1 iNTT 2^26, device-resident, ONE card",
            "ms": round(ms_all, 2), "msm_part_ms": round(ms_msm, 2), "ntt_part_ms": round(ms_ntt, 2), "ms_per_msm_2^24": round(ms_msm / 18, 3),
-           "ms_per_ntt_2^26": round(one_ntt26, 3), "Mpoints_per_s_2^24": round(n / (ms_msm / 18) / 1e3, 1),
+           "ms_per_ntt_2^26": round(one_ntt26, 3), "ms_per_intt_2^24": round(one_intt24, 3), "Mpoints_per_s_2^24": round(n / (ms_msm / 18) / 1e3, 1),
            "proofs_per_s_msm_ntt_portion": round(1e3 / ms_all, 3),
            "note": "MSM+NTT portion only (no witness, transcript, quotient); the prepared table of 2^24 points is 13 GiB of the card's 288"}
     shard = c4.get("per_shard_ms")
     if shard:
         # 8 cards: every MSM = one 2^21-point shard per card (measured: per_shard_ms of config4_wrapper_k24_msm, the same kernels on 2^21 points) +
-        # the exchange (8 x 96 bytes + fold, ~0.03 ms measured at N = 1 with the gather degenerated to a copy); transforms stay on one card
-        proj = 18 * (shard + 0.03) + ms_ntt
-        out["projection_8_gpus"] = {"ms": round(proj, 2), "proofs_per_s_msm_ntt_portion": round(1e3 / proj, 3),
+        # the exchange (8 x 96 bytes + fold, ~0.03 ms measured at N = 1 with the gather degenerated to a copy).  Transforms, three ways -- all
+        # PROJECTIONS from one card's measurements, none a measurement on 8:
+        #   unsharded             every transform on the primary card (rounds 1-4)
+        #   spread, copy back     round 5, the `_device` fan-out as built (zkhip_set_ntt_fanout(2)): the 13 + 13 batched transforms cut into 8 shares
+        #                         (2 + 2 on the busiest card), a secondary card pulls 0.5 GiB per input and pushes 0.5 / 2 GiB per result over ONE xGMI
+        #                         link, priced at an ASSUMED 64 GB/s per direction (not measurable on this one-card box) and not overlapped with its kernels
+        #   spread, left in place the same split with the results consumed where they were computed (the bound of SURVEY.md 8(e)'s second split: it needs
+        #                         the quotient phase re-cut by rows behind an all-to-all, DESIGN.md section 8 -- not built)
+        msm_proj = 18 * (shard + 0.03)
+        per_card = -(-13 // 8)                                           # 2 of the 13 inverse and 2 of the 13 extended transforms on the busiest card
+        kernels_spread = per_card * one_intt24 + per_card * one_ntt26 + one_ntt26        # + the lone 2^26 inverse transform of the quotient
+        gib = float(1 << 30)
+        xgmi_ms = (per_card * (0.5 + 0.5) + per_card * (0.5 + 2.0)) * gib / 64e9 * 1e3   # in + out of the iNTTs, in + out of the coset NTTs
+        proj_unsharded = msm_proj + ms_ntt
+        proj_copy_back = msm_proj + max(kernels_spread, per_card * (one_intt24 + one_ntt26) + xgmi_ms)
+        proj_in_place = msm_proj + kernels_spread
+        out["projection_8_gpus"] = {"ms": round(proj_unsharded, 2), "proofs_per_s_msm_ntt_portion": round(1e3 / proj_unsharded, 3),
                                     "how": f"18 x (per_shard_ms {shard} + 0.03 exchange) + ntt_part_ms {round(ms_ntt, 2)}: MSM / 8, NTT unsharded -- a PROJECTION from one card's measurements, not a measurement on 8",
-                                    "ntt_share_of_projection": round(ms_ntt / proj, 3)}
+                                    "ntt_share_of_projection": round(ms_ntt / proj_unsharded, 3),
+                                    "transforms_spread_copy_back": {"ms": round(proj_copy_back, 2), "xgmi_ms_per_secondary_card": round(xgmi_ms, 1),
+                                                                    "assumed_xgmi_GBps_per_direction": 64,
+                                                                    "how": "13 + 13 batched transforms cut into 8 shares (zkhip_set_ntt_fanout(2)), a secondary card's share = its kernels + its peer copies, not overlapped; PROJECTION with an ASSUMED link rate"},
+                                    "transforms_spread_left_in_place": {"ms": round(proj_in_place, 2), "proofs_per_s_msm_ntt_portion": round(1e3 / proj_in_place, 3),
+                                                                        "ntt_share_of_projection": round(kernels_spread / proj_in_place, 3),
+                                                                        "how": f"the busiest card runs {per_card} of the 13 iNTT 2^24 + {per_card} of the 13 NTT 2^26 + the iNTT 2^26, results consumed in place: the BOUND of the second split, needs the row-sharded quotient phase (not built); PROJECTION"}}
     return out
 
 

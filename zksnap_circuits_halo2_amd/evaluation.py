@@ -177,6 +177,28 @@ class RowProgram:
         keep = (arr, consts, rots, omega)      # keep the buffers alive for the duration of the call
         return prog, keep
 
+    def to_bytes(self) -> bytes:
+        """The program as the flat little-endian record a non-Python host reads back into a `zkhip_vm_program` (include/zkhip.h):
+        u32 n_insns, n_insns x 16-byte zkhip_vm_insn, u32 n_constants, n_constants x 4 u64 (Montgomery words), u32 n_rotations,
+        n_rotations x i32, i32 rot_scale, u32 result_reg, u32 has_omega, 4 u64 omega when has_omega.  This is what a patched
+        [DEP] plonk/evaluation.rs produces from its `GraphEvaluator` (rust-shim/prover_patch.rs); tests/cpp/prover_sequence.c loads it."""
+        import struct
+
+        out = [struct.pack("<I", len(self.insns))]
+        for op, dst, a, b, c in self.insns:
+            out.append(struct.pack("<BBH", op, dst, 0))
+            for o in (a, b, c):
+                out.append(struct.pack("<BBH", o[0], o[2], o[1]))          # kind, rot slot, index (zkhip_vm_operand)
+        out.append(struct.pack("<I", len(self.constants)))
+        if self.constants:
+            out.append(F.fr_encode(self.constants).astype("<u8").tobytes())
+        out.append(struct.pack("<I", len(self.rotations)))
+        out.append(struct.pack("<%di" % len(self.rotations), *self.rotations))
+        out.append(struct.pack("<iII", self.rot_scale, self.result_reg, 1 if self.omega is not None else 0))
+        if self.omega is not None:
+            out.append(F.fr_encode([self.omega])[0].astype("<u8").tobytes())
+        return b"".join(out)
+
     def run(self, columns: Sequence[np.ndarray], log_rows: int, out: Optional[np.ndarray] = None, accumulate: bool = False) -> np.ndarray:
         """Host columns ((2^log_rows, 4) uint64 each) -> (2^log_rows, 4) uint64."""
         rows = 1 << log_rows
@@ -434,3 +456,51 @@ def permute_expression_pair(input_expression: np.ndarray, table_expression: np.n
     ps = np.zeros((usable_rows, 4), dtype=np.uint64)
     _lib.check(_lib.load().zkhip_lookup_permute(a.ctypes.data, s.ctypes.data, usable_rows, pa.ctypes.data, ps.ctypes.data))
     return pa, ps
+
+
+# ---------------------------------------------------------------------------------------------------
+# the row programs of one proof, written out for a host that is not Python (rust-shim/prover_patch.rs, tests/cpp/prover_sequence.c)
+# ---------------------------------------------------------------------------------------------------
+def halo2_lib_shape(gate_cols: int, lookups: int, blinding: int = 5) -> ConstraintSystem:
+    """The halo2-lib `BaseConfig` shape the reference's circuits use (/root/reference/aggregator/benches/wrapper_circuit.rs:61-68,
+    state_transition_circuit.rs:48-50): `gate_cols` advice columns with the vertical gate q (a + b c - d), `lookups` range-lookup advice
+    columns against one table, one constants column; every advice column and the constants column take part in the permutation."""
+    G, NL = gate_cols, lookups
+    return ConstraintSystem(
+        num_fixed=G + 2, num_advice=G + NL, num_instance=0,
+        gates=[[Fixed(i) * (Advice(i, 0) + Advice(i, 1) * Advice(i, 2) - Advice(i, 3))] for i in range(G)],
+        lookups=[Lookup([Advice(G + j)], [Fixed(G + 1)]) for j in range(NL)],
+        permutation_columns=[("advice", i) for i in range(G + NL)] + [("fixed", G)], blinding_factors=blinding, degree=4)
+
+
+def export_prover_programs(k: int, gate_cols: int, lookups: int, seed: int = 1) -> bytes:
+    """Everything tests/cpp/prover_sequence.c needs for one proof of the halo2-lib shape at 2^k rows: the domain constants and the row
+    programs (challenges seeded -- there is no transcript on this side), in the order the C program reads them."""
+    import random
+    import struct
+
+    from .domain import EvaluationDomain
+
+    cs = halo2_lib_shape(gate_cols, lookups)
+    qc = quotient_columns(cs)
+    dom = EvaluationDomain(4, k)
+    rng = random.Random(seed)
+    beta, gamma, theta, y, x = (rng.randrange(1, F.R_MOD) for _ in range(5))
+    w = lambda a: np.ascontiguousarray(a).astype("<u8").tobytes()
+    out = [struct.pack("<4sI", b"ZKPS", 1),
+           struct.pack("<8I", k, dom.extended_k, gate_cols, lookups, len(cs.permutation_columns), cs.num_permutation_sets, cs.chunk_len, cs.blinding_factors),
+           struct.pack("<7I", qc.total, qc.fixed, qc.advice, qc.l0, qc.sigma, qc.perm_product, qc.lookup),
+           w(dom.omega_inv), w(dom.ifft_divisor), w(dom.extended_omega), w(dom.extended_omega_inv), w(dom.extended_ifft_divisor), w(dom.g_coset),
+           w(F.fr_encode([x])[0]), struct.pack("<I", dom.t_evaluations.shape[0]), w(dom.t_evaluations)]
+    to_mont = RowProgram()                # raw integer words are the Montgomery form of a / R: multiply by R
+    to_mont.emit(OP_MUL, 0, to_mont.column(0), to_mont.constant(pow(2, 256, F.R_MOD)))
+    progs = [to_mont]
+    for si in range(cs.num_permutation_sets):
+        lo, hi = si * cs.chunk_len, min((si + 1) * cs.chunk_len, len(cs.permutation_columns))
+        progs.append(permutation_numerator_program(hi - lo, lo, beta, gamma, k))
+    for si in range(cs.num_permutation_sets):
+        lo, hi = si * cs.chunk_len, min((si + 1) * cs.chunk_len, len(cs.permutation_columns))
+        progs.append(permutation_denominator_program(hi - lo, beta, gamma))
+    progs += list(lookup_product_programs(1, 1, beta, gamma, theta))
+    progs.append(evaluate_h_program(cs, k, dom.extended_k, beta, gamma, theta, y))
+    return b"".join(out + [p.to_bytes() for p in progs])
