@@ -14,7 +14,7 @@
 //! these files are the binding a maintainer adds, kept compile-ready by review, not by rustc.
 
 use std::any::TypeId;
-use std::os::raw::{c_char, c_int};
+use std::os::raw::{c_char, c_int, c_void};
 use std::sync::atomic::{AtomicU8, Ordering};
 use std::sync::Once;
 
@@ -37,7 +37,62 @@ extern "C" {
     fn zkhip_g_to_lagrange(g_xyz: *const u64, k: u32, g_lagrange: *mut u64) -> c_int;
     fn zkhip_register_bases(bases: *const u64, n: usize) -> c_int;
     fn zkhip_unregister_bases(bases: *const u64) -> c_int;
+    // ---- prover_patch.rs, mode (a): one call per phase over host buffers --------------------------------------------------------------
+    fn zkhip_ifft_scaled_batch(a: *mut u64, omega_inv: *const u64, log_n: u32, divisor: *const u64, batch: u32) -> c_int;
+    fn zkhip_coeff_to_extended_batch(a: *const u64, k: u32, out: *mut u64, ext_k: u32, batch: u32, ext_omega: *const u64, zeta: *const u64) -> c_int;
+    // ---- prover_patch.rs, mode (b): device-resident columns (handles instead of host slices) ------------------------------------------
+    fn zkhip_alloc(bytes: usize, d_ptr: *mut *mut c_void) -> c_int;
+    fn zkhip_free(d_ptr: *mut c_void) -> c_int;
+    fn zkhip_upload(d_dst: *mut c_void, src: *const c_void, bytes: usize) -> c_int;
+    fn zkhip_download(dst: *mut c_void, d_src: *const c_void, bytes: usize) -> c_int;
+    fn zkhip_msm_g1_registered_batch_device(bases: *const u64, d_scalars: *const c_void, n: usize, batch: usize, scalar_stride: usize,
+                                            d_out_xyz: *mut c_void, stream: *mut c_void) -> c_int;
+    fn zkhip_ifft_scaled_batch_device(d_a: *mut c_void, omega_inv: *const u64, log_n: u32, divisor: *const u64, batch: u32, stride: usize,
+                                      stream: *mut c_void) -> c_int;
+    fn zkhip_coeff_to_extended_device(d_a: *const c_void, a_stride: usize, k: u32, d_out: *mut c_void, out_stride: usize, ext_k: u32, batch: u32,
+                                      ext_omega: *const u64, zeta: *const u64, stream: *mut c_void) -> c_int;
+    fn zkhip_extended_to_coeff_device(d_a: *const c_void, a_stride: usize, ext_k: u32, ext_omega_inv: *const u64, ext_divisor: *const u64,
+                                      zeta: *const u64, d_out: *mut c_void, out_stride: usize, out_len: usize, batch: u32, stream: *mut c_void) -> c_int;
+    fn zkhip_mul_periodic_device(d_a: *mut c_void, n: usize, d_table: *const c_void, period: u32, stream: *mut c_void) -> c_int;
+    fn zkhip_fr_eval_rows_device(prog: *const VmProgram, d_columns: *const *const c_void, n_columns: u32, log_rows: u32, accumulate: c_int,
+                                 d_out: *mut c_void, stream: *mut c_void) -> c_int;
+    fn zkhip_fr_grand_product_device(d_num: *const c_void, d_den: *mut c_void, n: usize, d_z: *mut c_void, stream: *mut c_void) -> c_int;
+    fn zkhip_lookup_permute_device(d_input: *const c_void, d_table: *const c_void, usable_rows: usize, d_permuted_input: *mut c_void,
+                                   d_permuted_table: *mut c_void, stream: *mut c_void) -> c_int;
+    fn zkhip_fr_eval_polynomial_batch_device(d_polys: *const *const c_void, count: usize, n: usize, point: *const u64, d_out: *mut c_void,
+                                             stream: *mut c_void) -> c_int;
 }
+
+/// `zkhip_vm_operand` / `zkhip_vm_insn` / `zkhip_vm_program` of include/zkhip.h (field order and widths checked by tests/test_rust_shim.py).
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub(crate) struct VmOperand { pub kind: u8, pub rot: u8, pub index: u16 }
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub(crate) struct VmInsn { pub op: u8, pub dst: u8, pub reserved: u16, pub a: VmOperand, pub b: VmOperand, pub c: VmOperand }
+#[repr(C)]
+pub(crate) struct VmProgram {
+    pub insns: *const VmInsn, pub n_insns: u32,
+    pub constants: *const u64, pub n_constants: u32,
+    pub rotations: *const i32, pub n_rotations: u32,
+    pub rot_scale: i32,
+    pub result_reg: u32,
+    pub omega: *const u64,
+}
+pub(crate) const VM_REGS: usize = 16;
+pub(crate) const SRC_CONST: u8 = 0;
+pub(crate) const SRC_REG: u8 = 1;
+pub(crate) const SRC_COLUMN: u8 = 2;
+pub(crate) const SRC_PREV: u8 = 3;
+pub(crate) const SRC_ROWPOW: u8 = 4;
+pub(crate) const OP_MOV: u8 = 0;
+pub(crate) const OP_ADD: u8 = 1;
+pub(crate) const OP_SUB: u8 = 2;
+pub(crate) const OP_MUL: u8 = 3;
+pub(crate) const OP_NEG: u8 = 4;
+pub(crate) const OP_DBL: u8 = 5;
+pub(crate) const OP_SQR: u8 = 6;
+pub(crate) const OP_MAD: u8 = 7;
 
 /// Below these sizes a call is answered by the crate's CPU body: a GPU call costs ~0.1 ms of launch chain and PCIe latency whatever its size, and the
 /// verifier / accumulation side of the reference (`verify_proof`, `AccumulatorStrategy`, /root/reference/aggregator/src/wrapper.rs:145) issues
@@ -125,9 +180,9 @@ pub(crate) fn try_ntt_fr<S: 'static, G: 'static>(a: &mut [G], omega: &S, log_n: 
     true
 }
 
-/// `ParamsKZG::{setup, read, read_custom, from_parts, clone, downsize}`: pin `g` / `g_lagrange` on the device(s) and build the fixed-base
+/// `Pinned::new` (commitment_patch.rs; reached from `ParamsKZG::{setup, read, read_custom, from_parts, clone, downsize}`): pin `g` / `g_lagrange` on the device(s) and build the fixed-base
 /// tables, so that `commit` / `commit_lagrange` (which pass `&self.g[..poly.len()]`) upload 32 n bytes of scalars and nothing else.
-/// No-op for every curve but bn256::G1Affine.  The memory must stay alive and unchanged until `unpin` (the `Drop` impl in commitment_patch.rs).
+/// No-op for every curve but bn256::G1Affine.  The memory must stay alive and unchanged until `unpin` (`Drop for Pinned` in commitment_patch.rs).
 pub(crate) fn pin<C: 'static>(bases: &[C]) {
     if !is::<C, G1Affine>() || bases.is_empty() || !usable() {
         return;
@@ -156,7 +211,7 @@ pub(crate) fn try_g_to_lagrange<C: 'static + Clone, P: 'static>(g_projective: &[
     Some(out)
 }
 
-/// Undo `pin`; must run before the memory is freed or rewritten (`Drop for ParamsKZG`, `downsize`).
+/// Undo `pin`; must run before the memory is freed or rewritten (`Drop for Pinned`, `Pinned::truncate` in commitment_patch.rs).
 pub(crate) fn unpin<C: 'static>(bases: &[C]) {
     if !is::<C, G1Affine>() || bases.is_empty() || STATE.load(Ordering::Acquire) != 1 {
         return;
@@ -222,4 +277,239 @@ pub(crate) fn try_mul_periodic<F: 'static>(a: &mut [F], table: &[F]) -> bool {
         warn_once("zkhip_mul_periodic", rc);
     }
     rc == 0
+}
+
+
+// ======================================================================================================================================
+// prover_patch.rs, mode (a): all columns of one phase through ONE call (the library shares launch sets between the vectors of a batch:
+// 256 commits of 2^13 points take 6.0 ms instead of 68 ms one by one -- bench.py `small_circuit_replays`)
+// ======================================================================================================================================
+
+/// Columns above this many elements gain nothing from sharing a launch set (each MSM / transform fills the card alone) and the gather
+/// into one contiguous buffer would cost a host copy of 32 n bytes per column: they stay on the per-column path.
+const MAX_BATCHED_LOG: u32 = 18;
+
+/// `params.commit_lagrange` / `params.commit` of every column of a phase: Some(results in column order) when C = bn256::G1Affine and the
+/// batched call succeeded, None otherwise (the caller runs its per-column loop).  Every column must have `bases.len()` or fewer elements
+/// and all columns the same length.
+pub(crate) fn try_msm_g1_many<C: 'static, S: 'static, P: 'static + Clone>(columns: &[&[S]], bases: &[C], identity: P) -> Option<Vec<P>> {
+    let batch = columns.len();
+    let n = columns.first().map_or(0, |c| c.len());
+    if !(is::<C, G1Affine>() && is::<S, Fr>() && is::<P, G1>()) || batch < 2 || n < MIN_GPU_MSM || n > bases.len() || n > 1usize << MAX_BATCHED_LOG
+        || columns.iter().any(|c| c.len() != n) || !usable() {
+        return None;
+    }
+    let mut flat: Vec<u64> = Vec::with_capacity(batch * n * 4);
+    for c in columns {
+        // SAFETY: &[S] = &[Fr]: n elements of 4 little-endian u64 limbs
+        flat.extend_from_slice(unsafe { std::slice::from_raw_parts(c.as_ptr() as *const u64, n * 4) });
+    }
+    let mut out = vec![identity; batch];
+    // SAFETY: batch contiguous vectors of n scalars, bases[..n], batch results of 12 limbs each (P = G1)
+    let rc = unsafe { zkhip_msm_g1_batch(flat.as_ptr(), bases.as_ptr() as *const u64, n, batch, out.as_mut_ptr() as *mut u64) };
+    if rc != 0 {
+        warn_once("zkhip_msm_g1_batch", rc);
+        return None;
+    }
+    Some(out)
+}
+
+/// `lagrange_to_coeff` of every column of a phase, in place: true when F = bn256::Fr and the batched call succeeded.
+pub(crate) fn try_ifft_scaled_many<F: 'static>(columns: &mut [&mut [F]], omega_inv: &F, log_n: u32, divisor: &F) -> bool {
+    let batch = columns.len();
+    let n = 1usize << log_n.min(28);
+    if !is::<F, Fr>() || batch < 2 || log_n < MIN_GPU_NTT_LOG || log_n > MAX_BATCHED_LOG || columns.iter().any(|c| c.len() != n) || !usable() {
+        return false;
+    }
+    let mut flat: Vec<u64> = Vec::with_capacity(batch * n * 4);
+    for c in columns.iter() {
+        // SAFETY: &[F] = &[Fr]
+        flat.extend_from_slice(unsafe { std::slice::from_raw_parts(c.as_ptr() as *const u64, n * 4) });
+    }
+    // SAFETY: batch contiguous polynomials of 2^log_n elements, transformed in place
+    let rc = unsafe { zkhip_ifft_scaled_batch(flat.as_mut_ptr(), omega_inv as *const F as *const u64, log_n, divisor as *const F as *const u64, batch as u32) };
+    if rc != 0 {
+        warn_once("zkhip_ifft_scaled_batch", rc);       // the caller's columns are untouched: its per-column loop still sees the inputs
+        return false;
+    }
+    for (i, c) in columns.iter_mut().enumerate() {
+        // SAFETY: as above, mutable
+        unsafe { std::slice::from_raw_parts_mut(c.as_mut_ptr() as *mut u64, n * 4) }.copy_from_slice(&flat[i * n * 4..(i + 1) * n * 4]);
+    }
+    true
+}
+
+/// `coeff_to_extended` of every column of the quotient phase: Some(extended evaluations, one Vec per column) or None.
+pub(crate) fn try_coeff_to_extended_many<F: 'static + Clone>(columns: &[&[F]], k: u32, ext_k: u32, ext_omega: &F, zeta: &F, zero: F) -> Option<Vec<Vec<F>>> {
+    let batch = columns.len();
+    let (n, en) = (1usize << k.min(28), 1usize << ext_k.min(28));
+    if !is::<F, Fr>() || batch < 2 || ext_k > MAX_BATCHED_LOG || k > ext_k || columns.iter().any(|c| c.len() != n) || !usable() {
+        return None;
+    }
+    let mut flat: Vec<u64> = Vec::with_capacity(batch * n * 4);
+    for c in columns {
+        // SAFETY: &[F] = &[Fr]
+        flat.extend_from_slice(unsafe { std::slice::from_raw_parts(c.as_ptr() as *const u64, n * 4) });
+    }
+    let mut ext: Vec<u64> = vec![0; batch * en * 4];
+    // SAFETY: batch polynomials of 2^k coefficients in, batch x 2^ext_k evaluations out, distinct buffers
+    let rc = unsafe { zkhip_coeff_to_extended_batch(flat.as_ptr(), k, ext.as_mut_ptr(), ext_k, batch as u32, ext_omega as *const F as *const u64,
+                                                    zeta as *const F as *const u64) };
+    if rc != 0 {
+        warn_once("zkhip_coeff_to_extended_batch", rc);
+        return None;
+    }
+    Some((0..batch).map(|i| {
+        let mut v = vec![zero.clone(); en];
+        // SAFETY: Vec<F> = Vec<Fr> of en elements
+        unsafe { std::slice::from_raw_parts_mut(v.as_mut_ptr() as *mut u64, en * 4) }.copy_from_slice(&ext[i * en * 4..(i + 1) * en * 4]);
+        v
+    }).collect())
+}
+
+// ======================================================================================================================================
+// prover_patch.rs, mode (b): device-resident columns.  A `DevCols` is `count` columns of `len` field elements in ONE zkhip_alloc'd block
+// (column i at element offset i * len): what `Vec<Polynomial<Fr, _>>` becomes while a proof is in flight.  Only commitments (96 bytes) and
+// evaluations (32 bytes) cross PCIe after the witness has gone up.  Every method returns false / None on a non-zero status; the caller then
+// abandons the device-resident proof and re-runs create_proof's CPU-orchestrated body (the witness columns are still on the host).
+// ======================================================================================================================================
+pub(crate) struct DevCols { ptr: *mut c_void, pub len: usize, pub count: usize }
+
+// SAFETY: the handle is a device address; the library serialises access per stream and create_proof drives one proof from one thread
+unsafe impl Send for DevCols {}
+
+impl DevCols {
+    pub(crate) fn alloc(len: usize, count: usize) -> Option<DevCols> {
+        if !usable() { return None; }
+        let mut ptr: *mut c_void = std::ptr::null_mut();
+        // SAFETY: out-parameter of the allocation
+        let rc = unsafe { zkhip_alloc(len * count * 32, &mut ptr) };
+        if rc != 0 { warn_once("zkhip_alloc", rc); return None; }
+        Some(DevCols { ptr, len, count })
+    }
+    /// device address of element `row` of column `col`
+    pub(crate) fn at(&self, col: usize, row: usize) -> *mut c_void {
+        debug_assert!(col < self.count && row <= self.len);
+        (self.ptr as usize + (col * self.len + row) * 32) as *mut c_void
+    }
+    /// host slice -> rows [row, row + src.len()) of column `col` (the witness going up; the blinding rows of a product)
+    pub(crate) fn upload<F: 'static>(&self, col: usize, row: usize, src: &[F]) -> bool {
+        if !is::<F, Fr>() || row + src.len() > self.len { return false; }
+        // SAFETY: src = &[Fr]; the destination range was checked
+        let rc = unsafe { zkhip_upload(self.at(col, row), src.as_ptr() as *const c_void, src.len() * 32) };
+        if rc != 0 { warn_once("zkhip_upload", rc); }
+        rc == 0
+    }
+    pub(crate) fn download<F: 'static>(&self, col: usize, row: usize, dst: &mut [F]) -> bool {
+        if !is::<F, Fr>() || row + dst.len() > self.len { return false; }
+        // SAFETY: dst = &mut [Fr]
+        let rc = unsafe { zkhip_download(dst.as_mut_ptr() as *mut c_void, self.at(col, row), dst.len() * 32) };
+        if rc != 0 { warn_once("zkhip_download", rc); }
+        rc == 0
+    }
+    /// commitments of columns [first, first + batch) against a pinned base array (`params.commit_lagrange` / `commit` of a whole phase)
+    pub(crate) fn commit_many<C: 'static, P: 'static + Clone>(&self, first: usize, batch: usize, n: usize, bases: &[C], identity: P) -> Option<Vec<P>> {
+        if !(is::<C, G1Affine>() && is::<P, G1>()) || first + batch > self.count || n > self.len || n > bases.len() { return None; }
+        let res = DevCols::alloc(3, batch)?;                 // batch x 96 bytes
+        let mut out = vec![identity; batch];
+        // SAFETY: device-resident scalars (column stride = self.len elements), host pointer into a registered array, batch x 12 limbs out
+        let rc = unsafe { zkhip_msm_g1_registered_batch_device(bases.as_ptr() as *const u64, self.at(first, 0), n, batch, self.len, res.ptr, std::ptr::null_mut()) };
+        // SAFETY: out = Vec<G1> of `batch` elements
+        let rc2 = if rc == 0 { unsafe { zkhip_download(out.as_mut_ptr() as *mut c_void, res.ptr, batch * 96) } } else { rc };
+        if rc2 != 0 { warn_once("zkhip_msm_g1_registered_batch_device", rc2); return None; }
+        Some(out)
+    }
+    /// `lagrange_to_coeff` of columns [first, first + batch) in place
+    pub(crate) fn ifft_scaled_many<F: 'static>(&self, first: usize, batch: usize, omega_inv: &F, log_n: u32, divisor: &F) -> bool {
+        if !is::<F, Fr>() || first + batch > self.count || self.len < 1usize << log_n.min(28) { return false; }
+        // SAFETY: in place on device memory this handle owns
+        let rc = unsafe { zkhip_ifft_scaled_batch_device(self.at(first, 0), omega_inv as *const F as *const u64, log_n, divisor as *const F as *const u64,
+                                                         batch as u32, self.len, std::ptr::null_mut()) };
+        if rc != 0 { warn_once("zkhip_ifft_scaled_batch_device", rc); }
+        rc == 0
+    }
+    /// `coeff_to_extended` of columns [first, first + batch) into columns [out_first, ..) of `out` (len = 2^ext_k)
+    pub(crate) fn coeff_to_extended_many<F: 'static>(&self, first: usize, batch: usize, k: u32, out: &DevCols, out_first: usize, ext_k: u32, ext_omega: &F,
+                                                     zeta: &F) -> bool {
+        if !is::<F, Fr>() || first + batch > self.count || out_first + batch > out.count || out.len != 1usize << ext_k.min(28) { return false; }
+        // SAFETY: distinct device blocks
+        let rc = unsafe { zkhip_coeff_to_extended_device(self.at(first, 0), self.len, k, out.at(out_first, 0), out.len, ext_k, batch as u32,
+                                                         ext_omega as *const F as *const u64, zeta as *const F as *const u64, std::ptr::null_mut()) };
+        if rc != 0 { warn_once("zkhip_coeff_to_extended_device", rc); }
+        rc == 0
+    }
+    /// one row program over device-resident columns: `out_col` of `out` = program(columns) for 2^log_rows rows
+    pub(crate) fn eval_rows(prog: &VmProgramOwned, columns: &[*const c_void], log_rows: u32, out: &DevCols, out_col: usize) -> bool {
+        let p = prog.as_ffi();
+        // SAFETY: `p` borrows the Vecs of `prog`, alive for the call; `columns` are device addresses of columns with >= 2^log_rows rows
+        let rc = unsafe { zkhip_fr_eval_rows_device(&p, columns.as_ptr(), columns.len() as u32, log_rows, 0, out.at(out_col, 0), std::ptr::null_mut()) };
+        if rc != 0 { warn_once("zkhip_fr_eval_rows_device", rc); }
+        rc == 0
+    }
+    /// z = grand product of num / den (num = column `z_col` on entry, den is consumed): `permutation::Argument::commit`, `lookup::commit_product`
+    pub(crate) fn grand_product(&self, z_col: usize, den: &DevCols, den_col: usize, n: usize) -> bool {
+        // SAFETY: z aliases num as the C ABI allows
+        let rc = unsafe { zkhip_fr_grand_product_device(self.at(z_col, 0), den.at(den_col, 0), n, self.at(z_col, 0), std::ptr::null_mut()) };
+        if rc != 0 { warn_once("zkhip_fr_grand_product_device", rc); }
+        rc == 0
+    }
+    /// `permute_expression_pair`: columns (input, table) of self -> (permuted_input, permuted_table) of `out`, first `usable_rows` rows
+    pub(crate) fn lookup_permute(&self, input: usize, table: usize, usable_rows: usize, out: &DevCols, pin: usize, ptab: usize) -> bool {
+        // SAFETY: outputs do not alias the inputs (different blocks or different columns)
+        let rc = unsafe { zkhip_lookup_permute_device(self.at(input, 0), self.at(table, 0), usable_rows, out.at(pin, 0), out.at(ptab, 0), std::ptr::null_mut()) };
+        if rc != 0 { warn_once("zkhip_lookup_permute_device", rc); }   // ZKHIP_EINVAL = an input value missing from the table (Error::ConstraintSystemFailure upstream)
+        rc == 0
+    }
+    /// h(X) (X^n - 1) evaluations in column `col` -> divided by the vanishing polynomial -> `out_len` coefficients in column `out_col` of `out`
+    pub(crate) fn quotient_to_coeff<F: 'static>(&self, col: usize, ext_k: u32, t_inv: &DevCols, period: u32, ext_omega_inv: &F, ext_divisor: &F, zeta: &F,
+                                                out: &DevCols, out_col: usize, out_len: usize) -> bool {
+        if !is::<F, Fr>() || self.len != 1usize << ext_k.min(28) || out_len > out.len { return false; }
+        // SAFETY: in place, then into a distinct block
+        let rc = unsafe { zkhip_mul_periodic_device(self.at(col, 0), self.len, t_inv.at(0, 0), period, std::ptr::null_mut()) };
+        let rc = if rc != 0 { rc } else { unsafe {
+            zkhip_extended_to_coeff_device(self.at(col, 0), self.len, ext_k, ext_omega_inv as *const F as *const u64, ext_divisor as *const F as *const u64,
+                                           zeta as *const F as *const u64, out.at(out_col, 0), out.len, out_len, 1, std::ptr::null_mut()) } };
+        if rc != 0 { warn_once("zkhip_extended_to_coeff_device", rc); }
+        rc == 0
+    }
+    /// evaluations of `polys` (device addresses of n-coefficient polynomials) at `point`: the `eval_polynomial` loop of create_proof in one call
+    pub(crate) fn eval_polys<F: 'static + Clone>(polys: &[*const c_void], n: usize, point: &F, zero: F) -> Option<Vec<F>> {
+        if !is::<F, Fr>() { return None; }
+        let res = DevCols::alloc(polys.len().max(1), 1)?;
+        let mut out = vec![zero; polys.len()];
+        // SAFETY: polys.len() results of 32 bytes each
+        let rc = unsafe { zkhip_fr_eval_polynomial_batch_device(polys.as_ptr(), polys.len(), n, point as *const F as *const u64, res.ptr, std::ptr::null_mut()) };
+        let rc2 = if rc == 0 { unsafe { zkhip_download(out.as_mut_ptr() as *mut c_void, res.ptr, polys.len() * 32) } } else { rc };
+        if rc2 != 0 { warn_once("zkhip_fr_eval_polynomial_batch_device", rc2); return None; }
+        Some(out)
+    }
+}
+
+impl Drop for DevCols {
+    fn drop(&mut self) {
+        // SAFETY: allocated by zkhip_alloc, freed once (zkhip_free waits for queued work on the block)
+        let _ = unsafe { zkhip_free(self.ptr) };
+    }
+}
+
+/// A row program with its storage: what evaluation.rs builds from a `GraphEvaluator` (prover_patch.rs `lower_graph`).
+pub(crate) struct VmProgramOwned {
+    pub insns: Vec<VmInsn>,
+    pub constants: Vec<[u64; 4]>,        // Montgomery limbs of bn256::Fr
+    pub rotations: Vec<i32>,
+    pub rot_scale: i32,
+    pub result_reg: u32,
+    pub omega: Option<[u64; 4]>,
+}
+
+impl VmProgramOwned {
+    fn as_ffi(&self) -> VmProgram {
+        VmProgram {
+            insns: self.insns.as_ptr(), n_insns: self.insns.len() as u32,
+            constants: self.constants.as_ptr() as *const u64, n_constants: self.constants.len() as u32,
+            rotations: self.rotations.as_ptr(), n_rotations: self.rotations.len() as u32,
+            rot_scale: self.rot_scale, result_reg: self.result_reg,
+            omega: self.omega.as_ref().map_or(std::ptr::null(), |w| w.as_ptr()),
+        }
+    }
 }

@@ -17,11 +17,12 @@ SHIM = os.path.join(ROOT, "rust-shim")
 # canonical parameter classes: (kind, bits, const) -- what has to agree across the FFI for the call to be sound on x86-64 / SysV
 C_TYPES = {
     "int": ("int", 32), "uint32_t": ("uint", 32), "int32_t": ("int", 32), "size_t": ("uint", 64), "uint64_t": ("uint", 64),
-    "uint8_t": ("uint", 8), "char": ("int", 8), "void": ("void", 0),
+    "uint8_t": ("uint", 8), "char": ("int", 8), "void": ("void", 0), "zkhip_vm_program": ("struct zkhip_vm_program", 0),
+    "uint16_t": ("uint", 16),
 }
 RUST_TYPES = {
     "c_int": ("int", 32), "i32": ("int", 32), "u32": ("uint", 32), "usize": ("uint", 64), "u64": ("uint", 64), "u8": ("uint", 8),
-    "c_char": ("int", 8), "c_void": ("void", 0),
+    "c_char": ("int", 8), "c_void": ("void", 0), "VmProgram": ("struct zkhip_vm_program", 0), "u16": ("uint", 16),
 }
 
 
@@ -39,6 +40,10 @@ def c_param(p):
     toks = [t for t in re.sub(r"[*]", " ", p).replace("const", " ").split()]
     base = toks[0]
     assert base in C_TYPES, f"unknown C type in {p!r}"
+    if stars + int(is_array) == 2:               # `void **d_ptr` (out-parameter), `const void *const *d_columns` (host array of device pointers)
+        n_const = len(re.findall(r"\bconst\b", p))
+        assert base == "void" and not is_array, f"pointer-to-pointer of {p!r}"
+        return ("ptrptr", C_TYPES[base], n_const)
     if stars or is_array:
         assert stars + int(is_array) == 1, f"pointer depth of {p!r}"
         return ("ptr", C_TYPES[base], const)
@@ -63,6 +68,10 @@ def c_prototypes():
 
 def rust_param(p):
     name, ty = [x.strip() for x in p.split(":", 1)]
+    m = re.fullmatch(r"\*(const|mut)\s+\*(const|mut)\s+(\w+)", ty)
+    if m:                                        # *mut *mut c_void = void **; *const *const c_void = const void *const *
+        assert m.group(3) == "c_void", f"pointer-to-pointer of {p!r}"
+        return ("ptrptr", RUST_TYPES[m.group(3)], [m.group(1), m.group(2)].count("const"))
     m = re.fullmatch(r"\*(const|mut)\s+(\w+)", ty)
     if m:
         assert m.group(2) in RUST_TYPES, f"unknown Rust pointee in {p!r}"
@@ -97,6 +106,8 @@ def test_extern_block_matches_the_header():
         for i, (r, c) in enumerate(zip(rparams, cparams)):
             assert r[0] == c[0], f"{name} parameter {i}: {r} vs {c} (pointer / value)"
             assert r[1] == c[1], f"{name} parameter {i}: {r} vs {c} (class / width)"
+            if r[0] == "ptrptr":
+                assert r[2] == c[2], f"{name} parameter {i}: constness of the two pointer levels"
             if r[0] == "ptr":
                 assert r[2] == c[2], f"{name} parameter {i}: *const / *mut does not match the header's const"
 
@@ -112,8 +123,9 @@ def test_every_ffi_call_in_the_shim_is_declared():
     used = set(re.findall(r"\b(zkhip_[a-z0-9_]+)\s*\(", ffi_text))
     assert used <= set(externs), f"called but not declared: {sorted(used - set(externs))}"
     # the patch files only go through zkhip_ffi::*, never through the C ABI directly
-    for f in ("arithmetic_patch.rs", "commitment_patch.rs", "domain_patch.rs"):
+    for f in ("arithmetic_patch.rs", "commitment_patch.rs", "domain_patch.rs", "prover_patch.rs"):
         body = re.sub(r"//[^\n]*", "", open(os.path.join(SHIM, f)).read())
+        body = re.sub(r"zkhip_ffi::(?:self|[A-Z][A-Za-z]*|[A-Z_0-9]+)\b", "", body)      # types and constants: checked in the prover-patch test below
         for call in re.findall(r"zkhip_ffi::(\w+)", body):
             assert re.search(r"pub\(crate\)\s+fn\s+" + call + r"\b", ffi_text), f"{f} calls zkhip_ffi::{call}, which zkhip_ffi.rs does not define"
         assert not re.search(r'extern\s+"C"', body), f'{f} must not declare its own extern "C" items'
@@ -133,18 +145,83 @@ def test_patch_keeps_the_generic_signatures_and_the_cpu_fall_through():
     assert "panic!" not in re.sub(r"//[^\n]*", "", ffi), "a non-zero status falls through to the CPU body, it does not panic"
 
 
-def test_params_kzg_unregisters_in_drop_and_pins_in_every_constructor():
+def test_srs_arrays_unregister_in_their_own_drop_and_pin_in_every_constructor():
+    """commitment_patch.rs: the arrays live in `Pinned<C>`, whose Drop unregisters BEFORE the heap block goes; `ParamsKZG` gains no Drop impl
+    (round-4 advice: a Drop on ParamsKZG forbids moving out of its fields anywhere in the dependency tree) and keeps its derived Clone"""
     c = open(os.path.join(SHIM, "commitment_patch.rs")).read()
-    drop = re.search(r"impl<E: Engine> Drop for ParamsKZG<E> \{.*?\n\}", c, flags=re.S)
-    assert drop and "self.zkhip_unpin()" in drop.group(0)
-    unpin = re.search(r"fn zkhip_unpin\(&self\) \{.*?\}", c, flags=re.S).group(0)
-    assert "unpin::<E::G1Affine>(&self.g)" in unpin and "unpin::<E::G1Affine>(&self.g_lagrange)" in unpin
+    code = re.sub(r"//[^\n]*", "", c)
+    drop = re.search(r"impl<C: 'static> Drop for Pinned<C> \{.*?\n\}", code, flags=re.S)
+    assert drop and "zkhip_ffi::unpin::<C>(&self.0)" in drop.group(0)
+    assert not re.search(r"impl<[^>]*>\s*Drop\s+for\s+ParamsKZG", code) and not re.search(r"impl<[^>]*>\s*Clone\s+for\s+ParamsKZG", code)
+    new = re.search(r"pub\(crate\) fn new\(v: Vec<C>\) -> Self \{.*?\}", code, flags=re.S).group(0)
+    assert "zkhip_ffi::pin::<C>(&v)" in new
+    clone = re.search(r"impl<C: 'static \+ Clone> Clone for Pinned<C> \{.*?\n\}", code, flags=re.S).group(0)
+    assert "Pinned::new(self.0.clone())" in clone                                   # the copy is registered as well
+    trunc = re.search(r"pub\(crate\) fn truncate\(&mut self, len: usize\) \{.*?\}", code, flags=re.S).group(0)
+    assert trunc.index("unpin") < trunc.index("self.0.truncate(len)") < trunc.index("zkhip_ffi::pin")
+    assert "type Target = [C];" in code
     for ctor in ("setup", "from_parts", "read_custom", "downsize"):
         assert re.search(r"`(?:Params::)?" + ctor + r"`", c), f"no instruction for {ctor}"
-    assert re.search(r"impl<E: Engine> Clone for ParamsKZG<E>.*?\.zkhip_pinned\(\)", c, flags=re.S)
+    assert c.count("Pinned::new(") >= 7
 
 
-@pytest.mark.parametrize("name", ["zkhip_ffi.rs", "arithmetic_patch.rs", "commitment_patch.rs", "domain_patch.rs", "build.rs"])
+def test_program_structs_match_the_header_field_by_field():
+    """`#[repr(C)]` VmOperand / VmInsn / VmProgram of zkhip_ffi.rs against zkhip_vm_operand / zkhip_vm_insn / zkhip_vm_program of the header:
+    the same fields, in the same order, of the same class and width; the opcode / source constants carry the header's values"""
+    hdr = strip_c_comments(open(os.path.join(ROOT, "include", "zkhip.h")).read())
+    ffi = re.sub(r"//[^\n]*", "", open(os.path.join(SHIM, "zkhip_ffi.rs")).read())
+    names = {"zkhip_vm_operand": "VmOperand", "zkhip_vm_insn": "VmInsn", "zkhip_vm_program": "VmProgram"}
+    for cname, rname in names.items():
+        cbody = re.search(r"typedef struct " + cname + r"\s*\{(.*?)\}\s*" + cname + r"\s*;", hdr, flags=re.S).group(1)
+        cfields = []
+        for decl in [d.strip() for d in cbody.split(";") if d.strip()]:
+            m = re.fullmatch(r"(const\s+)?(\w+)\s*(\*?)\s*(.+)", decl)
+            base, ptr = m.group(2), bool(m.group(3))
+            for nm in [x.strip() for x in m.group(4).split(",")]:
+                cfields.append((nm, ("ptr" if ptr else "val", names.get(base, None) or C_TYPES[base])))
+        rbody = re.search(r"pub\(crate\) struct " + rname + r"\s*\{(.*?)\}", ffi, flags=re.S).group(1)
+        rfields = []
+        for decl in [d.strip() for d in rbody.replace("\n", " ").split(",") if d.strip()]:
+            nm, ty = [x.strip() for x in decl.replace("pub ", "").split(":", 1)]
+            m = re.fullmatch(r"\*const\s+(\w+)", ty)
+            base = m.group(1) if m else ty
+            cls = base if base in names.values() else RUST_TYPES[base]
+            rfields.append((nm, ("ptr" if m else "val", cls)))
+        assert rfields == cfields, f"{rname} != {cname}: {rfields} vs {cfields}"
+    for group in (("ZKHIP_SRC_", "SRC_"), ("ZKHIP_OP_", "OP_")):
+        for nm, val in re.findall(group[0] + r"(\w+)\s*=\s*(\d+)", hdr):
+            assert re.search(r"pub\(crate\) const " + group[1] + nm + r": u8 = " + val + r";", ffi), f"{group[1]}{nm} != {val}"
+    assert re.search(r"#define ZKHIP_VM_REGS (\d+)", hdr).group(1) == re.search(r"pub\(crate\) const VM_REGS: usize = (\d+);", ffi).group(1)
+
+
+def test_prover_patch_uses_only_what_zkhip_ffi_defines():
+    """prover_patch.rs (code AND the quoted replacement loops in its comments): every `zkhip_ffi::name`, every `DevCols::name` / `dp.<handle>.name(`
+    exists in zkhip_ffi.rs; both modes are described; the generic CPU loops stay as the fall-back of every batched method"""
+    ffi = open(os.path.join(SHIM, "zkhip_ffi.rs")).read()
+    pp = open(os.path.join(SHIM, "prover_patch.rs")).read()
+    defined = set(re.findall(r"pub\(crate\) (?:fn|const|struct|enum) (\w+)", ffi)) | {"self", "is"}
+    assert re.search(r"\nfn is<", ffi)
+    used = set(re.findall(r"zkhip_ffi::(?:\{[^}]*\}|(\w+))", pp)) - {""}
+    for grp in re.findall(r"zkhip_ffi::\{([^}]*)\}", pp):
+        used |= {x.strip() for x in grp.split(",")}
+    assert used <= defined, f"prover_patch.rs uses undefined zkhip_ffi items: {sorted(used - defined)}"
+    methods = set(re.findall(r"pub\(crate\) fn (\w+)", re.search(r"impl DevCols \{.*?\n\}", ffi, flags=re.S).group(0)))
+    for m in re.findall(r"(?:DevCols::|\b(?:base|ext|h|den)\.)(\w+)\(", pp):
+        assert m in methods, f"prover_patch.rs calls DevCols::{m}, which zkhip_ffi.rs does not define"
+    for needle in ("commit_lagrange_many", "commit_many", "lagrange_to_coeff_many", "coeff_to_extended_many", "ZKHIP_DEVICE_RESIDENT", "lower_graph"):
+        assert needle in pp, needle
+    # every batched method keeps the per-polynomial loop as its last statement
+    assert pp.count("polys.iter().map(|p| self.commit_lagrange(p, Blind::default())).collect()") == 2
+    assert "polys.into_iter().map(|p| self.lagrange_to_coeff(p)).collect()" in pp and "polys.iter().map(|p| self.coeff_to_extended(p)).collect()" in pp
+    # the C99 replay names this file, and issues the entry points the handle type wraps
+    seq = open(os.path.join(ROOT, "tests", "cpp", "prover_sequence.c")).read()
+    for fn in ("zkhip_msm_g1_batch", "zkhip_ifft_scaled_batch", "zkhip_coeff_to_extended_batch", "zkhip_msm_g1_registered_batch_device",
+               "zkhip_ifft_scaled_batch_device", "zkhip_coeff_to_extended_device", "zkhip_fr_eval_rows_device", "zkhip_fr_grand_product_device",
+               "zkhip_lookup_permute_device", "zkhip_mul_periodic_device", "zkhip_extended_to_coeff_device", "zkhip_fr_eval_polynomial_batch_device"):
+        assert fn + "(" in seq and "fn " + fn + "(" in ffi, fn
+
+
+@pytest.mark.parametrize("name", ["zkhip_ffi.rs", "arithmetic_patch.rs", "commitment_patch.rs", "domain_patch.rs", "prover_patch.rs", "build.rs"])
 def test_rust_files_are_lexically_balanced(name):
     """the cheapest stand-in for a parse: brackets balance outside comments, strings and char / lifetime tokens"""
     text = open(os.path.join(SHIM, name)).read()
@@ -162,6 +239,6 @@ def test_rust_files_are_lexically_balanced(name):
 
 def test_integration_md_reproduces_the_shim_files_verbatim():
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
-    for name in ("Cargo.patch.toml", "build.rs", "zkhip_ffi.rs", "arithmetic_patch.rs", "commitment_patch.rs", "domain_patch.rs"):
+    for name in ("Cargo.patch.toml", "build.rs", "zkhip_ffi.rs", "arithmetic_patch.rs", "commitment_patch.rs", "domain_patch.rs", "prover_patch.rs"):
         body = open(os.path.join(SHIM, name)).read().rstrip()
         assert body in doc, f"INTEGRATION.md section 2 is out of date with rust-shim/{name}"
