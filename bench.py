@@ -1043,7 +1043,44 @@ def extras(lib, _lib, F, torch, dev, stream) -> dict:
     tot = ms + out["prover_phases_k22"]["total_ms"]
     out["wrapper_replay"]["with_prover_phases_ms"] = round(tot, 2)          # + quotient, grand products, multiopen (8(f) rows 1-3)
     out["wrapper_replay"]["proofs_per_s_device_portion"] = round(1e3 / tot, 3)
+    out["wrapper_replay"].update(shim_device_sequence(22, 4, torch))
     return out
+
+
+def shim_device_sequence(k: int, gate_cols: int, torch) -> dict:
+    """The device-resident call sequence of rust-shim/prover_patch.rs (mode (b)) for one proof of the wrapper's shape (k = 22, 4 gate columns + 1
+    lookup column: /root/reference/aggregator/benches/wrapper_circuit.rs:61-68), issued by the C99 replay tests/cpp/prover_sequence.c in a child
+    process: witness upload, advice / lookup / product commitments, grand products, lagrange_to_coeff, coeff_to_extended, the quotient program,
+    its commitments and the evaluations at x, with the commitments and evaluations read back (what the transcript needs).  PCIe-inclusive."""
+    import re
+    import subprocess
+    import tempfile
+
+    try:
+        from zksnap_circuits_halo2_amd import evaluation as E
+
+        lib_dir = os.path.join(ROOT, "zksnap_circuits_halo2_amd")
+        with tempfile.TemporaryDirectory() as tmp:
+            exe, rec = os.path.join(tmp, "prover_sequence"), os.path.join(tmp, "programs.bin")
+            subprocess.check_call(["gcc", "-std=c99", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "prover_sequence.c"),
+                                   "-o", exe, "-L", lib_dir, "-lzkhip", "-Wl,-rpath," + lib_dir])
+            with open(rec, "wb") as fh:
+                fh.write(E.export_prover_programs(k, gate_cols, 1, seed=k))
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            res = subprocess.run([exe, rec, "--device-only", "3"], capture_output=True, text=True, timeout=600)
+        m = re.search(r"sequence_ms device_resident=([\d.]+)", res.stdout)
+        if res.returncode != 0 or not m:
+            return {"shim_device_sequence_ms": None, "shim_device_sequence_error": (res.stdout + res.stderr)[-400:]}
+        ms = float(m.group(1))
+        return {"shim_device_sequence_ms": round(ms, 2),
+                "shim_device_sequence": {"how": "tests/cpp/prover_sequence.c --device-only 3 in a child process: the call sequence of rust-shim/prover_patch.rs mode (b), "
+                                                "three proofs over the same buffers, the fastest reported (first_ms = the process's first proof, cold clocks)",
+                                         "first_ms": float(re.search(r"first=([\d.]+)", res.stdout).group(1)),
+                                         "shape": re.search(r"shape: (.*)", res.stdout).group(1) if "shape: " in res.stdout else None,
+                                         "proofs_per_s": round(1e3 / ms, 3)}}
+    except Exception as exc:   # an extra: never fail the bench line
+        return {"shim_device_sequence_ms": None, "shim_device_sequence_error": repr(exc)}
 
 
 def wrapper_replay_k24(lib, _lib, F, torch, dev, stream, c4: dict) -> dict:

@@ -20,7 +20,9 @@
  * lookup column holds table values), so the constraint system is not satisfied and h is not the true quotient; all three sequences compute
  * the same h from the same columns, which is what is compared.  (Satisfied circuits: tools/prove_flow.py, tests/test_gpu_prover_flow.py.)
  *
- * usage: prover_sequence <programs.bin> [--device-only]        exit status 0 = every comparison passed */
+ * usage: prover_sequence <programs.bin> [--device-only [repeats]]        exit status 0 = every comparison passed
+ * (--device-only: sequence D alone, `repeats` times over the same buffers -- the first proof of a process runs at cold clocks -- reporting
+ * the first and the fastest) */
 #define _POSIX_C_SOURCE 199309L
 #include <stdio.h>
 #include <stdlib.h>
@@ -94,6 +96,8 @@ typedef struct {
 
 int main(int argc, char **argv) {
   int device_only = argc > 2 && strcmp(argv[2], "--device-only") == 0;
+  int repeats = device_only && argc > 3 && atoi(argv[3]) > 1 ? atoi(argv[3]) : 1, rep;
+  double first_ms = 0;
   FILE *f;
   long fsz;
   unsigned char *blob;
@@ -316,6 +320,7 @@ int main(int argc, char **argv) {
       const void **dptr = xmalloc(ncol * 2 * sizeof(*dptr));
       size_t c = 0, p;
       double t0;
+      res->ms = 0;
       res->n_commits = nadv + 2 + nsets + 1 + 3;
       res->commits = xmalloc(res->n_commits * 96);
       res->n_evals = nproof + 3;
@@ -341,6 +346,8 @@ int main(int argc, char **argv) {
       OK(zkhip_sync());
 #define DLAG(p_) (d_lag + (size_t)(p_) * n * 32)            /* proof column p_ (0 .. nproof): advice, then z sets, z_lookup, a', s' */
 #define DPCOL(c_) ((c_) < nadv ? (const void *)DLAG(c_) : (const void *)d_const_lag)
+      for (rep = 0; rep < repeats; rep++) {
+      c = 0;
       t0 = now_ms();
       /* 1. the witness goes up once; advice commitments in ONE call against the pinned g_lagrange */
       OK(zkhip_upload(d_lag, advice_flat, nadv * n * 32));
@@ -405,7 +412,12 @@ int main(int argc, char **argv) {
       /* the transcript's view: commitments and evaluations, one read-back */
       OK(zkhip_download(res->commits, d_out, res->n_commits * 96));
       OK(zkhip_download(res->evals, d_out + 96 * res->n_commits, res->n_evals * 32));
-      res->ms = now_ms() - t0;
+      {
+        const double ms = now_ms() - t0;
+        if (rep == 0) first_ms = ms;
+        if (rep == 0 || ms < res->ms) res->ms = ms;
+      }
+      }
       CHECK(c == res->n_commits, "commitment count");
       res->h = NULL; res->h_len = 0;
       if (!device_only) { res->h = xmalloc(3 * n * 32); res->h_len = 3 * n; OK(zkhip_download(res->h, d_hc, 3 * n * 32)); }
@@ -436,7 +448,7 @@ int main(int argc, char **argv) {
   } else {
     uint64_t aff[8];
     CHECK(zkhip_g1_batch_normalize(R[2].commits, 1, aff) == ZKHIP_OK, "first commitment normalises");
-    printf("sequence_ms device_resident=%.2f\n", R[2].ms);
+    printf("sequence_ms device_resident=%.2f first=%.2f repeats=%d\n", R[2].ms, first_ms, repeats);
   }
   OK(zkhip_unregister_bases(g)); OK(zkhip_unregister_bases(gl));
   zkhip_shutdown();
