@@ -966,35 +966,38 @@ def extras(lib, _lib, F, torch, dev, stream) -> dict:
     del g, ext, sc
     bufs.clear()
     torch.cuda.empty_cache()
-    # G2 MSM (best_multiexp::<G2Affine>; no prover call site, correctness-first kernels): 2^16 points = 64 distinct multiples of the
-    # generator (host big-integer arithmetic of the package's srs module) repeated, uniform scalars
+    # G2 MSM (best_multiexp::<G2Affine>; no prover call site): 2^16 and 2^20 points = 64 distinct multiples of the generator (host big-integer
+    # arithmetic of the package's srs module) repeated, uniform scalars.  Round 5: GLV digits on the twist, lazy Fq2 arithmetic in the accumulation.
     try:
         from zksnap_circuits_halo2_amd import srs as _srs
 
         base = np.stack([_srs.g2_encode(_srs.g2_mul(1000003 * (i + 1))) for i in range(64)])
-        n2 = 1 << 16
-        d_b2 = torch.from_numpy(np.ascontiguousarray(np.tile(base, (n2 // 64, 1))).view(np.int64)).to(dev)
-        d_s2 = torch.from_numpy(synth_scalars(n2, 4242).view(np.int64)).to(dev)
-        d_o2 = torch.zeros(24, dtype=torch.int64, device=dev)
-        ms_g2 = timed(lambda: _lib.check(lib.zkhip_msm_g2_device(d_s2.data_ptr(), d_b2.data_ptr(), n2, d_o2.data_ptr(), stream)), 3)
-        # the result is checked, not discarded: base i = (1000003 (i % 64 + 1)) G2, so MSM = [sum a_i 1000003 (i % 64 + 1)] G2 (host integers of the
-        # package's srs module; the scalars' integer values a = words / 2^256 mod r)
-        h_s2 = d_s2.cpu().numpy().view(np.uint64).reshape(n2, 4)
         r_inv = pow(1 << 256, -1, R_MOD)
-        want_k = 0
-        for i in range(n2):
-            a_i = sum(int(h_s2[i, j]) << (64 * j) for j in range(4)) * r_inv % R_MOD
-            want_k = (want_k + a_i * 1000003 * (i % 64 + 1)) % R_MOD
-        jac = d_o2.cpu().numpy().view(np.uint64)[:24]
         mont_inv = pow(1 << 256, -1, _srs.Q_MOD)
-        v = [sum(int(jac[4 * c_ + j]) << (64 * j) for j in range(4)) * mont_inv % _srs.Q_MOD for c_ in range(6)]
-        X, Y, Zc = (v[0], v[1]), (v[2], v[3]), (v[4], v[5])
-        iz = _srs._f2inv(Zc)
-        iz2 = _srs._f2mul(iz, iz)
-        got_pt = (_srs._f2mul(X, iz2), _srs._f2mul(Y, _srs._f2mul(iz2, iz)))
-        out["msm_g2_2^16"] = {"ms": round(ms_g2, 3), "Mpoints_per_s": round(n2 / ms_g2 / 1e3, 2), "result_equals_structured_identity": bool(got_pt == _srs.g2_mul(want_k)),
-                              "note": "general path; not on the prover's path"}
-        del d_b2, d_s2
+        for log_n2 in (16, 20):
+            n2 = 1 << log_n2
+            d_b2 = torch.from_numpy(np.ascontiguousarray(np.tile(base, (n2 // 64, 1))).view(np.int64)).to(dev)
+            d_s2 = torch.from_numpy(synth_scalars(n2, 4242 + log_n2).view(np.int64)).to(dev)
+            d_o2 = torch.zeros(24, dtype=torch.int64, device=dev)
+            ms_g2 = timed(lambda: _lib.check(lib.zkhip_msm_g2_device(d_s2.data_ptr(), d_b2.data_ptr(), n2, d_o2.data_ptr(), stream)), 3)
+            # the result is checked, not discarded: base i = (1000003 (i % 64 + 1)) G2, so MSM = [sum a_i 1000003 (i % 64 + 1)] G2 (host integers of the
+            # package's srs module; the scalars' integer values a = words / 2^256 mod r, summed per residue class of i mod 64 with numpy object arrays)
+            h_s2 = d_s2.cpu().numpy().view(np.uint64).reshape(n2, 4)
+            col = [h_s2[:, j].astype(object) for j in range(4)]
+            vals = col[0] + (col[1] << 64) + (col[2] << 128) + (col[3] << 192)
+            want_k = 0
+            for c_ in range(64):
+                want_k = (want_k + int(vals[c_::64].sum()) % R_MOD * r_inv % R_MOD * 1000003 * (c_ + 1)) % R_MOD
+            jac = d_o2.cpu().numpy().view(np.uint64)[:24]
+            v = [sum(int(jac[4 * c_ + j]) << (64 * j) for j in range(4)) * mont_inv % _srs.Q_MOD for c_ in range(6)]
+            X, Y, Zc = (v[0], v[1]), (v[2], v[3]), (v[4], v[5])
+            iz = _srs._f2inv(Zc)
+            iz2 = _srs._f2mul(iz, iz)
+            got_pt = (_srs._f2mul(X, iz2), _srs._f2mul(Y, _srs._f2mul(iz2, iz)))
+            out["msm_g2_2^%d" % log_n2] = {"ms": round(ms_g2, 3), "Mpoints_per_s": round(n2 / ms_g2 / 1e3, 2),
+                                           "result_equals_structured_identity": bool(got_pt == _srs.g2_mul(want_k)),
+                                           "note": "general path (GLV digits, c = 16); not on the prover's path"}
+            del d_b2, d_s2
     except Exception as exc:   # an extra: never fail the bench line
         out["msm_g2_2^16"] = {"error": repr(exc)}
     out["small_circuit_replays"] = small_replays(lib, _lib, F, torch, dev, stream, timed)

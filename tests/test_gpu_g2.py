@@ -178,3 +178,31 @@ def test_g2_msm_skewed_scalars(lib, cref, g2_walk_2p17, case):
         sc[:] = F.fr_encode([sum(5 << (16 * w) for w in range(16))])[0]          # digit 5 in every 16-bit window
     got = dec(A.best_multiexp_g2(sc, np.ascontiguousarray(pts[:n])))
     assert got == O.g2_scalar_mul(cref.expected_scalar(sc, t0, d), O.G2_GEN)
+
+
+def test_g2_msm_glv_edge_scalars_vs_naive_oracle(lib):
+    """the GLV split of the G2 path (round 5) at the scalars where a decomposition goes wrong first: 0, 1, r - 1, lambda and its neighbours,
+    lambda^2, the lattice vectors' entries, powers of two around 2^127 / 2^128, the largest 254-bit value -- against the oracle's naive sum"""
+    lam = 0xb3c4d79d41a917585bfc41088d8daaa78b17ea66b99c90dd
+    a1, nb1, a2 = 0x89d3256894d213e3, 0x6f4d8248eeb859fc8211bbeb7d4f1128, 0x6f4d8248eeb859fd0be4e1541221250b
+    r = O.R_MOD
+    vals = [0, 1, 2, r - 1, r - 2, lam, lam + 1, lam - 1, r - lam, lam * lam % r, (lam * lam + 1) % r, a1, nb1, a2, r - a1, r - a2,
+            1 << 127, (1 << 127) - 1, (1 << 128) - 1, 1 << 128, (1 << 253) + 12345, r >> 1, (r >> 1) + 1, 0xFFFF, 0x10000, 0x8000, 0x7FFF]
+    vals = [v % r for v in vals]
+    g = O.SplitMix64(79)
+    pts = [O.g2_scalar_mul(g.fr(), O.G2_GEN) for _ in vals]
+    got = dec(A.best_multiexp_g2(F.fr_encode(vals), enc(pts)))
+    assert got == O.g2_msm_naive(vals, pts)
+
+
+def test_g2_msm_two_level_sort_size(lib, cref, g2_walk_2p17):
+    """2^18 + 5 points: from 2^18 the GLV digits take the two-level LDS sort (msm.hip msm_two_level) with 288-byte work points.  Bases = the 2^17
+    walk repeated, so the expected scalar is the sum over the two halves"""
+    t0, d, pts = g2_walk_2p17
+    half = 1 << 17
+    n = 2 * half + 5
+    bases = np.ascontiguousarray(np.concatenate([pts[:half], pts[:half], pts[:5]]))
+    sc = cref.gen_scalars(8870, n, 0)
+    want = (cref.expected_scalar(np.ascontiguousarray(sc[:half]), t0, d) + cref.expected_scalar(np.ascontiguousarray(sc[half:2 * half]), t0, d)
+            + cref.expected_scalar(np.ascontiguousarray(sc[2 * half:]), t0, d)) % O.R_MOD
+    assert dec(A.best_multiexp_g2(sc, bases)) == O.g2_scalar_mul(want, O.G2_GEN)

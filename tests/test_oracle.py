@@ -191,6 +191,29 @@ def test_g2_oracle_public_facts():
     assert enc == [int(x) for x in srs.g2_encode(srs.G2_GENERATOR)]
 
 
+def test_the_twist_has_the_same_endomorphism_with_beta_squared():
+    """csrc/msm_g2.hip (round 5) reuses the G1 path's GLV split: on the twist y^2 = x^3 + 3 / (9 + u) the map (x, y) -> (beta' x, y) multiplies
+    points of the order-r subgroup by the SAME lambda as on G1 exactly when beta' = beta^2 (beta: the constant of msm.hip's GLV).  Checked on
+    the EIP-197 generator and on a second point; the kernel source carries beta^2 in Montgomery words."""
+    import os
+    import re
+
+    r, q = O.R_MOD, O.Q_MOD
+    lam = 0xb3c4d79d41a917585bfc41088d8daaa78b17ea66b99c90dd
+    beta = 0x59e26bcea0d48bacd4f263f1acdb5c4f5763473177fffffe
+    beta2 = beta * beta % q
+    assert pow(beta2, 3, q) == 1 and beta2 != 1
+    phi = lambda P, b: ((P[0][0] * b % q, P[0][1] * b % q), P[1])
+    for P in (O.G2_GEN, O.g2_scalar_mul(0xC0FFEE, O.G2_GEN)):
+        assert O.g2_on_curve(phi(P, beta2))
+        assert O.g2_scalar_mul(lam, P) == phi(P, beta2)
+        assert O.g2_scalar_mul(lam, P) != phi(P, beta)               # beta itself acts as lambda^2 there
+        assert O.g2_scalar_mul(lam * lam % r, P) == phi(P, beta)
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "zksnap_circuits_halo2_amd", "csrc", "msm_g2.hip")).read()
+    m = re.search(r"constexpr uint32_t BETA2_EXT\[8\] = \{([^}]*)\}", src)
+    assert [int(x.strip().rstrip("u"), 16) for x in m.group(1).split(",")] == [(beta2 * (1 << 256) % q >> (32 * i)) & 0xffffffff for i in range(8)]
+
+
 def test_glv_parameters_of_the_general_path_msm():
     """csrc/msm.hip splits the scalars of the general-path MSM with the curve's endomorphism phi(x, y) = (beta x, y) = lambda (x, y).  The constants
     in the kernel source are re-derived here: lambda / beta are matching cube roots of unity (checked on the generator), the lattice basis comes out

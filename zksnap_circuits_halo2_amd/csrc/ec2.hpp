@@ -57,6 +57,54 @@ ZK_HD bool f2_is_zero(const fe2& a) {
   return fe_mulout_is_zero<Fq>(fe_mul<Fq>(one, a.c0)) && fe_mulout_is_zero<Fq>(fe_mul<Fq>(one, a.c1));
 }
 
+// ---- lazy Fq2 arithmetic for the bucket accumulation (round 5) -------------------------------------------------------------------------
+// The standard-form layer above ends every Fq2 operation with a ~77-instruction reduction per component (a Karatsuba product spends 385
+// instructions on five of them -- more than one of its three multiplications), which put the G2 mixed addition at ~10.8 k instructions,
+// 5 x G1's, where the multiplication count says 2.8 x.  Here a product is two FUSED pairs, each under ONE Montgomery reduction
+// (fe_mul_add, fp29.hpp): c0 = a0 b0 + a1 (K p - b1), c1 = a0 b1 + a1 b0 -- 486 multiply-adds like Karatsuba's three products, but no
+// pre-additions, no post-subtractions and no reductions in between -- and additions / subtractions stay lazy with the bounds written at
+// every call site, as in ec.hpp.  `red` = K p in borrow-proof form with b.c1 < (K - 1) p, N form.
+// fe_mul_add's column bound: 9 (2^29 * 2^29 + 2^29 * 2^30.1) + 9 * 2^58 < 2^63.3.
+template <bool CHAIN>
+ZK_HD fe2 f2_mul_lazy(const fe2& a, const fe2& b, const uint32_t (&red)[NL]) {
+  fe2 r;
+  r.c0 = fe_mul_add<Fq, CHAIN>(a.c0, b.c0, a.c1, fe_neg_red(b.c1, red));
+  r.c1 = fe_mul_add<Fq, CHAIN>(a.c0, b.c1, a.c1, b.c0);
+  return r;
+}
+// (a0 + a1)(a0 - a1 + K p) + 2 a0 a1 u; `red` = K p with a.c1 < (K - 1) p.  Operands N form; the sum and the doubled factor have limbs < 2^30.
+template <bool CHAIN>
+ZK_HD fe2 f2_sqr_lazy(const fe2& a, const uint32_t (&red)[NL]) {
+  const fe d = fe_norm(fe_sub_red(a.c0, a.c1, red));
+  fe2 r;
+  r.c0 = fe_mul<Fq, CHAIN>(fe_add(a.c0, a.c1), d);
+  r.c1 = fe_mul<Fq, CHAIN>(fe_dbl(a.c0), a.c1);
+  return r;
+}
+
+// limb i of 2p in N form (limbs 0..7 < 2^29, limb 8 the rest)
+template <class P> ZK_HD constexpr uint32_t two_p_limb(int i) {
+  uint32_t carry = 0, out = 0;
+  for (int j = 0; j <= i; j++) {
+    const uint32_t t = 2u * P::P[j] + carry;
+    out = j < NL - 1 ? (t & LMASK) : t;
+    carry = j < NL - 1 ? (t >> LB) : 0;
+  }
+  return out;
+}
+// N-form value below 3p: is it 0 mod p?  (0, p or 2p: the N form of an integer is unique)
+template <class P>
+ZK_HD bool fe_is_zero_lt3p(const fe& a) {
+  uint32_t o = 0, e = 0, e2 = 0;
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    o |= a.l[i];
+    e |= a.l[i] ^ P::P[i];
+    e2 |= a.l[i] ^ two_p_limb<P>(i);
+  }
+  return (o == 0) | (e == 0) | (e2 == 0);
+}
+
 // ---- points ------------------------------------------------------------------------------------------------------------
 struct xyzz2 {
   fe2 X, Y, ZZ, ZZZ;        // x = X / ZZ, y = Y / ZZZ; identity <=> ZZ has all limbs zero
@@ -121,6 +169,91 @@ ZK_HD void xyzz2_madd(xyzz2& acc, const fe2& x2, const fe2& y2) {
   acc.X = X3;
   acc.ZZ = f2_mul(acc.ZZ, PP);
   acc.ZZZ = f2_mul(acc.ZZZ, PPP);
+}
+
+// acc += +-(x2, y2), the mixed addition of the bucket accumulation with lazy Fq2 arithmetic.  x2, y2: the lazily unpacked external
+// coordinates (N-limbed, value < 32p: fe_from_ext_lazy), negated when `neg`; the point is not the identity.
+// Accumulator invariant (all components N form): X < 2p + 2^233, Y < 5p, ZZ < 2p, ZZZ < 2p; identity <=> ZZ all-zero limbs.
+// 8 lazy products + 2 lazy squares = 20 reductions (standard form: 28 multiplications + ~45 reductions), ~6.3 k instructions.
+template <bool CHAIN>
+ZK_HD void xyzz2_madd_lazy(xyzz2& acc, const fe2& x2, const fe2& y2, bool neg) {
+  if (xyzz2_is_identity(acc)) {
+    acc.X = {fe_reduce_soft<Fq>(x2.c0), fe_reduce_soft<Fq>(x2.c1)};                     // < 2p + 2^233
+    acc.Y = neg ? fe2{fe_reduce_soft<Fq>(fe_norm(fe_neg_red(y2.c0, Fq::P64_S1))), fe_reduce_soft<Fq>(fe_norm(fe_neg_red(y2.c1, Fq::P64_S1)))}
+                : fe2{fe_reduce_soft<Fq>(y2.c0), fe_reduce_soft<Fq>(y2.c1)};
+    acc.ZZ = f2_one(); acc.ZZZ = f2_one();
+    return;
+  }
+  fe2 U2 = f2_mul_lazy<CHAIN>(acc.ZZ, x2, Fq::P64_S1);      // c0 < (2*32 + 2*64)/169.3 + 1 = 2.14p, c1 < (2*32*2)/169.3 + 1 = 1.76p
+  fe2 S2 = f2_mul_lazy<CHAIN>(acc.ZZZ, y2, Fq::P64_S1);     // same
+  if (neg) S2 = {fe_neg_red(S2.c0, Fq::P4_S1), fe_neg_red(S2.c1, Fq::P4_S1)};          // 4p - S2: < 4p, limbs < 2^30.1
+  const fe2 P = {fe_norm(fe_sub_red(U2.c0, acc.X.c0, Fq::P4_S1)), fe_norm(fe_sub_red(U2.c1, acc.X.c1, Fq::P4_S1))};   // X < 3p; P < 6.14p
+  const fe2 R = {fe_norm(fe_sub_red(S2.c0, acc.Y.c0, Fq::P6_S1)), fe_norm(fe_sub_red(S2.c1, acc.Y.c1, Fq::P6_S1))};   // Y < 5p; R < 10p
+  const fe2 PP = f2_sqr_lazy<CHAIN>(P, Fq::P8_S1);          // c0 < 12.28 * 14.14 / 169.3 + 1 = 2.03p, c1 < 2 * 6.14^2 / 169.3 + 1 = 1.45p
+  if (fe_is_zero_lt3p<Fq>(PP.c0) && fe_mulout_is_zero<Fq>(PP.c1)) {                    // P^2 = 0 <=> P = 0: same x (rare)
+    const fe2 RR0 = f2_sqr_lazy<false>(R, Fq::P12_S1);      // < 3.6p, 2.2p
+    if (fe_is_zero_lt3p<Fq>(fe_reduce_soft<Fq>(RR0.c0)) && fe_is_zero_lt3p<Fq>(RR0.c1)) {
+      xyzz2 t;                                               // the same point: 2 (x2, +-y2) through the standard-form doubling
+      const fe one = fe_one<Fq>();
+      t.X = {fe_mul<Fq>(one, x2.c0), fe_mul<Fq>(one, x2.c1)};
+      t.Y = {fe_mul<Fq>(one, y2.c0), fe_mul<Fq>(one, y2.c1)};
+      if (neg) t.Y = f2_neg(t.Y);
+      t.ZZ = f2_one(); t.ZZZ = f2_one();
+      acc = xyzz2_dbl(t);
+    } else {
+      acc = xyzz2_identity();
+    }
+    return;
+  }
+  const fe2 PPP = f2_mul_lazy<CHAIN>(P, PP, Fq::P4_S1);     // < (6.14*2.03 + 6.14*4)/169.3 + 1 = 1.22p
+  const fe2 Q = f2_mul_lazy<CHAIN>(acc.X, PP, Fq::P4_S1);   // < (2.01*2.03 + 2.01*4)/169.3 + 1 = 1.08p
+  const fe2 RR = f2_sqr_lazy<CHAIN>(R, Fq::P12_S1);         // c0 < 20 * 22 / 169.3 + 1 = 3.6p, c1 < 2.2p
+  // X3 = RR - PPP - 2Q: subtrahend < 1.22 + 2.16 = 3.4p with limbs < 3 * 2^29 -> 7p in S3 form; < 10.6p -> reduced to < 2p + 2^233 (X feeds the
+  // next addition's P = U2 - X1, whose square's first factor pair grows with 4 x the bound: without this reduction the bounds do not close)
+  const fe2 X3 = {fe_reduce_soft<Fq>(fe_norm(fe_sub_red(RR.c0, fe_add(PPP.c0, fe_dbl(Q.c0)), Fq::P7_S3))),
+                  fe_reduce_soft<Fq>(fe_norm(fe_sub_red(RR.c1, fe_add(PPP.c1, fe_dbl(Q.c1)), Fq::P7_S3)))};
+  const fe2 T = {fe_norm(fe_sub_red(Q.c0, X3.c0, Fq::P4_S1)), fe_norm(fe_sub_red(Q.c1, X3.c1, Fq::P4_S1))};           // < 1.08 + 4 = 5.08p, N form
+  const fe2 A = f2_mul_lazy<CHAIN>(R, T, Fq::P8_S1);        // < (10*5.08 + 10*8)/169.3 + 1 = 1.78p
+  const fe2 B = f2_mul_lazy<CHAIN>(acc.Y, PPP, Fq::P4_S1);  // < (5*1.22 + 5*4)/169.3 + 1 = 1.16p
+  acc.Y = {fe_norm(fe_sub_red(A.c0, B.c0, Fq::P3_S1)), fe_norm(fe_sub_red(A.c1, B.c1, Fq::P3_S1))};                   // < 1.78 + 3 = 4.78p
+  acc.X = X3;
+  acc.ZZ = f2_mul_lazy<CHAIN>(acc.ZZ, PP, Fq::P4_S1);       // < (2*2.03 + 2*4)/169.3 + 1 = 1.08p
+  acc.ZZZ = f2_mul_lazy<CHAIN>(acc.ZZZ, PPP, Fq::P4_S1);    // < 1.07p
+}
+
+// A + B (add-2008-s) with lazy Fq2 arithmetic: inputs and result in standard form (every component N form below 2p + 2^233), the
+// doubling / opposite-point cases through the standard-form code.  12 lazy products + 2 lazy squares + 4 soft reductions, ~8.7 k
+// instructions against ~15 k for xyzz2_add.
+template <bool CHAIN>
+ZK_HD xyzz2 xyzz2_add_lazy(const xyzz2& A, const xyzz2& B) {
+  if (xyzz2_is_identity(A)) return B;
+  if (xyzz2_is_identity(B)) return A;
+  const fe2 U1 = f2_mul_lazy<CHAIN>(A.X, B.ZZ, Fq::P4_S1), U2 = f2_mul_lazy<CHAIN>(B.X, A.ZZ, Fq::P4_S1);      // < (2.01^2 + 2.01*4)/169.3 + 1 = 1.08p
+  const fe2 S1 = f2_mul_lazy<CHAIN>(A.Y, B.ZZZ, Fq::P4_S1), S2 = f2_mul_lazy<CHAIN>(B.Y, A.ZZZ, Fq::P4_S1);
+  const fe2 P = {fe_norm(fe_sub_red(U2.c0, U1.c0, Fq::P3_S1)), fe_norm(fe_sub_red(U2.c1, U1.c1, Fq::P3_S1))};  // < 4.08p
+  const fe2 R = {fe_norm(fe_sub_red(S2.c0, S1.c0, Fq::P3_S1)), fe_norm(fe_sub_red(S2.c1, S1.c1, Fq::P3_S1))};
+  const fe2 PP = f2_sqr_lazy<CHAIN>(P, Fq::P6_S1);          // c0 < 8.16 * 10.08 / 169.3 + 1 = 1.49p, c1 < 1.2p
+  if (fe_mulout_is_zero<Fq>(PP.c0) && fe_mulout_is_zero<Fq>(PP.c1)) return xyzz2_add(A, B);       // same x (rare): doubling or the identity
+  const fe2 PPP = f2_mul_lazy<CHAIN>(P, PP, Fq::P4_S1);     // < (4.08*1.49 + 4.08*4)/169.3 + 1 = 1.14p
+  const fe2 Q = f2_mul_lazy<CHAIN>(U1, PP, Fq::P4_S1);      // < 1.04p
+  const fe2 RR = f2_sqr_lazy<CHAIN>(R, Fq::P6_S1);          // < 1.49p
+  xyzz2 r;
+  r.X = {fe_reduce_soft<Fq>(fe_norm(fe_sub_red(RR.c0, fe_add(PPP.c0, fe_dbl(Q.c0)), Fq::P7_S3))),                // subtrahend < 3.3p, limbs < 3 * 2^29; < 8.5p -> standard form
+         fe_reduce_soft<Fq>(fe_norm(fe_sub_red(RR.c1, fe_add(PPP.c1, fe_dbl(Q.c1)), Fq::P7_S3)))};
+  const fe2 T = {fe_norm(fe_sub_red(Q.c0, r.X.c0, Fq::P4_S1)), fe_norm(fe_sub_red(Q.c1, r.X.c1, Fq::P4_S1))};    // < 5.04p, N form
+  const fe2 Am = f2_mul_lazy<CHAIN>(R, T, Fq::P8_S1);       // < (4.08*5.04 + 4.08*8)/169.3 + 1 = 1.32p
+  const fe2 Bm = f2_mul_lazy<CHAIN>(S1, PPP, Fq::P4_S1);    // < 1.04p
+  r.Y = {fe_reduce_soft<Fq>(fe_norm(fe_sub_red(Am.c0, Bm.c0, Fq::P3_S1))), fe_reduce_soft<Fq>(fe_norm(fe_sub_red(Am.c1, Bm.c1, Fq::P3_S1)))};   // < 4.32p -> standard form
+  r.ZZ = f2_mul_lazy<CHAIN>(f2_mul_lazy<CHAIN>(A.ZZ, B.ZZ, Fq::P4_S1), PP, Fq::P4_S1);
+  r.ZZZ = f2_mul_lazy<CHAIN>(f2_mul_lazy<CHAIN>(A.ZZZ, B.ZZZ, Fq::P4_S1), PPP, Fq::P4_S1);
+  return r;
+}
+
+// accumulator of xyzz2_madd_lazy -> standard form (every component N form below 2p + 2^233), what the other kernels' formulas expect
+ZK_HD xyzz2 xyzz2_to_std(const xyzz2& a) {
+  xyzz2 r = a;
+  r.Y = {fe_reduce_soft<Fq>(a.Y.c0), fe_reduce_soft<Fq>(a.Y.c1)};
+  return r;
 }
 
 #if defined(__HIPCC__)

@@ -1521,7 +1521,7 @@ struct msm_layout {
 // Task length.  With >= 2^17 tasks of 64 entries the chip is full and 64 is best (throughput-bound, see TASK_SHIFT).  Below
 // that the MSM is latency-bound: a task of L entries is L sequential mixed adds (~5 us each at low occupancy) and a bucket
 // of s entries leaves s/L partials to sum (~10 us each): pick L = 2^shift minimising 5 L + 10 (s/L - 1).
-static uint32_t msm_task_shift(size_t entries /* W n K */, size_t NB) {
+static uint32_t msm_task_shift(size_t entries /* W n K */, size_t NB, size_t xyzz_bytes = 144) {
   uint32_t task_shift = TASK_SHIFT;
   // 128-entry tasks halve the partials the combine step has to add, and pay once the launch is many rounds of waves deep even
   // so: measured (6 / 7) 2^24 21.40 / 21.00 ms (combine 0.71 -> 0.27), but 2^22 6.00 / 6.07 and 2^20 1.72 / 1.85 (too few tasks).
@@ -1529,12 +1529,15 @@ static uint32_t msm_task_shift(size_t entries /* W n K */, size_t NB) {
   static const int knob = [] { const char* e = getenv("ZKHIP_TASK_SHIFT"); return e ? atoi(e) : 0; }();
   if (knob >= 2 && knob <= 7) task_shift = (uint32_t)knob;
   else if ((entries >> 7) >= ((size_t)3 << 16)) task_shift = 7;      // (with the balanced windows: 2^21 2.397 / 2.380 ms, 2^22 4.812 / 4.815 -- from 2^21 points on)
-  if ((entries >> TASK_SHIFT) < ((size_t)1 << 17)) {
+  // G2 (xyzz_bytes 288): a general addition costs ~1.4 mixed ones in instructions but runs in the combine step's thinly occupied lanes, and the
+  // accumulation holds 2 waves per SIMD: the chip is full from 2^16 tasks, and a partial is priced at 3 mixed additions
+  const bool g2 = xyzz_bytes == 288;
+  if ((entries >> TASK_SHIFT) < ((size_t)1 << (g2 ? 14 : 17))) {
     const double occ = (double)entries / (double)NB;
     double best = 1e300;
     for (uint32_t sh = 2; sh <= (uint32_t)TASK_SHIFT; sh++) {
       const double L = (double)(1u << sh), parts = occ / L;
-      const double est = 5.0 * L + 10.0 * (parts > 1.0 ? parts - 1.0 : 0.0);
+      const double est = 5.0 * L + (g2 ? 15.0 : 10.0) * (parts > 1.0 ? parts - 1.0 : 0.0);
       if (est < best) { best = est; task_shift = sh; }
     }
   }
@@ -1562,7 +1565,7 @@ static msm_layout msm_lay_out(char* base, size_t n_in, size_t K, int c, bool pre
   const bool wide = msm_two_level(c, glv, n_in, prepared, K);
   const size_t nk = n * K, entries = W * nk;
   const size_t n_pad = (n + 7) & ~(size_t)7;
-  L.task_shift = msm_task_shift(entries, NB);
+  L.task_shift = msm_task_shift(entries, NB, xyzz_bytes);
   L.max_tasks = (entries >> L.task_shift) + NB + 1;        // every bucket adds at most one task that is not full
   // expected partials per bucket decide how many lanes sum a bucket in the combine step; a bucket with more than 16 partials per lane
   // is handled by a workgroup of its own, so a skewed bucket (a selector column, a short top window) never becomes a long chain
@@ -1595,13 +1598,15 @@ static msm_layout msm_lay_out(char* base, size_t n_in, size_t K, int c, bool pre
   L.pyrA = (uint32_t*)carve(WB * B * xyzz_bytes);          // pyramid ping-pong: per bucket set N + (s-1) N/2 <= B elements at every step
   L.pyrB = (uint32_t*)carve(WB * B * xyzz_bytes);
   L.winsum = (uint32_t*)carve((W + K) * xyzz_bytes);       // window / bucket-set sums
-  L.endo = glv ? (uint32_t*)carve(n_in * 64) : nullptr;
+  L.endo = glv ? (uint32_t*)carve(n_in * (xyzz_bytes == 288 ? 128 : 64)) : nullptr;     // phi(bases): G1Affine 64 B, G2Affine 128 B
   L.total = (size_t)(p - base);
   return L;
 }
 
-// GLV applies to the G1 general path: arbitrary bases, one scalar vector (the prepared path has its doublings in the table already)
-static inline bool msm_uses_glv(bool prepared, size_t batch, size_t xyzz_bytes) { return !prepared && batch == 1 && xyzz_bytes == 144 && msm_glv_enabled(); }
+// GLV applies to the general path of both curves (xyzz_bytes 144 = G1, 288 = G2; round 5: the twist has the same endomorphism with beta^2):
+// arbitrary bases, one scalar vector (the prepared path has its doublings in the table already)
+bool msm_uses_glv(bool prepared, size_t batch, size_t xyzz_bytes) { return !prepared && batch == 1 && (xyzz_bytes == 144 || xyzz_bytes == 288) && msm_glv_enabled(); }
+int msm_glv_windows(int c) { return msm_windows(c, true); }
 
 // Direct tables (below: "Direct tables") serve single MSMs over prepared sets of at most 2^ZKHIP_DIRECT_MAX_LOG points (default 15; 0 = never; at most 18)
 int msm_direct_max_log() {

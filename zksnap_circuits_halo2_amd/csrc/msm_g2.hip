@@ -7,6 +7,12 @@
 // per-bucket combination of the task partials, the log-depth bucket pyramid (same index algebra as k_pyramid_step in msm.hip), the
 // per-window weighted sum and the window fold.  One bucket set per window (no prepared tables: there is no fixed-base caller).
 // Work points are 288 bytes (8 x 9 limbs).
+//
+// Round 5: the general-path machinery of G1 applies unchanged, because it depends on the scalars only -- GLV digits (the twist E': y^2 = x^3 + 3 / (9 + u)
+// has j-invariant 0 as well: phi(x, y) = (beta' x, y) is an endomorphism, and on the order-r subgroup phi = lambda for the SAME lambda as on G1 when
+// beta' = beta^2, beta the constant of msm.hip glv::BETA_EXT -- checked against the big-integer oracle in tests/test_oracle.py), hence 2 n points,
+// ceil(128 / c) windows of c = 16 bits at every size from 2^12 up, the two-level LDS sort from 2^18 points, and a window fold of 128 - c dependent
+// doublings instead of 256 - c (240 quad doublings at ~8 us were 1.9 ms of a 5.8 ms MSM at 2^16).
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include "ec2.hpp"
@@ -21,22 +27,65 @@ struct task_t {
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s failed: %s", #x, hipGetErrorString(e_)); return ZKHIP_EHIP; } } while (0)
 
+// beta^2 (Montgomery-256 words): the cube root of unity in Fq with (beta^2 x, y) = lambda (x, y) on G2 for the lambda of msm.hip's GLV split
+__device__ constexpr uint32_t BETA2_EXT[8] = {0x13e80b9cu, 0x3350c88eu, 0xdb5e56b9u, 0x7dce557cu, 0xb615564au, 0x6001b4b8u, 0x020217e0u, 0x2682e617u};
+
+// endo[i] = phi(bases[i]) = (beta^2 x.c0, beta^2 x.c1, y) in the G2Affine memory format; the identity (all zero) stays the identity
+__global__ void __launch_bounds__(256) k2_endo_bases(const uint32_t* __restrict__ bases, uint32_t n, uint32_t* __restrict__ endo) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const affine2_words pt = load_affine2(bases, i);
+  const fe beta = fq_from_ext(BETA2_EXT);
+  uint32_t out[32];
+  fq_to_ext(fe_mul<Fq>(beta, fq_from_ext(pt.w)), out);
+  fq_to_ext(fe_mul<Fq>(beta, fq_from_ext(pt.w + 8)), out + 8);
+#pragma unroll
+  for (int k = 16; k < 32; k++) out[k] = pt.w[k];
+  uint4* o = reinterpret_cast<uint4*>(endo + (size_t)i * 32);
+#pragma unroll
+  for (int k = 0; k < 8; k++) o[k] = make_uint4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
+}
+
+// point references >= split (GLV digits) are the endomorphism images, a second array (bases2[ref - split]).
+// Round 5: lazy Fq2 arithmetic (ec2.hpp xyzz2_madd_lazy: fused product pairs, bound-tracked additions) with single-chain product columns, the
+// coordinates unpacked lazily (no multiplication on load) and the next point gathered under the current addition.
 __global__ void __launch_bounds__(64) k2_accumulate(const uint32_t* __restrict__ ntasks_p, const uint4* __restrict__ order, const uint32_t* __restrict__ sorted,
-                                                    const uint32_t* __restrict__ bases, uint32_t* __restrict__ partials, uint32_t* __restrict__ buckets) {
+                                                    const uint32_t* __restrict__ bases, uint32_t* __restrict__ partials, uint32_t* __restrict__ buckets,
+                                                    const uint32_t* __restrict__ bases2, uint32_t split) {
+  auto point = [&](uint32_t ref) -> affine2_words {
+    const uint32_t idx = ref & 0x7fffffffu;
+    return idx >= split ? load_affine2(bases2, idx - split) : load_affine2(bases, idx);
+  };
   const uint32_t ntasks = *ntasks_p;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ntasks; i += gridDim.x * blockDim.x) {
     const uint4 rec = order[i];
     const uint32_t t = rec.x, start = rec.y, len = rec.z;
     xyzz2 acc = xyzz2_identity();
+    uint32_t ref = rec.w;                                        // the task's first reference rides in the order record
+    affine2_words pt = point(ref);
 #pragma unroll 1
     for (uint32_t j = 0; j < len; j++) {
-      const uint32_t ref = sorted[start + j];
-      const affine2_words pt = load_affine2(bases, ref & 0x7fffffffu);
-      if (affine2_is_identity(pt)) continue;
+      const affine2_words cur = pt;
+      const uint32_t cref = ref;
+      if (j + 1 < len) { ref = sorted[start + j + 1]; pt = point(ref); }
+      if (affine2_is_identity(cur)) continue;
+      uint32_t w[8];
       fe2 x, y;
-      affine2_coords(pt, (ref >> 31) != 0, x, y);
-      xyzz2_madd(acc, x, y);
+#pragma unroll
+      for (int k = 0; k < 8; k++) w[k] = cur.w[k];
+      x.c0 = fe_from_ext_lazy(w);
+#pragma unroll
+      for (int k = 0; k < 8; k++) w[k] = cur.w[8 + k];
+      x.c1 = fe_from_ext_lazy(w);
+#pragma unroll
+      for (int k = 0; k < 8; k++) w[k] = cur.w[16 + k];
+      y.c0 = fe_from_ext_lazy(w);
+#pragma unroll
+      for (int k = 0; k < 8; k++) w[k] = cur.w[24 + k];
+      y.c1 = fe_from_ext_lazy(w);
+      xyzz2_madd_lazy<true>(acc, x, y, (cref >> 31) != 0);
     }
+    acc = xyzz2_to_std(acc);
     if (t >> 31) store_xyzz2(buckets, t & 0x7fffffffu, acc);      // the bucket's only task writes the bucket itself
     else store_xyzz2(partials, t, acc);
   }
@@ -53,15 +102,17 @@ __device__ __forceinline__ xyzz2 xyzz2_shfl_xor(const xyzz2& a, int mask) {
   return r;
 }
 
-// 8 adjacent lanes per bucket: lane q sums the task partials q, q + 8, ..., three xor-shuffle steps add the lane sums (a bucket with a
-// single task was written by k2_accumulate).  A short top window puts thousands of entries into a handful of buckets: with one thread
-// per bucket their partials were a chain of 256 dependent additions (5 ms of a 19 ms MSM at 2^16).  (Quads instead of lanes were
-// measured slower here: 2^19 buckets x 32 lanes is throughput, not latency.)
+// LANES adjacent lanes per bucket (1, 2, 4 or 8: msm_lay_out picks it from the expected partials per bucket, as for G1): lane q sums the task
+// partials q, q + LANES, ..., log2(LANES) xor-shuffle steps add the lane sums (a bucket with a single task was written by k2_accumulate).
+// A short top window puts thousands of entries into a handful of buckets: with one thread per bucket their partials were a chain of 256
+// dependent additions (5 ms of a 19 ms MSM at 2^16).  Round 5: the lane count follows the layout (always 8 before: a bucket of two partials
+// then paid one addition and three shuffle-tree additions on eight lanes -- 2.9 ms of a 6.2 ms MSM at 2^18) and the additions are the lazy ones.
+template <int LANES>
 __global__ void __launch_bounds__(64) k2_combine(const uint32_t* __restrict__ task_off, uint32_t nbuckets, const uint32_t* __restrict__ partials,
                                                  uint32_t* __restrict__ buckets, uint32_t seq_parts) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t k = gid >> 3, q = gid & 7;
-  const bool live = k < nbuckets;                 // whole groups of 8 lanes are live or dead together
+  const uint32_t k = gid / LANES, q = gid % LANES;
+  const bool live = k < nbuckets;                 // whole groups of LANES lanes are live or dead together
   xyzz2 acc = xyzz2_identity();
   uint32_t m = 0;
   if (live) {
@@ -70,11 +121,11 @@ __global__ void __launch_bounds__(64) k2_combine(const uint32_t* __restrict__ ta
     if (m > seq_parts) m = 1;                     // a heavy bucket: k2_combine_heavy's (treated here like the single-task case: nothing to do)
     if (m != 1) {
 #pragma unroll 1
-      for (uint32_t j = q; j < m; j += 8) acc = xyzz2_add(acc, load_xyzz2(partials, t + j));
+      for (uint32_t j = q; j < m; j += LANES) acc = xyzz2_add_lazy<false>(acc, load_xyzz2(partials, t + j));
     }
   }
 #pragma unroll 1
-  for (int mask = 1; mask < 8; mask <<= 1) acc = xyzz2_add(acc, xyzz2_shfl_xor(acc, mask));
+  for (int mask = 1; mask < LANES; mask <<= 1) acc = xyzz2_add_lazy<false>(acc, xyzz2_shfl_xor(acc, mask));
   if (live && q == 0 && m != 1) store_xyzz2(buckets, k, acc);
 }
 
@@ -91,13 +142,13 @@ __global__ void __launch_bounds__(64) k2_combine_heavy(const uint32_t* __restric
     const uint32_t k = e.x, t = task_off[k], m = task_off[k + 1] - t;
     xyzz2 acc = xyzz2_identity();
 #pragma unroll 1
-    for (uint32_t j = threadIdx.x; j < m; j += 64) acc = xyzz2_add(acc, load_xyzz2(partials, t + j));
+    for (uint32_t j = threadIdx.x; j < m; j += 64) acc = xyzz2_add_lazy<false>(acc, load_xyzz2(partials, t + j));
 #pragma unroll 1
     for (uint32_t half = 32; half >= 1; half >>= 1) {
       __syncthreads();
       if (threadIdx.x >= half && threadIdx.x < 2 * half) store_xyzz2(xch, threadIdx.x - half, acc);
       __syncthreads();
-      if (threadIdx.x < half) acc = xyzz2_add(acc, load_xyzz2(xch, threadIdx.x));
+      if (threadIdx.x < half) acc = xyzz2_add_lazy<false>(acc, load_xyzz2(xch, threadIdx.x));
     }
     if (threadIdx.x == 0) store_xyzz2(buckets, k, acc);
   }
@@ -120,7 +171,7 @@ __global__ void __launch_bounds__(64) k2_pyramid_step(const uint32_t* __restrict
     if ((int)l == s - 1) { ia = 4 * u + 1; ib = 4 * u + 3; }
     else { ia = N + l * (N / 2) + 2 * u; ib = ia + 1; }
   }
-  store_xyzz2(wo, tid, xyzz2_add(load_xyzz2(wi, ia), load_xyzz2(wi, ib)));
+  store_xyzz2(wo, tid, xyzz2_add_lazy<false>(load_xyzz2(wi, ia), load_xyzz2(wi, ib)));
 }
 
 // the same step with one quad per addition, for steps far smaller than the chip (their time is the latency of one addition)
@@ -224,20 +275,22 @@ __global__ void __launch_bounds__(64) k2_test_op(int op, const uint32_t* __restr
   store_jacobian2(acc, out + i * 48);
 }
 
-static int pick_window_g2(size_t n) {
-  // additions cost ~3.5x the G1 ones, the tail is single-lane: the model of msm_pick_window with a heavier bucket term
+static int pick_window_g2(size_t n, bool glv) {
+  // the model of msm_pick_window (W windows x (n' mixed additions + 2 general additions per bucket)) with G2's costs in G1 multiplications:
+  // a mixed addition 8 M2 + 2 S2 ~ 28 + the Fq2 additions ~ 34, a general one ~ 48; plus the fold's c (W - 1) dependent quad doublings at
+  // ~8 us each, i.e. ~1.3 M multiplication slots of the accumulation kernel per doubling (what makes small windows lose at small n)
   int best = 2;
   double best_cost = 1e300;
   for (int c = 2; c <= 16; c++) {
-    const int W = (256 + c - 1) / c, top_bits = 254 - (W - 1) * c;
+    const int W = glv ? msm_glv_windows(c) : (256 + c - 1) / c, top_bits = (glv ? 127 : 254) - (W - 1) * c;
     if (top_bits > 0 && top_bits < 6) continue;
-    const double cost = (double)W * ((double)n + 6.0 * (double)(1u << (c - 1)));
+    const double cost = (double)W * (34.0 * (double)(glv ? 2 * n : n) + 96.0 * (double)(1u << (c - 1))) + 1.3e6 * (double)c * (double)(W - 1) / 16.0;
     if (cost < best_cost) { best_cost = cost; best = c; }
   }
   return best;
 }
 
-size_t msm_g2_workspace_bytes(size_t n) { return n ? msm_workspace_bytes(n, pick_window_g2(n), false, 1, 288) : 0; }
+size_t msm_g2_workspace_bytes(size_t n) { return n ? msm_workspace_bytes(n, pick_window_g2(n, msm_uses_glv(false, 1, 288)), false, 1, 288) : 0; }
 
 // d_scalars: n x 8 words (Fr, Montgomery), d_bases: n x 32 words (G2Affine), d_out: 48 words (G2 Jacobian)
 int msm_g2_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, uint32_t* d_out, void* ws, size_t ws_bytes, hipStream_t stream) {
@@ -247,17 +300,26 @@ int msm_g2_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
     return ZKHIP_OK;
   }
   if (n >= (1ull << 31)) { set_error("msm_g2: n = %zu too large", n); return ZKHIP_EINVAL; }
-  const int c = pick_window_g2(n);
+  const bool glv = msm_uses_glv(false, 1, 288);
+  const int c = pick_window_g2(n, glv);
   msm_tasks_view tv;
-  int rc = msm_build_tasks(d_scalars, n, 1, n, c, false, 0u, 0u, 288, ws, ws_bytes, stream, &tv);
+  int rc = msm_build_tasks(d_scalars, n, 1, n, c, false, 0u, 0u, 288, ws, ws_bytes, stream, &tv, glv);
   if (rc != ZKHIP_OK) return rc;
+  if (glv) hipLaunchKernelGGL(k2_endo_bases, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_bases, (uint32_t)n, tv.endo);
   {
     uint32_t blocks = (uint32_t)((tv.max_tasks + 63) / 64);
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(k2_accumulate, dim3(blocks), dim3(64), 0, stream, tv.ntasks, tv.order, tv.sorted, d_bases, tv.partials, tv.pyrA);
+    hipLaunchKernelGGL(k2_accumulate, dim3(blocks), dim3(64), 0, stream, tv.ntasks, tv.order, tv.sorted, d_bases, tv.partials, tv.pyrA, (const uint32_t*)tv.endo,
+                       glv ? (uint32_t)n : 0xffffffffu);
   }
   prof_mark(stream, "accumulate_g2");
-  hipLaunchKernelGGL(k2_combine, dim3((unsigned)(((size_t)tv.NB * 8 + 63) / 64)), dim3(64), 0, stream, tv.task_off, tv.NB, tv.partials, tv.pyrA, tv.seq_parts);
+  {
+    const unsigned cblocks = (unsigned)(((size_t)tv.NB * (size_t)tv.combine_lanes + 63) / 64);
+    if (tv.combine_lanes == 1) hipLaunchKernelGGL(k2_combine<1>, dim3(cblocks), dim3(64), 0, stream, tv.task_off, tv.NB, tv.partials, tv.pyrA, tv.seq_parts);
+    else if (tv.combine_lanes == 2) hipLaunchKernelGGL(k2_combine<2>, dim3(cblocks), dim3(64), 0, stream, tv.task_off, tv.NB, tv.partials, tv.pyrA, tv.seq_parts);
+    else if (tv.combine_lanes == 4) hipLaunchKernelGGL(k2_combine<4>, dim3(cblocks), dim3(64), 0, stream, tv.task_off, tv.NB, tv.partials, tv.pyrA, tv.seq_parts);
+    else hipLaunchKernelGGL(k2_combine<8>, dim3(cblocks), dim3(64), 0, stream, tv.task_off, tv.NB, tv.partials, tv.pyrA, tv.seq_parts);
+  }
   hipLaunchKernelGGL(k2_combine_heavy, dim3(256), dim3(64), 0, stream, tv.task_off, tv.partials, tv.pyrA, tv.heavy_count, (const uint2*)tv.heavy, tv.heavy_cap);
   prof_mark(stream, "combine_g2");
   uint32_t* cur = tv.pyrA;

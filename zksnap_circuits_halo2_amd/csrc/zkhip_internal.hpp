@@ -42,8 +42,10 @@ struct msm_tasks_view {
   uint32_t* heavy_done;
   uint32_t* endo;                  // G1 general path with GLV digits: room for the endomorphism images of the n bases
 };
-// glv (G1 general path only): the scalars are split with the curve's endomorphism (msm.hip k_digits_glv): the sort sees 2 n points and
+// glv (general path of either curve): the scalars are split with the curve's endomorphism (msm.hip k_digits_glv): the sort sees 2 n points and
 // ceil(128 / c) windows, point references >= n mean "the image of point ref - n"
+bool msm_uses_glv(bool prepared, size_t batch, size_t xyzz_bytes);
+int msm_glv_windows(int c);
 int msm_build_tasks(const uint32_t* d_scalars, size_t n, size_t batch, size_t scalar_stride, int c, bool shared_buckets, uint32_t ref_base, uint32_t ref_stride,
                     size_t xyzz_bytes, void* ws, size_t ws_bytes, hipStream_t stream, msm_tasks_view* out, bool glv = false);
 // msm_g2.hip
