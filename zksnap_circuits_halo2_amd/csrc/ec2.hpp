@@ -224,29 +224,69 @@ ZK_HD void xyzz2_madd_lazy(xyzz2& acc, const fe2& x2, const fe2& y2, bool neg) {
 // A + B (add-2008-s) with lazy Fq2 arithmetic: inputs and result in standard form (every component N form below 2p + 2^233), the
 // doubling / opposite-point cases through the standard-form code.  12 lazy products + 2 lazy squares + 4 soft reductions, ~8.7 k
 // instructions against ~15 k for xyzz2_add.
-template <bool CHAIN>
-ZK_HD xyzz2 xyzz2_add_lazy(const xyzz2& A, const xyzz2& B) {
-  if (xyzz2_is_identity(A)) return B;
-  if (xyzz2_is_identity(B)) return A;
-  const fe2 U1 = f2_mul_lazy<CHAIN>(A.X, B.ZZ, Fq::P4_S1), U2 = f2_mul_lazy<CHAIN>(B.X, A.ZZ, Fq::P4_S1);      // < (2.01^2 + 2.01*4)/169.3 + 1 = 1.08p
-  const fe2 S1 = f2_mul_lazy<CHAIN>(A.Y, B.ZZZ, Fq::P4_S1), S2 = f2_mul_lazy<CHAIN>(B.Y, A.ZZZ, Fq::P4_S1);
+// 2A (dbl-2008-s-1, a = 0) with lazy Fq2 arithmetic; A in standard form through a component provider (see xyzz2_add_lazy_core), not the
+// identity; result in standard form.  6 lazy products + 3 lazy squares + 4 soft reductions.
+template <bool CHAIN, class GA>
+ZK_HD xyzz2 xyzz2_dbl_lazy_core(GA a) {
+  const fe2 AY = a(1), AX = a(0);
+  const fe2 U = {fe_norm(fe_dbl(AY.c0)), fe_norm(fe_dbl(AY.c1))};          // < 4.02p
+  const fe2 V = f2_sqr_lazy<CHAIN>(U, Fq::P6_S1);                            // c0 < 8.04 * 10.02 / 169.3 + 1 = 1.48p
+  const fe2 W = f2_mul_lazy<CHAIN>(U, V, Fq::P4_S1);                         // < (4.02*1.48 + 4.02*4)/169.3 + 1 = 1.13p
+  const fe2 S = f2_mul_lazy<CHAIN>(AX, V, Fq::P4_S1);                        // < 1.07p
+  const fe2 XX = f2_sqr_lazy<CHAIN>(AX, Fq::P4_S1);                          // c0 < 4.02 * 6.01 / 169.3 + 1 = 1.14p
+  const fe2 M = {fe_norm(fe_add(XX.c0, fe_dbl(XX.c0))), fe_norm(fe_add(XX.c1, fe_dbl(XX.c1)))};          // 3 x^2 < 3.42p
+  const fe2 MM = f2_sqr_lazy<CHAIN>(M, Fq::P6_S1);                           // c0 < 6.84 * 9.42 / 169.3 + 1 = 1.38p
+  xyzz2 r;
+  r.X = {fe_reduce_soft<Fq>(fe_norm(fe_sub_red(MM.c0, fe_dbl(S.c0), Fq::P7_S3))), fe_reduce_soft<Fq>(fe_norm(fe_sub_red(MM.c1, fe_dbl(S.c1), Fq::P7_S3)))};   // 2S: limbs < 2^30
+  const fe2 T = {fe_norm(fe_sub_red(S.c0, r.X.c0, Fq::P4_S1)), fe_norm(fe_sub_red(S.c1, r.X.c1, Fq::P4_S1))};      // < 5.07p, N form
+  const fe2 Am = f2_mul_lazy<CHAIN>(M, T, Fq::P8_S1);                        // < (3.42*5.07 + 3.42*8)/169.3 + 1 = 1.26p
+  const fe2 Bm = f2_mul_lazy<CHAIN>(W, AY, Fq::P4_S1);                       // < 1.04p
+  r.Y = {fe_reduce_soft<Fq>(fe_norm(fe_sub_red(Am.c0, Bm.c0, Fq::P3_S1))), fe_reduce_soft<Fq>(fe_norm(fe_sub_red(Am.c1, Bm.c1, Fq::P3_S1)))};
+  r.ZZ = f2_mul_lazy<CHAIN>(V, a(2), Fq::P4_S1);
+  r.ZZZ = f2_mul_lazy<CHAIN>(W, a(3), Fq::P4_S1);
+  return r;
+}
+
+// The operands come through component providers (a(0..3) = X, Y, ZZ, ZZZ), so that a kernel adding two points that live in memory loads each
+// coordinate when the formula first needs it (with both 72-register operands loaded up front, and the rare equal-x case falling into the
+// standard-form code, the kernels needed 256 VGPRs + 196 AGPRs + scratch: one wave per SIMD).  full_a / full_b supply a whole operand when
+// the other one is the identity.
+template <bool CHAIN, class GA, class GB, class FULLA, class FULLB>
+ZK_HD xyzz2 xyzz2_add_lazy_core(GA a, GB b, FULLA full_a, FULLB full_b) {
+  const fe2 AZZ = a(2), BZZ = b(2);
+  if (f2_is_zero_limbs(AZZ)) return full_b();
+  if (f2_is_zero_limbs(BZZ)) return full_a();
+  const fe2 U1 = f2_mul_lazy<CHAIN>(a(0), BZZ, Fq::P4_S1), U2 = f2_mul_lazy<CHAIN>(b(0), AZZ, Fq::P4_S1);      // < (2.01^2 + 2.01*4)/169.3 + 1 = 1.08p
+  const fe2 ZZ12 = f2_mul_lazy<CHAIN>(AZZ, BZZ, Fq::P4_S1);
   const fe2 P = {fe_norm(fe_sub_red(U2.c0, U1.c0, Fq::P3_S1)), fe_norm(fe_sub_red(U2.c1, U1.c1, Fq::P3_S1))};  // < 4.08p
-  const fe2 R = {fe_norm(fe_sub_red(S2.c0, S1.c0, Fq::P3_S1)), fe_norm(fe_sub_red(S2.c1, S1.c1, Fq::P3_S1))};
   const fe2 PP = f2_sqr_lazy<CHAIN>(P, Fq::P6_S1);          // c0 < 8.16 * 10.08 / 169.3 + 1 = 1.49p, c1 < 1.2p
-  if (fe_mulout_is_zero<Fq>(PP.c0) && fe_mulout_is_zero<Fq>(PP.c1)) return xyzz2_add(A, B);       // same x (rare): doubling or the identity
+  const fe2 AZZZ = a(3), BZZZ = b(3);
+  const fe2 S1 = f2_mul_lazy<CHAIN>(a(1), BZZZ, Fq::P4_S1), S2 = f2_mul_lazy<CHAIN>(b(1), AZZZ, Fq::P4_S1);
+  const fe2 R = {fe_norm(fe_sub_red(S2.c0, S1.c0, Fq::P3_S1)), fe_norm(fe_sub_red(S2.c1, S1.c1, Fq::P3_S1))};
+  const fe2 RR = f2_sqr_lazy<CHAIN>(R, Fq::P6_S1);          // < 1.49p
+  if (fe_mulout_is_zero<Fq>(PP.c0) && fe_mulout_is_zero<Fq>(PP.c1)) {       // P^2 = 0 <=> P = 0: same x (rare)
+    if (fe_mulout_is_zero<Fq>(RR.c0) && fe_mulout_is_zero<Fq>(RR.c1)) return xyzz2_dbl_lazy_core<CHAIN>(a);     // the same point
+    return xyzz2_identity();                                                  // opposite points
+  }
+  xyzz2 r;
+  r.ZZ = f2_mul_lazy<CHAIN>(ZZ12, PP, Fq::P4_S1);
   const fe2 PPP = f2_mul_lazy<CHAIN>(P, PP, Fq::P4_S1);     // < (4.08*1.49 + 4.08*4)/169.3 + 1 = 1.14p
   const fe2 Q = f2_mul_lazy<CHAIN>(U1, PP, Fq::P4_S1);      // < 1.04p
-  const fe2 RR = f2_sqr_lazy<CHAIN>(R, Fq::P6_S1);          // < 1.49p
-  xyzz2 r;
+  r.ZZZ = f2_mul_lazy<CHAIN>(f2_mul_lazy<CHAIN>(AZZZ, BZZZ, Fq::P4_S1), PPP, Fq::P4_S1);
   r.X = {fe_reduce_soft<Fq>(fe_norm(fe_sub_red(RR.c0, fe_add(PPP.c0, fe_dbl(Q.c0)), Fq::P7_S3))),                // subtrahend < 3.3p, limbs < 3 * 2^29; < 8.5p -> standard form
          fe_reduce_soft<Fq>(fe_norm(fe_sub_red(RR.c1, fe_add(PPP.c1, fe_dbl(Q.c1)), Fq::P7_S3)))};
   const fe2 T = {fe_norm(fe_sub_red(Q.c0, r.X.c0, Fq::P4_S1)), fe_norm(fe_sub_red(Q.c1, r.X.c1, Fq::P4_S1))};    // < 5.04p, N form
   const fe2 Am = f2_mul_lazy<CHAIN>(R, T, Fq::P8_S1);       // < (4.08*5.04 + 4.08*8)/169.3 + 1 = 1.32p
   const fe2 Bm = f2_mul_lazy<CHAIN>(S1, PPP, Fq::P4_S1);    // < 1.04p
   r.Y = {fe_reduce_soft<Fq>(fe_norm(fe_sub_red(Am.c0, Bm.c0, Fq::P3_S1))), fe_reduce_soft<Fq>(fe_norm(fe_sub_red(Am.c1, Bm.c1, Fq::P3_S1)))};   // < 4.32p -> standard form
-  r.ZZ = f2_mul_lazy<CHAIN>(f2_mul_lazy<CHAIN>(A.ZZ, B.ZZ, Fq::P4_S1), PP, Fq::P4_S1);
-  r.ZZZ = f2_mul_lazy<CHAIN>(f2_mul_lazy<CHAIN>(A.ZZZ, B.ZZZ, Fq::P4_S1), PPP, Fq::P4_S1);
   return r;
+}
+
+template <bool CHAIN>
+ZK_HD xyzz2 xyzz2_add_lazy(const xyzz2& A, const xyzz2& B) {
+  auto ga = [&](int c) -> const fe2& { return c == 0 ? A.X : (c == 1 ? A.Y : (c == 2 ? A.ZZ : A.ZZZ)); };
+  auto gb = [&](int c) -> const fe2& { return c == 0 ? B.X : (c == 1 ? B.Y : (c == 2 ? B.ZZ : B.ZZZ)); };
+  return xyzz2_add_lazy_core<CHAIN>(ga, gb, [&]() -> xyzz2 { return A; }, [&]() -> xyzz2 { return B; });
 }
 
 // accumulator of xyzz2_madd_lazy -> standard form (every component N form below 2p + 2^233), what the other kernels' formulas expect
@@ -311,6 +351,29 @@ ZK_D xyzz2 load_xyzz2(const uint32_t* base, size_t idx) {
 #pragma unroll
     for (int i = 0; i < 9; i++) f[k]->l[i] = w[9 * k + i];
   return r;
+}
+// one coordinate (18 words) of a work point in memory: comp 0..3 = X, Y, ZZ, ZZZ (72 comp bytes into the record: 8-byte aligned loads)
+ZK_D fe2 load_xyzz2_coord(const uint32_t* base, size_t idx, int comp) {
+  const uint2* q = reinterpret_cast<const uint2*>(base + idx * 72 + comp * 18);
+  uint32_t w[18];
+#pragma unroll
+  for (int i = 0; i < 9; i++) { const uint2 v = q[i]; w[2 * i] = v.x; w[2 * i + 1] = v.y; }
+  fe2 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) { r.c0.l[i] = w[i]; r.c1.l[i] = w[9 + i]; }
+  return r;
+}
+// a[ia] + b[ib], both operands in memory, coordinates loaded on demand
+template <bool CHAIN>
+ZK_D xyzz2 xyzz2_add_lazy_mem(const uint32_t* a, size_t ia, const uint32_t* b, size_t ib) {
+  return xyzz2_add_lazy_core<CHAIN>([&](int c) { return load_xyzz2_coord(a, ia, c); }, [&](int c) { return load_xyzz2_coord(b, ib, c); },
+                                    [&]() { return load_xyzz2(a, ia); }, [&]() { return load_xyzz2(b, ib); });
+}
+// A + b[ib], the second operand in memory
+template <bool CHAIN>
+ZK_D xyzz2 xyzz2_add_lazy_regmem(const xyzz2& A, const uint32_t* b, size_t ib) {
+  auto ga = [&](int c) -> const fe2& { return c == 0 ? A.X : (c == 1 ? A.Y : (c == 2 ? A.ZZ : A.ZZZ)); };
+  return xyzz2_add_lazy_core<CHAIN>(ga, [&](int c) { return load_xyzz2_coord(b, ib, c); }, [&]() -> xyzz2 { return A; }, [&]() { return load_xyzz2(b, ib); });
 }
 ZK_D void store_xyzz2(uint32_t* base, size_t idx, const xyzz2& a) {
   uint32_t w[72];

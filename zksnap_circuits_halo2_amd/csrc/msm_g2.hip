@@ -121,11 +121,11 @@ __global__ void __launch_bounds__(64) k2_combine(const uint32_t* __restrict__ ta
     if (m > seq_parts) m = 1;                     // a heavy bucket: k2_combine_heavy's (treated here like the single-task case: nothing to do)
     if (m != 1) {
 #pragma unroll 1
-      for (uint32_t j = q; j < m; j += LANES) acc = xyzz2_add_lazy<false>(acc, load_xyzz2(partials, t + j));
+      for (uint32_t j = q; j < m; j += LANES) acc = xyzz2_add_lazy_regmem<true>(acc, partials, t + j);
     }
   }
 #pragma unroll 1
-  for (int mask = 1; mask < LANES; mask <<= 1) acc = xyzz2_add_lazy<false>(acc, xyzz2_shfl_xor(acc, mask));
+  for (int mask = 1; mask < LANES; mask <<= 1) acc = xyzz2_add_lazy<true>(acc, xyzz2_shfl_xor(acc, mask));
   if (live && q == 0 && m != 1) store_xyzz2(buckets, k, acc);
 }
 
@@ -142,13 +142,13 @@ __global__ void __launch_bounds__(64) k2_combine_heavy(const uint32_t* __restric
     const uint32_t k = e.x, t = task_off[k], m = task_off[k + 1] - t;
     xyzz2 acc = xyzz2_identity();
 #pragma unroll 1
-    for (uint32_t j = threadIdx.x; j < m; j += 64) acc = xyzz2_add_lazy<false>(acc, load_xyzz2(partials, t + j));
+    for (uint32_t j = threadIdx.x; j < m; j += 64) acc = xyzz2_add_lazy_regmem<true>(acc, partials, t + j);
 #pragma unroll 1
     for (uint32_t half = 32; half >= 1; half >>= 1) {
       __syncthreads();
       if (threadIdx.x >= half && threadIdx.x < 2 * half) store_xyzz2(xch, threadIdx.x - half, acc);
       __syncthreads();
-      if (threadIdx.x < half) acc = xyzz2_add_lazy<false>(acc, load_xyzz2(xch, threadIdx.x));
+      if (threadIdx.x < half) acc = xyzz2_add_lazy_regmem<true>(acc, xch, threadIdx.x);
     }
     if (threadIdx.x == 0) store_xyzz2(buckets, k, acc);
   }
@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(64) k2_pyramid_step(const uint32_t* __restrict
     if ((int)l == s - 1) { ia = 4 * u + 1; ib = 4 * u + 3; }
     else { ia = N + l * (N / 2) + 2 * u; ib = ia + 1; }
   }
-  store_xyzz2(wo, tid, xyzz2_add_lazy<false>(load_xyzz2(wi, ia), load_xyzz2(wi, ib)));
+  store_xyzz2(wo, tid, xyzz2_add_lazy_mem<true>(wi, ia, wi, ib));
 }
 
 // the same step with one quad per addition, for steps far smaller than the chip (their time is the latency of one addition)
