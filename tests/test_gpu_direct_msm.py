@@ -148,3 +148,53 @@ def test_direct_path_through_registered_host_arrays_and_batches(lib, cref):
             assert np.array_equal(cref.jac_to_affine(single[k]), e) and np.array_equal(cref.jac_to_affine(batch[k]), e)
     finally:
         _lib.check(lib.zkhip_unregister_bases(hb.ctypes.data))
+
+
+def test_direct_tables_respect_the_budget():
+    """(round 4 advice) a direct table is 256 KiB per point: it is built only within $ZKHIP_DIRECT_BUDGET_GIB (all tables of the process) and half of
+    the free HBM.  With a budget of 1 GiB a 2^11-point set (512 MiB) gets its table, a second set of 2^12 points (1 GiB more) does not and keeps
+    the bucket path -- with the same result.  The knob is read once per process: a child process."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import ctypes as C, sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+from oracle import cpu_ref as cref
+from zksnap_circuits_halo2_amd import _lib, fields as F
+cref.load()
+lib = _lib.load()
+D, T0 = 0x9E3779B97F4A7C15F39CC0605CEDC835, 0x5A4B534E41500002 + 4242
+def run(n):
+    bases = torch.empty(n * 8, dtype=torch.int64, device="cuda")
+    t0m, dm = F.fr_encode([T0])[0], F.fr_encode([D])[0]
+    _lib.check(lib.zkhip_g1_gen_walk_device(t0m.ctypes.data, dm.ctypes.data, n, bases.data_ptr(), None))
+    torch.cuda.synchronize()
+    h = C.c_uint64(0)
+    _lib.check(lib.zkhip_prepare_bases_device(bases.data_ptr(), n, C.byref(h)))
+    sc = cref.gen_scalars(900 + n, n, 0)
+    d_sc = torch.from_numpy(sc.view(np.int64)).cuda()
+    out = torch.zeros(12, dtype=torch.int64, device="cuda")
+    lib.zkhip_profile_enable(1)
+    _lib.check(lib.zkhip_msm_g1_prepared_device(h, 0, d_sc.data_ptr(), n, out.data_ptr(), None))
+    torch.cuda.synchronize()
+    ms = (C.c_double * 32)(); names = ((C.c_char * 64) * 32)()
+    k = lib.zkhip_profile_read(ms, names, 32)
+    lib.zkhip_profile_enable(0)
+    ph = [names[i].value.decode() for i in range(k)]
+    want = cref.jac_to_affine(cref.scalar_mul(cref.expected_scalar(sc, T0, D), cref.generator()))
+    assert np.array_equal(cref.jac_to_affine(out.cpu().numpy().view(np.uint64)), want), n
+    return h, "direct_accumulate" in ph
+h1, d1 = run(1 << 11)
+h2, d2 = run(1 << 12)
+lib.zkhip_release_bases(h1)
+h3, d3 = run(1 << 11)            # the first table's bytes were returned to the budget
+print("DIRECT", d1, d2, d3)
+''' % root
+    env = dict(os.environ, ZKHIP_DIRECT_BUDGET_GIB="1")
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "DIRECT True False True" in res.stdout, res.stdout

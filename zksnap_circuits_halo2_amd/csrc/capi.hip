@@ -572,6 +572,13 @@ static int msm_shard_enqueue_chunked(lane* L, scratch* sc, hipStream_t s, const 
   const size_t ws_bytes = msm_chunk_workspace_bytes(cap, pb->c);
   if ((rc = sc->scalars.reserve((region + n) * 32)) != ZKHIP_OK) return rc;      // (a no-op inside a fan-out: reserve_for_pieces sized the buffer for all pieces)
   if ((rc = sc->ws.reserve(ws_bytes)) != ZKHIP_OK) return rc;
+  // (round 4 advice) every non-OK exit below waits for the copy stream and for `s`: the caller's scalars may be pinned host memory, in which case an
+  // earlier piece could still be crossing PCIe from the caller's buffer into the lane's after this call has returned its error and released the lane
+  struct drain_t {
+    hipStream_t a, b;
+    bool armed = true;
+    ~drain_t() { if (armed) { (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b); } }
+  } drain{L->copy, s};
   // Every piece of a call has its own region of the lane's scalar buffer (`region`, in scalars), so the copy stream may run ahead of the kernels:
   // while shard k is being accumulated on `s`, the pieces of shard k + 1 are already crossing PCIe (virtual shards on one lane).  A call ends with
   // hipStreamSynchronize(s), and `s` waits for every copy it used, so nothing of an earlier call is in flight here.
@@ -583,13 +590,12 @@ static int msm_shard_enqueue_chunked(lane* L, scratch* sc, hipStream_t s, const 
     HIPCHK(hipMemcpyAsync(dst + lo * 32, scalars + lo * 4, len * 32, hipMemcpyHostToDevice, L->copy));
     HIPCHK(hipEventRecord(L->copied[j], L->copy));
     HIPCHK(hipStreamWaitEvent(s, L->copied[j], 0));
-    if ((rc = msm_chunk_add((const uint32_t*)(dst + lo * 32), len, pb, pb_off + lo, cap, j == 0, sc->ws.p, sc->ws.cap, s)) != ZKHIP_OK) {
-      (void)hipStreamSynchronize(L->copy);     // no upload of a failed call may still be writing the lane's scalar buffer when the lane is handed on
-      return rc;
-    }
+    if ((rc = msm_chunk_add((const uint32_t*)(dst + lo * 32), len, pb, pb_off + lo, cap, j == 0, sc->ws.p, sc->ws.cap, s)) != ZKHIP_OK) return rc;
     lo += len;
   }
-  return msm_chunk_finish(pb, cap, d_partial, sc->ws.p, sc->ws.cap, s);
+  if ((rc = msm_chunk_finish(pb, cap, d_partial, sc->ws.p, sc->ws.cap, s)) != ZKHIP_OK) return rc;
+  drain.armed = false;
+  return ZKHIP_OK;
 }
 
 // region: offset (in scalars) of this piece inside the lane's scalar buffer -- the pieces one lane runs back to back (virtual shards) do not share

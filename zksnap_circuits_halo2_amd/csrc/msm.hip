@@ -22,6 +22,7 @@
 // HBM layout: digits int16 [W][n]; sorted refs u32 [W*n]; counts/offsets u32 [W*B+1]; XYZZ points are
 // 36 x u32 (9 limbs x 4 coordinates, 144 B) arrays-of-structs.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -1887,7 +1888,8 @@ int msm_g1_device(const uint32_t* d_scalars, const uint32_t* d_bases, size_t n, 
 // MSM into independent shards this pays one elementwise pass of 2^(c-1) general additions per extra piece (~0.05 ms at c = 20) instead of a whole
 // tail (0.34 ms), and the table, the window size and the bucket set are those of the unchunked MSM: the result is the same group element.
 //   msm_chunk_workspace_bytes(chunk, c)   workspace for pieces of at most `chunk` scalars
-//   msm_chunk_begin / msm_chunk_add (x pieces, any sizes <= chunk, in any order) / msm_chunk_finish
+//   msm_chunk_add (once per piece, any sizes <= chunk; the FIRST piece is passed with first = true and must be enqueued before the others: it
+//   initialises the running bucket sums the later pieces add into) / msm_chunk_finish
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(128) k_bucket_sets_add(uint32_t* __restrict__ acc, const uint32_t* __restrict__ add, uint32_t nb) {
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2228,10 +2230,13 @@ int prepare_bases_device(const uint32_t* d_bases, size_t n, hipStream_t stream, 
   return ZKHIP_OK;
 }
 
+size_t direct_table_bytes(size_t n);
+static std::atomic<size_t> g_direct_bytes{0};          // bytes held by the direct tables of all prepared sets of the process (prepare_direct_table's budget)
+
 void release_prepared(prepared_bases* pb) {
   if (!pb) return;
   if (pb->table) (void)hipFree(pb->table);
-  if (pb->direct) (void)hipFree(pb->direct);
+  if (pb->direct) { (void)hipFree(pb->direct); g_direct_bytes -= direct_table_bytes(pb->n); }
   delete pb;
 }
 
@@ -2407,6 +2412,7 @@ __global__ void __launch_bounds__(512) k_points_sum_quad(const uint32_t* __restr
 }
 
 size_t direct_table_bytes(size_t n) { return n * (size_t)DIRECT_W * DIRECT_M * 64; }
+
 static inline size_t direct_partials(size_t n) { return n * (size_t)DIRECT_W / (size_t)direct_wpt(n); }
 size_t msm_direct_workspace_bytes(size_t n) { return align_up(direct_partials(n) * 144, 256) + align_up(((direct_partials(n) + 511) / 512 + 1) * 144, 256); }
 
@@ -2418,6 +2424,20 @@ int prepare_direct_table(prepared_bases* pb, const uint32_t* d_bases, hipStream_
   const size_t wt_bytes = (size_t)DIRECT_W * n * 64, wtmp_pts = align_up((size_t)(DIRECT_W - 1) * n * 144, 256), wtmp_pref = align_up((size_t)(DIRECT_W - 1) * n * 36, 256);
   const size_t tmp_pts = align_up((size_t)(DIRECT_M - 1) * T * 144, 256), tmp_pref = align_up((size_t)(DIRECT_M - 1) * T * 36, 256);
   const size_t tmp_bytes = std::max(wtmp_pts + wtmp_pref, tmp_pts + tmp_pref);
+  // (round 4 advice) the table is an accelerator, not a requirement: 256 KiB per point (8 GiB at 2^15) + up to ~3 GiB of build temporaries must not
+  // starve the allocations that matter (a k = 22 SRS pair holds 7 GiB of wide tables; the rust shim pins g and g_lagrange of every ParamsKZG,
+  // clones included).  It is built only while ALL direct tables of the process stay within $ZKHIP_DIRECT_BUDGET_GIB (default 24) and the table
+  // plus its temporaries leave at least half of the currently free HBM; otherwise the set keeps the bucket path (same results).
+  {
+    static const size_t budget = [] { const char* e = getenv("ZKHIP_DIRECT_BUDGET_GIB"); const long v = e ? atol(e) : 24; return (size_t)(v >= 0 && v <= 4096 ? v : 24) << 30; }();
+    size_t free_b = 0, total_b = 0;
+    const size_t want = direct_table_bytes(n) + wt_bytes + tmp_bytes;
+    if (g_direct_bytes.load() + direct_table_bytes(n) > budget || hipMemGetInfo(&free_b, &total_b) != hipSuccess || want > free_b / 2) {
+      (void)hipGetLastError();
+      set_error("direct table: %zu bytes not built (budget %zu, in use %zu, free %zu)", direct_table_bytes(n), budget, g_direct_bytes.load(), free_b);
+      return ZKHIP_ENOMEM;
+    }
+  }
   if (hipMalloc(&direct, direct_table_bytes(n)) != hipSuccess) { (void)hipGetLastError(); set_error("direct table: hipMalloc(%zu) failed", direct_table_bytes(n)); return ZKHIP_ENOMEM; }
   if (hipMalloc(&wt, wt_bytes) != hipSuccess || hipMalloc(&tmp, tmp_bytes) != hipSuccess) {
     (void)hipGetLastError();
@@ -2438,6 +2458,7 @@ int prepare_direct_table(prepared_bases* pb, const uint32_t* d_bases, hipStream_
   (void)hipFree(wt); (void)hipFree(tmp);
   if (e != hipSuccess) { (void)hipFree(direct); set_error("direct table: %s", hipGetErrorString(e)); return ZKHIP_EHIP; }
   pb->direct = (uint32_t*)direct;
+  g_direct_bytes += direct_table_bytes(n);
   return ZKHIP_OK;
 }
 
