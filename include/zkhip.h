@@ -181,6 +181,13 @@ int zkhip_fr_eval_rows(const zkhip_vm_program *prog, const uint64_t *const *colu
  * only if that column is read at rotation 0 exclusively) */
 int zkhip_fr_eval_rows_device(const zkhip_vm_program *prog, const void *const *d_columns, uint32_t n_columns, uint32_t log_rows,
                               int accumulate, void *d_out, void *stream);
+/* Short programs over many rows (at most 256 instructions, at least 2^18 rows, at most 96 columns) run as straight-line code compiled at
+ * run time with hiprtc -- once per (program shape, rows, device), cached; constants stay a table, so one compilation serves every proof of a
+ * circuit -- and every other program, or any failure to compile, through the interpreter: same results.  $ZKHIP_VM_JIT = 0 switches it off.
+ * zkhip_vm_jit_source returns the generated source (buf may be NULL; *len = bytes needed incl. NUL); zkhip_vm_jit_compile compiles it without
+ * launching anything (no device needed), e.g. at keygen, so that the first proof does not pay the seconds of compilation. */
+int zkhip_vm_jit_source(const zkhip_vm_program *prog, uint32_t n_columns, uint32_t log_rows, char *buf, size_t cap, size_t *len);
+int zkhip_vm_jit_compile(const zkhip_vm_program *prog, uint32_t n_columns, uint32_t log_rows, size_t *code_bytes);
 /* out[j] = a[index_a[j]] * b[index_b[j]] (u32 indices, device-resident): the inner loop of `permutation::keygen::Assembly::build_pk`
  * [DEP halo2-axiom plonk/permutation/keygen.rs; keygen_pk at /root/reference/aggregator/src/wrapper.rs:108] -- sigma_i[j] =
  * delta^(column the cell (i, j) maps to) * omega^(its row) -- so that the sigma columns of a proving key are built in HBM.  Indices

@@ -25,6 +25,8 @@ _SIGS = {
     "zkhip_ntt_fr_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]),
     "zkhip_ifft_scaled_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]),
     "zkhip_coeff_to_extended_batch": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "zkhip_vm_jit_source": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "zkhip_vm_jit_compile": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "zkhip_set_ntt_fanout": (C.c_int, [C.c_int]),
     "zkhip_ntt_fanout": (C.c_int, []),
     "zkhip_register_bases": (C.c_int, [C.c_void_p, C.c_size_t]),

@@ -482,6 +482,7 @@ void zkhip_shutdown(void) {
   (void)hipSetDevice(primary().device);
   (void)hipDeviceSynchronize();
   ntt_clear_cache();
+  row_vm_jit_clear();
   g_ctx.registered.clear();                                  // last references: tables are freed by ~registered_t
   for (auto& kv : g_ctx.handles) release_prepared(kv.second);
   g_ctx.handles.clear();
@@ -1726,6 +1727,26 @@ int zkhip_fr_eval_rows_device(const zkhip_vm_program* prog, const void* const* d
   scratch* sc = scratch_for(primary(), s);
   if ((rc = sc->vm.reserve(row_vm_workspace_bytes(prog, n_columns, log_rows))) != ZKHIP_OK) return rc;
   return row_vm_device(prog, d_columns, n_columns, log_rows, accumulate, (uint32_t*)d_out, sc->vm.p, sc->vm.cap, s, &sc->vm_stage);
+}
+
+// The straight-line HIP source rowvm_jit.hip generates for `prog` (buf may be NULL: *len receives the size needed, NUL included), and a
+// compile-only run of it through hiprtc -- no device needed (the generator's CPU-side test; a host may also use it to warm hiprtc's caches at keygen).
+int zkhip_vm_jit_source(const zkhip_vm_program* prog, uint32_t n_columns, uint32_t log_rows, char* buf, size_t cap, size_t* len) {
+  ZK_API_RANGE();
+  int rc = row_vm_validate(prog, n_columns, log_rows, 0);
+  if (rc != ZKHIP_OK) return rc;
+  std::string src;
+  if ((rc = row_vm_jit_source(prog, n_columns, log_rows, &src)) != ZKHIP_OK) return rc;
+  if (len) *len = src.size() + 1;
+  if (buf && cap) { const size_t m = std::min(cap - 1, src.size()); memcpy(buf, src.data(), m); buf[m] = 0; }
+  return ZKHIP_OK;
+}
+
+int zkhip_vm_jit_compile(const zkhip_vm_program* prog, uint32_t n_columns, uint32_t log_rows, size_t* code_bytes) {
+  ZK_API_RANGE();
+  int rc = row_vm_validate(prog, n_columns, log_rows, 0);
+  if (rc != ZKHIP_OK) return rc;
+  return row_vm_jit_compile_only(prog, n_columns, log_rows, code_bytes);
 }
 
 int zkhip_fr_eval_rows(const zkhip_vm_program* prog, const uint64_t* const* columns, uint32_t n_columns, uint32_t log_rows,

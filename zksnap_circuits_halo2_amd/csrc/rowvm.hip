@@ -493,6 +493,11 @@ int row_vm_device(const zkhip_vm_program* p, const void* const* d_columns, uint3
     L.pow_lo = (const uint32_t*)(d + o_lo);
     L.pow_hi = (const uint32_t*)(d + o_hi);
   }
+  // a short program over many rows runs as compiled straight-line code when a kernel for its shape exists or can be built (rowvm_jit.hip);
+  // any failure there leaves nothing launched and the interpreter below takes the call
+  if (row_vm_jit_wanted(p, n_columns, log_rows) &&
+      row_vm_jit_launch(p, d_columns, n_columns, log_rows, accumulate, L.consts, L.pow_lo, L.pow_hi, d_out, stream) == ZKHIP_OK)
+    return ZKHIP_OK;
   // smallest register-file variant that holds every register the program names
   uint32_t top = p->result_reg;
   for (uint32_t pc = 0; pc < p->n_insns; pc++) {

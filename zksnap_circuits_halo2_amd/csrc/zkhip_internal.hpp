@@ -1,5 +1,6 @@
 // Internal declarations shared by the translation units of libzkhip.so (not installed).
 #pragma once
+#include <string>
 #include <hip/hip_runtime.h>
 #include <cstddef>
 #include <cstdint>
@@ -114,6 +115,14 @@ struct vm_staging {
   int turn = 0;
   void release();
 };
+// rowvm_jit.hip: row programs compiled at run time with hiprtc (straight-line code per program shape, cached per device); row_vm_device
+// tries it first for short programs over many rows and runs the interpreter otherwise
+bool row_vm_jit_wanted(const zkhip_vm_program* p, uint32_t n_columns, uint32_t log_rows);
+int row_vm_jit_launch(const zkhip_vm_program* p, const void* const* d_columns, uint32_t n_columns, uint32_t log_rows, int accumulate, const uint32_t* d_consts,
+                      const uint32_t* d_pow_lo, const uint32_t* d_pow_hi, uint32_t* d_out, hipStream_t stream);
+void row_vm_jit_clear();
+int row_vm_jit_source(const zkhip_vm_program* p, uint32_t n_columns, uint32_t log_rows, std::string* out);
+int row_vm_jit_compile_only(const zkhip_vm_program* p, uint32_t n_columns, uint32_t log_rows, size_t* code_bytes);
 int row_vm_device(const zkhip_vm_program* p, const void* const* d_columns, uint32_t n_columns, uint32_t log_rows, int accumulate,
                   uint32_t* d_out, void* ws, size_t ws_bytes, hipStream_t stream, vm_staging* staging = nullptr);
 int fr_pointwise_mul_device(const uint32_t* d_a, const uint32_t* d_b, size_t n, uint32_t* d_out, hipStream_t stream);
