@@ -31,10 +31,11 @@ extern "C" {
 
 /* ---- lifecycle ----------------------------------------------------------------------------------- */
 /* Name the HIP devices this process drives (`zkhip_init(const int *devices, int ndev)`).  devices == NULL
- * or ndev == 0: device 0 (or $ZKHIP_DEVICE).  devices[0] is the PRIMARY device: every `_device` entry point, every NTT and every
- * other vector operation runs there, and `_device` pointers are pointers into its memory.  With ndev > 1 the MSM over registered
- * bases is sharded by point range over all the devices (zkhip_register_bases below) -- the 8 GPUs of one node behind one
- * `create_proof` process (/root/reference/aggregator/src/wrapper.rs:129).  Lazy init on first use is allowed (device 0).
+ * or ndev == 0: device 0 (or $ZKHIP_DEVICE).  devices[0] is the PRIMARY device: every `_device` entry point, every single transform and
+ * every other vector operation runs there, and `_device` pointers are pointers into its memory.  With ndev > 1 the MSM over registered
+ * bases is sharded by point range over all the devices (zkhip_register_bases below) and the polynomials of a BATCHED transform are
+ * spread over them, each transform on one device (zkhip_set_ntt_fanout below) -- the 8 GPUs of one node behind one `create_proof`
+ * process (/root/reference/aggregator/src/wrapper.rs:129).  Lazy init on first use is allowed (device 0).
  * Calling it again with the same list is a no-op; with a different list it shuts the library down first (ZKHIP_EBUSY while
  * host-buffer calls of other threads are still running).
  * Environment: ZKHIP_DEVICE (default device), ZKHIP_SHARDS (see zkhip_set_msm_shards), ZKHIP_HOST_LANES (1..4, default 2: host-buffer
