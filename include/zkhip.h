@@ -341,7 +341,8 @@ int zkhip_test_field_op(int field, int op, const uint64_t *a, const uint64_t *b,
 int zkhip_test_g1_op(int op, const uint64_t *a, const uint64_t *b, uint64_t *out_xyz, size_t n);
 
 /* G2 (Fq2 + twist curve arithmetic): op 0 = a[i] + b[i], 1 = 2 a[i], 2 = a[i] - b[i]; with the quad-cooperative formulas of the MSM's
- * latency-bound end: 3 = 2 a[i] + b[i], 4 = 4 a[i].  a, b: n G2Affine points, out: n G2 Jacobian points */
+ * latency-bound end: 3 = 2 a[i] + b[i], 4 = 4 a[i]; with their lazy forms chained as in the window fold: 5 = 4 a[i] + b[i], 6 = 16 a[i].
+ * a, b: n G2Affine points, out: n G2 Jacobian points */
 int zkhip_test_g2_op(int op, const uint64_t *a, const uint64_t *b, uint64_t *out_xyz, size_t n);
 
 #ifdef __cplusplus

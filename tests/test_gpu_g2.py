@@ -53,9 +53,12 @@ def test_g2_quad_cooperative_point_ops_vs_oracle(lib):
     Pa[3] = None; Pb[4] = None; Pa[5] = None; Pb[5] = None
     Pb[6] = O.g2_add(Pa[6], Pa[6])                                            # 2 a + b with b = 2 a: equal points
     Pb[7] = O.g2_neg(O.g2_add(Pa[7], Pa[7]))                                  # b = -2 a: the sum is the identity
-    a, b = enc(Pa), enc(Pb)
     dbl = lambda P: O.g2_add(P, P)
-    for op, f in ((3, lambda P, Q: O.g2_add(dbl(P), Q)), (4, lambda P, Q: dbl(dbl(P)))):
+    Pb[8] = dbl(dbl(Pa[8]))                                                   # op 5: 4 a + b with b = 4 a (equal points inside the lazy addition)
+    Pb[9] = O.g2_neg(dbl(dbl(Pa[9])))                                         # op 5: b = -4 a
+    a, b = enc(Pa), enc(Pb)
+    for op, f in ((3, lambda P, Q: O.g2_add(dbl(P), Q)), (4, lambda P, Q: dbl(dbl(P))),
+                  (5, lambda P, Q: O.g2_add(dbl(dbl(P)), Q)), (6, lambda P, Q: dbl(dbl(dbl(dbl(P)))))):     # 5 / 6: the lazy quad chains of the fold
         out = np.zeros((n, 24), dtype=np.uint64)
         _lib.check(lib.zkhip_test_g2_op(op, a.ctypes.data, b.ctypes.data, out.ctypes.data, n))
         assert [dec(r) for r in out] == [f(P, Q) for P, Q in zip(Pa, Pb)], op

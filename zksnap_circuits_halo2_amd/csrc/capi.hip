@@ -2177,7 +2177,7 @@ int zkhip_test_g1_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out
 
 int zkhip_test_g2_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out_xyz, size_t n) {
   ZK_API_RANGE();
-  if (op < 0 || op > 4 || (n && (!a || !b || !out_xyz))) { set_error("test_g2_op: bad argument"); return ZKHIP_EINVAL; }
+  if (op < 0 || op > 6 || (n && (!a || !b || !out_xyz))) { set_error("test_g2_op: bad argument"); return ZKHIP_EINVAL; }
   if (n == 0) return ZKHIP_OK;
   lane_hold H;
   if (H.rc != ZKHIP_OK) return H.rc;

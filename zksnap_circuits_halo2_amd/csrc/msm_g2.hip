@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(64) k2_pyramid_step_quad(const uint32_t* __res
     if ((int)l == s - 1) { ia = 4 * u + 1; ib = 4 * u + 3; }
     else { ia = N + l * (N / 2) + 2 * u; ib = ia + 1; }
   }
-  const xyzz2 r = xyzz2_add_quad(load_xyzz2(wi, ia), load_xyzz2(wi, ib), q);
+  const xyzz2 r = xyzz2_quad_to_std(xyzz2_add_quad_lazy(load_xyzz2(wi, ia), load_xyzz2(wi, ib), q));      // stored points are in standard form
   if (q == 0) store_xyzz2(wo, tid, r);
 }
 
@@ -209,15 +209,17 @@ __global__ void __launch_bounds__(128) k2_window_sum(const uint32_t* __restrict_
   int dbl = 0;
   if (term < nz) { acc = load_xyzz2(wi, 2 + term); dbl = term; }
   else if (term == nz) { acc = load_xyzz2(wi, 1); dbl = nz; }
-  else if (term == nz + 1) acc = xyzz2_add_quad(load_xyzz2(wi, 0), load_xyzz2(wi, 1), q);
+  else if (term == nz + 1) acc = xyzz2_add_quad_lazy(load_xyzz2(wi, 0), load_xyzz2(wi, 1), q);
+  // the chains run on the lazy quad formulas (ec2_quad.hpp): X, Y standard form, ZZ / ZZZ below 5p between the steps
 #pragma unroll 1
-  for (int i = 0; i < dbl; i++) acc = xyzz2_dbl_quad(acc, q);
+  for (int i = 0; i < dbl; i++) acc = xyzz2_dbl_quad_lazy(acc, q);
 #pragma unroll 1
-  for (int mask = 4; mask < 64; mask <<= 1) acc = xyzz2_add_quad(acc, xyzz2_shfl_xor(acc, mask), q);
+  for (int mask = 4; mask < 64; mask <<= 1) acc = xyzz2_add_quad_lazy(acc, xyzz2_quad_to_std(xyzz2_shfl_xor(acc, mask)), q);
+  acc = xyzz2_quad_to_std(acc);
   if (threadIdx.x == 64) store_xyzz2(xch, 0, acc);      // sum of terms 16..31
   __syncthreads();
   if (threadIdx.x < 4) {
-    acc = xyzz2_add_quad(acc, load_xyzz2(xch, 0), q);
+    acc = xyzz2_quad_to_std(xyzz2_add_quad_lazy(acc, load_xyzz2(xch, 0), q));
     if (q == 0) store_xyzz2(winsum, win, acc);
   }
 }
@@ -232,17 +234,17 @@ __global__ void __launch_bounds__(64) k2_fold(const uint32_t* __restrict__ winsu
   xyzz2 acc = load_xyzz2(winsum, W - 1);
   for (int w = W - 2; w >= 0; w--) {
 #pragma unroll 1
-    for (int i = 0; i < c; i++) acc = xyzz2_dbl_quad(acc, q);
-    acc = xyzz2_add_quad(acc, load_xyzz2(winsum, w), q);
+    for (int i = 0; i < c; i++) acc = xyzz2_dbl_quad_lazy(acc, q);
+    acc = xyzz2_add_quad_lazy(acc, load_xyzz2(winsum, w), q);
   }
-  if (q == 0) store_jacobian2(acc, out);
+  if (q == 0) store_jacobian2(xyzz2_quad_to_std(acc), out);
 }
 
 __global__ void __launch_bounds__(64) k2_store_identity(uint32_t* __restrict__ out) {
   if (threadIdx.x == 0 && blockIdx.x == 0) store_jacobian2(xyzz2_identity(), out);
 }
 
-// parity hook for the quad formulas: out[i] = a[i] + b[i] (op 3), 2 a[i] (op 4); four lanes per row
+// parity hook for the quad formulas: 2 a[i] + b[i] (op 3), 4 a[i] (op 4), and the lazy chains 4 a[i] + b[i] (op 5), 16 a[i] (op 6); four lanes per row
 __global__ void __launch_bounds__(64) k2_test_op_quad(int op, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint32_t* __restrict__ out, size_t n) {
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t i = gid >> 2;
@@ -253,7 +255,11 @@ __global__ void __launch_bounds__(64) k2_test_op_quad(int op, const uint32_t* __
   fe2 x, y;
   if (!affine2_is_identity(pa)) { affine2_coords(pa, false, x, y); xyzz2_madd(A, x, y); A = xyzz2_dbl(A); }     // (a general representative: 2 a[i])
   if (!affine2_is_identity(pb)) { affine2_coords(pb, false, x, y); xyzz2_madd(B, x, y); }
-  const xyzz2 r = op == 4 ? xyzz2_dbl_quad(A, q) : xyzz2_add_quad(A, B, q);      // 4 a[i]  /  2 a[i] + b[i]
+  xyzz2 r;
+  if (op == 3) r = xyzz2_add_quad(A, B, q);                                         // 2 a[i] + b[i]
+  else if (op == 4) r = xyzz2_dbl_quad(A, q);                                       // 4 a[i]
+  else if (op == 5) r = xyzz2_quad_to_std(xyzz2_add_quad_lazy(xyzz2_dbl_quad_lazy(A, q), B, q));                       // lazy chain: 4 a[i] + b[i]
+  else r = xyzz2_quad_to_std(xyzz2_dbl_quad_lazy(xyzz2_dbl_quad_lazy(xyzz2_dbl_quad_lazy(A, q), q), q));                // lazy chain: 16 a[i]
   if (q == 0) store_jacobian2(r, out + i * 48);
 }
 
