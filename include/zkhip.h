@@ -200,6 +200,21 @@ int zkhip_fr_gather_mul_device(const void *d_a, size_t a_len, const void *d_inde
  * num is preserved, den is overwritten (inverted in place), z may alias num. */
 int zkhip_fr_grand_product(const uint64_t *num, const uint64_t *den, size_t n, uint64_t *z);
 int zkhip_fr_grand_product_device(const void *d_num, void *d_den, size_t n, void *d_z, void *stream);
+/* The permutation argument's grand products, every set in one call: [DEP] halo2-axiom plonk/permutation/prover.rs `Argument::commit`
+ * (the loop over `columns.chunks(chunk_len)`; reached from create_proof, /root/reference/aggregator/src/wrapper.rs:129).  `values[c]` / `sigmas[c]`
+ * are the Lagrange values of permutation column c and of its sigma polynomial (2^log_n rows each); set s holds columns
+ * [s chunk_len, min((s + 1) chunk_len, n_columns)); `usable_rows` = n - (blinding_factors + 1), `delta` = Fr::DELTA, `omega` the domain's
+ * generator.  z is [ceil(n_columns / chunk_len)][2^log_n], dense:
+ *     z_0[0] = 1,  z_s[0] = z_(s-1)[usable_rows],  z_s[i + 1] = z_s[i] prod_j (v_j[i] + beta delta^c omega^i + gamma) / (v_j[i] + beta sigma_j[i] + gamma)
+ * for i < usable_rows; the rows after usable_rows repeat z_s[usable_rows] (the caller overwrites them with its blinding scalars, as the
+ * reference does).  Zero denominators count as zero, like BatchInvert.  A handful of launches whatever the number of sets: the chained
+ * products of all sets are one prefix product over the [sets][n] array. */
+int zkhip_permutation_products(const uint64_t *const *values, const uint64_t *const *sigmas, uint32_t n_columns, uint32_t chunk_len, uint32_t log_n,
+                               size_t usable_rows, const uint64_t beta[4], const uint64_t gamma[4], const uint64_t delta[4], const uint64_t omega[4],
+                               uint64_t *z);
+int zkhip_permutation_products_device(const void *const *d_values, const void *const *d_sigmas, uint32_t n_columns, uint32_t chunk_len, uint32_t log_n,
+                                      size_t usable_rows, const uint64_t beta[4], const uint64_t gamma[4], const uint64_t delta[4],
+                                      const uint64_t omega[4], void *d_z, void *stream);
 
 /* `permute_expression_pair` of the lookup argument [DEP plonk/lookup/prover.rs]: the first `usable_rows` rows of `input` sorted by
  * canonical value into permuted_input; permuted_table holds, at the first row of every run of equal input values, that value, and at

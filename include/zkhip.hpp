@@ -346,6 +346,27 @@ inline std::vector<Fr> grand_product(const std::vector<Fr>& num, const std::vect
   if (!num.empty()) check(zkhip_fr_grand_product(num.data()->l, den.data()->l, num.size(), z.data()->l), "grand_product");
   return z;
 }
+// plonk::permutation::prover `Argument::commit`: the product column of every set of `chunk_len` permutation columns in one call, chained
+// through z[usable_rows]; `values[c]` / `sigmas[c]` are the Lagrange values of permutation column c and of its sigma polynomial.  The
+// rows after usable_rows repeat z[usable_rows]: the caller writes its blinding scalars there, as the reference does.
+inline std::vector<std::vector<Fr>> permutation_products(const std::vector<std::vector<Fr>>& values, const std::vector<std::vector<Fr>>& sigmas, uint32_t chunk_len,
+                                                         uint32_t log_n, size_t usable_rows, const Fr& beta, const Fr& gamma, const Fr& delta, const Fr& omega) {
+  if (values.size() != sigmas.size() || chunk_len == 0) throw std::invalid_argument("permutation_products: values / sigmas / chunk_len");
+  const size_t n = size_t(1) << log_n, sets = (values.size() + chunk_len - 1) / chunk_len;
+  std::vector<const uint64_t*> vp(values.size()), sp(values.size());
+  for (size_t c = 0; c < values.size(); c++) {
+    if (values[c].size() != n || sigmas[c].size() != n) throw std::invalid_argument("permutation_products: a column is not 2^log_n rows long");
+    vp[c] = values[c].data()->l;
+    sp[c] = sigmas[c].data()->l;
+  }
+  std::vector<Fr> flat(sets * n);
+  if (!values.empty())
+    check(zkhip_permutation_products(vp.data(), sp.data(), (uint32_t)values.size(), chunk_len, log_n, usable_rows, beta.l, gamma.l, delta.l, omega.l, flat.data()->l),
+          "permutation_products");
+  std::vector<std::vector<Fr>> z(sets);
+  for (size_t s = 0; s < sets; s++) z[s].assign(flat.begin() + s * n, flat.begin() + (s + 1) * n);
+  return z;
+}
 // plonk::lookup::prover::permute_expression_pair on the usable rows; throws (like the reference's ConstraintSystemFailure) when an
 // input value is missing from the table
 inline std::pair<std::vector<Fr>, std::vector<Fr>> permute_expression_pair(const std::vector<Fr>& input, const std::vector<Fr>& table,

@@ -128,9 +128,11 @@ pub(crate) struct DeviceProof {
 //   lookups, theta         compressed input / table expressions = DevCols::eval_rows(&lower_expression(..)) over base columns (a lookup of plain
 //                          columns needs no program); base.lookup_permute(..) writes the permuted pair; blinding rows:
 //                          base.upload(col, usable_rows, &random_rows); commit_many of the pair
-//   permutation, beta/gamma  per chunk: numerator / denominator programs (prod_j (v_j + beta delta^j omega^row + gamma) with SRC_ROWPOW,
-//                          prod_j (v_j + beta sigma_j + gamma)) -> base.grand_product; chaining: download the 32 bytes z[usable_rows] of the previous
-//                          chunk, scale by a one-instruction program; blinding rows uploaded; commit_many over all chunks
+//   permutation, beta/gamma  base.permutation_products(first_perm_product, &value_addresses, &sigma_addresses, chunk_len, k, usable_rows, &beta, &gamma,
+//                          &F::DELTA, &omega): every chunk's z, chained through z[usable_rows], in one call (a handful of launches whatever the
+//                          number of chunks: hundreds at the voter / state-transition column counts); blinding rows uploaded; commit_many over
+//                          all chunks.  (Before this entry point existed: per chunk a numerator and a denominator program,
+//                          base.grand_product, a 32-byte download and a scaling program.)
 //   lookup products        (a' + beta)(s' + gamma) denominators, (compressed input + beta)(compressed table + gamma) numerators, grand_product
 //   vanishing random poly  generated on the host as upstream, committed through best_multiexp (one column; stays on the host path)
 //   y                      base.ifft_scaled_many(first_advice, all witness-dependent columns, ..): lagrange_to_coeff in place, one call

@@ -57,6 +57,9 @@ extern "C" {
     fn zkhip_fr_eval_rows_device(prog: *const VmProgram, d_columns: *const *const c_void, n_columns: u32, log_rows: u32, accumulate: c_int,
                                  d_out: *mut c_void, stream: *mut c_void) -> c_int;
     fn zkhip_fr_grand_product_device(d_num: *const c_void, d_den: *mut c_void, n: usize, d_z: *mut c_void, stream: *mut c_void) -> c_int;
+    fn zkhip_permutation_products_device(d_values: *const *const c_void, d_sigmas: *const *const c_void, n_columns: u32, chunk_len: u32, log_n: u32,
+                                         usable_rows: usize, beta: *const u64, gamma: *const u64, delta: *const u64, omega: *const u64, d_z: *mut c_void,
+                                         stream: *mut c_void) -> c_int;
     fn zkhip_lookup_permute_device(d_input: *const c_void, d_table: *const c_void, usable_rows: usize, d_permuted_input: *mut c_void,
                                    d_permuted_table: *mut c_void, stream: *mut c_void) -> c_int;
     fn zkhip_fr_eval_polynomial_batch_device(d_polys: *const *const c_void, count: usize, n: usize, point: *const u64, d_out: *mut c_void,
@@ -451,6 +454,21 @@ impl DevCols {
         // SAFETY: z aliases num as the C ABI allows
         let rc = unsafe { zkhip_fr_grand_product_device(self.at(z_col, 0), den.at(den_col, 0), n, self.at(z_col, 0), std::ptr::null_mut()) };
         if rc != 0 { warn_once("zkhip_fr_grand_product_device", rc); }
+        rc == 0
+    }
+    /// every set's product column of the permutation argument in ONE call (`permutation::Argument::commit`'s loop over
+    /// `columns.chunks(chunk_len)`): `values[c]` / `sigmas[c]` = device addresses of permutation column c and of its sigma column in the
+    /// Lagrange basis; columns [z_first, z_first + ceil(columns / chunk_len)) of self receive z, chained through z[usable_rows]; the
+    /// caller then uploads its blinding rows behind usable_rows as upstream does
+    pub(crate) fn permutation_products<F: 'static>(&self, z_first: usize, values: &[*const c_void], sigmas: &[*const c_void], chunk_len: usize, log_n: u32,
+                                                   usable_rows: usize, beta: &F, gamma: &F, delta: &F, omega: &F) -> bool {
+        let sets = (values.len() + chunk_len.max(1) - 1) / chunk_len.max(1);
+        if !is::<F, Fr>() || values.len() != sigmas.len() || chunk_len == 0 || self.len != 1usize << log_n.min(28) || z_first + sets > self.count { return false; }
+        // SAFETY: z columns are adjacent in this block (stride = len = 2^log_n elements: the dense [sets][n] layout the C ABI writes)
+        let rc = unsafe { zkhip_permutation_products_device(values.as_ptr(), sigmas.as_ptr(), values.len() as u32, chunk_len as u32, log_n, usable_rows,
+                                                            beta as *const F as *const u64, gamma as *const F as *const u64, delta as *const F as *const u64,
+                                                            omega as *const F as *const u64, self.at(z_first, 0), std::ptr::null_mut()) };
+        if rc != 0 { warn_once("zkhip_permutation_products_device", rc); }
         rc == 0
     }
     /// `permute_expression_pair`: columns (input, table) of self -> (permuted_input, permuted_table) of `out`, first `usable_rows` rows

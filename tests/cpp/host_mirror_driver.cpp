@@ -5,7 +5,8 @@
 //   out: omega, extended_omega (Fr each), commit (G1), best_fft(poly, omega), lagrange_to_coeff(poly), coeff_to_extended(poly),
 //        divide_by_vanishing_poly(ext), extended_to_coeff(ext), eval_polynomial(poly, omega), kate_division(poly, omega),
 //        grand_product, permute_expression_pair (2 vectors of 2^k - 6), a row program's output column,
-//        setup(k, s): g[0..4), commit(poly), commit_lagrange(poly)
+//        setup(k, s): g[0..4), commit(poly), commit_lagrange(poly), ...; permutation_products (2 sets of 2^k)
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <sstream>
@@ -112,6 +113,16 @@ int main(int argc, char** argv) {
       const std::vector<G1Affine> gl = g_to_lagrange(ps.get_g(), k);
       const uint64_t same_gl = std::memcmp(gl.data(), ps.get_g_lagrange().data(), n * sizeof(G1Affine)) == 0 ? 1 : 0;
       fwrite(&same_gl, 8, 1, out);
+    }
+    // permutation argument: 3 columns in sets of 2 -- columns = rotations of the polynomial's values, sigmas = other rotations; beta / gamma = omega / omega^2
+    {
+      std::vector<std::vector<Fr>> vals(3, poly), sig(3, poly);
+      for (size_t c = 0; c < 3; c++) {
+        std::rotate(vals[c].begin(), vals[c].begin() + (c + 1), vals[c].end());
+        std::rotate(sig[c].begin(), sig[c].begin() + 5 * (c + 1), sig[c].end());
+      }
+      const Fr beta = domain.get_omega(), gamma = detail::from_u64(12345);
+      for (const auto& z : permutation_products(vals, sig, 2, k, n - 6, beta, gamma, fr_delta(), domain.get_omega())) put(out, z);
     }
     fclose(out);
     // error behaviour: the reference's assert_eq!(coeffs.len(), bases.len())

@@ -102,7 +102,7 @@ int main(int argc, char **argv) {
   long fsz;
   unsigned char *blob;
   uint32_t k, ek, G, NL, nperm, nsets, chunk, blind, ncol, q_fixed, q_advice, q_l0, q_sigma, q_perm, q_lookup, period, i, j, si;
-  uint64_t om_inv[4], divisor[4], ext_om[4], ext_om_inv[4], ext_div[4], zeta[4], xpt[4];
+  uint64_t om_inv[4], divisor[4], ext_om[4], ext_om_inv[4], ext_div[4], zeta[4], xpt[4], omega[4], delta[4], beta[4], gamma[4];
   const uint64_t *t_eval;
   zkhip_vm_program to_mont, perm_num[16], perm_den[16], lk_num, lk_den, eval_h;
   size_t n, en, u, nadv, nproof, first_proof2;
@@ -117,10 +117,10 @@ int main(int argc, char **argv) {
   if (fread(blob, 1, (size_t)fsz, f) != (size_t)fsz) { fprintf(stderr, "short read\n"); return 2; }
   fclose(f);
   rd_ptr = blob; rd_end = blob + fsz;
-  if (memcmp(rd(4), "ZKPS", 4) != 0 || rd_u32() != 1) { fprintf(stderr, "not a prover-sequence record\n"); return 2; }
+  if (memcmp(rd(4), "ZKPS", 4) != 0 || rd_u32() != 2) { fprintf(stderr, "not a prover-sequence record (version 2)\n"); return 2; }
   k = rd_u32(); ek = rd_u32(); G = rd_u32(); NL = rd_u32(); nperm = rd_u32(); nsets = rd_u32(); chunk = rd_u32(); blind = rd_u32();
   ncol = rd_u32(); q_fixed = rd_u32(); q_advice = rd_u32(); q_l0 = rd_u32(); q_sigma = rd_u32(); q_perm = rd_u32(); q_lookup = rd_u32();
-  rd_fr(om_inv); rd_fr(divisor); rd_fr(ext_om); rd_fr(ext_om_inv); rd_fr(ext_div); rd_fr(zeta); rd_fr(xpt);
+  rd_fr(om_inv); rd_fr(divisor); rd_fr(ext_om); rd_fr(ext_om_inv); rd_fr(ext_div); rd_fr(zeta); rd_fr(xpt); rd_fr(omega); rd_fr(delta); rd_fr(beta); rd_fr(gamma);
   period = rd_u32();
   t_eval = (const uint64_t *)rd_copy((size_t)period * 32);
   if (NL != 1 || nsets > 16 || q_fixed != 0) { fprintf(stderr, "shape not supported by this program\n"); return 2; }
@@ -243,7 +243,12 @@ int main(int argc, char **argv) {
       /* 3. grand products: permutation sets (chained), lookup; commitments */
       {
         uint64_t *den = xmalloc(n * 32), last[4] = {0, 0, 0, 0};
-        for (si = 0; si < nsets; si++) {
+        if (mode == 1) {                                  /* every set in ONE call; z sets are adjacent in proof_flat: the dense [sets][n] layout */
+          for (j = 0; j < nperm; j++) { cptr[j] = PCOL(j); cptr[nperm + j] = lag[q_sigma + j]; }
+          OK(zkhip_permutation_products(cptr, cptr + nperm, nperm, chunk, k, u, beta, gamma, delta, omega, col[q_perm]));
+          for (si = 0; si < nsets; si++) memcpy(col[q_perm + si] + 4 * (u + 1), BLIND_ROWS(si) + 4, (n - u - 1) * 32);
+        }
+        for (si = 0; si < nsets && mode == 0; si++) {
           const uint32_t lo = si * chunk, hi = lo + chunk < nperm ? lo + chunk : nperm, cnt = hi - lo;
           uint64_t *z = col[q_perm + si];
           for (j = 0; j < cnt; j++) { cptr[j] = PCOL(lo + j); cptr[cnt + j] = lag[q_sigma + lo + j]; }
@@ -360,29 +365,11 @@ int main(int argc, char **argv) {
         OK(zkhip_upload(ps + u * 32, BLIND_ROWS(nsets + 2), (n - u) * 32));
         OK(zkhip_msm_g1_registered_batch_device(gl, pa, n, 2, n, d_out + 96 * c, NULL)); c += 2;
       }
-      /* 3. grand products on the device; one 32-byte read-back per set for the chaining factor (the transcript would see z's commitment only) */
+      /* 3. grand products on the device: every permutation set in ONE call (chained on the device: no read-back), then the lookup's */
       {
-        uint64_t last[4] = {0, 0, 0, 0};
-        for (si = 0; si < nsets; si++) {
-          const uint32_t lo = si * chunk, hi = lo + chunk < nperm ? lo + chunk : nperm, cnt = hi - lo;
-          char *z = DLAG(nadv + si);
-          for (j = 0; j < cnt; j++) { dptr[j] = DPCOL(lo + j); dptr[cnt + j] = d_sigma_lag + (size_t)(lo + j) * n * 32; }
-          OK(zkhip_fr_eval_rows_device(&perm_num[si], dptr, cnt, k, 0, z, NULL));
-          OK(zkhip_fr_eval_rows_device(&perm_den[si], dptr, 2 * cnt, k, 0, d_den, NULL));
-          OK(zkhip_fr_grand_product_device(z, d_den, n, z, NULL));
-          if (si > 0) {
-            zkhip_vm_insn ins;
-            zkhip_vm_program sc;
-            const int32_t rot0 = 0;
-            memset(&ins, 0, sizeof(ins)); memset(&sc, 0, sizeof(sc));
-            ins.op = ZKHIP_OP_MUL; ins.dst = 0; ins.a.kind = ZKHIP_SRC_COLUMN; ins.a.index = 0; ins.a.rot = 0; ins.b.kind = ZKHIP_SRC_CONST; ins.b.index = 0;
-            sc.insns = &ins; sc.n_insns = 1; sc.constants = last; sc.n_constants = 1; sc.rotations = &rot0; sc.n_rotations = 1; sc.rot_scale = 1; sc.result_reg = 0;
-            dptr[0] = z;
-            OK(zkhip_fr_eval_rows_device(&sc, dptr, 1, k, 0, z, NULL));        /* in place: the column is read at rotation 0 only */
-          }
-          OK(zkhip_download(last, z + u * 32, 32));
-          OK(zkhip_upload(z + (u + 1) * 32, BLIND_ROWS(si) + 4, (n - u - 1) * 32));
-        }
+        for (j = 0; j < nperm; j++) { dptr[j] = DPCOL(j); dptr[nperm + j] = d_sigma_lag + (size_t)j * n * 32; }
+        OK(zkhip_permutation_products_device(dptr, dptr + nperm, nperm, chunk, k, u, beta, gamma, delta, omega, DLAG(nadv), NULL));
+        for (si = 0; si < nsets; si++) OK(zkhip_upload(DLAG(nadv + si) + (u + 1) * 32, BLIND_ROWS(si) + 4, (n - u - 1) * 32));
         {
           char *zl = DLAG(nadv + nsets);
           dptr[0] = DLAG(G); dptr[1] = d_table_lag;

@@ -705,6 +705,23 @@ def test_cpp_host_mirror(cref, tmp_path):
     assert F.g1_decode_jacobian(take(1, 12)[0]) == F.g1_decode_jacobian(c2)
     assert int(take(1, 1)[0, 0]) == 1
     assert int(take(1, 1)[0, 0]) == 1                        # g_to_lagrange(setup.g) == setup.g_lagrange
+    # permutation_products: 3 columns (rotations of the polynomial's values) in sets of 2, chained through z[n - 6]
+    vals = [pv[c + 1:] + pv[:c + 1] for c in range(3)]
+    sig = [pv[5 * (c + 1):] + pv[:5 * (c + 1)] for c in range(3)]
+    beta, gamma, usable, last = dom.omega, 12345, n - 6, 1
+    for lo in (0, 2):
+        z = [last]
+        for i in range(n - 1):
+            if i < usable:
+                a = b = 1
+                for c in range(lo, min(lo + 2, 3)):
+                    a = a * (vals[c][i] + pow(O.FR_DELTA, c, O.R_MOD) * beta % O.R_MOD * pow(dom.omega, i, O.R_MOD) + gamma) % O.R_MOD
+                    b = b * (vals[c][i] + beta * sig[c][i] + gamma) % O.R_MOD
+                z.append(z[-1] * a % O.R_MOD * pow(b, -1, O.R_MOD) % O.R_MOD)
+            else:
+                z.append(z[-1])
+        last = z[usable]
+        assert F.fr_decode(take(n, 4)) == z
     assert pos == raw.size
 
 

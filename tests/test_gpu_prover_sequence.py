@@ -43,16 +43,16 @@ def test_prover_patch_call_sequence_from_c99(tmp_path, k, gate_cols):
 
 
 def test_exported_programs_record_is_well_formed():
-    """(CPU) the record's header and the count of programs: magic, shape words, 7 domain constants, t_evaluations, then
+    """(CPU) the record's header and the count of programs: magic, shape words, 11 constants (domain, x, omega, delta, beta, gamma), t_evaluations, then
     to_mont + 2 * sets + 2 + 1 programs, consumed to the last byte"""
     import struct
 
     k, G = 9, 2
     b = E.export_prover_programs(k, G, 1)
-    assert b[:4] == b"ZKPS" and struct.unpack_from("<I", b, 4)[0] == 1
+    assert b[:4] == b"ZKPS" and struct.unpack_from("<I", b, 4)[0] == 2
     kk, ek, g, nl, nperm, nsets, chunk, blind = struct.unpack_from("<8I", b, 8)
     assert (kk, ek, g, nl, nperm, nsets, chunk, blind) == (k, k + 2, G, 1, G + 2, 2, 2, 5)
-    off = 8 + 32 + 28 + 7 * 32
+    off = 8 + 32 + 28 + 11 * 32
     period = struct.unpack_from("<I", b, off)[0]
     off += 4 + period * 32
     assert period == 4

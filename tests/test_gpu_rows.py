@@ -391,3 +391,116 @@ def test_golden_prover_steps(lib):
     z = np.zeros_like(num)
     _lib.check(lib.zkhip_fr_grand_product(num.ctypes.data, den.ctypes.data, num.shape[0], z.ctypes.data))
     assert np.array_equal(z, words(gp["z"]))
+
+
+def _permutation_products_expected(vals, sig, chunk, k, usable, beta, gamma):
+    """[DEP] plonk/permutation/prover.rs written out with big integers: per set the running product of num / den over the rows below
+    `usable`, the sets chained through z[usable]; rows after `usable` repeat z[usable] (the caller's blinding rows)"""
+    n, omega = 1 << k, O.omega_for(k)
+    out, last = [], 1
+    for lo in range(0, len(vals), chunk):
+        z = [last]
+        for i in range(n - 1):
+            if i < usable:
+                a = b = 1
+                for c in range(lo, min(lo + chunk, len(vals))):
+                    a = a * (vals[c][i] + pow(O.FR_DELTA, c, R) * beta % R * pow(omega, i, R) + gamma) % R
+                    b = b * (vals[c][i] + beta * sig[c][i] + gamma) % R
+                z.append(z[-1] * a % R * pow(b, -1, R) % R if b else 0)
+            else:
+                z.append(z[-1])
+        last = z[usable]
+        out.append(z)
+    return out
+
+
+@pytest.mark.parametrize("k,nperm,chunk", [(6, 5, 2), (5, 1, 2), (7, 6, 3), (4, 9, 1), (9, 4, 4)])
+def test_permutation_products_every_set_in_one_call(lib, k, nperm, chunk):
+    """zkhip_permutation_products (host buffers) == the permutation argument's products written out; the device form on the same columns ==
+    the host form"""
+    import torch
+
+    rng = random.Random(1000 * k + nperm)
+    n, usable = 1 << k, (1 << k) - 6
+    beta, gamma = rng.randrange(R), rng.randrange(R)
+    vals = [[rng.randrange(R) for _ in range(n)] for _ in range(nperm)]
+    sig = [[rng.randrange(R) for _ in range(n)] for _ in range(nperm)]
+    nsets = -(-nperm // chunk)
+    V, S = [enc(c) for c in vals], [enc(c) for c in sig]
+    consts = [F.fr_encode([x])[0] for x in (beta, gamma, O.FR_DELTA, O.omega_for(k))]
+    z = np.zeros((nsets * n, 4), dtype=np.uint64)
+    vp, sp = (C.c_void_p * nperm)(*[a.ctypes.data for a in V]), (C.c_void_p * nperm)(*[a.ctypes.data for a in S])
+    _lib.check(lib.zkhip_permutation_products(vp, sp, nperm, chunk, k, usable, *[c.ctypes.data for c in consts], z.ctypes.data))
+    exp = _permutation_products_expected(vals, sig, chunk, k, usable, beta, gamma)
+    got = F.fr_decode(z)
+    for s in range(nsets):
+        assert got[s * n:(s + 1) * n] == exp[s], f"set {s}"
+    dev = torch.device("cuda", 0)
+    dV = [torch.from_numpy(a.view(np.int64)).to(dev) for a in V]
+    dS = [torch.from_numpy(a.view(np.int64)).to(dev) for a in S]
+    dz = torch.zeros((nsets * n, 4), dtype=torch.int64, device=dev)
+    vp, sp = (C.c_void_p * nperm)(*[t.data_ptr() for t in dV]), (C.c_void_p * nperm)(*[t.data_ptr() for t in dS])
+    _lib.check(lib.zkhip_permutation_products_device(vp, sp, nperm, chunk, k, usable, *[c.ctypes.data for c in consts], dz.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert np.array_equal(dz.cpu().numpy().view(np.uint64), z)
+
+
+def test_permutation_products_equal_the_row_program_path_at_2p14(lib):
+    """the one-call form against the composition it replaces (numerator / denominator row programs, zkhip_fr_grand_product, chaining by a
+    scaling program) on 7 columns in sets of 2 at k = 14, with a zero denominator in the second set (every later value is zero, like BatchInvert)"""
+    import torch
+
+    k, nperm, chunk = 14, 7, 2
+    n, usable = 1 << k, (1 << k) - 6
+    dev = torch.device("cuda", 0)
+    rng = random.Random(5)
+    beta, gamma = rng.randrange(R), rng.randrange(R)
+    g = torch.Generator(device="cpu"); g.manual_seed(11)
+
+    def rand_cols(m):
+        a = torch.randint(-(1 << 63), (1 << 63) - 1, (m, n, 4), dtype=torch.int64, generator=g)
+        a[:, :, 3] = torch.randint(0, 1 << 61, (m, n), dtype=torch.int64, generator=g)
+        return a
+
+    V, S = rand_cols(nperm), rand_cols(nperm)
+    # a zero denominator: v + beta sigma + gamma = 0 at row 100 of column 2 (set 1)
+    v100 = F.fr_decode(V[2, 100:101].numpy().view(np.uint64))[0]
+    sig100 = (-(v100 + gamma)) * pow(beta, -1, R) % R
+    S[2, 100] = torch.from_numpy(F.fr_encode([sig100]).view(np.int64))[0]
+    dV, dS = V.to(dev), S.to(dev)
+    nsets = -(-nperm // chunk)
+    consts = [F.fr_encode([x])[0] for x in (beta, gamma, O.FR_DELTA, O.omega_for(k))]
+    dz = torch.zeros((nsets, n, 4), dtype=torch.int64, device=dev)
+    vp, sp = (C.c_void_p * nperm)(*[dV[i].data_ptr() for i in range(nperm)]), (C.c_void_p * nperm)(*[dS[i].data_ptr() for i in range(nperm)])
+    _lib.check(lib.zkhip_permutation_products_device(vp, sp, nperm, chunk, k, usable, *[c.ctypes.data for c in consts], dz.data_ptr(), None))
+    torch.cuda.synchronize()
+    last = 1
+    for s in range(nsets):
+        lo, hi = s * chunk, min((s + 1) * chunk, nperm)
+        num = torch.empty((n, 4), dtype=torch.int64, device=dev)
+        den = torch.empty((n, 4), dtype=torch.int64, device=dev)
+        E.permutation_numerator_program(hi - lo, lo, beta, gamma, k).run_device([dV[c].data_ptr() for c in range(lo, hi)], k, num.data_ptr())
+        E.permutation_denominator_program(hi - lo, beta, gamma).run_device([dV[c].data_ptr() for c in range(lo, hi)] + [dS[c].data_ptr() for c in range(lo, hi)], k, den.data_ptr())
+        _lib.check(lib.zkhip_fr_grand_product_device(num.data_ptr(), den.data_ptr(), n, num.data_ptr(), None))
+        torch.cuda.synchronize()
+        zs = F.fr_decode(num[:usable + 1].cpu().numpy().view(np.uint64))
+        got = F.fr_decode(dz[s, :usable + 1].cpu().numpy().view(np.uint64))
+        assert got == [last * x % R for x in zs], f"set {s}"
+        tail = F.fr_decode(dz[s, usable:].cpu().numpy().view(np.uint64))
+        assert tail == [tail[0]] * len(tail)
+        last = got[usable]
+    assert last == 0
+
+
+def test_permutation_products_reject_bad_arguments(lib):
+    col = enc([1, 2, 3, 4])
+    z = np.zeros((4, 4), dtype=np.uint64)
+    one = F.fr_encode([1])[0]
+    ptrs = (C.c_void_p * 1)(col.ctypes.data)
+    null = (C.c_void_p * 1)(None)
+    args = (one.ctypes.data,) * 4
+    assert lib.zkhip_permutation_products(ptrs, ptrs, 1, 0, 2, 3, *args, z.ctypes.data) == -1          # chunk_len 0
+    assert lib.zkhip_permutation_products(ptrs, ptrs, 1, 2, 2, 5, *args, z.ctypes.data) == -1          # usable_rows > n
+    assert lib.zkhip_permutation_products(ptrs, null, 1, 2, 2, 3, *args, z.ctypes.data) == -1          # a null column
+    assert lib.zkhip_permutation_products(ptrs, ptrs, 1, 2, 2, 3, *args, None) == -1
+    assert lib.zkhip_permutation_products(ptrs, ptrs, 0, 2, 2, 3, *args, None) == 0                    # no columns: nothing to do

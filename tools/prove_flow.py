@@ -212,26 +212,18 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk
             return t_
 
         sigma = [from_key(dpk.permutation_values(i), k) for i in range(len(perm_cols))]
-        # every set's product starts at 1 and is computed without a host round trip; ONE read-back of the sets' last usable values then gives the
-        # chaining factors z_k[0] = z_{k-1}[u] (with hundreds of columns a per-set read-back was most of this phase)
-        z_sets = []
-        for si in range(cs.num_permutation_sets):
-            lo, hi = si * cs.chunk_len, min((si + 1) * cs.chunk_len, len(perm_cols))
-            vals = [pcol(c) for c in range(lo, hi)]
-            num = run_prog(E.permutation_numerator_program(hi - lo, lo, beta, gamma, k), vals, k)
-            den = run_prog(E.permutation_denominator_program(hi - lo, beta, gamma), vals + sigma[lo:hi], k)
-            _lib.check(lib.zkhip_fr_grand_product_device(num.data_ptr(), den.data_ptr(), n, num.data_ptr(), None))
-            z_sets.append(num)
-        lasts = F.fr_decode(torch.stack([z[u] for z in z_sets]).cpu().numpy().view(np.uint64).reshape(-1, 4))
-        last_z = 1
-        for si, own_last in enumerate(lasts):
-            if last_z != 1:                                                        # chain: z_k[0] = z_{k-1}[u]
-                sc = E.RowProgram()
-                sc.emit(E.OP_MUL, 0, sc.column(0), sc.constant(last_z))
-                z_sets[si] = run_prog(sc, [z_sets[si]], k)
-            last_z = last_z * own_last % R
-            z_sets[si][u + 1:] = rand_fr(n - u - 1)                                # blinding rows
-        perm_closes = last_z == 1
+        # every set's product column in ONE call (zkhip_permutation_products_device: the sets are chained on the device through z[u]); one
+        # read-back of the last set's z[u] says whether the argument closes
+        nsets_, npc = cs.num_permutation_sets, len(perm_cols)
+        z_all = torch.empty((nsets_, n, 4), dtype=torch.int64, device=dev)
+        vptr = (C.c_void_p * npc)(*[pcol(c).data_ptr() for c in range(npc)])
+        sptr = (C.c_void_p * npc)(*[sg.data_ptr() for sg in sigma])
+        pconsts = [F.fr_encode([v_])[0] for v_ in (beta, gamma, E.DELTA, F.omega_for(k))]
+        _lib.check(lib.zkhip_permutation_products_device(vptr, sptr, npc, cs.chunk_len, k, u, *[c_.ctypes.data for c_ in pconsts], z_all.data_ptr(), None))
+        z_sets = [z_all[si] for si in range(nsets_)]
+        perm_closes = F.fr_decode(z_all[nsets_ - 1, u:u + 1].cpu().numpy().view(np.uint64))[0] == 1
+        for z in z_sets:
+            z[u + 1:] = rand_fr(n - u - 1)                                         # blinding rows
         lap("permutation_products")
 
         # ---- lookup argument ---------------------------------------------------------------------------------------------------

@@ -91,6 +91,9 @@ _SIGS = {
     "zkhip_g1_compress_device": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),
     "zkhip_g1_decompress": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]),
     "zkhip_g1_decompress_device": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.c_void_p]),
+    "zkhip_permutation_products": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "zkhip_permutation_products_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                    C.c_void_p, C.c_void_p]),
     "zkhip_profile_enable": (C.c_int, [C.c_int]),
     "zkhip_profile_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "zkhip_profile_read_calls": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),

@@ -1819,6 +1819,63 @@ int zkhip_fr_grand_product(const uint64_t* num, const uint64_t* den, size_t n, u
   return ZKHIP_OK;
 }
 
+static int perm_args_ok(const void* const* values, const void* const* sigmas, uint32_t n_columns, uint32_t chunk_len, uint32_t log_n, size_t usable_rows,
+                        const uint64_t* beta, const uint64_t* gamma, const uint64_t* delta, const uint64_t* omega, const void* z) {
+  if (n_columns == 0) return ZKHIP_OK;
+  if (!values || !sigmas || !beta || !gamma || !delta || !omega || !z) { set_error("permutation_products: null pointer"); return ZKHIP_EINVAL; }
+  if (chunk_len == 0 || log_n > 28 || usable_rows > ((size_t)1 << log_n)) {
+    set_error("permutation_products: bad shape (chunk_len %u, log_n %u, usable_rows %zu)", chunk_len, log_n, usable_rows);
+    return ZKHIP_EINVAL;
+  }
+  for (uint32_t i = 0; i < n_columns; i++)
+    if (!values[i] || !sigmas[i]) { set_error("permutation_products: column %u is null", i); return ZKHIP_EINVAL; }
+  return ZKHIP_OK;
+}
+
+int zkhip_permutation_products_device(const void* const* d_values, const void* const* d_sigmas, uint32_t n_columns, uint32_t chunk_len, uint32_t log_n,
+                                      size_t usable_rows, const uint64_t beta[4], const uint64_t gamma[4], const uint64_t delta[4], const uint64_t omega[4],
+                                      void* d_z, void* stream) {
+  ZK_API_RANGE();
+  guard_t g(g_mu);
+  int rc = ensure_init();
+  if (rc != ZKHIP_OK) return rc;
+  if ((rc = perm_args_ok(d_values, d_sigmas, n_columns, chunk_len, log_n, usable_rows, beta, gamma, delta, omega, d_z)) != ZKHIP_OK) return rc;
+  if (n_columns == 0) return ZKHIP_OK;
+  hipStream_t s = caller_stream(stream);
+  scratch* sc = scratch_for(primary(), s);
+  if ((rc = sc->ws.reserve(perm_workspace_bytes(n_columns, chunk_len, log_n))) != ZKHIP_OK) return rc;
+  return fr_permutation_products_device(d_values, d_sigmas, n_columns, chunk_len, log_n, usable_rows, (const uint32_t*)beta, (const uint32_t*)gamma,
+                                        (const uint32_t*)delta, (const uint32_t*)omega, (uint32_t*)d_z, sc->ws.p, sc->ws.cap, s);
+}
+
+int zkhip_permutation_products(const uint64_t* const* values, const uint64_t* const* sigmas, uint32_t n_columns, uint32_t chunk_len, uint32_t log_n,
+                               size_t usable_rows, const uint64_t beta[4], const uint64_t gamma[4], const uint64_t delta[4], const uint64_t omega[4],
+                               uint64_t* z) {
+  ZK_API_RANGE();
+  int rc;
+  if ((rc = perm_args_ok((const void* const*)values, (const void* const*)sigmas, n_columns, chunk_len, log_n, usable_rows, beta, gamma, delta, omega, z)) != ZKHIP_OK)
+    return rc;
+  if (n_columns == 0) return ZKHIP_OK;
+  lane_hold H;
+  if (H.rc != ZKHIP_OK) return H.rc;
+  hipStream_t s = H.s;
+  const size_t n = (size_t)1 << log_n, bytes = n * 32, nsets = (n_columns + chunk_len - 1) / chunk_len;
+  if ((rc = H.sc->poly.reserve((size_t)2 * n_columns * bytes)) != ZKHIP_OK) return rc;
+  if ((rc = H.sc->poly2.reserve(nsets * bytes)) != ZKHIP_OK) return rc;
+  std::vector<const void*> d_cols((size_t)2 * n_columns);
+  for (uint32_t i = 0; i < n_columns; i++) {
+    d_cols[i] = (char*)H.sc->poly.p + (size_t)i * bytes;
+    d_cols[n_columns + i] = (char*)H.sc->poly.p + (size_t)(n_columns + i) * bytes;
+    HIPCHK(hipMemcpyAsync((void*)d_cols[i], values[i], bytes, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync((void*)d_cols[n_columns + i], sigmas[i], bytes, hipMemcpyHostToDevice, s));
+  }
+  if ((rc = zkhip_permutation_products_device(d_cols.data(), d_cols.data() + n_columns, n_columns, chunk_len, log_n, usable_rows, beta, gamma, delta, omega,
+                                              H.sc->poly2.p, s)) != ZKHIP_OK) return rc;
+  HIPCHK(hipMemcpyAsync(z, H.sc->poly2.p, nsets * bytes, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return ZKHIP_OK;
+}
+
 int zkhip_profile_enable(int on) {
   guard_t g(g_mu);
   g_prof_mode = on == 2 ? 2 : (on != 0 ? 1 : 0);

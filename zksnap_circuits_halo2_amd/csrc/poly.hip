@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
 #include "fp29.hpp"
 #include "fe_inverse.hpp"
 #include "fr_vec.hpp"
@@ -131,22 +132,25 @@ __global__ void __launch_bounds__(256) k_prod_apply(const uint32_t* __restrict__
 // a^-1 in Fr, a internal & reduced: division steps instead of the Fermat chain a^(r-2) (fe_inverse.hpp)
 __device__ __forceinline__ fe fr_inverse(const fe& a) { return fe_inverse<Fr>(a); }
 
+// One wavefront per workgroup owns a tile of 64 * ch consecutive elements; lane l inverts the elements l, l + 64, l + 128, ... of the tile
+// (Montgomery's trick groups ANY elements: with the lanes interleaved every load and store of the wavefront is one contiguous 2 KiB run,
+// where consecutive elements per lane -- the layout of rounds 1-4 -- made each of them 64 separate 32-byte pieces 32 * ch bytes apart).
+// The parked prefix products are limb-major (scratch[limb][element]) for the same reason.
 __global__ void __launch_bounds__(64) k_batch_invert(uint32_t* __restrict__ a, size_t n, uint32_t* __restrict__ scratch, uint32_t ch) {
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t lo = t * ch;
-  if (lo >= n) return;
-  const size_t hi = lo + ch < n ? lo + ch : n;
+  const size_t first = (size_t)blockIdx.x * 64 * ch + threadIdx.x;
+  if (first >= n) return;
   // x*2^256 read as the internal form of x' = x*2^-5.  prefix products of the non-zero x' (internal form), parked in scratch
   const fe one = fe_one<Fr>();
   fe pref = one;
   uint32_t w[8];
-  for (size_t i = lo; i < hi; i++) {
+  uint32_t cnt = 0;
+  for (size_t i = first; cnt < ch && i < n; i += 64, cnt++) {
     load_words(a + i * 8, w);
     uint32_t o = 0;
 #pragma unroll
     for (int k = 0; k < 8; k++) o |= w[k];
 #pragma unroll
-    for (int k = 0; k < NL; k++) scratch[i * 9 + k] = pref.l[k];
+    for (int k = 0; k < NL; k++) scratch[(size_t)k * n + i] = pref.l[k];
     if (o) pref = fe_mul<Fr>(pref, fe_unpack<0>(w));
   }
   // inverse of the product, rescaled once so that the outputs come out in the external domain:
@@ -154,7 +158,8 @@ __global__ void __launch_bounds__(64) k_batch_invert(uint32_t* __restrict__ a, s
   fe c251 = fe_zero();
   c251.l[8] = 1u << (251 - 232);
   fe inv = fe_mul<Fr>(fr_inverse(pref), c251);
-  for (size_t i = hi; i-- > lo;) {
+  for (uint32_t j = cnt; j-- > 0;) {
+    const size_t i = first + (size_t)j * 64;
     load_words(a + i * 8, w);
     uint32_t o = 0;
 #pragma unroll
@@ -162,7 +167,7 @@ __global__ void __launch_bounds__(64) k_batch_invert(uint32_t* __restrict__ a, s
     if (!o) continue;
     fe pre;
 #pragma unroll
-    for (int k = 0; k < NL; k++) pre.l[k] = scratch[i * 9 + k];
+    for (int k = 0; k < NL; k++) pre.l[k] = scratch[(size_t)k * n + i];
     fe out = fe_mul<Fr>(inv, pre);
     inv = fe_mul<Fr>(inv, fe_unpack<0>(w));
     uint32_t wo[8];
@@ -307,6 +312,129 @@ static int prefix_product_rec(const uint32_t* d_v, size_t n, const uint32_t* car
   hipLaunchKernelGGL(k_prod_apply, grid_for(m, 256), dim3(256), 0, stream, d_v, n, (const uint32_t*)agg, d_out);
   HIPCHK(hipGetLastError());
   return ZKHIP_OK;
+}
+
+// ---- permutation argument: every set's grand product in one call ----------------------------------------------------------------
+// [DEP] halo2-axiom plonk/permutation/prover.rs `Argument::commit` (reached from create_proof, /root/reference/aggregator/src/wrapper.rs:129):
+// the permutation's columns are cut into sets of `chunk` (= degree - 2) columns; per set and row
+//     den = prod_j (v_j[i] + beta sigma_j[i] + gamma)        num = prod_j (v_j[i] + beta delta^c omega^i + gamma),  c = the column's index
+//     z_s[0] = z_(s-1)[u] (1 for the first set),  z_s[i + 1] = z_s[i] num[i] / den[i]
+// with u the last usable row.  Only the rows below u enter any set's z[u], so with the ratio of the rows >= u forced to 1 the chained
+// products of ALL sets are ONE exclusive prefix product over the [sets][n] array: set s starts at the product of the earlier sets' usable
+// rows, which is z_(s-1)[u].  Three kernels of (sets x n) threads + the scan, whatever the number of sets (the state-transition and voter
+// shapes of the reference have hundreds of columns at k = 13 .. 15: one call per set was 5 launches of 2^13 threads each, 135 times).
+
+// table[i] = scale * base^(i << shift) in the INTERNAL form (x 2^261), canonical words: fe_unpack<0> of an entry is a reduced operand
+__global__ void __launch_bounds__(256) k_pow_table_internal(fe_arg base, fe_arg scale, int has_scale, uint32_t shift, uint32_t count, uint32_t* __restrict__ table) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  fe b = fr_const_internal(base);
+  for (uint32_t s = 0; s < shift; s++) b = fe_sqr<Fr>(b);
+  fe v = fr_pow_u32(b, i);                                                          // < 2p, N
+  if (has_scale) v = fe_mul<Fr>(v, fr_const_internal(scale));
+  store_canon(table, i, v);
+}
+
+// z[s][i] = prod_j (v_j[i] + beta sigma_j[i] + gamma) over the columns of set s, external domain
+__global__ void __launch_bounds__(256) k_perm_den(const uint32_t* const* __restrict__ values, const uint32_t* const* __restrict__ sigmas, uint32_t nperm,
+                                                  uint32_t chunk, size_t n, const uint32_t* __restrict__ ctab, fe_arg gamma, uint32_t* __restrict__ z) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t s = blockIdx.y, lo = s * chunk, cnt = nperm - lo < chunk ? nperm - lo : chunk;
+  const fe b = load_ext(ctab, 0), g_int = load_ext(ctab, 1);                          // beta, gamma in the internal form (canonical: < p, N)
+  // first column in the external domain (beta_internal x sigma_external is external), the others in the internal one: external x internal
+  // products stay external, so the result needs no conversion.  Sums of three: limbs < 3 * 2^29.
+  fe acc = fe_add(fe_add(load_ext(values[lo], i), fe_mul<Fr>(b, load_ext(sigmas[lo], i))), fe_unpack<0>(gamma.w));     // < 4p
+  for (uint32_t j = 1; j < cnt; j++) {
+    uint32_t wv[8], ws[8];
+    load_words(values[lo + j] + i * 8, wv);
+    load_words(sigmas[lo + j] + i * 8, ws);
+    const fe t = fe_add(fe_add(fe_unpack<5>(wv), fe_mul<Fr>(b, fe_unpack<5>(ws))), g_int);                              // < 36p
+    acc = fe_mul<Fr>(fe_norm(acc), t);                                                                                 // 4 * 36 < 169: < 2p, N
+  }
+  if (cnt == 1) acc = fe_mul<Fr>(fe_norm(acc), fe_one<Fr>());                                                         // reduce the lone sum
+  store_canon(z + (size_t)s * n * 8, i, acc);
+}
+
+// z[s][i] <- z[s][i] * prod_j (v_j[i] + (beta delta^c) omega^i + gamma) for i < usable, 1 for the rows from `usable` on
+__global__ void __launch_bounds__(256) k_perm_num_mul(const uint32_t* const* __restrict__ values, uint32_t nperm, uint32_t chunk, size_t n, size_t usable,
+                                                      const uint32_t* __restrict__ ctab, const uint32_t* __restrict__ dtab, const uint32_t* __restrict__ pow_lo,
+                                                      const uint32_t* __restrict__ pow_hi, uint32_t h, uint32_t* __restrict__ z) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t s = blockIdx.y, lo = s * chunk, cnt = nperm - lo < chunk ? nperm - lo : chunk;
+  uint32_t* zs = z + (size_t)s * n * 8;
+  if (i >= usable) {                                                                  // 1 in the external domain = 2^256 mod r
+    fe one;
+#pragma unroll
+    for (int k = 0; k < NL; k++) one.l[k] = Fr::TO_EXT[k];
+    store_canon(zs, i, one);
+    return;
+  }
+  const fe g_int = load_ext(ctab, 1);
+  const fe x = fe_mul<Fr>(load_ext(pow_lo, i & ((1u << h) - 1)), load_ext(pow_hi, i >> h));   // omega^i, internal, < 2p (table entries are internal forms)
+  fe acc = fe_zero();
+  for (uint32_t j = 0; j < cnt; j++) {
+    uint32_t wv[8];
+    load_words(values[lo + j] + i * 8, wv);
+    const fe t = fe_add(fe_add(fe_unpack<5>(wv), fe_mul<Fr>(load_ext(dtab, lo + j), x)), g_int);   // internal, < 36p, limbs < 3 * 2^29
+    acc = j == 0 ? t : fe_mul<Fr>(fe_norm(acc), t);                                              // 36 * 36 / 169 + 1 < 9p, then < 3p, < 2p: N
+  }
+  store_canon(zs, i, fe_mul<Fr>(load_ext(zs, i), fe_norm(acc)));                                 // external (1 / den) x internal: external, < 2p
+}
+
+size_t perm_workspace_bytes(uint32_t nperm, uint32_t chunk, uint32_t log_n) {
+  const size_t n = (size_t)1 << log_n, nsets = chunk ? (nperm + chunk - 1) / chunk : 0;
+  const uint32_t h = (log_n + 1) / 2;
+  const size_t tables = (((size_t)nperm * 16 + 255) / 256) * 256 + (((size_t)nperm * 32 + 255) / 256) * 256 + (((size_t)1 << h) + (n >> h)) * 32 + 768;
+  return tables + poly_workspace_bytes(nsets * n);
+}
+
+int fr_permutation_products_device(const void* const* d_values_host, const void* const* d_sigmas_host, uint32_t nperm, uint32_t chunk, uint32_t log_n,
+                                   size_t usable, const uint32_t beta[8], const uint32_t gamma[8], const uint32_t delta[8], const uint32_t omega[8],
+                                   uint32_t* d_z, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (nperm == 0) return ZKHIP_OK;
+  const size_t n = (size_t)1 << log_n, nsets = (nperm + chunk - 1) / chunk;
+  if (nsets > 65535) { set_error("permutation_products: more than 65535 sets"); return ZKHIP_EINVAL; }
+  if (ws_bytes < perm_workspace_bytes(nperm, chunk, log_n)) { set_error("permutation_products: workspace too small"); return ZKHIP_EINVAL; }
+  const uint32_t h = (log_n + 1) / 2;
+  char* p = (char*)ws;
+  const uint32_t** d_ptrs = (const uint32_t**)p;                  // [values ..., sigmas ...]
+  p += (((size_t)nperm * 16 + 255) / 256) * 256;
+  uint32_t* dtab = (uint32_t*)p;
+  p += (((size_t)nperm * 32 + 255) / 256) * 256;
+  uint32_t* pow_lo = (uint32_t*)p;
+  p += ((size_t)1 << h) * 32;
+  uint32_t* pow_hi = (uint32_t*)p;
+  p += (n >> h) * 32;
+  uint32_t* ctab = (uint32_t*)p;                                  // beta, gamma in the internal form: converted once, not per row
+  p += 64;
+  p = (char*)ws + ((((size_t)(p - (char*)ws)) + 255) / 256) * 256;
+  const size_t rest = ws_bytes - (size_t)(p - (char*)ws);
+  HIPCHK(hipMemcpyAsync(d_ptrs, d_values_host, (size_t)nperm * 8, hipMemcpyHostToDevice, stream));
+  HIPCHK(hipMemcpyAsync(d_ptrs + nperm, d_sigmas_host, (size_t)nperm * 8, hipMemcpyHostToDevice, stream));
+  HIPCHK(hipStreamSynchronize(stream));                           // both pointer lists are caller memory
+  fe_arg b, g, d, w;
+  memcpy(b.w, beta, 32); memcpy(g.w, gamma, 32); memcpy(d.w, delta, 32); memcpy(w.w, omega, 32);
+  hipLaunchKernelGGL(k_pow_table_internal, dim3(1), dim3(256), 0, stream, d, b, 1, 0u, 1u, ctab);            // delta^0 beta
+  hipLaunchKernelGGL(k_pow_table_internal, dim3(1), dim3(256), 0, stream, d, g, 1, 0u, 1u, ctab + 8);        // delta^0 gamma
+  hipLaunchKernelGGL(k_pow_table_internal, grid_for(nperm, 256), dim3(256), 0, stream, d, b, 1, 0u, nperm, dtab);
+  hipLaunchKernelGGL(k_pow_table_internal, grid_for((size_t)1 << h, 256), dim3(256), 0, stream, w, w, 0, 0u, 1u << h, pow_lo);
+  hipLaunchKernelGGL(k_pow_table_internal, grid_for(n >> h, 256), dim3(256), 0, stream, w, w, 0, h, (uint32_t)(n >> h), pow_hi);
+  const dim3 grid((unsigned)((n + 255) / 256), (unsigned)nsets);
+  hipLaunchKernelGGL(k_perm_den, grid, dim3(256), 0, stream, (const uint32_t* const*)d_ptrs, (const uint32_t* const*)(d_ptrs + nperm), nperm, chunk, n, (const uint32_t*)ctab, g, d_z);
+  HIPCHK(hipGetLastError());
+  prof_mark(stream, "perm_den");
+  int rc = fr_batch_invert_device(d_z, nsets * n, p, rest, stream);
+  if (rc != ZKHIP_OK) return rc;
+  prof_mark(stream, "perm_invert");
+  hipLaunchKernelGGL(k_perm_num_mul, grid, dim3(256), 0, stream, (const uint32_t* const*)d_ptrs, nperm, chunk, n, usable, (const uint32_t*)ctab, (const uint32_t*)dtab,
+                     (const uint32_t*)pow_lo, (const uint32_t*)pow_hi, h, d_z);
+  HIPCHK(hipGetLastError());
+  prof_mark(stream, "perm_num");
+  rc = fr_prefix_product_device(d_z, nsets * n, d_z, p, rest, stream);
+  prof_mark(stream, "perm_scan");
+  return rc;
 }
 
 int fr_batch_invert_device(uint32_t* d_a, size_t n, void* ws, size_t ws_bytes, hipStream_t stream) {

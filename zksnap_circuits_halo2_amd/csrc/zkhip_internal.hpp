@@ -101,6 +101,10 @@ int fr_eval_polynomial_batch_device(const void* const* d_polys_host, size_t coun
 int fr_kate_division_device(const uint32_t* d_a, size_t n, const uint32_t b_host[8], uint32_t* d_q, void* ws, size_t ws_bytes, hipStream_t stream);
 int fr_prefix_product_device(const uint32_t* d_v, size_t n, uint32_t* d_out, void* ws, size_t ws_bytes, hipStream_t stream);
 int fr_batch_invert_device(uint32_t* d_a, size_t n, void* ws, size_t ws_bytes, hipStream_t stream);
+size_t perm_workspace_bytes(uint32_t nperm, uint32_t chunk, uint32_t log_n);
+int fr_permutation_products_device(const void* const* d_values_host, const void* const* d_sigmas_host, uint32_t nperm, uint32_t chunk, uint32_t log_n,
+                                   size_t usable, const uint32_t beta[8], const uint32_t gamma[8], const uint32_t delta[8], const uint32_t omega[8],
+                                   uint32_t* d_z, void* ws, size_t ws_bytes, hipStream_t stream);
 
 // rowvm.hip
 int row_vm_validate(const zkhip_vm_program* p, uint32_t n_columns, uint32_t log_rows, int accumulate);

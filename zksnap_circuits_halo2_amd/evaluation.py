@@ -487,11 +487,12 @@ def export_prover_programs(k: int, gate_cols: int, lookups: int, seed: int = 1) 
     rng = random.Random(seed)
     beta, gamma, theta, y, x = (rng.randrange(1, F.R_MOD) for _ in range(5))
     w = lambda a: np.ascontiguousarray(a).astype("<u8").tobytes()
-    out = [struct.pack("<4sI", b"ZKPS", 1),
+    out = [struct.pack("<4sI", b"ZKPS", 2),
            struct.pack("<8I", k, dom.extended_k, gate_cols, lookups, len(cs.permutation_columns), cs.num_permutation_sets, cs.chunk_len, cs.blinding_factors),
            struct.pack("<7I", qc.total, qc.fixed, qc.advice, qc.l0, qc.sigma, qc.perm_product, qc.lookup),
            w(dom.omega_inv), w(dom.ifft_divisor), w(dom.extended_omega), w(dom.extended_omega_inv), w(dom.extended_ifft_divisor), w(dom.g_coset),
-           w(F.fr_encode([x])[0]), struct.pack("<I", dom.t_evaluations.shape[0]), w(dom.t_evaluations)]
+           w(F.fr_encode([x])[0]), w(F.fr_encode([F.omega_for(k)])[0]), w(F.fr_encode([DELTA])[0]), w(F.fr_encode([beta])[0]), w(F.fr_encode([gamma])[0]),
+           struct.pack("<I", dom.t_evaluations.shape[0]), w(dom.t_evaluations)]      # (version 2: omega, delta, beta, gamma for zkhip_permutation_products)
     to_mont = RowProgram()                # raw integer words are the Montgomery form of a / R: multiply by R
     to_mont.emit(OP_MUL, 0, to_mont.column(0), to_mont.constant(pow(2, 256, F.R_MOD)))
     progs = [to_mont]
