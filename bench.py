@@ -1235,8 +1235,23 @@ def prover_phases(lib, _lib, F, torch, dev, stream, timed) -> dict:
         lk_den.run_device(polys[6:8], k, den_b, stream=stream)
         _lib.check(lib.zkhip_fr_grand_product_device(num_b, den_b, n, num_b, stream))
 
-    ms_p = timed(products, 3)
-    res["grand_products_4_perm_sets_1_lookup_2^22"] = {"ms": round(ms_p, 3)}
+    ms_p_sets = timed(products, 3)
+    # the same 7 permutation columns in ONE call (zkhip_permutation_products_device: the sets chained on the device) + the lookup's product
+    pconsts = [F.fr_encode([v_])[0] for v_ in (beta, gamma, E.DELTA, F.omega_for(k))]
+    vptr, sptr = (C.c_void_p * 7)(*polys[:7]), (C.c_void_p * 7)(*polys[7:14])
+    z_buf = torch.empty((4, n, 4), dtype=torch.int64, device=dev)
+    z_all = z_buf.data_ptr()
+
+    def products_one_call():
+        _lib.check(lib.zkhip_permutation_products_device(vptr, sptr, 7, 2, k, n - 6, *[c_.ctypes.data for c_ in pconsts], z_all, stream))
+        lk_num.run_device(polys[4:6], k, num_b, stream=stream)
+        lk_den.run_device(polys[6:8], k, den_b, stream=stream)
+        _lib.check(lib.zkhip_fr_grand_product_device(num_b, den_b, n, num_b, stream))
+
+    ms_p = timed(products_one_call, 3)
+    del z_buf
+    res["grand_products_4_perm_sets_1_lookup_2^22"] = {"ms": round(ms_p, 3), "ms_one_call_per_set": round(ms_p_sets, 3),
+                                                       "how": "zkhip_permutation_products_device (all sets, chained on the device) + the lookup's row programs and grand product"}
     # lookup argument: permute_expression_pair on a range-check shaped pair (lookup_bits = 21: inputs below 2^21, table = the range)
     usable = n - 6
     lk_in = torch.zeros((n, 4), dtype=torch.int64, device=dev)

@@ -251,7 +251,46 @@ def fuzz_g2(seed):
     got = O.g2_jac_from_limbs([int(x) for x in A.best_multiexp_g2(sc, _g2_walk["enc"][:n])])
     assert got == O.g2_scalar_mul(Cr.expected_scalar(sc, T0, D), O.G2_GEN), f"g2 msm n={n}"
 
-fns = [fuzz_msm, fuzz_host_chunked] if LARGE else [fuzz_msm, fuzz_ntt, fuzz_poly, fuzz_rows, fuzz_lookup, fuzz_batched, fuzz_sharded, fuzz_g2]
+def fuzz_perm(seed):
+    """zkhip_permutation_products (every set of the permutation argument in one call) against the products written out with big integers"""
+    k = rng.randint(0, 9); n = 1 << k; nperm = rng.randint(1, 9); chunk = rng.randint(1, 4); usable = rng.randint(0, n)
+    beta, gamma = rng.randrange(1, R), rng.randrange(R)
+    vals = [[rng.randrange(R) if rng.random() < 0.9 else rng.choice([0, 1, R - 1]) for _ in range(n)] for _ in range(nperm)]
+    sig = [[rng.randrange(R) for _ in range(n)] for _ in range(nperm)]
+    if rng.random() < 0.2 and usable:                  # a zero denominator: every later value of every later set is zero (BatchInvert's convention)
+        c, i = rng.randrange(nperm), rng.randrange(usable)
+        sig[c][i] = (-(vals[c][i] + gamma)) * pow(beta, -1, R) % R
+    omega = O.omega_for(k)
+    exp, last = [], 1
+    for lo in range(0, nperm, chunk):
+        z = [last]
+        for i in range(n - 1):
+            if i < usable:
+                a = b = 1
+                for c in range(lo, min(lo + chunk, nperm)):
+                    a = a * (vals[c][i] + pow(O.FR_DELTA, c, R) * beta % R * pow(omega, i, R) + gamma) % R
+                    b = b * (vals[c][i] + beta * sig[c][i] + gamma) % R
+                z.append(z[-1] * a % R * pow(b, -1, R) % R if b else 0)
+            else:
+                z.append(z[-1])
+        if usable < n:
+            last = z[usable]
+        else:                                            # every row is usable: the next set starts at the product over all n rows
+            a = b = 1
+            for c in range(lo, min(lo + chunk, nperm)):
+                a = a * (vals[c][n - 1] + pow(O.FR_DELTA, c, R) * beta % R * pow(omega, n - 1, R) + gamma) % R
+                b = b * (vals[c][n - 1] + beta * sig[c][n - 1] + gamma) % R
+            last = z[-1] * a % R * pow(b, -1, R) % R if b else 0
+        exp += z
+    V, S = [F.fr_encode(c) for c in vals], [F.fr_encode(c) for c in sig]
+    consts = [F.fr_encode([x])[0] for x in (beta, gamma, O.FR_DELTA, omega)]
+    nsets = -(-nperm // chunk)
+    z = np.zeros((nsets * n, 4), dtype=np.uint64)
+    vp, sp = (C.c_void_p * nperm)(*[a.ctypes.data for a in V]), (C.c_void_p * nperm)(*[a.ctypes.data for a in S])
+    _lib.check(lib.zkhip_permutation_products(vp, sp, nperm, chunk, k, usable, *[c.ctypes.data for c in consts], z.ctypes.data))
+    assert F.fr_decode(z) == exp, f"permutation products k={k} columns={nperm} chunk={chunk} usable={usable}"
+
+fns = [fuzz_msm, fuzz_host_chunked] if LARGE else [fuzz_msm, fuzz_ntt, fuzz_poly, fuzz_rows, fuzz_lookup, fuzz_batched, fuzz_sharded, fuzz_g2, fuzz_perm]
 t_end = time.time() + budget
 it = 0
 while time.time() < t_end:
