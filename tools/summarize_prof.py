@@ -35,9 +35,13 @@ def kernel_stats(d):
     per = defaultdict(list)
     for name, dur in sqlite3.connect(dbs[0]).execute("select name, duration from kernels"): per[name].append(int(dur))
     total = sum(sum(v) for v in per.values())
-    rows = [["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"]]
+    # MedianNs (round 5) beside rocprofv3's own columns: the first launches of a process run at the clocks the card idled at (30-40 ms of work
+    # to ramp: profiles/r03_clock_ramp.txt), so the average of a short profiled run sits a few per cent above the steady state the bench line times
+    rows = [["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "MedianNs"]]
     for name, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
-        rows.append([name, len(v), sum(v), round(sum(v) / len(v), 1), round(100.0 * sum(v) / total, 2), min(v), max(v)])
+        sv = sorted(v)
+        med = sv[len(sv) // 2] if len(sv) % 2 else (sv[len(sv) // 2 - 1] + sv[len(sv) // 2]) / 2.0
+        rows.append([name, len(v), sum(v), round(sum(v) / len(v), 1), round(100.0 * sum(v) / total, 2), min(v), max(v), med])
     return rows
 
 if sys.argv[1] == "pmc_ntt":
