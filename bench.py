@@ -755,14 +755,16 @@ def extras(lib, _lib, F, torch, dev, stream) -> dict:
     p24 = ntt["2^24"]["passes_ms"]
     ntt_traffic, ntt_traffic_source = None, None
     try:   # PMC bytes per k_ntt_pass launch at 2^24: separate rocprofv3 --pmc passes (tools/collect_profiles.sh), a committed constant like roofline.traffic
-        path = os.path.join(ROOT, "profiles", "r04_pmc_traffic_ntt.json")
+        path = os.path.join(ROOT, "profiles", "r05_pmc_traffic_ntt.json")
+        if not os.path.exists(path):
+            path = os.path.join(ROOT, "profiles", "r04_pmc_traffic_ntt.json")
         if os.path.exists(path):
             rec = json.load(open(path))
             rows = [v for k_, v in rec["ntt"]["2^24"].items() if "k_ntt_pass" in k_]
             if rows:
                 tot_d = sum(v["dispatches"] for v in rows)
                 ntt_traffic = round(sum(v["hbm_bytes_per_launch"] * v["dispatches"] for v in rows) / tot_d)
-                ntt_traffic_source = f"profiles/r04_pmc_traffic_ntt.json@{rec.get('commit', '?')}: average over the k_ntt_pass launches of the 2^24 transform (FETCH_SIZE x2 + WRITE_SIZE)"
+                ntt_traffic_source = f"profiles/{os.path.basename(path)}@{rec.get('commit', '?')}: average over the k_ntt_pass launches of the 2^24 transform (FETCH_SIZE x2 + WRITE_SIZE)"
     except Exception:
         ntt_traffic, ntt_traffic_source = None, None
     if p24:
