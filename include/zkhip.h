@@ -200,6 +200,33 @@ int zkhip_fr_gather_mul_device(const void *d_a, size_t a_len, const void *d_inde
  * num is preserved, den is overwritten (inverted in place), z may alias num. */
 int zkhip_fr_grand_product(const uint64_t *num, const uint64_t *den, size_t n, uint64_t *z);
 int zkhip_fr_grand_product_device(const void *d_num, void *d_den, size_t n, void *d_z, void *stream);
+/* The KZG multi-open provers for a host that keeps its polynomials as device addresses (a Rust host's handles: rust-shim/prover_patch.rs):
+ * `ProverGWC::create_proof` (the reference's gen_snark path, /root/reference/aggregator/src/wrapper.rs:59-60, 127-137) and
+ * `ProverSHPLONK::create_proof` (the benches' gen_proof path, /root/reference/aggregator/benches/wrapper_circuit.rs:140)
+ * [DEP halo2-axiom poly/kzg/multiopen/{gwc, shplonk}/prover.rs].  A query opens the polynomial of 2^k coefficients at `d_poly` at
+ * `point`; `eval` is its value there when `has_eval` is non-zero (the prover has computed and written it to the transcript already:
+ * zkhip_fr_eval_polynomial_batch_device), otherwise the library evaluates.  Polynomials are told apart by their addresses.  `bases` is a
+ * base array registered with zkhip_register_bases (`ParamsKZG::g`): the commitments are MSMs against its first 2^k points.  The
+ * transcript stays with the host: challenges come in, commitments (Jacobian, 12 words each) go out.
+ *   GWC      one witness commitment per distinct point, in the order the points first appear among the queries; `capacity` is the room
+ *            of `out_points` in points, `*n_out` the number there are (ZKHIP_EINVAL if that is more than `capacity`).
+ *   SHPLONK  `begin` (y and v squeezed) returns H = commit(h(X)) and a state; the host writes H, squeezes u; `finish` returns H' and
+ *            releases the state whatever it returns (ZKHIP_EINVAL when an evaluation does not belong to its polynomial: the reference's
+ *            L(u) = 0 debug assertion).  The polynomials must stay alive and unchanged in between.  `abort` releases a state unused. */
+typedef struct zkhip_prover_query {
+  uint64_t point[4];
+  const void *d_poly;
+  uint64_t eval[4];
+  uint32_t has_eval;
+  uint32_t reserved;
+} zkhip_prover_query;   /* 80 bytes */
+typedef struct zkhip_shplonk zkhip_shplonk;
+int zkhip_multiopen_gwc_device(const uint64_t *bases, uint32_t k, const zkhip_prover_query *queries, size_t n_queries, const uint64_t v[4],
+                               uint64_t *out_points, size_t capacity, size_t *n_out);
+int zkhip_multiopen_shplonk_begin_device(const uint64_t *bases, uint32_t k, const zkhip_prover_query *queries, size_t n_queries, const uint64_t y[4],
+                                         const uint64_t v[4], uint64_t out_h[12], zkhip_shplonk **state);
+int zkhip_multiopen_shplonk_finish_device(zkhip_shplonk *state, const uint64_t u[4], uint64_t out_hp[12]);
+int zkhip_multiopen_shplonk_abort(zkhip_shplonk *state);
 /* The permutation argument's grand products, every set in one call: [DEP] halo2-axiom plonk/permutation/prover.rs `Argument::commit`
  * (the loop over `columns.chunks(chunk_len)`; reached from create_proof, /root/reference/aggregator/src/wrapper.rs:129).  `values[c]` / `sigmas[c]`
  * are the Lagrange values of permutation column c and of its sigma polynomial (2^log_n rows each); set s holds columns

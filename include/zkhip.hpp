@@ -18,6 +18,7 @@
 #include <array>
 #include <cstdint>
 #include <cstring>
+#include <functional>
 #include <istream>
 #include <memory>
 #include <ostream>
@@ -387,8 +388,15 @@ class DeviceVec {
   }
   DeviceVec(const DeviceVec&) = delete;
   DeviceVec& operator=(const DeviceVec&) = delete;
-  DeviceVec(DeviceVec&& o) noexcept : p_(o.p_), len_(o.len_) { o.p_ = nullptr; o.len_ = 0; }
-  ~DeviceVec() { (void)zkhip_free(p_); }
+  DeviceVec(DeviceVec&& o) noexcept : p_(o.p_), len_(o.len_), owned_(o.owned_) { o.p_ = nullptr; o.len_ = 0; }
+  ~DeviceVec() { if (owned_) (void)zkhip_free(p_); }
+  // a view of `len` elements of device memory somebody else owns (a host that keeps its polynomials as handles of its own: the C entry
+  // points zkhip_multiopen_* wrap their callers' addresses this way); never freed here
+  static DeviceVec borrow(const void* p, size_t len) {
+    DeviceVec v;
+    v.p_ = const_cast<void*>(p); v.len_ = len; v.owned_ = false;
+    return v;
+  }
   void* data() const { return p_; }
   size_t size() const { return len_; }
   std::vector<Fr> to_host() const {
@@ -398,8 +406,10 @@ class DeviceVec {
   }
 
  private:
+  DeviceVec() = default;
   void* p_ = nullptr;
   size_t len_ = 0;
+  bool owned_ = true;
 };
 
 // A row program (plonk::evaluation::GraphEvaluator lowered to include/zkhip.h's instruction set) over device-resident columns.
@@ -1178,8 +1188,13 @@ inline Fr vanishing_at(const std::vector<Fr>& points, const Fr& x) {
 }
 }  // namespace detail
 
+// how a multi-open prover commits to n device-resident coefficients: a DeviceCommitter's prepared table, or any callable (the C entry
+// points zkhip_multiopen_* commit against a base array registered with zkhip_register_bases)
+using CommitFn = std::function<G1(const void* d_coeffs)>;
+inline CommitFn commit_with(const DeviceCommitter& params) { return [&params](const void* d) { return params.commit(d); }; }
+
 // `ProverGWC::create_proof`: for every distinct point z (order of first appearance): W_z = commit((sum_i v^i p_i - sum_i v^i e_i) / (X - z))
-inline std::vector<G1> gwc_create_proof(const DeviceCommitter& params, uint32_t k, std::vector<ProverQuery> queries, const Fr& v) {
+inline std::vector<G1> gwc_create_proof(const CommitFn& commit, uint32_t k, std::vector<ProverQuery> queries, const Fr& v) {
   const size_t n = (size_t)1 << k;
   detail::evaluate_queries(queries, n);
   std::vector<Fr> points;
@@ -1204,111 +1219,143 @@ inline std::vector<G1> gwc_create_proof(const DeviceCommitter& params, uint32_t 
     detail::linear_combination(powers, cols, k, batch);
     detail::sub_const_at(batch, 0, eval_batch);
     detail::divide_by_root(batch, z, quot);
-    out.push_back(params.commit(quot.data()));
+    out.push_back(commit(quot.data()));
   }
   return out;
 }
+inline std::vector<G1> gwc_create_proof(const DeviceCommitter& params, uint32_t k, std::vector<ProverQuery> queries, const Fr& v) {
+  return gwc_create_proof(commit_with(params), k, std::move(queries), v);
+}
 
-// `ProverSHPLONK::create_proof` -> (H, H'): see zksnap_circuits_halo2_amd/multiopen.py for the formulas; the same steps in the same order
-inline std::pair<G1, G1> shplonk_create_proof(const DeviceCommitter& params, uint32_t k, std::vector<ProverQuery> queries, const Fr& y, const Fr& v, const Fr& u) {
-  const size_t n = (size_t)1 << k;
-  detail::evaluate_queries(queries, n);
-  // polynomial -> its set of points (order of first appearance), then sets of points -> their polynomials (order of first appearance)
-  struct poly_pts { const DeviceVec* poly; std::vector<Fr> pts; };
-  std::vector<poly_pts> by_poly;
-  std::vector<Fr> super;
-  auto insert_sorted = [](std::vector<Fr>& vset, const Fr& p) {
-    for (const Fr& e : vset) if (e == p) return;
-    auto it = vset.begin();
-    while (it != vset.end() && detail::less_fr(*it, p)) ++it;
-    vset.insert(it, p);
-  };
-  for (const auto& q : queries) {
-    insert_sorted(super, q.point);
-    bool found = false;
-    for (auto& pp : by_poly) if (pp.poly == q.poly) { insert_sorted(pp.pts, q.point); found = true; break; }
-    if (!found) by_poly.push_back({q.poly, {q.point}});
+// `ProverSHPLONK::create_proof` in the two steps the transcript imposes (see zksnap_circuits_halo2_amd/multiopen.py for the formulas; the
+// same operations in the same order): `begin` -- y and v are squeezed -- builds h(X) and returns its commitment H; the host writes H to the
+// transcript and squeezes u; `finish` builds L(X) / (X - u) and returns H'.  The polynomials of the queries must stay alive in between.
+class ShplonkProver {
+ public:
+  ShplonkProver(CommitFn commit, uint32_t k) : commit_(std::move(commit)), k_(k), n_((size_t)1 << k) {}
+
+  G1 begin(std::vector<ProverQuery> queries, const Fr& y, const Fr& v) {
+    if (begun_) throw std::logic_error("ShplonkProver::begin called twice");
+    y_ = y;
+    detail::evaluate_queries(queries, n_);
+    // polynomial -> its set of points (order of first appearance), then sets of points -> their polynomials (order of first appearance)
+    struct poly_pts { const DeviceVec* poly; std::vector<Fr> pts; };
+    std::vector<poly_pts> by_poly;
+    auto insert_sorted = [](std::vector<Fr>& vset, const Fr& p) {
+      for (const Fr& e : vset) if (e == p) return;
+      auto it = vset.begin();
+      while (it != vset.end() && detail::less_fr(*it, p)) ++it;
+      vset.insert(it, p);
+    };
+    for (const auto& q : queries) {
+      insert_sorted(super_, q.point);
+      bool found = false;
+      for (auto& pp : by_poly) if (pp.poly == q.poly) { insert_sorted(pp.pts, q.point); found = true; break; }
+      if (!found) by_poly.push_back({q.poly, {q.point}});
+    }
+    auto same = [](const std::vector<Fr>& a, const std::vector<Fr>& b) {
+      if (a.size() != b.size()) return false;
+      for (size_t i = 0; i < a.size(); i++) if (!(a[i] == b[i])) return false;
+      return true;
+    };
+    for (const auto& pp : by_poly) {
+      rotation_set* rs = nullptr;
+      for (auto& s_ : sets_) if (same(s_.points, pp.pts)) rs = &s_;
+      if (!rs) { sets_.push_back({pp.pts, {}, {}}); rs = &sets_.back(); }
+      std::vector<Fr> ev;
+      for (const Fr& z : pp.pts)
+        for (const auto& q : queries) if (q.poly == pp.poly && q.point == z) { ev.push_back(q.eval); break; }
+      rs->polys.push_back(pp.poly);
+      rs->evals.push_back(std::move(ev));
+    }
+    // h(X)
+    std::vector<const DeviceVec*> quotients;
+    for (const auto& rs : sets_) {
+      std::vector<Fr> ypow;
+      Fr yp = detail::one();
+      for (size_t j = 0; j < rs.polys.size(); j++) { ypow.push_back(yp); yp = detail::mul(yp, y); }
+      DeviceVec* acc = fresh();
+      DeviceVec* tmp = fresh();
+      detail::linear_combination(ypow, rs.polys, k_, *acc);
+      std::vector<Fr> low(rs.points.size(), Fr{});
+      for (size_t j = 0; j < rs.polys.size(); j++) {
+        const std::vector<Fr> r = detail::lagrange_interpolate(rs.points, rs.evals[j]);
+        for (size_t t = 0; t < low.size(); t++) low[t] = detail::add_fr(low[t], detail::mul(ypow[j], r[t]));
+      }
+      for (size_t t = 0; t < low.size(); t++) detail::sub_const_at(*acc, t, low[t]);
+      DeviceVec *src = acc, *dst = tmp;
+      for (const Fr& z : rs.points) { detail::divide_by_root(*src, z, *dst); std::swap(src, dst); }
+      quotients.push_back(src);
+    }
+    Fr vp = detail::one();
+    for (size_t i = 0; i < sets_.size(); i++) { vpow_.push_back(vp); vp = detail::mul(vp, v); }
+    h_x_ = fresh();
+    detail::linear_combination(vpow_, quotients, k_, *h_x_);
+    begun_ = true;
+    return commit_(h_x_->data());
   }
-  struct rotation_set { std::vector<Fr> points; std::vector<const DeviceVec*> polys; std::vector<std::vector<Fr>> evals; };
-  std::vector<rotation_set> sets;
-  auto same = [](const std::vector<Fr>& a, const std::vector<Fr>& b) {
-    if (a.size() != b.size()) return false;
-    for (size_t i = 0; i < a.size(); i++) if (!(a[i] == b[i])) return false;
-    return true;
-  };
-  for (const auto& pp : by_poly) {
-    rotation_set* rs = nullptr;
-    for (auto& s_ : sets) if (same(s_.points, pp.pts)) rs = &s_;
-    if (!rs) { sets.push_back({pp.pts, {}, {}}); rs = &sets.back(); }
-    std::vector<Fr> ev;
-    for (const Fr& z : pp.pts)
-      for (const auto& q : queries) if (q.poly == pp.poly && q.point == z) { ev.push_back(q.eval); break; }
-    rs->polys.push_back(pp.poly);
-    rs->evals.push_back(std::move(ev));
-  }
-  // h(X)
-  std::vector<std::unique_ptr<DeviceVec>> keep;
-  auto fresh = [&]() { keep.emplace_back(new DeviceVec(n)); return keep.back().get(); };
-  std::vector<const DeviceVec*> quotients;
-  for (const auto& rs : sets) {
-    std::vector<Fr> ypow;
-    Fr yp = detail::one();
-    for (size_t j = 0; j < rs.polys.size(); j++) { ypow.push_back(yp); yp = detail::mul(yp, y); }
-    DeviceVec* acc = fresh();
+
+  G1 finish(const Fr& u) {
+    if (!begun_ || finished_) throw std::logic_error("ShplonkProver::finish without begin (or twice)");
+    finished_ = true;
+    std::vector<Fr> z_diffs;
+    for (const auto& rs : sets_) {
+      std::vector<Fr> diff;
+      for (const Fr& p : super_) { bool in = false; for (const Fr& q : rs.points) in = in || q == p; if (!in) diff.push_back(p); }
+      z_diffs.push_back(detail::vanishing_at(diff, u));
+    }
+    const Fr zt_eval = detail::vanishing_at(super_, u), norm = detail::invert(z_diffs[0]);
+    std::vector<Fr> coeffs;
+    std::vector<const DeviceVec*> cols;
+    Fr constant{};
+    for (size_t i = 0; i < sets_.size(); i++) {
+      Fr yp = detail::one();
+      for (size_t j = 0; j < sets_[i].polys.size(); j++) {
+        const Fr c = detail::mul(detail::mul(detail::mul(vpow_[i], z_diffs[i]), yp), norm);
+        cols.push_back(sets_[i].polys[j]);
+        coeffs.push_back(c);
+        constant = detail::add_fr(constant, detail::mul(c, detail::eval_small(detail::lagrange_interpolate(sets_[i].points, sets_[i].evals[j]), u)));
+        yp = detail::mul(yp, y_);
+      }
+    }
+    cols.push_back(h_x_);
+    coeffs.push_back(detail::neg_fr(detail::mul(zt_eval, norm)));
+    DeviceVec* l_x = fresh();
     DeviceVec* tmp = fresh();
-    detail::linear_combination(ypow, rs.polys, k, *acc);
-    std::vector<Fr> low(rs.points.size(), Fr{});
-    for (size_t j = 0; j < rs.polys.size(); j++) {
-      const std::vector<Fr> r = detail::lagrange_interpolate(rs.points, rs.evals[j]);
-      for (size_t t = 0; t < low.size(); t++) low[t] = detail::add_fr(low[t], detail::mul(ypow[j], r[t]));
+    detail::linear_combination(coeffs, cols, k_, *l_x);
+    detail::sub_const_at(*l_x, 0, constant);
+    {
+      DeviceVec chk(1);
+      check(zkhip_fr_eval_polynomial_device(l_x->data(), n_, u.l, chk.data(), nullptr), "eval_polynomial");
+      const Fr r = chk.to_host()[0];
+      if (!(r == Fr{})) throw std::runtime_error("SHPLONK: L(u) != 0 -- an evaluation does not belong to its polynomial");
     }
-    for (size_t t = 0; t < low.size(); t++) detail::sub_const_at(*acc, t, low[t]);
-    DeviceVec *src = acc, *dst = tmp;
-    for (const Fr& z : rs.points) { detail::divide_by_root(*src, z, *dst); std::swap(src, dst); }
-    quotients.push_back(src);
+    detail::divide_by_root(*l_x, u, *tmp);
+    return commit_(tmp->data());
   }
-  std::vector<Fr> vpow;
-  Fr vp = detail::one();
-  for (size_t i = 0; i < sets.size(); i++) { vpow.push_back(vp); vp = detail::mul(vp, v); }
-  DeviceVec* h_x = fresh();
-  detail::linear_combination(vpow, quotients, k, *h_x);
-  const G1 H = params.commit(h_x->data());
-  // L(X) and the final quotient
-  std::vector<Fr> z_diffs;
-  for (const auto& rs : sets) {
-    std::vector<Fr> diff;
-    for (const Fr& p : super) { bool in = false; for (const Fr& q : rs.points) in = in || q == p; if (!in) diff.push_back(p); }
-    z_diffs.push_back(detail::vanishing_at(diff, u));
-  }
-  const Fr zt_eval = detail::vanishing_at(super, u), norm = detail::invert(z_diffs[0]);
-  std::vector<Fr> coeffs;
-  std::vector<const DeviceVec*> cols;
-  Fr constant{};
-  for (size_t i = 0; i < sets.size(); i++) {
-    Fr yp = detail::one();
-    for (size_t j = 0; j < sets[i].polys.size(); j++) {
-      const Fr c = detail::mul(detail::mul(detail::mul(vpow[i], z_diffs[i]), yp), norm);
-      cols.push_back(sets[i].polys[j]);
-      coeffs.push_back(c);
-      constant = detail::add_fr(constant, detail::mul(c, detail::eval_small(detail::lagrange_interpolate(sets[i].points, sets[i].evals[j]), u)));
-      yp = detail::mul(yp, y);
-    }
-  }
-  cols.push_back(h_x);
-  coeffs.push_back(detail::neg_fr(detail::mul(zt_eval, norm)));
-  DeviceVec* l_x = fresh();
-  DeviceVec* tmp = fresh();
-  detail::linear_combination(coeffs, cols, k, *l_x);
-  detail::sub_const_at(*l_x, 0, constant);
-  {
-    DeviceVec chk(1);
-    check(zkhip_fr_eval_polynomial_device(l_x->data(), n, u.l, chk.data(), nullptr), "eval_polynomial");
-    const Fr r = chk.to_host()[0];
-    if (!(r == Fr{})) throw std::runtime_error("SHPLONK: L(u) != 0 -- an evaluation does not belong to its polynomial");
-  }
-  detail::divide_by_root(*l_x, u, *tmp);
-  const G1 Hp = params.commit(tmp->data());
+
+ private:
+  struct rotation_set { std::vector<Fr> points; std::vector<const DeviceVec*> polys; std::vector<std::vector<Fr>> evals; };
+  DeviceVec* fresh() { keep_.emplace_back(new DeviceVec(n_)); return keep_.back().get(); }
+  CommitFn commit_;
+  uint32_t k_;
+  size_t n_;
+  Fr y_{};
+  std::vector<Fr> super_, vpow_;
+  std::vector<rotation_set> sets_;
+  std::vector<std::unique_ptr<DeviceVec>> keep_;
+  DeviceVec* h_x_ = nullptr;
+  bool begun_ = false, finished_ = false;
+};
+
+inline std::pair<G1, G1> shplonk_create_proof(const CommitFn& commit, uint32_t k, std::vector<ProverQuery> queries, const Fr& y, const Fr& v, const Fr& u) {
+  ShplonkProver prover(commit, k);
+  const G1 H = prover.begin(std::move(queries), y, v);
+  const G1 Hp = prover.finish(u);
   return {H, Hp};
+}
+inline std::pair<G1, G1> shplonk_create_proof(const DeviceCommitter& params, uint32_t k, std::vector<ProverQuery> queries, const Fr& y, const Fr& v, const Fr& u) {
+  return shplonk_create_proof(commit_with(params), k, std::move(queries), y, v, u);
 }
 
 }  // namespace halo2

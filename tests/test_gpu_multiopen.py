@@ -255,3 +255,97 @@ def test_cpp_multiopen_mirror_matches_python(lib, cref, tmp_path):
         _lib.check(lib.zkhip_release_bases(h))
         for ptr in d_polys + [d_g, d_out]:
             lib.zkhip_free(ptr)
+
+
+def _c_queries(plan, d_polys, evals=None):
+    qs = (_lib.ProverQueryC * len(plan))()
+    for i, (pi, pt) in enumerate(plan):
+        qs[i].point[:] = [int(x) for x in F.fr_encode([pt])[0]]
+        qs[i].d_poly = d_polys[pi].value
+        if evals is not None and evals[i] is not None:
+            qs[i].eval[:] = [int(x) for x in F.fr_encode([evals[i]])[0]]
+            qs[i].has_eval = 1
+    return qs
+
+
+def test_c_abi_multiopen_matches_the_python_provers(lib, cref):
+    """zkhip_multiopen_gwc_device / zkhip_multiopen_shplonk_{begin, finish}_device -- the C++ provers behind `extern "C"`, on borrowed device
+    addresses, committing against a REGISTERED base array as the Rust shim does -- against the Python provers on the same queries (which
+    are checked against the oracle and the KZG equation above); with and without evaluations supplied by the caller; an evaluation that
+    does not belong to its polynomial is refused by `finish`, which still releases the state"""
+    k, s = 10, 0x5A5A1234F00D
+    n = 1 << k
+    polys = [cref.gen_scalars(3700 + i, n, i % 2) for i in range(6)]
+    gen = O.SplitMix64(37)
+    x = gen.fr()
+    w = F.omega_for(k)
+    px, pn, pp, p2 = x, x * w % R, x * pow(w, -1, R) % R, x * w * w % R
+    plan = [(0, px), (1, px), (1, pn), (2, pp), (2, px), (2, pn), (3, px), (4, pp), (4, px), (4, pn), (5, p2), (5, px)]
+    y, v, u = gen.fr(), gen.fr(), gen.fr()
+    with Z.ParamsKZG.setup(k, s) as params:
+        g = params.g.copy()
+    d_polys = []
+    for p in polys:
+        ptr = C.c_void_p()
+        _lib.check(lib.zkhip_alloc(n * 32, C.byref(ptr)))
+        _lib.check(lib.zkhip_upload(ptr, p.ctypes.data, n * 32))
+        d_polys.append(ptr)
+    _lib.check(lib.zkhip_register_bases(g.ctypes.data, n))
+    d_out = C.c_void_p()
+    _lib.check(lib.zkhip_alloc(96, C.byref(d_out)))
+
+    def commit(d_coeffs):
+        _lib.check(lib.zkhip_msm_g1_registered_device(g.ctypes.data, C.c_void_p(d_coeffs), n, d_out, None))
+        out = np.zeros(12, dtype=np.uint64)
+        _lib.check(lib.zkhip_download(out.ctypes.data, d_out, 96))
+        return out
+
+    yw, vw, uw = (F.fr_encode([t])[0] for t in (y, v, u))          # kept alive: the calls below take their addresses
+    try:
+        gwc = M.ProverGWC(k, commit)
+        W = gwc.create_proof([M.ProverQuery(pt, d_polys[pi].value) for pi, pt in plan], v)
+        gwc.close()
+        sh = M.ProverSHPLONK(k, commit)
+        qpy = [M.ProverQuery(pt, d_polys[pi].value) for pi, pt in plan]
+        H, Hp = sh.create_proof(qpy, y, v, u)
+        sh.close()
+        evals = [q.eval for q in qpy]                                   # filled in by the Python prover
+        aff = lambda a: cref.jac_to_affine(np.ascontiguousarray(a))
+        for supplied in (None, evals):
+            qs = _c_queries(plan, d_polys, supplied)
+            out = np.zeros((8, 12), dtype=np.uint64)
+            cnt = C.c_size_t(0)
+            _lib.check(lib.zkhip_multiopen_gwc_device(g.ctypes.data, k, qs, len(plan), vw.ctypes.data, out.ctypes.data, 8, C.byref(cnt)))
+            assert cnt.value == len(W) == 4
+            for a, b in zip(out[:4], W):
+                assert np.array_equal(aff(a), aff(b))
+            h_out, hp_out = np.zeros(12, dtype=np.uint64), np.zeros(12, dtype=np.uint64)
+            st = C.c_void_p()
+            _lib.check(lib.zkhip_multiopen_shplonk_begin_device(g.ctypes.data, k, qs, len(plan), yw.ctypes.data, vw.ctypes.data, h_out.ctypes.data, C.byref(st)))
+            assert st.value
+            _lib.check(lib.zkhip_multiopen_shplonk_finish_device(st, uw.ctypes.data, hp_out.ctypes.data))
+            assert np.array_equal(aff(h_out), aff(H)) and np.array_equal(aff(hp_out), aff(Hp))
+        # room for fewer witnesses than there are points
+        cnt = C.c_size_t(0)
+        assert lib.zkhip_multiopen_gwc_device(g.ctypes.data, k, qs, len(plan), vw.ctypes.data, out.ctypes.data, 3, C.byref(cnt)) == -1 and cnt.value == 4
+        # a wrong evaluation: begin succeeds (h is built from what it was given), finish refuses (L(u) != 0) and releases the state
+        bad = list(evals)
+        bad[1] = (bad[1] + 1) % R
+        qs = _c_queries(plan, d_polys, bad)
+        st = C.c_void_p()
+        _lib.check(lib.zkhip_multiopen_shplonk_begin_device(g.ctypes.data, k, qs, len(plan), yw.ctypes.data, vw.ctypes.data, h_out.ctypes.data, C.byref(st)))
+        assert lib.zkhip_multiopen_shplonk_finish_device(st, uw.ctypes.data, hp_out.ctypes.data) == -1
+        assert b"L(u) != 0" in lib.zkhip_last_error()
+        # abort; bad arguments
+        st = C.c_void_p()
+        _lib.check(lib.zkhip_multiopen_shplonk_begin_device(g.ctypes.data, k, _c_queries(plan, d_polys), len(plan), yw.ctypes.data, vw.ctypes.data,
+                                                            h_out.ctypes.data, C.byref(st)))
+        assert lib.zkhip_multiopen_shplonk_abort(st) == 0
+        assert lib.zkhip_multiopen_shplonk_finish_device(None, uw.ctypes.data, hp_out.ctypes.data) == -1
+        assert lib.zkhip_multiopen_shplonk_begin_device(g.ctypes.data, k, qs, 0, yw.ctypes.data, vw.ctypes.data, h_out.ctypes.data, C.byref(st)) == -1
+        qs[3].d_poly = None
+        assert lib.zkhip_multiopen_gwc_device(g.ctypes.data, k, qs, len(plan), vw.ctypes.data, out.ctypes.data, 8, C.byref(cnt)) == -1
+    finally:
+        _lib.check(lib.zkhip_unregister_bases(g.ctypes.data))
+        for ptr in d_polys + [d_out]:
+            lib.zkhip_free(ptr)

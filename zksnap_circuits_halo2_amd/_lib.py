@@ -94,6 +94,10 @@ _SIGS = {
     "zkhip_permutation_products": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "zkhip_permutation_products_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                     C.c_void_p, C.c_void_p]),
+    "zkhip_multiopen_gwc_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "zkhip_multiopen_shplonk_begin_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "zkhip_multiopen_shplonk_finish_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "zkhip_multiopen_shplonk_abort": (C.c_int, [C.c_void_p]),
     "zkhip_profile_enable": (C.c_int, [C.c_int]),
     "zkhip_profile_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "zkhip_profile_read_calls": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
@@ -101,6 +105,10 @@ _SIGS = {
     "zkhip_test_g1_op": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
 }
 
+
+
+class ProverQueryC(C.Structure):   # zkhip_prover_query (80 bytes)
+    _fields_ = [("point", C.c_uint64 * 4), ("d_poly", C.c_void_p), ("eval", C.c_uint64 * 4), ("has_eval", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class VmOperand(C.Structure):      # zkhip_vm_operand
