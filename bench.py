@@ -1059,7 +1059,8 @@ def shim_device_sequence(k: int, gate_cols: int, torch) -> dict:
     """The device-resident call sequence of rust-shim/prover_patch.rs (mode (b)) for one proof of the wrapper's shape (k = 22, 4 gate columns + 1
     lookup column: /root/reference/aggregator/benches/wrapper_circuit.rs:61-68), issued by the C99 replay tests/cpp/prover_sequence.c in a child
     process: witness upload, advice / lookup / product commitments, grand products, lagrange_to_coeff, coeff_to_extended, the quotient program,
-    its commitments and the evaluations at x, with the commitments and evaluations read back (what the transcript needs).  PCIe-inclusive."""
+    its commitments and the evaluations at x, with the commitments and evaluations read back (what the transcript needs); then (reported
+    separately) the multi-open argument -- SHPLONK over the same device-resident polynomials.  PCIe-inclusive."""
     import re
     import subprocess
     import tempfile
@@ -1081,7 +1082,9 @@ def shim_device_sequence(k: int, gate_cols: int, torch) -> dict:
         if res.returncode != 0 or not m:
             return {"shim_device_sequence_ms": None, "shim_device_sequence_error": (res.stdout + res.stderr)[-400:]}
         ms = float(m.group(1))
+        m2 = re.search(r"with_multiopen=([\d.]+)", res.stdout)
         return {"shim_device_sequence_ms": round(ms, 2),
+                "shim_device_sequence_with_multiopen_ms": round(float(m2.group(1)), 2) if m2 else None,    # + SHPLONK on the device-resident polynomials (zkhip_multiopen_shplonk_*: 2 more MSMs)
                 "shim_device_sequence": {"how": "tests/cpp/prover_sequence.c --device-only 3 in a child process: the call sequence of rust-shim/prover_patch.rs mode (b), "
                                                 "three proofs over the same buffers, the fastest reported (first_ms = the process's first proof, cold clocks)",
                                          "first_ms": float(re.search(r"first=([\d.]+)", res.stdout).group(1)),

@@ -140,10 +140,38 @@ pub(crate) struct DeviceProof {
 //                          columns of ext, extended_k, &h, 0); h.quotient_to_coeff(..) (divide_by_vanishing_poly + extended_to_coeff);
 //                          the three pieces = h.commit_many(1, ..) with stride n over column 1 (coefficients), against &params.g
 //   x                      DevCols::eval_polys(addresses of every opened polynomial, n, &x, F::ZERO) -> transcript
-//   multiopen              `P::create_proof` receives `ProverQuery { poly: &Polynomial }`: the opened polynomials are downloaded ONCE here
-//                          (base.download) -- SHPLONK / GWC then run as upstream through best_multiexp / kate_division.  (Device-side
-//                          multiopen exists in this repository's C++ / Python mirrors, include/zkhip.hpp `multiopen`; binding it needs
-//                          `ProverQuery` to carry a handle and is left to a second patch.)
+//   multiopen              the opened polynomials stay on the device: instead of `ProverQuery { point, poly: &Polynomial, blind }` the prover
+//                          collects `zkhip_ffi::dev_query(&point, base.at(column, 0), &eval)` in the order upstream builds its queries
+//                          (instances, advice, permutation, lookups, fixed, vanishing) and calls `open_on_device` below in place of
+//                          `P::create_proof(rng, transcript, queries)`.  Which argument runs is the scheme's: GWC on the gen_snark path
+//                          (/root/reference/aggregator/src/wrapper.rs:127-129), SHPLONK on the benches' (halo2-base `gen_proof`).  When the
+//                          device path declines (None), the polynomials are downloaded once (base.download) and the upstream prover runs.
+
+/// What poly/kzg/multiopen/{gwc, shplonk}/prover.rs do with the transcript, around the device-side provers: the SAME squeezes and writes
+/// in the SAME order as upstream (GWC: v, then one witness per point; SHPLONK: y, v, H, u, H'), so the proof bytes do not change.
+/// `T` is the transcript (`TranscriptWrite<C, E>`), `squeeze` / `write` are its `squeeze_challenge_scalar` / `write_point` closures --
+/// passed in because their trait bounds are the patched file's, not this module's.
+pub(crate) enum OpenWith { Gwc, Shplonk }
+pub(crate) fn open_on_device<C: 'static, F: 'static, P: 'static + Clone>(which: OpenWith, g: &[C], k: u32, queries: &[zkhip_ffi::ProverQueryC], identity: P,
+                                                                         squeeze: &mut dyn FnMut() -> F, write: &mut dyn FnMut(&P) -> bool) -> Option<()> {
+    match which {
+        OpenWith::Gwc => {
+            let v = squeeze();
+            for w in zkhip_ffi::multiopen_gwc(g, k, queries, &v, identity)? { if !write(&w) { return None; } }
+        }
+        OpenWith::Shplonk => {
+            let (y, v) = (squeeze(), squeeze());
+            let (session, h) = zkhip_ffi::ShplonkSession::begin(g, k, queries, &y, &v, identity.clone())?;
+            if !write(&h) { return None; }                      // (the session drops and releases its state)
+            let u = squeeze();
+            let hp = session.finish(&u, identity)?;
+            if !write(&hp) { return None; }
+        }
+    }
+    Some(())
+}
+// NOTE on `None` after the first squeeze: the transcript has advanced, so the caller must not re-run the upstream prover on the same
+// transcript; treat it as the proof failing (Error::Opening upstream), exactly as a failed MSM inside the upstream prover would.
 
 /// `GraphEvaluator` -> row program (plonk/evaluation.rs).  `calcs[i]` writes intermediate `i`; sources are mapped by the closures the
 /// caller passes, because the column indices depend on the `DeviceProof` layout above:

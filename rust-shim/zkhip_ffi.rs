@@ -57,6 +57,12 @@ extern "C" {
     fn zkhip_fr_eval_rows_device(prog: *const VmProgram, d_columns: *const *const c_void, n_columns: u32, log_rows: u32, accumulate: c_int,
                                  d_out: *mut c_void, stream: *mut c_void) -> c_int;
     fn zkhip_fr_grand_product_device(d_num: *const c_void, d_den: *mut c_void, n: usize, d_z: *mut c_void, stream: *mut c_void) -> c_int;
+    fn zkhip_multiopen_gwc_device(bases: *const u64, k: u32, queries: *const ProverQueryC, n_queries: usize, v: *const u64, out_points: *mut u64,
+                                  capacity: usize, n_out: *mut usize) -> c_int;
+    fn zkhip_multiopen_shplonk_begin_device(bases: *const u64, k: u32, queries: *const ProverQueryC, n_queries: usize, y: *const u64, v: *const u64,
+                                            out_h: *mut u64, state: *mut *mut ShplonkState) -> c_int;
+    fn zkhip_multiopen_shplonk_finish_device(state: *mut ShplonkState, u: *const u64, out_hp: *mut u64) -> c_int;
+    fn zkhip_multiopen_shplonk_abort(state: *mut ShplonkState) -> c_int;
     fn zkhip_permutation_products_device(d_values: *const *const c_void, d_sigmas: *const *const c_void, n_columns: u32, chunk_len: u32, log_n: u32,
                                          usable_rows: usize, beta: *const u64, gamma: *const u64, delta: *const u64, omega: *const u64, d_z: *mut c_void,
                                          stream: *mut c_void) -> c_int;
@@ -82,6 +88,14 @@ pub(crate) struct VmProgram {
     pub result_reg: u32,
     pub omega: *const u64,
 }
+/// `zkhip_prover_query`: one opening -- the polynomial of 2^k coefficients at device address `d_poly`, opened at `point`; `eval` is its value
+/// there when `has_eval != 0` (the prover has written it to the transcript already), otherwise the library evaluates
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub(crate) struct ProverQueryC { pub point: [u64; 4], pub d_poly: *const c_void, pub eval: [u64; 4], pub has_eval: u32, pub reserved: u32 }
+/// `zkhip_shplonk`: the state between the two steps of the SHPLONK prover (opaque)
+#[repr(C)]
+pub(crate) struct ShplonkState { _opaque: [u8; 0] }
 pub(crate) const VM_REGS: usize = 16;
 pub(crate) const SRC_CONST: u8 = 0;
 pub(crate) const SRC_REG: u8 = 1;
@@ -507,6 +521,62 @@ impl Drop for DevCols {
     fn drop(&mut self) {
         // SAFETY: allocated by zkhip_alloc, freed once (zkhip_free waits for queued work on the block)
         let _ = unsafe { zkhip_free(self.ptr) };
+    }
+}
+
+/// One query of the multi-open argument over device-resident polynomials: what `ProverQuery { point, poly, blind }` becomes when `poly`
+/// lives in a `DevCols` (prover_patch.rs mode (b)); `eval` as written to the transcript.
+pub(crate) fn dev_query<F: 'static>(point: &F, d_poly: *const c_void, eval: &F) -> Option<ProverQueryC> {
+    if !is::<F, Fr>() { return None; }
+    // SAFETY: F = Fr = 4 x u64 (checked)
+    let (p, e) = unsafe { (*(point as *const F as *const [u64; 4]), *(eval as *const F as *const [u64; 4])) };
+    Some(ProverQueryC { point: p, d_poly, eval: e, has_eval: 1, reserved: 0 })
+}
+
+/// `ProverGWC::create_proof` on device-resident polynomials: one witness commitment per distinct point (order of first appearance),
+/// committed against the pinned `params.g`.  None = not taken (the caller downloads the polynomials and runs the upstream prover).
+pub(crate) fn multiopen_gwc<C: 'static, F: 'static, P: 'static + Clone>(g: &[C], k: u32, queries: &[ProverQueryC], v: &F, identity: P) -> Option<Vec<P>> {
+    if !(is::<C, G1Affine>() && is::<F, Fr>() && is::<P, G1>()) || !usable() || queries.is_empty() || g.len() < 1usize << k.min(28) { return None; }
+    let mut out = vec![identity; queries.len()];           // at most one witness per query
+    let mut n_out = 0usize;
+    // SAFETY: `g` is a registered base array (Pinned<C>), queries are repr(C), out has room for queries.len() points of 12 limbs
+    let rc = unsafe { zkhip_multiopen_gwc_device(g.as_ptr() as *const u64, k, queries.as_ptr(), queries.len(), v as *const F as *const u64,
+                                                 out.as_mut_ptr() as *mut u64, out.len(), &mut n_out) };
+    if rc != 0 { warn_once("zkhip_multiopen_gwc_device", rc); return None; }
+    out.truncate(n_out);
+    Some(out)
+}
+
+/// `ProverSHPLONK::create_proof` in the two steps the transcript imposes: `begin` (y, v squeezed) -> H; the caller writes H and squeezes u;
+/// `finish` -> H'.  Dropping a session that was not finished releases the library's state.
+pub(crate) struct ShplonkSession { state: *mut ShplonkState }
+impl ShplonkSession {
+    pub(crate) fn begin<C: 'static, F: 'static, P: 'static + Clone>(g: &[C], k: u32, queries: &[ProverQueryC], y: &F, v: &F, identity: P) -> Option<(ShplonkSession, P)> {
+        if !(is::<C, G1Affine>() && is::<F, Fr>() && is::<P, G1>()) || !usable() || queries.is_empty() || g.len() < 1usize << k.min(28) { return None; }
+        let mut h = identity;
+        let mut state: *mut ShplonkState = std::ptr::null_mut();
+        // SAFETY: as multiopen_gwc; `h` = G1 = 12 limbs; `state` is an out-parameter
+        let rc = unsafe { zkhip_multiopen_shplonk_begin_device(g.as_ptr() as *const u64, k, queries.as_ptr(), queries.len(), y as *const F as *const u64,
+                                                               v as *const F as *const u64, &mut h as *mut P as *mut u64, &mut state) };
+        if rc != 0 || state.is_null() { warn_once("zkhip_multiopen_shplonk_begin_device", rc); return None; }
+        Some((ShplonkSession { state }, h))
+    }
+    pub(crate) fn finish<F: 'static, P: 'static + Clone>(mut self, u: &F, identity: P) -> Option<P> {
+        if !(is::<F, Fr>() && is::<P, G1>()) { return None; }        // (self drops: the state is released by Drop)
+        let mut hp = identity;
+        let state = std::mem::replace(&mut self.state, std::ptr::null_mut());   // finish releases the state whatever it returns
+        // SAFETY: `state` came from begin and is used once
+        let rc = unsafe { zkhip_multiopen_shplonk_finish_device(state, u as *const F as *const u64, &mut hp as *mut P as *mut u64) };
+        if rc != 0 { warn_once("zkhip_multiopen_shplonk_finish_device", rc); return None; }
+        Some(hp)
+    }
+}
+impl Drop for ShplonkSession {
+    fn drop(&mut self) {
+        if !self.state.is_null() {
+            // SAFETY: a state that finish never consumed
+            let _ = unsafe { zkhip_multiopen_shplonk_abort(self.state) };
+        }
     }
 }
 

@@ -5,7 +5,8 @@
  *                                    column, one zkhip_ifft_scaled / zkhip_coeff_to_extended per column, host-buffer row programs
  *   B  host-buffer, one call per phase   prover_patch.rs mode (a): zkhip_msm_g1_batch, zkhip_ifft_scaled_batch, zkhip_coeff_to_extended_batch
  *   D  device-resident               prover_patch.rs mode (b): the columns are zkhip_alloc'd handles from the upload of the witness to the
- *                                    quotient commitments; only commitments and evaluations come back for the transcript
+ *                                    quotient commitments and the multi-open argument (SHPLONK on the device-resident polynomials); only
+ *                                    commitments and evaluations come back for the transcript
  *
  * [DEP] halo2-axiom plonk/prover.rs create_proof, plonk/permutation/prover.rs, plonk/lookup/prover.rs, plonk/evaluation.rs -- reached from
  * /root/reference/aggregator/src/wrapper.rs:129 (gen_snark) and /root/reference/aggregator/benches/state_transition_circuit.rs:84 (k = 15);
@@ -97,12 +98,15 @@ typedef struct {
 int main(int argc, char **argv) {
   int device_only = argc > 2 && strcmp(argv[2], "--device-only") == 0;
   int repeats = device_only && argc > 3 && atoi(argv[3]) > 1 ? atoi(argv[3]) : 1, rep;
-  double first_ms = 0;
+  double first_ms = 0, with_open_ms = 0;
   FILE *f;
   long fsz;
   unsigned char *blob;
   uint32_t k, ek, G, NL, nperm, nsets, chunk, blind, ncol, q_fixed, q_advice, q_l0, q_sigma, q_perm, q_lookup, period, i, j, si;
   uint64_t om_inv[4], divisor[4], ext_om[4], ext_om_inv[4], ext_div[4], zeta[4], xpt[4], omega[4], delta[4], beta[4], gamma[4];
+  uint64_t rotpt[6][4], y_mo[4], v_mo[4], u_mo[4];     /* x omega^r for r = 0, 1, 2, 3, -1, usable; the multi-open argument's challenges */
+  size_t mo_queries = 0, mo_witnesses = 0;
+  int mo_refused = 0;
   const uint64_t *t_eval;
   zkhip_vm_program to_mont, perm_num[16], perm_den[16], lk_num, lk_den, eval_h;
   size_t n, en, u, nadv, nproof, first_proof2;
@@ -117,10 +121,12 @@ int main(int argc, char **argv) {
   if (fread(blob, 1, (size_t)fsz, f) != (size_t)fsz) { fprintf(stderr, "short read\n"); return 2; }
   fclose(f);
   rd_ptr = blob; rd_end = blob + fsz;
-  if (memcmp(rd(4), "ZKPS", 4) != 0 || rd_u32() != 2) { fprintf(stderr, "not a prover-sequence record (version 2)\n"); return 2; }
+  if (memcmp(rd(4), "ZKPS", 4) != 0 || rd_u32() != 3) { fprintf(stderr, "not a prover-sequence record (version 3)\n"); return 2; }
   k = rd_u32(); ek = rd_u32(); G = rd_u32(); NL = rd_u32(); nperm = rd_u32(); nsets = rd_u32(); chunk = rd_u32(); blind = rd_u32();
   ncol = rd_u32(); q_fixed = rd_u32(); q_advice = rd_u32(); q_l0 = rd_u32(); q_sigma = rd_u32(); q_perm = rd_u32(); q_lookup = rd_u32();
   rd_fr(om_inv); rd_fr(divisor); rd_fr(ext_om); rd_fr(ext_om_inv); rd_fr(ext_div); rd_fr(zeta); rd_fr(xpt); rd_fr(omega); rd_fr(delta); rd_fr(beta); rd_fr(gamma);
+  for (i = 0; i < 6; i++) rd_fr(rotpt[i]);
+  rd_fr(y_mo); rd_fr(v_mo); rd_fr(u_mo);
   period = rd_u32();
   t_eval = (const uint64_t *)rd_copy((size_t)period * 32);
   if (NL != 1 || nsets > 16 || q_fixed != 0) { fprintf(stderr, "shape not supported by this program\n"); return 2; }
@@ -400,9 +406,53 @@ int main(int argc, char **argv) {
       OK(zkhip_download(res->commits, d_out, res->n_commits * 96));
       OK(zkhip_download(res->evals, d_out + 96 * res->n_commits, res->n_evals * 32));
       {
-        const double ms = now_ms() - t0;
+        const double ms = now_ms() - t0;                   /* phases 1-7: what sequences H and B time as well */
         if (rep == 0) first_ms = ms;
         if (rep == 0 || ms < res->ms) res->ms = ms;
+      }
+      /* 8. multi-open argument on the device-resident polynomials (prover_patch.rs `open_on_device`): the query plan of create_proof for this
+       * shape -- fixed at x; gate advice at x, omega x, omega^2 x, omega^3 x; lookup advice and the sigma polynomials at x; every permutation
+       * product at x and omega x, all but the last also at omega^u x; the lookup's product at x and omega x, its permuted input at x and
+       * omega^-1 x, its permuted table at x; the quotient's pieces at x -- through SHPLONK, the benches' argument
+       * (/root/reference/aggregator/benches/wrapper_circuit.rs:140); the library evaluates (has_eval = 0) */
+      {
+        const size_t max_q = (size_t)(G + 2) + 4 * (size_t)G + 1 + nperm + 3 * (size_t)nsets + 5 + 3;
+        zkhip_prover_query *q = xmalloc(max_q * sizeof(*q));
+        zkhip_shplonk *st = NULL;
+        uint64_t hh[12], hp[12];
+        size_t nq = 0;
+#define ADDQ(ptr_, rot_) do { memset(&q[nq], 0, sizeof(q[nq])); memcpy(q[nq].point, rotpt[rot_], 32); q[nq].d_poly = (ptr_); nq++; } while (0)
+#define DKEY(col_) (d_coeff + (size_t)(col_) * n * 32)       /* a proving-key column in coefficient form */
+        for (i = q_fixed; i < q_advice; i++) ADDQ(DKEY(i), 0);
+        for (i = 0; i < G; i++) for (j = 0; j < 4; j++) ADDQ(DLAG(i), j);
+        ADDQ(DLAG(G), 0);
+        for (i = 0; i < nperm; i++) ADDQ(DKEY(q_sigma + i), 0);
+        for (si = 0; si < nsets; si++) { ADDQ(DLAG(nadv + si), 0); ADDQ(DLAG(nadv + si), 1); if (si + 1 < nsets) ADDQ(DLAG(nadv + si), 5); }
+        ADDQ(DLAG(nadv + nsets), 0); ADDQ(DLAG(nadv + nsets), 1);
+        ADDQ(DLAG(nadv + nsets + 1), 0); ADDQ(DLAG(nadv + nsets + 1), 4);
+        ADDQ(DLAG(nadv + nsets + 2), 0);
+        for (i = 0; i < 3; i++) ADDQ(d_hc + (size_t)i * n * 32, 0);
+        CHECK(nq <= max_q, "query count");
+        mo_queries = nq;
+        OK(zkhip_multiopen_shplonk_begin_device(g, k, q, nq, y_mo, v_mo, hh, &st));
+        OK(zkhip_multiopen_shplonk_finish_device(st, u_mo, hp));
+        {
+          const double ms = now_ms() - t0;                 /* the whole device side of the proof */
+          if (rep == 0 || ms < with_open_ms) with_open_ms = ms;
+        }
+        if (!device_only) {                                /* outside the timing: GWC (the gen_snark path's argument) on the same queries; a wrong evaluation */
+          uint64_t *wit = xmalloc(8 * 96), aff[16];
+          OK(zkhip_multiopen_gwc_device(g, k, q, nq, v_mo, wit, 8, &mo_witnesses));
+          memcpy(wit, hh, 96); memcpy(wit + 12, hp, 96);
+          CHECK(zkhip_g1_batch_normalize(wit, 2, aff) == ZKHIP_OK && (aff[0] | aff[1] | aff[2] | aff[3]) != 0 && (aff[8] | aff[9] | aff[10] | aff[11]) != 0,
+                "H and H' are points other than the identity");
+          memcpy(q[1].eval, res->evals, 32);               /* some other polynomial's evaluation: finish must refuse (L(u) != 0) and free the state */
+          q[1].has_eval = 1;
+          OK(zkhip_multiopen_shplonk_begin_device(g, k, q, nq, y_mo, v_mo, hh, &st));
+          mo_refused = zkhip_multiopen_shplonk_finish_device(st, u_mo, hp) == ZKHIP_EINVAL;
+          free(wit);
+        }
+        free(q);
       }
       }
       CHECK(c == res->n_commits, "commitment count");
@@ -430,12 +480,14 @@ int main(int argc, char **argv) {
       for (r = 0; r < R[0].h_len * 4; r++) nz += R[0].h[r] != 0;
       CHECK(nz > R[0].h_len, "the quotient's coefficients are not trivially zero");
     }
-    printf("sequence_ms host_call_by_call=%.2f host_one_call_per_phase=%.2f device_resident=%.2f\n", R[0].ms, R[1].ms, R[2].ms);
+    printf("sequence_ms host_call_by_call=%.2f host_one_call_per_phase=%.2f device_resident=%.2f (with the multi-open argument %.2f)\n", R[0].ms, R[1].ms, R[2].ms, with_open_ms);
     printf("commitments compared: %zu, evaluations compared: %zu, quotient coefficients compared: %zu\n", R[0].n_commits, R[0].n_evals, R[0].h_len);
+    CHECK(mo_witnesses == 6 && mo_refused, "multi-open argument");
+    printf("multiopen on the device: %zu queries, SHPLONK H and H', GWC %zu witnesses, a wrong evaluation %s\n", mo_queries, mo_witnesses, mo_refused ? "refused" : "ACCEPTED");
   } else {
     uint64_t aff[8];
     CHECK(zkhip_g1_batch_normalize(R[2].commits, 1, aff) == ZKHIP_OK, "first commitment normalises");
-    printf("sequence_ms device_resident=%.2f first=%.2f repeats=%d\n", R[2].ms, first_ms, repeats);
+    printf("sequence_ms device_resident=%.2f first=%.2f repeats=%d with_multiopen=%.2f\n", R[2].ms, first_ms, repeats, with_open_ms);
   }
   OK(zkhip_unregister_bases(g)); OK(zkhip_unregister_bases(gl));
   zkhip_shutdown();

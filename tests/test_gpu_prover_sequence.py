@@ -40,19 +40,21 @@ def test_prover_patch_call_sequence_from_c99(tmp_path, k, gate_cols):
     nsets = -(-(nadv + 1) // 2)
     assert m and int(m.group(1)) == nadv + 2 + nsets + 1 + 3 and int(m.group(2)) == nadv + nsets + 3 + 3 and int(m.group(3)) == 3 << k
     assert re.search(r"sequence_ms host_call_by_call=[\d.]+ host_one_call_per_phase=[\d.]+ device_resident=[\d.]+", res.stdout)
+    nq = (gate_cols + 2) + 4 * gate_cols + 1 + (nadv + 1) + (3 * nsets - 1) + 5 + 3
+    assert f"multiopen on the device: {nq} queries, SHPLONK H and H', GWC 6 witnesses, a wrong evaluation refused" in res.stdout
 
 
 def test_exported_programs_record_is_well_formed():
-    """(CPU) the record's header and the count of programs: magic, shape words, 11 constants (domain, x, omega, delta, beta, gamma), t_evaluations, then
+    """(CPU) the record's header and the count of programs: magic, shape words, 20 constants (domain, x, omega, delta, beta, gamma, 6 opening points, 3 multi-open challenges), t_evaluations, then
     to_mont + 2 * sets + 2 + 1 programs, consumed to the last byte"""
     import struct
 
     k, G = 9, 2
     b = E.export_prover_programs(k, G, 1)
-    assert b[:4] == b"ZKPS" and struct.unpack_from("<I", b, 4)[0] == 2
+    assert b[:4] == b"ZKPS" and struct.unpack_from("<I", b, 4)[0] == 3
     kk, ek, g, nl, nperm, nsets, chunk, blind = struct.unpack_from("<8I", b, 8)
     assert (kk, ek, g, nl, nperm, nsets, chunk, blind) == (k, k + 2, G, 1, G + 2, 2, 2, 5)
-    off = 8 + 32 + 28 + 11 * 32
+    off = 8 + 32 + 28 + 20 * 32
     period = struct.unpack_from("<I", b, off)[0]
     off += 4 + period * 32
     assert period == 4

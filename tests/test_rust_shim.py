@@ -18,11 +18,12 @@ SHIM = os.path.join(ROOT, "rust-shim")
 C_TYPES = {
     "int": ("int", 32), "uint32_t": ("uint", 32), "int32_t": ("int", 32), "size_t": ("uint", 64), "uint64_t": ("uint", 64),
     "uint8_t": ("uint", 8), "char": ("int", 8), "void": ("void", 0), "zkhip_vm_program": ("struct zkhip_vm_program", 0),
-    "uint16_t": ("uint", 16),
+    "uint16_t": ("uint", 16), "zkhip_prover_query": ("struct zkhip_prover_query", 0), "zkhip_shplonk": ("struct zkhip_shplonk", 0),
 }
 RUST_TYPES = {
     "c_int": ("int", 32), "i32": ("int", 32), "u32": ("uint", 32), "usize": ("uint", 64), "u64": ("uint", 64), "u8": ("uint", 8),
     "c_char": ("int", 8), "c_void": ("void", 0), "VmProgram": ("struct zkhip_vm_program", 0), "u16": ("uint", 16),
+    "ProverQueryC": ("struct zkhip_prover_query", 0), "ShplonkState": ("struct zkhip_shplonk", 0),
 }
 
 
@@ -42,7 +43,7 @@ def c_param(p):
     assert base in C_TYPES, f"unknown C type in {p!r}"
     if stars + int(is_array) == 2:               # `void **d_ptr` (out-parameter), `const void *const *d_columns` (host array of device pointers)
         n_const = len(re.findall(r"\bconst\b", p))
-        assert base == "void" and not is_array, f"pointer-to-pointer of {p!r}"
+        assert base in ("void", "zkhip_shplonk") and not is_array, f"pointer-to-pointer of {p!r}"
         return ("ptrptr", C_TYPES[base], n_const)
     if stars or is_array:
         assert stars + int(is_array) == 1, f"pointer depth of {p!r}"
@@ -70,7 +71,7 @@ def rust_param(p):
     name, ty = [x.strip() for x in p.split(":", 1)]
     m = re.fullmatch(r"\*(const|mut)\s+\*(const|mut)\s+(\w+)", ty)
     if m:                                        # *mut *mut c_void = void **; *const *const c_void = const void *const *
-        assert m.group(3) == "c_void", f"pointer-to-pointer of {p!r}"
+        assert m.group(3) in ("c_void", "ShplonkState"), f"pointer-to-pointer of {p!r}"
         return ("ptrptr", RUST_TYPES[m.group(3)], [m.group(1), m.group(2)].count("const"))
     m = re.fullmatch(r"\*(const|mut)\s+(\w+)", ty)
     if m:
@@ -192,6 +193,25 @@ def test_program_structs_match_the_header_field_by_field():
         for nm, val in re.findall(group[0] + r"(\w+)\s*=\s*(\d+)", hdr):
             assert re.search(r"pub\(crate\) const " + group[1] + nm + r": u8 = " + val + r";", ffi), f"{group[1]}{nm} != {val}"
     assert re.search(r"#define ZKHIP_VM_REGS (\d+)", hdr).group(1) == re.search(r"pub\(crate\) const VM_REGS: usize = (\d+);", ffi).group(1)
+
+
+def test_prover_query_struct_matches_the_header():
+    """`#[repr(C)] ProverQueryC` against `zkhip_prover_query`: point[4] | d_poly | eval[4] | has_eval | reserved -- 80 bytes on both sides (and
+    in the ctypes mirror the GPU tests use)"""
+    import ctypes as C
+
+    from zksnap_circuits_halo2_amd import _lib
+
+    hdr = strip_c_comments(open(os.path.join(ROOT, "include", "zkhip.h")).read())
+    body = re.search(r"typedef struct zkhip_prover_query\s*\{(.*?)\}\s*zkhip_prover_query\s*;", hdr, flags=re.S).group(1)
+    cfields = [" ".join(d.split()) for d in body.split(";") if d.strip()]
+    assert cfields == ["uint64_t point[4]", "const void *d_poly", "uint64_t eval[4]", "uint32_t has_eval", "uint32_t reserved"]
+    ffi = re.sub(r"//[^\n]*", "", open(os.path.join(SHIM, "zkhip_ffi.rs")).read())
+    rbody = re.search(r"pub\(crate\) struct ProverQueryC\s*\{(.*?)\}", ffi, flags=re.S).group(1)
+    rfields = [" ".join(d.replace("pub ", "").split()) for d in rbody.split(",") if d.strip()]
+    assert rfields == ["point: [u64; 4]", "d_poly: *const c_void", "eval: [u64; 4]", "has_eval: u32", "reserved: u32"]
+    assert re.search(r"#\[repr\(C\)\]\s*#\[derive\(Clone, Copy\)\]\s*pub\(crate\) struct ProverQueryC", ffi)
+    assert C.sizeof(_lib.ProverQueryC) == 80 and _lib.ProverQueryC.d_poly.offset == 32 and _lib.ProverQueryC.has_eval.offset == 72
 
 
 def test_prover_patch_uses_only_what_zkhip_ffi_defines():

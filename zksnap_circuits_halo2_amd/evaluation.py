@@ -487,12 +487,16 @@ def export_prover_programs(k: int, gate_cols: int, lookups: int, seed: int = 1) 
     rng = random.Random(seed)
     beta, gamma, theta, y, x = (rng.randrange(1, F.R_MOD) for _ in range(5))
     w = lambda a: np.ascontiguousarray(a).astype("<u8").tobytes()
-    out = [struct.pack("<4sI", b"ZKPS", 2),
+    wk, usable = F.omega_for(k), (1 << k) - (cs.blinding_factors + 1)
+    rot_points = [x * pow(wk, r, F.R_MOD) % F.R_MOD for r in (0, 1, 2, 3, -1, usable)]      # the opening points of the multi-open argument
+    y_mo, v_mo, u_mo = (rng.randrange(1, F.R_MOD) for _ in range(3))
+    out = [struct.pack("<4sI", b"ZKPS", 3),
            struct.pack("<8I", k, dom.extended_k, gate_cols, lookups, len(cs.permutation_columns), cs.num_permutation_sets, cs.chunk_len, cs.blinding_factors),
            struct.pack("<7I", qc.total, qc.fixed, qc.advice, qc.l0, qc.sigma, qc.perm_product, qc.lookup),
            w(dom.omega_inv), w(dom.ifft_divisor), w(dom.extended_omega), w(dom.extended_omega_inv), w(dom.extended_ifft_divisor), w(dom.g_coset),
            w(F.fr_encode([x])[0]), w(F.fr_encode([F.omega_for(k)])[0]), w(F.fr_encode([DELTA])[0]), w(F.fr_encode([beta])[0]), w(F.fr_encode([gamma])[0]),
-           struct.pack("<I", dom.t_evaluations.shape[0]), w(dom.t_evaluations)]      # (version 2: omega, delta, beta, gamma for zkhip_permutation_products)
+           w(F.fr_encode(rot_points)), w(F.fr_encode([y_mo, v_mo, u_mo])),
+           struct.pack("<I", dom.t_evaluations.shape[0]), w(dom.t_evaluations)]      # (version 2: omega, delta, beta, gamma; version 3: x omega^r for r = 0, 1, 2, 3, -1, u and the multi-open challenges)
     to_mont = RowProgram()                # raw integer words are the Montgomery form of a / R: multiply by R
     to_mont.emit(OP_MUL, 0, to_mont.column(0), to_mont.constant(pow(2, 256, F.R_MOD)))
     progs = [to_mont]
