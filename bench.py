@@ -1006,6 +1006,7 @@ def extras(lib, _lib, F, torch, dev, stream) -> dict:
     except Exception as exc:   # an extra: never fail the bench line
         out["msm_g2_2^16"] = {"error": repr(exc)}
     out["small_circuit_replays"] = small_replays(lib, _lib, F, torch, dev, stream, timed)
+    out["small_circuit_replays"]["prover_sequences_c99"] = shim_sequences_small(torch)
     out["prover_phases_k22"] = prover_phases(lib, _lib, F, torch, dev, stream, timed)
     out["wrapper_replay"] = {"workload": "k=22: 18 MSM 2^22 + 13 iNTT 2^22 + 13 NTT 2^24 + 1 iNTT 2^24, device-resident",
                              "ms": round(ms, 2), "proofs_per_s_msm_ntt_portion": round(1e3 / ms, 3),
@@ -1092,6 +1093,47 @@ def shim_device_sequence(k: int, gate_cols: int, torch) -> dict:
                                          "proofs_per_s": round(1e3 / ms, 3)}}
     except Exception as exc:   # an extra: never fail the bench line
         return {"shim_device_sequence_ms": None, "shim_device_sequence_error": repr(exc)}
+
+
+def shim_sequences_small(torch) -> dict:
+    """The same C99 replay at the reference's small circuits' sizes and column counts -- the voter at k = 13 and the state transition at k = 15
+    size their columns with `calculate_params` (/root/reference/voter/benches/voter_circuit.rs:49-51,
+    /root/reference/aggregator/benches/state_transition_circuit.rs:48-50: hundreds of advice columns at these k; BASELINE configs[0] and [2]) --
+    all three ways over one witness with every commitment, evaluation and quotient coefficient compared by the program itself: host buffers
+    call by call (the plain drop-in), host buffers with one call per phase (prover_patch.rs mode (a)), device-resident handles (mode (b)),
+    and the last one with the multi-open argument (SHPLONK) on top.  One lookup column (the program's limit), so 256 / 64 gate columns."""
+    import re
+    import subprocess
+    import tempfile
+
+    out = {}
+    try:
+        from zksnap_circuits_halo2_amd import evaluation as E
+
+        lib_dir = os.path.join(ROOT, "zksnap_circuits_halo2_amd")
+        with tempfile.TemporaryDirectory() as tmp:
+            exe = os.path.join(tmp, "prover_sequence")
+            subprocess.check_call(["gcc", "-std=c99", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "prover_sequence.c"),
+                                   "-o", exe, "-L", lib_dir, "-lzkhip", "-Wl,-rpath," + lib_dir])
+            for name, k, gate_cols in (("voter_shape_k13_256_columns", 13, 256), ("state_transition_shape_k15_64_columns", 15, 64)):
+                rec = os.path.join(tmp, f"programs_{k}.bin")
+                with open(rec, "wb") as fh:
+                    fh.write(E.export_prover_programs(k, gate_cols, 1, seed=k))
+                torch.cuda.synchronize()
+                res = subprocess.run([exe, rec], capture_output=True, text=True, timeout=600)
+                m = re.search(r"sequence_ms host_call_by_call=([\d.]+) host_one_call_per_phase=([\d.]+) device_resident=([\d.]+) \(with the multi-open argument ([\d.]+)\)", res.stdout)
+                if res.returncode != 0 or not m or "prover sequence OK" not in res.stdout:
+                    out[name] = {"error": (res.stdout + res.stderr)[-300:]}
+                    continue
+                shape = re.search(r"shape: (.*)", res.stdout)
+                out[name] = {"host_call_by_call_ms": float(m.group(1)), "host_one_call_per_phase_ms": float(m.group(2)), "device_resident_ms": float(m.group(3)),
+                             "device_resident_with_multiopen_ms": float(m.group(4)), "proofs_per_s_device_side": round(1e3 / float(m.group(4)), 1),
+                             "shape": shape.group(1) if shape else None, "results_compared": True}
+        out["how"] = ("tests/cpp/prover_sequence.c in a child process, ONE proof per way (cold: the first calls of a process), PCIe-inclusive; no witness generation, "
+                      "no transcript; the proving key's columns are transformed outside the timed region, as pk.fixed_cosets / permutation.cosets are")
+    except Exception as exc:   # an extra: never fail the bench line
+        out["error"] = repr(exc)
+    return out
 
 
 def wrapper_replay_k24(lib, _lib, F, torch, dev, stream, c4: dict) -> dict:

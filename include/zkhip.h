@@ -189,6 +189,16 @@ int zkhip_fr_eval_rows_device(const zkhip_vm_program *prog, const void *const *d
  * launching anything (no device needed), e.g. at keygen, so that the first proof does not pay the seconds of compilation. */
 int zkhip_vm_jit_source(const zkhip_vm_program *prog, uint32_t n_columns, uint32_t log_rows, char *buf, size_t cap, size_t *len);
 int zkhip_vm_jit_compile(const zkhip_vm_program *prog, uint32_t n_columns, uint32_t log_rows, size_t *code_bytes);
+/* out[row] = sum_p weights[p] * progs[p](row): `n_progs` independent row programs over the same columns, run side by side in one launch
+ * (one grid row per program) and combined with zkhip_fr_linear_combination_device's kernel.  Programs that read ZKHIP_SRC_ROWPOW must
+ * name the same omega.  For programs that are
+ * long and run over few rows: the quotient numerator of a circuit with hundreds of columns at 2^13 .. 2^15 rows (the reference's voter and
+ * state-transition shapes) is thousands of instructions, and one program there is a handful of wavefronts walking the whole list.  The
+ * y-fold of `evaluate_h` is linear in its terms, h = sum_i term_i y^(T-1-i), so a host cuts the term list into consecutive runs, folds each
+ * into a program of its own and passes weights[p] = y^(number of terms after run p) (zksnap_circuits_halo2_amd/evaluation.py
+ * `evaluate_h_parts`).  `weights`: n_progs x 4 words.  ZKHIP_SRC_PREV reads 0 in every program (there is no previous value). */
+int zkhip_fr_eval_rows_sum_device(const zkhip_vm_program *progs, const uint64_t *weights, uint32_t n_progs, const void *const *d_columns, uint32_t n_columns,
+                                  uint32_t log_rows, void *d_out, void *stream);
 /* out[j] = a[index_a[j]] * b[index_b[j]] (u32 indices, device-resident): the inner loop of `permutation::keygen::Assembly::build_pk`
  * [DEP halo2-axiom plonk/permutation/keygen.rs; keygen_pk at /root/reference/aggregator/src/wrapper.rs:108] -- sigma_i[j] =
  * delta^(column the cell (i, j) maps to) * omega^(its row) -- so that the sigma columns of a proving key are built in HBM.  Indices
@@ -200,6 +210,12 @@ int zkhip_fr_gather_mul_device(const void *d_a, size_t a_len, const void *d_inde
  * num is preserved, den is overwritten (inverted in place), z may alias num. */
 int zkhip_fr_grand_product(const uint64_t *num, const uint64_t *den, size_t n, uint64_t *z);
 int zkhip_fr_grand_product_device(const void *d_num, void *d_den, size_t n, void *d_z, void *stream);
+/* out[i] = sum_j coeffs[j] * d_cols[j][i] for i < n: the y- / v-combinations and L(X) of the multi-open provers over `count` device-resident
+ * polynomials ([DEP] poly/kzg/multiopen/shplonk/prover.rs; hundreds of polynomials at the voter / state-transition column counts).  The
+ * columns are cut into groups that run side by side, two products under one reduction, so the call does not degrade into `count`
+ * dependent multiply-adds per row the way the same sum written as a row program does on few rows.  `d_cols` and `coeffs` (count x 4
+ * words, Montgomery) are host arrays; d_out may be one of the columns.  count = 0 gives zeros. */
+int zkhip_fr_linear_combination_device(const void *const *d_cols, const uint64_t *coeffs, size_t count, size_t n, void *d_out, void *stream);
 /* The KZG multi-open provers for a host that keeps its polynomials as device addresses (a Rust host's handles: rust-shim/prover_patch.rs):
  * `ProverGWC::create_proof` (the reference's gen_snark path, /root/reference/aggregator/src/wrapper.rs:59-60, 127-137) and
  * `ProverSHPLONK::create_proof` (the benches' gen_proof path, /root/reference/aggregator/benches/wrapper_circuit.rs:140)

@@ -1103,14 +1103,18 @@ struct ProverQuery {
 };
 
 namespace detail {
-// out[row] = sum_k coeffs[k] * column_k[row]: a chain of multiply-adds in one register (plonk::evaluation's Horner shape)
+// out[row] = sum_k coeffs[k] * column_k[row] (zkhip_fr_linear_combination_device: groups of columns side by side, two products per
+// reduction -- the same sum as a row program is `coeffs.size()` dependent multiply-adds per row, which is what the Python mirror runs)
 inline void linear_combination(const std::vector<Fr>& coeffs, const std::vector<const DeviceVec*>& cols, uint32_t k, DeviceVec& out) {
-  RowProgram p;
-  p.rotations = {0};
-  p.constants = coeffs;
-  p.emit(ZKHIP_OP_MUL, 0, RowProgram::column(0, 0), RowProgram::constant(0));
-  for (size_t i = 1; i < coeffs.size(); i++) p.emit(ZKHIP_OP_MAD, 0, RowProgram::column((uint16_t)i, 0), RowProgram::constant((uint16_t)i), RowProgram::reg(0));
-  p.run(cols, k, out);
+  if (coeffs.size() != cols.size()) throw std::invalid_argument("linear_combination: coeffs.len() != columns.len()");
+  const size_t n = (size_t)1 << k;
+  std::vector<const void*> ptrs;
+  for (const DeviceVec* c : cols) {
+    if (c->size() < n) throw std::invalid_argument("linear_combination: column shorter than 2^k");
+    ptrs.push_back(c->data());
+  }
+  if (out.size() < n) throw std::invalid_argument("linear_combination: output shorter than 2^k");
+  check(zkhip_fr_linear_combination_device(ptrs.data(), coeffs.empty() ? nullptr : coeffs.data()->l, coeffs.size(), n, out.data(), nullptr), "linear_combination");
 }
 // d_poly[index] -= value / d_poly[index] = 0: one-row programs on the element itself (no host round trip)
 inline void sub_const_at(DeviceVec& poly, size_t index, const Fr& value) {
@@ -1175,6 +1179,19 @@ inline std::vector<Fr> lagrange_interpolate(const std::vector<Fr>& points, const
     for (size_t t = 0; t < m; t++) coeffs[t] = add_fr(coeffs[t], mul(scale, num[t]));
   }
   return coeffs;
+}
+// the Lagrange basis over `points`: basis[i] = coefficients (low to high) of the polynomial that is 1 at points[i] and 0 at the others.
+// One inversion per point of the SET -- interpolating hundreds of polynomials over the same few points reuses it
+// (interpolant of evals = sum_i evals[i] * basis[i]: lagrange_interpolate above, without its per-call inversions)
+inline std::vector<std::vector<Fr>> lagrange_basis(const std::vector<Fr>& points) {
+  std::vector<std::vector<Fr>> basis;
+  std::vector<Fr> unit(points.size(), Fr{});
+  for (size_t i = 0; i < points.size(); i++) {
+    unit[i] = one();
+    basis.push_back(lagrange_interpolate(points, unit));
+    unit[i] = Fr{};
+  }
+  return basis;
 }
 inline Fr eval_small(const std::vector<Fr>& coeffs, const Fr& x) {
   Fr acc{};
@@ -1261,7 +1278,7 @@ class ShplonkProver {
     for (const auto& pp : by_poly) {
       rotation_set* rs = nullptr;
       for (auto& s_ : sets_) if (same(s_.points, pp.pts)) rs = &s_;
-      if (!rs) { sets_.push_back({pp.pts, {}, {}}); rs = &sets_.back(); }
+      if (!rs) { sets_.push_back({pp.pts, {}, {}, detail::lagrange_basis(pp.pts)}); rs = &sets_.back(); }
       std::vector<Fr> ev;
       for (const Fr& z : pp.pts)
         for (const auto& q : queries) if (q.poly == pp.poly && q.point == z) { ev.push_back(q.eval); break; }
@@ -1277,11 +1294,12 @@ class ShplonkProver {
       DeviceVec* acc = fresh();
       DeviceVec* tmp = fresh();
       detail::linear_combination(ypow, rs.polys, k_, *acc);
-      std::vector<Fr> low(rs.points.size(), Fr{});
-      for (size_t j = 0; j < rs.polys.size(); j++) {
-        const std::vector<Fr> r = detail::lagrange_interpolate(rs.points, rs.evals[j]);
-        for (size_t t = 0; t < low.size(); t++) low[t] = detail::add_fr(low[t], detail::mul(ypow[j], r[t]));
-      }
+      // sum_j y^j R_j with R_j = sum_i evals[j][i] basis[i]: first the weights w_i = sum_j y^j evals[j][i], then m basis polynomials
+      std::vector<Fr> low(rs.points.size(), Fr{}), weight(rs.points.size(), Fr{});
+      for (size_t j = 0; j < rs.polys.size(); j++)
+        for (size_t i = 0; i < weight.size(); i++) weight[i] = detail::add_fr(weight[i], detail::mul(ypow[j], rs.evals[j][i]));
+      for (size_t i = 0; i < weight.size(); i++)
+        for (size_t t = 0; t < low.size(); t++) low[t] = detail::add_fr(low[t], detail::mul(weight[i], rs.basis[i][t]));
       for (size_t t = 0; t < low.size(); t++) detail::sub_const_at(*acc, t, low[t]);
       DeviceVec *src = acc, *dst = tmp;
       for (const Fr& z : rs.points) { detail::divide_by_root(*src, z, *dst); std::swap(src, dst); }
@@ -1309,12 +1327,16 @@ class ShplonkProver {
     std::vector<const DeviceVec*> cols;
     Fr constant{};
     for (size_t i = 0; i < sets_.size(); i++) {
+      std::vector<Fr> basis_at_u;                          // R_ij(u) = sum_t evals[j][t] basis_t(u)
+      for (const auto& b : sets_[i].basis) basis_at_u.push_back(detail::eval_small(b, u));
       Fr yp = detail::one();
       for (size_t j = 0; j < sets_[i].polys.size(); j++) {
         const Fr c = detail::mul(detail::mul(detail::mul(vpow_[i], z_diffs[i]), yp), norm);
         cols.push_back(sets_[i].polys[j]);
         coeffs.push_back(c);
-        constant = detail::add_fr(constant, detail::mul(c, detail::eval_small(detail::lagrange_interpolate(sets_[i].points, sets_[i].evals[j]), u)));
+        Fr r_at_u{};
+        for (size_t t = 0; t < basis_at_u.size(); t++) r_at_u = detail::add_fr(r_at_u, detail::mul(sets_[i].evals[j][t], basis_at_u[t]));
+        constant = detail::add_fr(constant, detail::mul(c, r_at_u));
         yp = detail::mul(yp, y_);
       }
     }
@@ -1335,7 +1357,7 @@ class ShplonkProver {
   }
 
  private:
-  struct rotation_set { std::vector<Fr> points; std::vector<const DeviceVec*> polys; std::vector<std::vector<Fr>> evals; };
+  struct rotation_set { std::vector<Fr> points; std::vector<const DeviceVec*> polys; std::vector<std::vector<Fr>> evals; std::vector<std::vector<Fr>> basis; };
   DeviceVec* fresh() { keep_.emplace_back(new DeviceVec(n_)); return keep_.back().get(); }
   CommitFn commit_;
   uint32_t k_;

@@ -139,6 +139,10 @@ pub(crate) struct DeviceProof {
 //   quotient               base.coeff_to_extended_many(.., &ext, ..) for the witness-dependent columns; DevCols::eval_rows(&quotient_program, all
 //                          columns of ext, extended_k, &h, 0); h.quotient_to_coeff(..) (divide_by_vanishing_poly + extended_to_coeff);
 //                          the three pieces = h.commit_many(1, ..) with stride n over column 1 (coefficients), against &params.g
+//                          For a circuit with hundreds of columns at k = 13 .. 15 (the voter and the state transition) the quotient program is
+//                          thousands of instructions over a few thousand rows: cut the evaluator's calculations into ~16 runs at `Store`
+//                          boundaries (the y-fold is linear: h = sum_i term_i y^(T-1-i)), lower each run, and call
+//                          DevCols::eval_rows_sum(&programs, &weights, ..) with weights[p] = y^(terms after run p) -- 4.8 -> 1.2 ms at 947 columns
 //   x                      DevCols::eval_polys(addresses of every opened polynomial, n, &x, F::ZERO) -> transcript
 //   multiopen              the opened polynomials stay on the device: instead of `ProverQuery { point, poly: &Polynomial, blind }` the prover
 //                          collects `zkhip_ffi::dev_query(&point, base.at(column, 0), &eval)` in the order upstream builds its queries

@@ -57,6 +57,9 @@ extern "C" {
     fn zkhip_fr_eval_rows_device(prog: *const VmProgram, d_columns: *const *const c_void, n_columns: u32, log_rows: u32, accumulate: c_int,
                                  d_out: *mut c_void, stream: *mut c_void) -> c_int;
     fn zkhip_fr_grand_product_device(d_num: *const c_void, d_den: *mut c_void, n: usize, d_z: *mut c_void, stream: *mut c_void) -> c_int;
+    fn zkhip_fr_eval_rows_sum_device(progs: *const VmProgram, weights: *const u64, n_progs: u32, d_columns: *const *const c_void, n_columns: u32, log_rows: u32,
+                                     d_out: *mut c_void, stream: *mut c_void) -> c_int;
+    fn zkhip_fr_linear_combination_device(d_cols: *const *const c_void, coeffs: *const u64, count: usize, n: usize, d_out: *mut c_void, stream: *mut c_void) -> c_int;
     fn zkhip_multiopen_gwc_device(bases: *const u64, k: u32, queries: *const ProverQueryC, n_queries: usize, v: *const u64, out_points: *mut u64,
                                   capacity: usize, n_out: *mut usize) -> c_int;
     fn zkhip_multiopen_shplonk_begin_device(bases: *const u64, k: u32, queries: *const ProverQueryC, n_queries: usize, y: *const u64, v: *const u64,
@@ -461,6 +464,27 @@ impl DevCols {
         // SAFETY: `p` borrows the Vecs of `prog`, alive for the call; `columns` are device addresses of columns with >= 2^log_rows rows
         let rc = unsafe { zkhip_fr_eval_rows_device(&p, columns.as_ptr(), columns.len() as u32, log_rows, 0, out.at(out_col, 0), std::ptr::null_mut()) };
         if rc != 0 { warn_once("zkhip_fr_eval_rows_device", rc); }
+        rc == 0
+    }
+    /// the quotient numerator as a SUM of row programs over consecutive runs of the y-fold's terms (`weights[p]` = y^(number of terms after
+    /// run p)): for circuits with hundreds of columns at 2^13 .. 2^15 rows, where ONE program is thousands of instructions walked by a handful
+    /// of wavefronts; the programs run side by side in one launch.  `lower_graph` is called once per run of `Calculation`s ending at a `Store`
+    pub(crate) fn eval_rows_sum<F: 'static>(progs: &[VmProgramOwned], weights: &[F], columns: &[*const c_void], log_rows: u32, out: &DevCols, out_col: usize) -> bool {
+        if !is::<F, Fr>() || progs.is_empty() || progs.len() != weights.len() { return false; }
+        let ffi: Vec<VmProgram> = progs.iter().map(|p| p.as_ffi()).collect();
+        // SAFETY: `ffi` borrows the Vecs of `progs`, alive for the call; weights = &[Fr]; columns are device addresses of >= 2^log_rows rows
+        let rc = unsafe { zkhip_fr_eval_rows_sum_device(ffi.as_ptr(), weights.as_ptr() as *const u64, ffi.len() as u32, columns.as_ptr(), columns.len() as u32, log_rows,
+                                                        out.at(out_col, 0), std::ptr::null_mut()) };
+        if rc != 0 { warn_once("zkhip_fr_eval_rows_sum_device", rc); }
+        rc == 0
+    }
+    /// column `out_col` of `out` = sum_j coeffs[j] * columns[j] over n rows (the linear combinations of lookups' compressed expressions with
+    /// many inputs, of the multi-open argument when it is assembled on this side)
+    pub(crate) fn linear_combination<F: 'static>(columns: &[*const c_void], coeffs: &[F], n: usize, out: &DevCols, out_col: usize) -> bool {
+        if !is::<F, Fr>() || columns.len() != coeffs.len() || n > out.len { return false; }
+        // SAFETY: coeffs = &[Fr]; columns are device addresses of >= n rows
+        let rc = unsafe { zkhip_fr_linear_combination_device(columns.as_ptr(), coeffs.as_ptr() as *const u64, columns.len(), n, out.at(out_col, 0), std::ptr::null_mut()) };
+        if rc != 0 { warn_once("zkhip_fr_linear_combination_device", rc); }
         rc == 0
     }
     /// z = grand product of num / den (num = column `z_col` on entry, den is consumed): `permutation::Argument::commit`, `lookup::commit_product`

@@ -108,7 +108,9 @@ int main(int argc, char **argv) {
   size_t mo_queries = 0, mo_witnesses = 0;
   int mo_refused = 0;
   const uint64_t *t_eval;
-  zkhip_vm_program to_mont, perm_num[16], perm_den[16], lk_num, lk_den, eval_h;
+  zkhip_vm_program to_mont, *perm_num, *perm_den, lk_num, lk_den, eval_h, *eval_h_parts = NULL;
+  uint32_t n_parts = 0;
+  const uint64_t *part_weights = NULL;
   size_t n, en, u, nadv, nproof, first_proof2;
   uint64_t *g, *gl, **lag, *advice_flat;
   void *d_g, *d_gl;
@@ -129,11 +131,18 @@ int main(int argc, char **argv) {
   rd_fr(y_mo); rd_fr(v_mo); rd_fr(u_mo);
   period = rd_u32();
   t_eval = (const uint64_t *)rd_copy((size_t)period * 32);
-  if (NL != 1 || nsets > 16 || q_fixed != 0) { fprintf(stderr, "shape not supported by this program\n"); return 2; }
+  if (NL != 1 || q_fixed != 0) { fprintf(stderr, "shape not supported by this program\n"); return 2; }
+  perm_num = xmalloc((size_t)(nsets ? nsets : 1) * sizeof(*perm_num)); perm_den = xmalloc((size_t)(nsets ? nsets : 1) * sizeof(*perm_den));
   rd_prog(&to_mont);
   for (si = 0; si < nsets; si++) rd_prog(&perm_num[si]);
   for (si = 0; si < nsets; si++) rd_prog(&perm_den[si]);
   rd_prog(&lk_num); rd_prog(&lk_den); rd_prog(&eval_h);
+  n_parts = rd_u32();            /* the quotient numerator as a sum of programs (long program, few rows): count, weights, programs */
+  if (n_parts) {
+    part_weights = (const uint64_t *)rd_copy((size_t)n_parts * 32);
+    eval_h_parts = xmalloc((size_t)n_parts * sizeof(*eval_h_parts));
+    for (i = 0; i < n_parts; i++) rd_prog(&eval_h_parts[i]);
+  }
   n = (size_t)1 << k; en = (size_t)1 << ek; u = n - (blind + 1);
   nadv = G + NL;
   /* witness-dependent columns of the quotient, in column order: advice [q_advice, q_l0) and products / permuted pair [q_perm, ncol) */
@@ -394,7 +403,8 @@ int main(int argc, char **argv) {
       OK(zkhip_coeff_to_extended_device(DLAG(nadv), n, k, d_ext + (size_t)q_perm * en * 32, en, ek, (uint32_t)(nproof - nadv), ext_om, zeta, NULL));
       /* 6. quotient */
       for (i = 0; i < ncol; i++) dptr[i] = d_ext + (size_t)i * en * 32;
-      OK(zkhip_fr_eval_rows_device(&eval_h, dptr, ncol, ek, 0, d_hext, NULL));
+      if (n_parts) OK(zkhip_fr_eval_rows_sum_device(eval_h_parts, part_weights, n_parts, dptr, ncol, ek, d_hext, NULL));   /* the parts side by side */
+      else OK(zkhip_fr_eval_rows_device(&eval_h, dptr, ncol, ek, 0, d_hext, NULL));
       OK(zkhip_mul_periodic_device(d_hext, en, d_teval, period, NULL));
       OK(zkhip_extended_to_coeff_device(d_hext, en, ek, ext_om_inv, ext_div, zeta, d_hc, en, 3 * n, 1, NULL));
       OK(zkhip_msm_g1_registered_batch_device(g, d_hc, n, 3, n, d_out + 96 * c, NULL)); c += 3;

@@ -27,7 +27,7 @@ def build(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k,gate_cols", [(15, 3), (11, 1), (13, 6)])
+@pytest.mark.parametrize("k,gate_cols", [(15, 3), (11, 1), (13, 6), (10, 40)])      # (10, 40): a 600-instruction quotient program, run as a sum of parts by sequence D
 def test_prover_patch_call_sequence_from_c99(tmp_path, k, gate_cols):
     exe = build(tmp_path)
     rec = tmp_path / "programs.bin"
@@ -59,6 +59,8 @@ def test_exported_programs_record_is_well_formed():
     off += 4 + period * 32
     assert period == 4
     nprog = 0
+    assert struct.unpack_from("<I", b, len(b) - 4)[0] == 0           # the count of quotient parts: none for a 100-instruction program
+    b = b[:-4]
     while off < len(b):
         n_insns = struct.unpack_from("<I", b, off)[0]; off += 4 + 16 * n_insns
         n_const = struct.unpack_from("<I", b, off)[0]; off += 4 + 32 * n_const

@@ -504,3 +504,75 @@ def test_permutation_products_reject_bad_arguments(lib):
     assert lib.zkhip_permutation_products(ptrs, null, 1, 2, 2, 3, *args, z.ctypes.data) == -1          # a null column
     assert lib.zkhip_permutation_products(ptrs, ptrs, 1, 2, 2, 3, *args, None) == -1
     assert lib.zkhip_permutation_products(ptrs, ptrs, 0, 2, 2, 3, *args, None) == 0                    # no columns: nothing to do
+
+
+@pytest.mark.parametrize("log_n,count", [(0, 1), (3, 2), (7, 33), (9, 70), (10, 1), (6, 0), (5, 2100)])
+def test_linear_combination_of_many_columns(lib, log_n, count):
+    """zkhip_fr_linear_combination_device == sum_j c_j col_j with big integers (one group, several groups, an odd column left over, more than
+    64 groups, no column at all), also with the output aliasing a column"""
+    import torch
+
+    rng = random.Random(100 * log_n + count)
+    n = 1 << log_n
+    dev = torch.device("cuda", 0)
+    base = [[rng.randrange(R) if rng.random() < 0.9 else rng.choice([0, 1, R - 1]) for _ in range(n)] for _ in range(min(count, 40))]
+    cols = [base[j % len(base)] for j in range(count)] if count else []
+    coeffs = [rng.choice([0, 1, R - 1, rng.randrange(R)]) for _ in range(count)]
+    d_base = [torch.from_numpy(enc(c).view(np.int64)).to(dev) for c in base]
+    d_cols = [d_base[j % len(d_base)] for j in range(count)]
+    cw = F.fr_encode(coeffs) if count else np.zeros((1, 4), dtype=np.uint64)
+    out = torch.full((n, 4), -1, dtype=torch.int64, device=dev)
+    ptrs = (C.c_void_p * max(count, 1))(*[t.data_ptr() for t in d_cols])
+    _lib.check(lib.zkhip_fr_linear_combination_device(ptrs, cw.ctypes.data, count, n, out.data_ptr(), None))
+    torch.cuda.synchronize()
+    exp = [sum(c * col[i] for c, col in zip(coeffs, cols)) % R for i in range(n)]
+    assert F.fr_decode(out.cpu().numpy().view(np.uint64)) == exp
+    if count:                                  # in place: the output is the first column
+        first = d_cols[0].clone()
+        ptrs = (C.c_void_p * count)(*([first.data_ptr()] + [t.data_ptr() if t is not d_cols[0] else first.data_ptr() for t in d_cols[1:]]))
+        _lib.check(lib.zkhip_fr_linear_combination_device(ptrs, cw.ctypes.data, count, n, first.data_ptr(), None))
+        torch.cuda.synchronize()
+        assert F.fr_decode(first.cpu().numpy().view(np.uint64)) == exp
+
+
+@pytest.mark.parametrize("parts", [1, 2, 7, 64])
+def test_quotient_numerator_as_a_sum_of_programs(lib, parts):
+    """evaluate_h_parts + zkhip_fr_eval_rows_sum_device == evaluate_h_program (one fold over all terms) on random columns of a halo2-lib
+    shaped constraint system (6 gate columns, 2 lookups: 25 terms); `parts` beyond the number of terms is clamped"""
+    import torch
+
+    k, ek = 6, 8
+    rows = 1 << ek
+    cs = E.halo2_lib_shape(6, 2)
+    qc = E.quotient_columns(cs)
+    rng = random.Random(parts)
+    beta, gamma, theta, y = (rng.randrange(1, R) for _ in range(4))
+    dev = torch.device("cuda", 0)
+    cols = torch.randint(-(1 << 63), (1 << 63) - 1, (qc.total, rows, 4), dtype=torch.int64, device=dev)
+    cols[:, :, 3] = torch.randint(0, 1 << 61, (qc.total, rows), dtype=torch.int64, device=dev)
+    ptrs = [cols[i].data_ptr() for i in range(qc.total)]
+    whole = torch.empty((rows, 4), dtype=torch.int64, device=dev)
+    E.evaluate_h_program(cs, k, ek, beta, gamma, theta, y).run_device(ptrs, ek, whole.data_ptr())
+    progs, weights = E.evaluate_h_parts(cs, k, ek, beta, gamma, theta, y, parts)
+    assert 1 <= len(progs) <= parts and weights[-1] == 1
+    summed = torch.full((rows, 4), -1, dtype=torch.int64, device=dev)
+    E.run_programs_sum_device(progs, weights, ptrs, ek, summed.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(summed, whole)
+
+
+def test_eval_rows_sum_rejects_bad_arguments(lib):
+    import torch
+
+    p = E.RowProgram(); p.emit(E.OP_MOV, 0, p.column(0))
+    prog, keep = p._marshal()
+    arr = (_lib.VmProgram * 1)(prog)
+    col = torch.zeros((4, 4), dtype=torch.int64, device="cuda")
+    out = torch.zeros((4, 4), dtype=torch.int64, device="cuda")
+    w = F.fr_encode([1])
+    ptrs = (C.c_void_p * 1)(col.data_ptr())
+    assert lib.zkhip_fr_eval_rows_sum_device(arr, w.ctypes.data, 1, ptrs, 1, 2, out.data_ptr(), None) == 0
+    assert lib.zkhip_fr_eval_rows_sum_device(arr, w.ctypes.data, 0, ptrs, 1, 2, out.data_ptr(), None) == -1
+    assert lib.zkhip_fr_eval_rows_sum_device(arr, None, 1, ptrs, 1, 2, out.data_ptr(), None) == -1
+    assert lib.zkhip_fr_eval_rows_sum_device(arr, w.ctypes.data, 1, ptrs, 0, 2, out.data_ptr(), None) == -1        # the program names column 0
+    torch.cuda.synchronize()

@@ -296,7 +296,14 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk
 
         # ---- quotient ---------------------------------------------------------------------------------------------------------------
         prog = E.evaluate_h_program(cs, k, ek, beta, gamma, theta, y)
-        h_ext = run_prog(prog, [ext[i] for i in range(ncol)], ek)
+        if len(prog.insns) > 512 and ek < 18:
+            # thousands of instructions over a few thousand rows: as one program a handful of wavefronts walk the whole list; as a sum of
+            # programs over runs of the y-fold's terms (evaluate_h_parts + zkhip_fr_eval_rows_sum_device) they run side by side
+            parts, weights = E.evaluate_h_parts(cs, k, ek, beta, gamma, theta, y, 16)
+            h_ext = torch.empty((en, 4), dtype=torch.int64, device=dev)
+            E.run_programs_sum_device(parts, weights, [ext[i].data_ptr() for i in range(ncol)], ek, h_ext.data_ptr())
+        else:
+            h_ext = run_prog(prog, [ext[i] for i in range(ncol)], ek)
         tinv = torch.from_numpy(dom.t_evaluations.view(np.int64)).to(dev)
         _lib.check(lib.zkhip_mul_periodic_device(h_ext.data_ptr(), en, tinv.data_ptr(), tinv.shape[0], None))
         lap("evaluate_h")

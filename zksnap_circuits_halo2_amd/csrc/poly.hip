@@ -437,6 +437,82 @@ int fr_permutation_products_device(const void* const* d_values_host, const void*
   return rc;
 }
 
+// ---- linear combination of many columns: out[i] = sum_j c_j col_j[i] -------------------------------------------------------------------
+// The y- / v-combinations and L(X) of the multi-open provers ([DEP] poly/kzg/multiopen/shplonk/prover.rs: hundreds of polynomials at the
+// voter / state-transition column counts).  As a row program this is a chain of `count` dependent multiply-adds per row -- at 2^13 rows
+// 128 wavefronts walking 650 instructions one after the other.  Here the columns are cut into groups of LC_GROUP: thread (row, group) adds
+// its group's products two at a time under ONE Montgomery reduction (fe_mul_add), a second kernel adds the groups' partial sums; with one
+// group the first kernel writes the result itself.  Coefficients are converted to the internal form once, by `count` threads.
+constexpr uint32_t LC_GROUP = 32;
+
+__global__ void __launch_bounds__(256) k_to_internal(const uint32_t* __restrict__ ext, uint32_t count, uint32_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  fe_arg c;
+#pragma unroll
+  for (int k = 0; k < 8; k++) c.w[k] = ext[(size_t)i * 8 + k];
+  store_canon(out, i, fr_const_internal(c));
+}
+
+__global__ void __launch_bounds__(256) k_lincomb(const uint32_t* const* __restrict__ cols, const uint32_t* __restrict__ coeff_int, uint32_t count, size_t n,
+                                                 uint32_t* __restrict__ out /* [groups][n] */) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t lo = blockIdx.y * LC_GROUP, hi = lo + LC_GROUP < count ? lo + LC_GROUP : count;
+  fe acc = fe_zero();
+  uint32_t j = lo;
+  for (; j + 1 < hi; j += 2) {          // internal-form coefficient x external value = external; both operands N-form < p: each pair < 2p
+    const fe t = fe_mul_add<Fr>(load_ext(coeff_int, j), load_ext(cols[j], i), load_ext(coeff_int, j + 1), load_ext(cols[j + 1], i));
+    acc = fe_norm(fe_add(acc, t));
+  }
+  if (j < hi) acc = fe_norm(fe_add(acc, fe_mul<Fr>(load_ext(coeff_int, j), load_ext(cols[j], i))));
+  store_canon(out + (size_t)blockIdx.y * n * 8, i, fe_reduce_soft<Fr>(acc));       // < 34p < 2^261 -> < 2p + 2^233 -> canonical
+}
+
+// out[i] = sum_g partial[g][i]
+__global__ void __launch_bounds__(256) k_sum_columns(const uint32_t* __restrict__ partial, uint32_t groups, size_t n, uint32_t* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fe acc = load_ext(partial, i);
+  for (uint32_t g = 1; g < groups; g++) {
+    acc = fe_add(acc, load_ext(partial + (size_t)g * n * 8, i));
+    if ((g & 3) == 3) acc = fe_norm(acc);           // four more canonical values per round: limbs stay below 2^32
+    if ((g & 63) == 63) acc = fe_reduce_soft<Fr>(acc);     // ... and the value below 2^261 (~169 p) whatever the number of groups
+  }
+  store_canon(out, i, fe_reduce_soft<Fr>(fe_norm(acc)));
+}
+
+size_t lincomb_workspace_bytes(size_t count, size_t n) {
+  const size_t groups = (count + LC_GROUP - 1) / LC_GROUP;
+  return ((count * 8 + 255) / 256) * 256 + 2 * ((count * 32 + 255) / 256) * 256 + (groups > 1 ? groups * n * 32 : 0) + 256;
+}
+
+int fr_linear_combination_device(const void* const* d_cols_host, const uint32_t* coeffs_host, size_t count, size_t n, uint32_t* d_out, void* ws, size_t ws_bytes,
+                                 hipStream_t stream) {
+  if (n == 0) return ZKHIP_OK;
+  if (count == 0) { HIPCHK(hipMemsetAsync(d_out, 0, n * 32, stream)); return ZKHIP_OK; }
+  const size_t groups = (count + LC_GROUP - 1) / LC_GROUP;
+  if (groups > 65535) { set_error("linear_combination: more than %u columns", 65535u * LC_GROUP); return ZKHIP_EINVAL; }
+  if (ws_bytes < lincomb_workspace_bytes(count, n)) { set_error("linear_combination: workspace too small"); return ZKHIP_EINVAL; }
+  char* p = (char*)ws;
+  const uint32_t** d_ptrs = (const uint32_t**)p;
+  p += ((count * 8 + 255) / 256) * 256;
+  uint32_t* d_ext = (uint32_t*)p;
+  p += ((count * 32 + 255) / 256) * 256;
+  uint32_t* d_int = (uint32_t*)p;
+  p += ((count * 32 + 255) / 256) * 256;
+  uint32_t* partial = (uint32_t*)p;
+  HIPCHK(hipMemcpyAsync(d_ptrs, d_cols_host, count * 8, hipMemcpyHostToDevice, stream));
+  HIPCHK(hipMemcpyAsync(d_ext, coeffs_host, count * 32, hipMemcpyHostToDevice, stream));
+  HIPCHK(hipStreamSynchronize(stream));                     // both sources are caller memory
+  hipLaunchKernelGGL(k_to_internal, grid_for(count, 256), dim3(256), 0, stream, (const uint32_t*)d_ext, (uint32_t)count, d_int);
+  hipLaunchKernelGGL(k_lincomb, dim3((unsigned)((n + 255) / 256), (unsigned)groups), dim3(256), 0, stream, (const uint32_t* const*)d_ptrs, (const uint32_t*)d_int,
+                     (uint32_t)count, n, groups > 1 ? partial : d_out);
+  if (groups > 1) hipLaunchKernelGGL(k_sum_columns, grid_for(n, 256), dim3(256), 0, stream, (const uint32_t*)partial, (uint32_t)groups, n, d_out);
+  HIPCHK(hipGetLastError());
+  return ZKHIP_OK;
+}
+
 int fr_batch_invert_device(uint32_t* d_a, size_t n, void* ws, size_t ws_bytes, hipStream_t stream) {
   if (n == 0) return ZKHIP_OK;
   if (ws_bytes < poly_workspace_bytes(n)) { set_error("batch_invert: workspace too small"); return ZKHIP_EINVAL; }

@@ -39,7 +39,17 @@ struct vm_launch {
   uint32_t* out;
   uint64_t rows;
   uint32_t accumulate;
+  const struct vm_part* parts;  // nullptr, or one record per blockIdx.y: several programs over the same columns in ONE launch (row_vm_device_multi)
 };
+// what differs between the programs of a multi-program launch (the column table, the power tables and the rows are shared)
+struct vm_part {
+  const void* prog;
+  const uint32_t* consts;
+  const uint32_t* rot_off;
+  uint32_t* out;
+  uint32_t n_insns, result_reg;
+};
+static_assert(sizeof(vm_part) == 40, "the kernel reads a part record as five 64-bit words");
 
 // 2r as normalised limbs
 struct fr_two_p {
@@ -242,8 +252,19 @@ __device__ __forceinline__ void vm_prefetch(const vm_launch& L, const vm_decoded
 }
 
 template <int R>
-__global__ void __launch_bounds__(VM_THREADS) k_row_vm(const vm_launch L) {
+__global__ void __launch_bounds__(VM_THREADS) k_row_vm(const vm_launch L0) {
   __shared__ uint32_t s_prev[NL * VM_THREADS], s_pow[NL * VM_THREADS];
+  vm_launch L = L0;
+  if (L0.parts) {                                          // uniform: the record of this workgroup's program, through scalar loads
+    const vm_c64 q = (vm_c64)(L0.parts + blockIdx.y);
+    const uint64_t w4 = q[4];
+    L.prog = (const void*)q[0];
+    L.consts = (const uint32_t*)q[1];
+    L.rot_off = (const uint32_t*)q[2];
+    L.out = (uint32_t*)q[3];
+    L.n_insns = (uint32_t)w4;
+    L.result_reg = (uint32_t)(w4 >> 32);
+  }
   const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= L.rows) return;
   fe r[R];
@@ -400,6 +421,138 @@ void vm_staging::release() {
   }
 }
 
+// One program's region of a staged blob -- [micro-ops (+ 4 padding no-ops) | constants | rotation offsets], `region` on the host, `dev`
+// its device address, the constants at `o_const` and the rotation offsets at `o_rot` from its start.
+// micro-ops: the instruction + its operands' resolved addresses; a product's second factor is fetched scaled by 2^5 -- free for a column /
+// constant (the other unpacking shift), a repack for a register -- so the memory operand goes second where the host did not put it there
+static void vm_fill_region(const zkhip_vm_program* p, const void* const* d_columns, uint64_t rows, unsigned char* region, uint64_t dev, size_t o_const, size_t o_rot) {
+  static_assert(sizeof(zkhip_vm_insn) == 16, "instruction layout");
+  std::vector<uint32_t> rot_rows(p->n_rotations ? p->n_rotations : 1, 0u);
+  for (uint32_t i = 0; i < p->n_rotations; i++) {
+    const int64_t off = ((int64_t)p->rotations[i] * (int64_t)p->rot_scale) % (int64_t)rows;
+    rot_rows[i] = (uint32_t)(off < 0 ? off + (int64_t)rows : off);
+  }
+  const uint64_t d_consts = dev + o_const;
+  vm_uop* uops = (vm_uop*)region;
+  for (uint32_t pc = 0; pc < p->n_insns + 4; pc++) {
+    vm_uop& u = uops[pc];
+    std::memset(&u, 0, sizeof(u));
+    u.base_a = u.base_b = d_consts;                      // dummy address for operands that are not in memory (and for the padding no-ops)
+    if (pc >= p->n_insns) { u.head = ZKHIP_OP_MOV | ((uint32_t)0 << 8); u.oa = ZKHIP_SRC_REG; continue; }   // MOV r0 <- r0 (never executed)
+    zkhip_vm_insn in = p->insns[pc];
+    const bool a_mem = in.a.kind == ZKHIP_SRC_COLUMN || in.a.kind == ZKHIP_SRC_CONST;
+    const bool b_mem = in.b.kind == ZKHIP_SRC_COLUMN || in.b.kind == ZKHIP_SRC_CONST;
+    if ((in.op == ZKHIP_OP_MUL || in.op == ZKHIP_OP_MAD) && a_mem && !b_mem) { const zkhip_vm_operand t = in.a; in.a = in.b; in.b = t; }
+    std::memcpy(&u, &in, 16);
+    const bool uses_b = in.op == ZKHIP_OP_MUL || in.op == ZKHIP_OP_MAD || in.op == ZKHIP_OP_ADD || in.op == ZKHIP_OP_SUB;
+    auto resolve = [&](const zkhip_vm_operand& o, bool used, uint64_t* base, uint32_t* off, uint32_t* mask) {
+      if (!used) return;
+      if (o.kind == ZKHIP_SRC_COLUMN) { *base = (uint64_t)d_columns[o.index]; *off = rot_rows[o.rot]; *mask = 0xffffffffu; }
+      else if (o.kind == ZKHIP_SRC_CONST) { *base = d_consts + (uint64_t)o.index * 32; }
+    };
+    resolve(in.a, true, &u.base_a, &u.off_a, &u.mask_a);
+    resolve(in.b, uses_b, &u.base_b, &u.off_b, &u.mask_b);
+  }
+  if (p->n_constants) std::memcpy(region + o_const, p->constants, (size_t)p->n_constants * 32);
+  for (uint32_t i = 0; i < p->n_rotations; i++) std::memcpy(region + o_rot + (size_t)i * 4, &rot_rows[i], 4);      // (a MAD's column addend still goes through the tables)
+}
+
+// highest register a program names (the kernel variant is sized for it)
+static uint32_t vm_top_register(const zkhip_vm_program* p) {
+  uint32_t top = p->result_reg;
+  for (uint32_t pc = 0; pc < p->n_insns; pc++) {
+    const zkhip_vm_insn& in = p->insns[pc];
+    if (in.dst > top) top = in.dst;
+    const zkhip_vm_operand* o[3] = {&in.a, &in.b, &in.c};
+    for (int k = 0; k < 3; k++) if (o[k]->kind == ZKHIP_SRC_REG && o[k]->index < (uint32_t)VM_MAX_REGS && o[k]->index > top) top = o[k]->index;
+  }
+  return top;
+}
+
+static int vm_launch_kernel(const vm_launch& L, uint32_t top, uint32_t n_parts, hipStream_t stream) {
+  const dim3 grid((unsigned)((L.rows + VM_THREADS - 1) / VM_THREADS), n_parts);
+  if (top < 6) hipLaunchKernelGGL(k_row_vm<6>, grid, dim3(VM_THREADS), 0, stream, L);
+  else if (top < 8) hipLaunchKernelGGL(k_row_vm<8>, grid, dim3(VM_THREADS), 0, stream, L);
+  else if (top < 12) hipLaunchKernelGGL(k_row_vm<12>, grid, dim3(VM_THREADS), 0, stream, L);
+  else hipLaunchKernelGGL(k_row_vm<16>, grid, dim3(VM_THREADS), 0, stream, L);
+  HIPCHK(hipGetLastError());
+  return ZKHIP_OK;
+}
+
+// `n_progs` programs over the same columns in ONE launch (blockIdx.y = program), program p writing d_outs[p]: what
+// zkhip_fr_eval_rows_sum_device runs its parts with.  Separate launches on separate streams overlap four at a time (the hardware queues);
+// one grid has no such limit.  Blob: [columns | omega | part records | region of program 0 | region of program 1 | ...], power tables behind.
+// Programs that read ZKHIP_SRC_ROWPOW must agree on omega.  Interpreter only (these are long programs over few rows).
+size_t row_vm_multi_workspace_bytes(const zkhip_vm_program* progs, uint32_t n_progs, uint32_t n_columns, uint32_t log_rows) {
+  const size_t rows = (size_t)1 << log_rows;
+  size_t total = align256((size_t)n_columns * 8 + 8) + 256 + align256((size_t)n_progs * sizeof(vm_part));
+  for (uint32_t i = 0; i < n_progs; i++)
+    total += align256(((size_t)progs[i].n_insns + 4) * sizeof(vm_uop)) + align256((size_t)progs[i].n_constants * 32 + 32) + align256((size_t)progs[i].n_rotations * 4 + 4);
+  return total + align256(((size_t)1 << POW_LO_BITS) * 32) + align256(((rows >> POW_LO_BITS) + 1) * 32);
+}
+
+int row_vm_device_multi(const zkhip_vm_program* progs, uint32_t n_progs, const void* const* d_columns, uint32_t n_columns, uint32_t log_rows, uint32_t* const* d_outs,
+                        void* ws, size_t ws_bytes, hipStream_t stream) {
+  const uint64_t rows = (uint64_t)1 << log_rows;
+  if (n_progs == 0 || n_progs > 65535) { set_error("eval_rows: %u programs in one launch", n_progs); return ZKHIP_EINVAL; }
+  if (ws_bytes < row_vm_multi_workspace_bytes(progs, n_progs, n_columns, log_rows)) { set_error("eval_rows: workspace too small"); return ZKHIP_EINVAL; }
+  for (uint32_t i = 0; i < n_columns; i++)
+    if (!d_columns[i]) { set_error("eval_rows: column %u is null", i); return ZKHIP_EINVAL; }
+  const uint64_t* omega = nullptr;
+  uint32_t top = 0;
+  for (uint32_t i = 0; i < n_progs; i++) {
+    if (progs[i].omega) {
+      if (omega && std::memcmp(omega, progs[i].omega, 32) != 0) { set_error("eval_rows: programs of one launch disagree on omega"); return ZKHIP_EINVAL; }
+      omega = progs[i].omega;
+    }
+    const uint32_t t = vm_top_register(&progs[i]);
+    if (t > top) top = t;
+  }
+  const size_t o_cols = 0, o_omega = o_cols + align256((size_t)n_columns * 8 + 8), o_parts = o_omega + 256;
+  size_t off = o_parts + align256((size_t)n_progs * sizeof(vm_part));
+  std::vector<size_t> o_region(n_progs), o_const(n_progs), o_rot(n_progs);
+  for (uint32_t i = 0; i < n_progs; i++) {
+    o_region[i] = off;
+    o_const[i] = align256(((size_t)progs[i].n_insns + 4) * sizeof(vm_uop));
+    o_rot[i] = o_const[i] + align256((size_t)progs[i].n_constants * 32 + 32);
+    off += o_rot[i] + align256((size_t)progs[i].n_rotations * 4 + 4);
+  }
+  const size_t o_lo = off, o_hi = o_lo + align256(((size_t)1 << POW_LO_BITS) * 32);
+  std::vector<unsigned char> blob(o_lo, 0);
+  char* d = (char*)ws;
+  for (uint32_t i = 0; i < n_columns; i++) std::memcpy(blob.data() + o_cols + (size_t)i * 8, &d_columns[i], 8);
+  if (omega) std::memcpy(blob.data() + o_omega, omega, 32);
+  vm_part* parts = (vm_part*)(blob.data() + o_parts);
+  for (uint32_t i = 0; i < n_progs; i++) {
+    vm_fill_region(&progs[i], d_columns, rows, blob.data() + o_region[i], (uint64_t)(d + o_region[i]), o_const[i], o_rot[i]);
+    parts[i].prog = (const void*)(d + o_region[i]);
+    parts[i].consts = (const uint32_t*)(d + o_region[i] + o_const[i]);
+    parts[i].rot_off = (const uint32_t*)(d + o_region[i] + o_rot[i]);
+    parts[i].out = d_outs[i];
+    parts[i].n_insns = progs[i].n_insns;
+    parts[i].result_reg = progs[i].result_reg;
+  }
+  HIPCHK(hipMemcpyAsync(d, blob.data(), o_lo, hipMemcpyHostToDevice, stream));
+  HIPCHK(hipStreamSynchronize(stream));                      // the blob is a local
+  vm_launch L;
+  L.prog = parts[0].prog; L.n_insns = parts[0].n_insns; L.result_reg = parts[0].result_reg;
+  L.cols = (const uint32_t* const*)(d + o_cols);
+  L.consts = parts[0].consts; L.rot_off = parts[0].rot_off;
+  L.pow_lo = nullptr; L.pow_hi = nullptr;
+  L.out = d_outs[0];
+  L.rows = rows;
+  L.accumulate = 0;
+  L.parts = (const vm_part*)(d + o_parts);
+  if (omega) {
+    const uint32_t n_lo = 1u << POW_LO_BITS, n_hi = (uint32_t)((rows >> POW_LO_BITS) ? (rows >> POW_LO_BITS) : 1);
+    hipLaunchKernelGGL(k_vm_pow_table, dim3((n_lo + 255) / 256), dim3(256), 0, stream, (const fe_arg*)(d + o_omega), 0u, n_lo, (uint32_t*)(d + o_lo));
+    hipLaunchKernelGGL(k_vm_pow_table, dim3((n_hi + 255) / 256), dim3(256), 0, stream, (const fe_arg*)(d + o_omega), POW_LO_BITS, n_hi, (uint32_t*)(d + o_hi));
+    L.pow_lo = (const uint32_t*)(d + o_lo);
+    L.pow_hi = (const uint32_t*)(d + o_hi);
+  }
+  return vm_launch_kernel(L, top, n_progs, stream);
+}
+
 int row_vm_device(const zkhip_vm_program* p, const void* const* d_columns, uint32_t n_columns, uint32_t log_rows, int accumulate,
                   uint32_t* d_out, void* ws, size_t ws_bytes, hipStream_t stream, vm_staging* staging) {
   const uint64_t rows = (uint64_t)1 << log_rows;
@@ -435,39 +588,9 @@ int row_vm_device(const zkhip_vm_program* p, const void* const* d_columns, uint3
     blob_p = local.data();
   }
   struct { unsigned char* p; unsigned char* data() const { return p; } } blob{blob_p};
-  static_assert(sizeof(zkhip_vm_insn) == 16, "instruction layout");
-  std::vector<uint32_t> rot_rows(p->n_rotations ? p->n_rotations : 1, 0u);
-  for (uint32_t i = 0; i < p->n_rotations; i++) {
-    const int64_t off = ((int64_t)p->rotations[i] * (int64_t)p->rot_scale) % (int64_t)rows;
-    rot_rows[i] = (uint32_t)(off < 0 ? off + (int64_t)rows : off);
-  }
-  const uint64_t d_consts = (uint64_t)((char*)ws + o_const);
   for (uint32_t i = 0; i < n_columns; i++)
     if (!d_columns[i]) { set_error("eval_rows: column %u is null", i); return ZKHIP_EINVAL; }
-  // micro-ops: the instruction + its operands' resolved addresses; a product's second factor is fetched scaled by 2^5 -- free for a column /
-  // constant (the other unpacking shift), a repack for a register -- so the memory operand goes second where the host did not put it there
-  vm_uop* uops = (vm_uop*)(blob.data() + o_prog);
-  for (uint32_t pc = 0; pc < p->n_insns + 4; pc++) {
-    vm_uop& u = uops[pc];
-    std::memset(&u, 0, sizeof(u));
-    u.base_a = u.base_b = d_consts;                      // dummy address for operands that are not in memory (and for the padding no-ops)
-    if (pc >= p->n_insns) { u.head = ZKHIP_OP_MOV | ((uint32_t)0 << 8); u.oa = ZKHIP_SRC_REG; continue; }   // MOV r0 <- r0 (never executed)
-    zkhip_vm_insn in = p->insns[pc];
-    const bool a_mem = in.a.kind == ZKHIP_SRC_COLUMN || in.a.kind == ZKHIP_SRC_CONST;
-    const bool b_mem = in.b.kind == ZKHIP_SRC_COLUMN || in.b.kind == ZKHIP_SRC_CONST;
-    if ((in.op == ZKHIP_OP_MUL || in.op == ZKHIP_OP_MAD) && a_mem && !b_mem) { const zkhip_vm_operand t = in.a; in.a = in.b; in.b = t; }
-    std::memcpy(&u, &in, 16);
-    const bool uses_b = in.op == ZKHIP_OP_MUL || in.op == ZKHIP_OP_MAD || in.op == ZKHIP_OP_ADD || in.op == ZKHIP_OP_SUB;
-    auto resolve = [&](const zkhip_vm_operand& o, bool used, uint64_t* base, uint32_t* off, uint32_t* mask) {
-      if (!used) return;
-      if (o.kind == ZKHIP_SRC_COLUMN) { *base = (uint64_t)d_columns[o.index]; *off = rot_rows[o.rot]; *mask = 0xffffffffu; }
-      else if (o.kind == ZKHIP_SRC_CONST) { *base = d_consts + (uint64_t)o.index * 32; }
-    };
-    resolve(in.a, true, &u.base_a, &u.off_a, &u.mask_a);
-    resolve(in.b, uses_b, &u.base_b, &u.off_b, &u.mask_b);
-  }
-  if (p->n_constants) std::memcpy(blob.data() + o_const, p->constants, (size_t)p->n_constants * 32);
-  for (uint32_t i = 0; i < p->n_rotations; i++) std::memcpy(blob.data() + o_rot + (size_t)i * 4, &rot_rows[i], 4);      // (a MAD's column addend still goes through the tables)
+  vm_fill_region(p, d_columns, rows, blob.data(), (uint64_t)(char*)ws, o_const, o_rot);
   for (uint32_t i = 0; i < n_columns; i++) std::memcpy(blob.data() + o_cols + (size_t)i * 8, &d_columns[i], 8);
   if (p->omega) std::memcpy(blob.data() + o_omega, p->omega, 32);
   char* d = (char*)ws;
@@ -475,6 +598,7 @@ int row_vm_device(const zkhip_vm_program* p, const void* const* d_columns, uint3
   if (staging) HIPCHK(hipEventRecord(staging->copied[slot], stream));
   else HIPCHK(hipStreamSynchronize(stream));   // the blob is a local
   vm_launch L;
+  L.parts = nullptr;
   L.prog = (const void*)(d + o_prog);
   L.n_insns = p->n_insns;
   L.result_reg = p->result_reg;
@@ -499,20 +623,7 @@ int row_vm_device(const zkhip_vm_program* p, const void* const* d_columns, uint3
       row_vm_jit_launch(p, d_columns, n_columns, log_rows, accumulate, L.consts, L.pow_lo, L.pow_hi, d_out, stream) == ZKHIP_OK)
     return ZKHIP_OK;
   // smallest register-file variant that holds every register the program names
-  uint32_t top = p->result_reg;
-  for (uint32_t pc = 0; pc < p->n_insns; pc++) {
-    const zkhip_vm_insn& in = p->insns[pc];
-    if (in.dst > top) top = in.dst;
-    const zkhip_vm_operand* o[3] = {&in.a, &in.b, &in.c};
-    for (int k = 0; k < 3; k++) if (o[k]->kind == ZKHIP_SRC_REG && o[k]->index < (uint32_t)VM_MAX_REGS && o[k]->index > top) top = o[k]->index;
-  }
-  const dim3 grid((unsigned)((rows + VM_THREADS - 1) / VM_THREADS));
-  if (top < 6) hipLaunchKernelGGL(k_row_vm<6>, grid, dim3(VM_THREADS), 0, stream, L);
-  else if (top < 8) hipLaunchKernelGGL(k_row_vm<8>, grid, dim3(VM_THREADS), 0, stream, L);
-  else if (top < 12) hipLaunchKernelGGL(k_row_vm<12>, grid, dim3(VM_THREADS), 0, stream, L);
-  else hipLaunchKernelGGL(k_row_vm<16>, grid, dim3(VM_THREADS), 0, stream, L);
-  HIPCHK(hipGetLastError());
-  return ZKHIP_OK;
+  return vm_launch_kernel(L, vm_top_register(p), 1, stream);
 }
 
 int fr_pointwise_mul_device(const uint32_t* d_a, const uint32_t* d_b, size_t n, uint32_t* d_out, hipStream_t stream) {

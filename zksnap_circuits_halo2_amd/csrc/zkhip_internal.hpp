@@ -101,6 +101,9 @@ int fr_eval_polynomial_batch_device(const void* const* d_polys_host, size_t coun
 int fr_kate_division_device(const uint32_t* d_a, size_t n, const uint32_t b_host[8], uint32_t* d_q, void* ws, size_t ws_bytes, hipStream_t stream);
 int fr_prefix_product_device(const uint32_t* d_v, size_t n, uint32_t* d_out, void* ws, size_t ws_bytes, hipStream_t stream);
 int fr_batch_invert_device(uint32_t* d_a, size_t n, void* ws, size_t ws_bytes, hipStream_t stream);
+size_t lincomb_workspace_bytes(size_t count, size_t n);
+int fr_linear_combination_device(const void* const* d_cols_host, const uint32_t* coeffs_host, size_t count, size_t n, uint32_t* d_out, void* ws, size_t ws_bytes,
+                                 hipStream_t stream);
 size_t perm_workspace_bytes(uint32_t nperm, uint32_t chunk, uint32_t log_n);
 int fr_permutation_products_device(const void* const* d_values_host, const void* const* d_sigmas_host, uint32_t nperm, uint32_t chunk, uint32_t log_n,
                                    size_t usable, const uint32_t beta[8], const uint32_t gamma[8], const uint32_t delta[8], const uint32_t omega[8],
@@ -119,6 +122,9 @@ struct vm_staging {
   int turn = 0;
   void release();
 };
+size_t row_vm_multi_workspace_bytes(const zkhip_vm_program* progs, uint32_t n_progs, uint32_t n_columns, uint32_t log_rows);
+int row_vm_device_multi(const zkhip_vm_program* progs, uint32_t n_progs, const void* const* d_columns, uint32_t n_columns, uint32_t log_rows, uint32_t* const* d_outs,
+                        void* ws, size_t ws_bytes, hipStream_t stream);
 // rowvm_jit.hip: row programs compiled at run time with hiprtc (straight-line code per program shape, cached per device); row_vm_device
 // tries it first for short programs over many rows and runs the interpreter otherwise
 bool row_vm_jit_wanted(const zkhip_vm_program* p, uint32_t n_columns, uint32_t log_rows);

@@ -326,74 +326,124 @@ def _add_expression(g: Graph, cs: ConstraintSystem, qc: QuotientColumns, e: Expr
 DELTA = pow(7, 1 << F.S, F.R_MOD)     # `Fr::DELTA` = g^(2^S), generator of the odd-order subgroup cosets
 
 
+def _evaluate_h_terms(cs: ConstraintSystem, beta: int, gamma: int, theta: int, challenges: Sequence[int], zeta: int):
+    """The terms `evaluate_h` folds with y, in the order of [DEP] plonk/evaluation.rs `Evaluator::evaluate_h` (custom gates, permutation,
+    lookups), each as a builder `term(g) -> node` so that one graph (the whole quotient numerator) or several (its parts) can be made."""
+    qc = quotient_columns(cs)
+    last_rotation = -(cs.blinding_factors + 1)
+    terms = []
+    for polys in cs.gates:                                              # custom gates: Horner(PreviousValue = 0, all gate polynomials in order, y)
+        for poly in polys:
+            terms.append(lambda g, poly=poly: _add_expression(g, cs, qc, poly, challenges))
+    l0 = lambda g: g.col(qc.l0)
+    l_last = lambda g: g.col(qc.l_last)
+    l_active = lambda g: g.col(qc.l_active_row)
+    one = lambda g: g.const(1)
+    if cs.permutation_columns:                                          # permutation argument
+        sets = cs.num_permutation_sets
+        z = lambda g, s_, rot=0: g.col(qc.perm_product + s_, rot)
+        terms.append(lambda g: g.mul(g.sub(one(g), z(g, 0)), l0(g)))                                          # l_0 (1 - z_0)
+        terms.append(lambda g: g.mul(g.sub(g.mul(z(g, sets - 1), z(g, sets - 1)), z(g, sets - 1)), l_last(g)))  # l_last (z_l^2 - z_l)
+        for s_ in range(1, sets):
+            terms.append(lambda g, s_=s_: g.mul(g.sub(z(g, s_), z(g, s_ - 1, last_rotation)), l0(g)))          # l_0 (z_i - z_{i-1}(w^last X))
+        col_of = {"fixed": qc.fixed, "advice": qc.advice, "instance": qc.instance}
+
+        def perm_set(g, s_):
+            # current_delta = beta * zeta * delta^j * extended_omega^row
+            x_term = g.mul(g.rowpow(), g.const(beta * zeta % F.R_MOD))
+            chunk = cs.permutation_columns[s_ * cs.chunk_len:(s_ + 1) * cs.chunk_len]
+            left = z(g, s_, 1)
+            for j, (kind, idx) in enumerate(chunk):
+                v = g.col(col_of[kind] + idx)
+                sig = g.col(qc.sigma + s_ * cs.chunk_len + j)
+                left = g.mul(left, g.add(g.mad(sig, g.const(beta), v), g.const(gamma)))          # v + beta sigma + gamma
+            right = z(g, s_)
+            delta_pow = pow(DELTA, s_ * cs.chunk_len, F.R_MOD)
+            for (kind, idx) in chunk:
+                v = g.col(col_of[kind] + idx)
+                cur = x_term if delta_pow == 1 else g.mul(x_term, g.const(delta_pow))
+                right = g.mul(right, g.add(g.add(v, cur), g.const(gamma)))                       # v + delta^j beta X + gamma
+                delta_pow = delta_pow * DELTA % F.R_MOD
+            return g.mul(g.sub(left, right), l_active(g))
+
+        for s_ in range(sets):
+            terms.append(lambda g, s_=s_: perm_set(g, s_))
+    for li, lk in enumerate(cs.lookups):                                # lookup arguments
+        prod = lambda g, rot=0, li=li: g.col(qc.lookup + 3 * li, rot)
+        pin = lambda g, rot=0, li=li: g.col(qc.lookup + 3 * li + 1, rot)
+        ptab = lambda g, li=li: g.col(qc.lookup + 3 * li + 2)
+
+        def table_value(g, lk=lk):
+            zero, th = g.const(0), g.const(theta)
+            cin = g.horner(zero, [_add_expression(g, cs, qc, e, challenges) for e in lk.input_expressions], th)
+            ctab = g.horner(zero, [_add_expression(g, cs, qc, e, challenges) for e in lk.table_expressions], th)
+            return g.mul(g.add(cin, g.const(beta)), g.add(ctab, g.const(gamma)))
+
+        a_minus_s = lambda g, pin=pin, ptab=ptab: g.sub(pin(g), ptab(g))
+        terms.append(lambda g, prod=prod: g.mul(g.sub(one(g), prod(g)), l0(g)))
+        terms.append(lambda g, prod=prod: g.mul(g.sub(g.mul(prod(g), prod(g)), prod(g)), l_last(g)))
+        terms.append(lambda g, prod=prod, pin=pin, ptab=ptab, table_value=table_value: g.mul(
+            g.sub(g.mul(g.mul(prod(g, 1), g.add(pin(g), g.const(beta))), g.add(ptab(g), g.const(gamma))), g.mul(prod(g), table_value(g))), l_active(g)))
+        terms.append(lambda g, a_minus_s=a_minus_s: g.mul(a_minus_s(g), l0(g)))
+        terms.append(lambda g, a_minus_s=a_minus_s, pin=pin: g.mul(g.mul(a_minus_s(g), g.sub(pin(g), pin(g, -1))), l_active(g)))
+    return terms
+
+
+def _fold_terms(terms, y: int, k: int, extended_k: int) -> RowProgram:
+    g = Graph()
+    Y = g.const(y)
+    value = g.const(0)
+    for term in terms:
+        value = g.mad(value, Y, term(g))
+    return compile_graph(g, value, rot_scale=1 << (extended_k - k), omega=F.omega_for(extended_k))
+
+
 def evaluate_h_program(cs: ConstraintSystem, k: int, extended_k: int, beta: int, gamma: int, theta: int, y: int,
                        challenges: Sequence[int] = (), zeta: int = F.ZETA) -> RowProgram:
     """The program whose output column is `evaluate_h`'s `values` (before `divide_by_vanishing_poly`).
     Terms and their order follow [DEP] plonk/evaluation.rs `Evaluator::evaluate_h`: custom gates, permutation, lookups."""
-    g = Graph()
-    qc = quotient_columns(cs)
-    Y, BETA, GAMMA, THETA, ONE = g.const(y), g.const(beta), g.const(gamma), g.const(theta), g.const(1)
-    value = g.const(0)
-    last_rotation = -(cs.blinding_factors + 1)
+    return _fold_terms(_evaluate_h_terms(cs, beta, gamma, theta, challenges, zeta), y, k, extended_k)
 
-    def fold(term: int):
-        nonlocal value
-        value = g.mad(value, Y, term)
 
-    # custom gates: Horner(PreviousValue = 0, all gate polynomials in order, y)
-    for polys in cs.gates:
-        for poly in polys:
-            fold(_add_expression(g, cs, qc, poly, challenges))
+def evaluate_h_parts(cs: ConstraintSystem, k: int, extended_k: int, beta: int, gamma: int, theta: int, y: int, parts: int,
+                     challenges: Sequence[int] = (), zeta: int = F.ZETA) -> Tuple[List[RowProgram], List[int]]:
+    """The same quotient numerator as a SUM of `parts` programs over consecutive runs of its terms: values = sum_p weights[p] * program_p
+    with weights[p] = y^(number of terms after part p) -- `zkhip_fr_eval_rows_sum_device` runs the programs side by side.  A circuit with
+    hundreds of columns at 2^13 .. 2^15 rows has thousands of instructions and few rows: one program is a handful of wavefronts walking
+    the whole list, `parts` programs fill the chip.  (The y-fold is linear in the terms: h = sum_i term_i y^(T-1-i).)"""
+    terms = _evaluate_h_terms(cs, beta, gamma, theta, challenges, zeta)
+    T = len(terms)
+    parts = max(1, min(parts, T))
+    # cut where the running instruction count crosses the next multiple of total / parts (a permutation set is ten times a gate polynomial)
+    cost = []
+    for term in terms:
+        g = Graph()
+        term(g)
+        cost.append(1 + sum(1 for nd in g.nodes if nd[0] == "op"))
+    total, run, bounds = sum(cost), 0, [0]
+    for i, c in enumerate(cost):
+        run += c
+        left, need = T - (i + 1), parts - len(bounds)                   # terms after this one, cuts still to make
+        if 0 < need and 0 < left and ((run * parts >= total * len(bounds) and left >= need) or left == need):
+            bounds.append(i + 1)
+    bounds.append(T)
+    parts = len(bounds) - 1
+    progs, weights = [], []
+    for p in range(parts):
+        lo, hi = bounds[p], bounds[p + 1]
+        progs.append(_fold_terms(terms[lo:hi], y, k, extended_k))
+        weights.append(pow(y, T - hi, F.R_MOD))
+    return progs, weights
 
-    l0, l_last, l_active = g.col(qc.l0), g.col(qc.l_last), g.col(qc.l_active_row)
 
-    # permutation argument
-    if cs.permutation_columns:
-        sets = cs.num_permutation_sets
-        z = lambda s, rot=0: g.col(qc.perm_product + s, rot)
-        fold(g.mul(g.sub(ONE, z(0)), l0))                                   # l_0 (1 - z_0)
-        zl = z(sets - 1)
-        fold(g.mul(g.sub(g.mul(zl, zl), zl), l_last))                       # l_last (z_l^2 - z_l)
-        for s in range(1, sets):
-            fold(g.mul(g.sub(z(s), z(s - 1, last_rotation)), l0))           # l_0 (z_i - z_{i-1}(w^last X))
-        # current_delta = beta * zeta * delta^j * extended_omega^row
-        x_term = g.mul(g.rowpow(), g.const(beta * zeta % F.R_MOD))
-        delta_pow = 1
-        col_of = {"fixed": qc.fixed, "advice": qc.advice, "instance": qc.instance}
-        for s in range(sets):
-            chunk = cs.permutation_columns[s * cs.chunk_len:(s + 1) * cs.chunk_len]
-            left = z(s, 1)
-            for j, (kind, idx) in enumerate(chunk):
-                v = g.col(col_of[kind] + idx)
-                sig = g.col(qc.sigma + s * cs.chunk_len + j)
-                left = g.mul(left, g.add(g.mad(sig, BETA, v), GAMMA))       # v + beta sigma + gamma
-            right = z(s)
-            for (kind, idx) in chunk:
-                v = g.col(col_of[kind] + idx)
-                cur = x_term if delta_pow == 1 else g.mul(x_term, g.const(delta_pow))
-                right = g.mul(right, g.add(g.add(v, cur), GAMMA))           # v + delta^j beta X + gamma
-                delta_pow = delta_pow * DELTA % F.R_MOD
-            fold(g.mul(g.sub(left, right), l_active))
-
-    # lookup arguments
-    for li, lk in enumerate(cs.lookups):
-        prod = lambda rot=0: g.col(qc.lookup + 3 * li, rot)
-        pin = lambda rot=0: g.col(qc.lookup + 3 * li + 1, rot)
-        ptab = g.col(qc.lookup + 3 * li + 2)
-        zero = g.const(0)
-        cin = g.horner(zero, [_add_expression(g, cs, qc, e, challenges) for e in lk.input_expressions], THETA)
-        ctab = g.horner(zero, [_add_expression(g, cs, qc, e, challenges) for e in lk.table_expressions], THETA)
-        table_value = g.mul(g.add(cin, BETA), g.add(ctab, GAMMA))
-        a_minus_s = g.sub(pin(), ptab)
-        fold(g.mul(g.sub(ONE, prod()), l0))
-        fold(g.mul(g.sub(g.mul(prod(), prod()), prod()), l_last))
-        lhs = g.mul(g.mul(prod(1), g.add(pin(), BETA)), g.add(ptab, GAMMA))
-        fold(g.mul(g.sub(lhs, g.mul(prod(), table_value)), l_active))
-        fold(g.mul(a_minus_s, l0))
-        fold(g.mul(g.mul(a_minus_s, g.sub(pin(), pin(-1))), l_active))
-
-    omega_ext = F.omega_for(extended_k)
-    return compile_graph(g, value, rot_scale=1 << (extended_k - k), omega=omega_ext)
+def run_programs_sum_device(progs: Sequence[RowProgram], weights: Sequence[int], columns: Sequence[int], log_rows: int, out: int, stream: int = 0) -> None:
+    """out[row] = sum_p weights[p] * progs[p](row) over device-resident columns (zkhip_fr_eval_rows_sum_device)"""
+    lib = _lib.load()
+    marshalled = [p._marshal() for p in progs]
+    arr = (_lib.VmProgram * len(progs))(*[m[0] for m in marshalled])
+    w = F.fr_encode(list(weights))
+    ptrs = (C.c_void_p * max(len(columns), 1))(*columns)
+    _lib.check(lib.zkhip_fr_eval_rows_sum_device(arr, w.ctypes.data, len(progs), ptrs, len(columns), log_rows, C.c_void_p(out), C.c_void_p(stream)))
 
 
 def linear_combination_program(coeffs: Sequence[int]) -> RowProgram:
@@ -508,4 +558,10 @@ def export_prover_programs(k: int, gate_cols: int, lookups: int, seed: int = 1) 
         progs.append(permutation_denominator_program(hi - lo, beta, gamma))
     progs += list(lookup_product_programs(1, 1, beta, gamma, theta))
     progs.append(evaluate_h_program(cs, k, dom.extended_k, beta, gamma, theta, y))
-    return b"".join(out + [p.to_bytes() for p in progs])
+    # the same quotient numerator as a sum of programs (zkhip_fr_eval_rows_sum_device), used by the device-resident sequence when the program is
+    # long and the rows are few: u32 count (0 = not worth it), count weights, count programs
+    tail = [struct.pack("<I", 0)]
+    if len(progs[-1].insns) > 512 and dom.extended_k < 18:
+        parts, weights = evaluate_h_parts(cs, k, dom.extended_k, beta, gamma, theta, y, 16)
+        tail = [struct.pack("<I", len(parts)), w(F.fr_encode(weights))] + [p.to_bytes() for p in parts]
+    return b"".join(out + [p.to_bytes() for p in progs] + tail)
