@@ -295,15 +295,19 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk
         lap("coeff_to_extended")
 
         # ---- quotient ---------------------------------------------------------------------------------------------------------------
-        prog = E.evaluate_h_program(cs, k, ek, beta, gamma, theta, y)
-        if len(prog.insns) > 512 and ek < 18:
-            # thousands of instructions over a few thousand rows: as one program a handful of wavefronts walk the whole list; as a sum of
-            # programs over runs of the y-fold's terms (evaluate_h_parts + zkhip_fr_eval_rows_sum_device) they run side by side
+        if ncol > 96 and ek < 18:
+            # hundreds of columns over a few thousand rows: as one program a handful of wavefronts walk thousands of instructions; as a sum of
+            # programs over runs of the y-fold's terms (evaluate_h_parts + zkhip_fr_eval_rows_sum_device) they run side by side in one launch
             parts, weights = E.evaluate_h_parts(cs, k, ek, beta, gamma, theta, y, 16)
             h_ext = torch.empty((en, 4), dtype=torch.int64, device=dev)
             E.run_programs_sum_device(parts, weights, [ext[i].data_ptr() for i in range(ncol)], ek, h_ext.data_ptr())
+            n_insns = sum(len(p_.insns) for p_ in parts)
+            n_regs = 1 + max(max([ins[1] for ins in p_.insns] + [o[1] for ins in p_.insns for o in ins[2:5] if o[0] == E.SRC_REG]) for p_ in parts)
         else:
+            prog = E.evaluate_h_program(cs, k, ek, beta, gamma, theta, y)
             h_ext = run_prog(prog, [ext[i] for i in range(ncol)], ek)
+            n_insns = len(prog.insns)
+            n_regs = 1 + max([ins[1] for ins in prog.insns] + [o[1] for ins in prog.insns for o in ins[2:5] if o[0] == E.SRC_REG])
         tinv = torch.from_numpy(dom.t_evaluations.view(np.int64)).to(dev)
         _lib.check(lib.zkhip_mul_periodic_device(h_ext.data_ptr(), en, tinv.data_ptr(), tinv.shape[0], None))
         lap("evaluate_h")
@@ -378,7 +382,7 @@ def run(k=16, gate_cols=4, seed=1, lookup_bits=8, corrupt=None, verbose=True, pk
             print(f"  {'prover steps (no setup/witness)':28s} {prove_ms:9.3f} ms")
             print("  checks:", checks)
         return {"timings_ms": t, "prove_ms": prove_ms, "checks": checks, "columns": ncol, "proof_columns": n_proof_cols, "msms": n_msm, "queries": len(queries),
-                "program_insns": len(prog.insns), "program_registers": 1 + max([ins[1] for ins in prog.insns] + [o[1] for ins in prog.insns for o in ins[2:5] if o[0] == E.SRC_REG]),
+                "program_insns": n_insns, "program_registers": n_regs,
                 "keygen_ms": t.get("keygen_vk", 0.0) + t.get("keygen_pk", 0.0) + t.get("keygen_device", 0.0), "pk_file_bytes": pk_bytes}
     finally:
         torch.cuda.synchronize()
