@@ -152,8 +152,9 @@ struct dev_buf {       // grow-only device scratch (hipFree waits for the device
 struct scratch {       // one user at a time: the calls of one stream
   dev_buf ws, scalars, bases, poly, poly2, small, ntt_tmp, vm, gather;
   vm_staging vm_stage;                 // pinned host staging of the row programs' blobs (rowvm.hip)
+  arg_ring args;                       // pinned slots for the small host arrays of `_device` calls (lists of column addresses, coefficients)
   uint64_t last_use = 0;
-  void release() { ws.release(); scalars.release(); bases.release(); poly.release(); poly2.release(); small.release(); ntt_tmp.release(); vm.release(); gather.release(); vm_stage.release(); }
+  void release() { ws.release(); scalars.release(); bases.release(); poly.release(); poly2.release(); small.release(); ntt_tmp.release(); vm.release(); gather.release(); vm_stage.release(); args.release(); }
 };
 
 constexpr int STREAM_PIECES_MAX = 64;      // pieces of one chunked host-buffer MSM
@@ -1527,7 +1528,7 @@ int zkhip_fr_eval_polynomial_batch_device(const void* const* d_polys, size_t cou
   hipStream_t s = caller_stream(stream);
   scratch* sc = scratch_for(primary(), s);
   if ((rc = sc->ws.reserve(poly_batch_workspace_bytes(n, count))) != ZKHIP_OK) return rc;
-  return fr_eval_polynomial_batch_device(d_polys, count, n, (const uint32_t*)point, (uint32_t*)d_out, sc->ws.p, sc->ws.cap, s);
+  return fr_eval_polynomial_batch_device(d_polys, count, n, (const uint32_t*)point, (uint32_t*)d_out, sc->ws.p, sc->ws.cap, s, &sc->args);
 }
 
 int zkhip_fr_kate_division_device(const void* d_a, size_t n, const uint64_t b[4], void* d_q, void* stream) {
@@ -1749,9 +1750,9 @@ int zkhip_fr_eval_rows_sum_device(const zkhip_vm_program* progs, const uint64_t*
   if ((rc = sc->vm.reserve(row_vm_multi_workspace_bytes(progs, n_progs, n_columns, log_rows))) != ZKHIP_OK) return rc;
   std::vector<uint32_t*> partial(n_progs);
   for (uint32_t p = 0; p < n_progs; p++) partial[p] = (uint32_t*)((char*)sc->poly2.p + (size_t)p * rows * 32);
-  if ((rc = row_vm_device_multi(progs, n_progs, d_columns, n_columns, log_rows, partial.data(), sc->vm.p, sc->vm.cap, s)) != ZKHIP_OK) return rc;
+  if ((rc = row_vm_device_multi(progs, n_progs, d_columns, n_columns, log_rows, partial.data(), sc->vm.p, sc->vm.cap, s, &sc->vm_stage)) != ZKHIP_OK) return rc;
   if ((rc = sc->ws.reserve(lincomb_workspace_bytes(n_progs, rows))) != ZKHIP_OK) return rc;
-  return fr_linear_combination_device((const void* const*)partial.data(), (const uint32_t*)weights, n_progs, rows, (uint32_t*)d_out, sc->ws.p, sc->ws.cap, s);
+  return fr_linear_combination_device((const void* const*)partial.data(), (const uint32_t*)weights, n_progs, rows, (uint32_t*)d_out, sc->ws.p, sc->ws.cap, s, &sc->args);
 }
 
 // The straight-line HIP source rowvm_jit.hip generates for `prog` (buf may be NULL: *len receives the size needed, NUL included), and a
@@ -1856,7 +1857,7 @@ int zkhip_fr_linear_combination_device(const void* const* d_cols, const uint64_t
   hipStream_t s = caller_stream(stream);
   scratch* sc = scratch_for(primary(), s);
   if ((rc = sc->ws.reserve(lincomb_workspace_bytes(count, n))) != ZKHIP_OK) return rc;
-  return fr_linear_combination_device(d_cols, (const uint32_t*)coeffs, count, n, (uint32_t*)d_out, sc->ws.p, sc->ws.cap, s);
+  return fr_linear_combination_device(d_cols, (const uint32_t*)coeffs, count, n, (uint32_t*)d_out, sc->ws.p, sc->ws.cap, s, &sc->args);
 }
 
 static int perm_args_ok(const void* const* values, const void* const* sigmas, uint32_t n_columns, uint32_t chunk_len, uint32_t log_n, size_t usable_rows,
@@ -1885,7 +1886,7 @@ int zkhip_permutation_products_device(const void* const* d_values, const void* c
   scratch* sc = scratch_for(primary(), s);
   if ((rc = sc->ws.reserve(perm_workspace_bytes(n_columns, chunk_len, log_n))) != ZKHIP_OK) return rc;
   return fr_permutation_products_device(d_values, d_sigmas, n_columns, chunk_len, log_n, usable_rows, (const uint32_t*)beta, (const uint32_t*)gamma,
-                                        (const uint32_t*)delta, (const uint32_t*)omega, (uint32_t*)d_z, sc->ws.p, sc->ws.cap, s);
+                                        (const uint32_t*)delta, (const uint32_t*)omega, (uint32_t*)d_z, sc->ws.p, sc->ws.cap, s, &sc->args);
 }
 
 int zkhip_permutation_products(const uint64_t* const* values, const uint64_t* const* sigmas, uint32_t n_columns, uint32_t chunk_len, uint32_t log_n,

@@ -213,13 +213,23 @@ static int horner_scan(const uint32_t* d_a, size_t n, const fe_arg* b, uint32_t*
   return ZKHIP_OK;
 }
 
-// the multiplier arrives from the host: park it in the last 256 bytes of the workspace
+// a constant that arrives from the host travels as a kernel argument (by value: the caller's memory is free when the launch returns, and
+// nothing waits for the stream -- a copy from the caller's memory would need a synchronisation) and is parked in device memory by one thread
+__global__ void k_store_const(fe_arg v, fe_arg* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *out = v;
+}
+static int store_const(const uint32_t host[8], fe_arg* d, hipStream_t stream) {
+  fe_arg v;
+  memcpy(v.w, host, 32);
+  hipLaunchKernelGGL(k_store_const, dim3(1), dim3(64), 0, stream, v, d);
+  HIPCHK(hipGetLastError());
+  return ZKHIP_OK;
+}
+// the multiplier of a scan: parked in the last 256 bytes of the workspace
 static int stage_const(const uint32_t host[8], char* ws, size_t ws_bytes, hipStream_t stream, fe_arg** out) {
   fe_arg* d = (fe_arg*)(ws + ws_bytes - 256);
-  HIPCHK(hipMemcpyAsync(d, host, 32, hipMemcpyHostToDevice, stream));
-  HIPCHK(hipStreamSynchronize(stream));   // `host` may be a caller stack buffer
   *out = d;
-  return ZKHIP_OK;
+  return store_const(host, d, stream);
 }
 
 // eval_polynomial: result (8 words, device) = sum a[i] x^i
@@ -242,7 +252,7 @@ size_t poly_batch_workspace_bytes(size_t n, size_t count) {
 }
 
 int fr_eval_polynomial_batch_device(const void* const* d_polys_host, size_t count, size_t n, const uint32_t x_host[8], uint32_t* d_results,
-                                    void* ws, size_t ws_bytes, hipStream_t stream) {
+                                    void* ws, size_t ws_bytes, hipStream_t stream, arg_ring* ring) {
   if (count == 0) return ZKHIP_OK;
   if (n == 0) { HIPCHK(hipMemsetAsync(d_results, 0, count * 32, stream)); return ZKHIP_OK; }
   if (count > 65535) { set_error("eval_polynomial_batch: more than 65535 polynomials"); return ZKHIP_EINVAL; }
@@ -252,9 +262,9 @@ int fr_eval_polynomial_batch_device(const void* const* d_polys_host, size_t coun
   p += ((count * 8 + 255) / 256) * 256;
   fe_arg* b = (fe_arg*)p;
   p += 256;
-  HIPCHK(hipMemcpyAsync(d_ptrs, d_polys_host, count * 8, hipMemcpyHostToDevice, stream));
-  HIPCHK(hipMemcpyAsync(b, x_host, 32, hipMemcpyHostToDevice, stream));
-  HIPCHK(hipStreamSynchronize(stream));                     // both sources are caller memory
+  int rc = upload_args(ring, d_ptrs, d_polys_host, count * 8, stream);        // caller memory: through the pinned ring, no wait for the stream
+  if (rc == ZKHIP_OK) rc = store_const(x_host, b, stream);
+  if (rc != ZKHIP_OK) return rc;
   const uint32_t* cur = nullptr;                            // level 0 reads through d_ptrs
   size_t cur_n = n;
   while (true) {
@@ -392,7 +402,7 @@ size_t perm_workspace_bytes(uint32_t nperm, uint32_t chunk, uint32_t log_n) {
 
 int fr_permutation_products_device(const void* const* d_values_host, const void* const* d_sigmas_host, uint32_t nperm, uint32_t chunk, uint32_t log_n,
                                    size_t usable, const uint32_t beta[8], const uint32_t gamma[8], const uint32_t delta[8], const uint32_t omega[8],
-                                   uint32_t* d_z, void* ws, size_t ws_bytes, hipStream_t stream) {
+                                   uint32_t* d_z, void* ws, size_t ws_bytes, hipStream_t stream, arg_ring* ring) {
   if (nperm == 0) return ZKHIP_OK;
   const size_t n = (size_t)1 << log_n, nsets = (nperm + chunk - 1) / chunk;
   if (nsets > 65535) { set_error("permutation_products: more than 65535 sets"); return ZKHIP_EINVAL; }
@@ -411,9 +421,9 @@ int fr_permutation_products_device(const void* const* d_values_host, const void*
   p += 64;
   p = (char*)ws + ((((size_t)(p - (char*)ws)) + 255) / 256) * 256;
   const size_t rest = ws_bytes - (size_t)(p - (char*)ws);
-  HIPCHK(hipMemcpyAsync(d_ptrs, d_values_host, (size_t)nperm * 8, hipMemcpyHostToDevice, stream));
-  HIPCHK(hipMemcpyAsync(d_ptrs + nperm, d_sigmas_host, (size_t)nperm * 8, hipMemcpyHostToDevice, stream));
-  HIPCHK(hipStreamSynchronize(stream));                           // both pointer lists are caller memory
+  int rc = upload_args(ring, d_ptrs, d_values_host, (size_t)nperm * 8, stream);          // caller memory: through the pinned ring, no wait for the stream
+  if (rc == ZKHIP_OK) rc = upload_args(ring, d_ptrs + nperm, d_sigmas_host, (size_t)nperm * 8, stream);
+  if (rc != ZKHIP_OK) return rc;
   fe_arg b, g, d, w;
   memcpy(b.w, beta, 32); memcpy(g.w, gamma, 32); memcpy(d.w, delta, 32); memcpy(w.w, omega, 32);
   hipLaunchKernelGGL(k_pow_table_internal, dim3(1), dim3(256), 0, stream, d, b, 1, 0u, 1u, ctab);            // delta^0 beta
@@ -425,7 +435,7 @@ int fr_permutation_products_device(const void* const* d_values_host, const void*
   hipLaunchKernelGGL(k_perm_den, grid, dim3(256), 0, stream, (const uint32_t* const*)d_ptrs, (const uint32_t* const*)(d_ptrs + nperm), nperm, chunk, n, (const uint32_t*)ctab, g, d_z);
   HIPCHK(hipGetLastError());
   prof_mark(stream, "perm_den");
-  int rc = fr_batch_invert_device(d_z, nsets * n, p, rest, stream);
+  rc = fr_batch_invert_device(d_z, nsets * n, p, rest, stream);
   if (rc != ZKHIP_OK) return rc;
   prof_mark(stream, "perm_invert");
   hipLaunchKernelGGL(k_perm_num_mul, grid, dim3(256), 0, stream, (const uint32_t* const*)d_ptrs, nperm, chunk, n, usable, (const uint32_t*)ctab, (const uint32_t*)dtab,
@@ -488,7 +498,7 @@ size_t lincomb_workspace_bytes(size_t count, size_t n) {
 }
 
 int fr_linear_combination_device(const void* const* d_cols_host, const uint32_t* coeffs_host, size_t count, size_t n, uint32_t* d_out, void* ws, size_t ws_bytes,
-                                 hipStream_t stream) {
+                                 hipStream_t stream, arg_ring* ring) {
   if (n == 0) return ZKHIP_OK;
   if (count == 0) { HIPCHK(hipMemsetAsync(d_out, 0, n * 32, stream)); return ZKHIP_OK; }
   const size_t groups = (count + LC_GROUP - 1) / LC_GROUP;
@@ -502,9 +512,9 @@ int fr_linear_combination_device(const void* const* d_cols_host, const uint32_t*
   uint32_t* d_int = (uint32_t*)p;
   p += ((count * 32 + 255) / 256) * 256;
   uint32_t* partial = (uint32_t*)p;
-  HIPCHK(hipMemcpyAsync(d_ptrs, d_cols_host, count * 8, hipMemcpyHostToDevice, stream));
-  HIPCHK(hipMemcpyAsync(d_ext, coeffs_host, count * 32, hipMemcpyHostToDevice, stream));
-  HIPCHK(hipStreamSynchronize(stream));                     // both sources are caller memory
+  int rc = upload_args(ring, d_ptrs, d_cols_host, count * 8, stream);          // caller memory: through the pinned ring, no wait for the stream
+  if (rc == ZKHIP_OK) rc = upload_args(ring, d_ext, coeffs_host, count * 32, stream);
+  if (rc != ZKHIP_OK) return rc;
   hipLaunchKernelGGL(k_to_internal, grid_for(count, 256), dim3(256), 0, stream, (const uint32_t*)d_ext, (uint32_t)count, d_int);
   hipLaunchKernelGGL(k_lincomb, dim3((unsigned)((n + 255) / 256), (unsigned)groups), dim3(256), 0, stream, (const uint32_t* const*)d_ptrs, (const uint32_t*)d_int,
                      (uint32_t)count, n, groups > 1 ? partial : d_out);

@@ -491,8 +491,26 @@ size_t row_vm_multi_workspace_bytes(const zkhip_vm_program* progs, uint32_t n_pr
   return total + align256(((size_t)1 << POW_LO_BITS) * 32) + align256(((rows >> POW_LO_BITS) + 1) * 32);
 }
 
+// the pinned buffer of `staging` whose turn it is, at least `bytes` long and zeroed (waits for the copy that last read it); nullptr = failure
+static unsigned char* vm_staging_acquire(vm_staging* staging, size_t bytes, int* slot_out) {
+  const int slot = staging->turn;
+  staging->turn ^= 1;
+  if (staging->copied[slot]) { if (hipEventSynchronize(staging->copied[slot]) != hipSuccess) { set_error("eval_rows: event wait failed"); return nullptr; } }
+  else if (hipEventCreateWithFlags(&staging->copied[slot], hipEventDisableTiming) != hipSuccess) { set_error("eval_rows: hipEventCreate failed"); return nullptr; }
+  if (staging->cap[slot] < bytes) {
+    if (staging->host[slot]) (void)hipHostFree(staging->host[slot]);
+    staging->host[slot] = nullptr; staging->cap[slot] = 0;
+    const size_t want = align256(bytes + bytes / 2 + 4096);
+    if (hipHostMalloc(&staging->host[slot], want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); set_error("eval_rows: hipHostMalloc(%zu) failed", want); return nullptr; }
+    staging->cap[slot] = want;
+  }
+  std::memset(staging->host[slot], 0, bytes);
+  *slot_out = slot;
+  return (unsigned char*)staging->host[slot];
+}
+
 int row_vm_device_multi(const zkhip_vm_program* progs, uint32_t n_progs, const void* const* d_columns, uint32_t n_columns, uint32_t log_rows, uint32_t* const* d_outs,
-                        void* ws, size_t ws_bytes, hipStream_t stream) {
+                        void* ws, size_t ws_bytes, hipStream_t stream, vm_staging* staging) {
   const uint64_t rows = (uint64_t)1 << log_rows;
   if (n_progs == 0 || n_progs > 65535) { set_error("eval_rows: %u programs in one launch", n_progs); return ZKHIP_EINVAL; }
   if (ws_bytes < row_vm_multi_workspace_bytes(progs, n_progs, n_columns, log_rows)) { set_error("eval_rows: workspace too small"); return ZKHIP_EINVAL; }
@@ -518,7 +536,17 @@ int row_vm_device_multi(const zkhip_vm_program* progs, uint32_t n_progs, const v
     off += o_rot[i] + align256((size_t)progs[i].n_rotations * 4 + 4);
   }
   const size_t o_lo = off, o_hi = o_lo + align256(((size_t)1 << POW_LO_BITS) * 32);
-  std::vector<unsigned char> blob(o_lo, 0);
+  // the blob: pinned staging of the caller's scratch set (no wait for the stream), or a local vector (then the stream is synchronised below)
+  std::vector<unsigned char> local;
+  int slot = -1;
+  struct { unsigned char* p; unsigned char* data() const { return p; } } blob{nullptr};
+  if (staging) {
+    blob.p = vm_staging_acquire(staging, o_lo, &slot);
+    if (!blob.p) return ZKHIP_EHIP;
+  } else {
+    local.assign(o_lo, 0);
+    blob.p = local.data();
+  }
   char* d = (char*)ws;
   for (uint32_t i = 0; i < n_columns; i++) std::memcpy(blob.data() + o_cols + (size_t)i * 8, &d_columns[i], 8);
   if (omega) std::memcpy(blob.data() + o_omega, omega, 32);
@@ -533,7 +561,8 @@ int row_vm_device_multi(const zkhip_vm_program* progs, uint32_t n_progs, const v
     parts[i].result_reg = progs[i].result_reg;
   }
   HIPCHK(hipMemcpyAsync(d, blob.data(), o_lo, hipMemcpyHostToDevice, stream));
-  HIPCHK(hipStreamSynchronize(stream));                      // the blob is a local
+  if (staging) HIPCHK(hipEventRecord(staging->copied[slot], stream));
+  else HIPCHK(hipStreamSynchronize(stream));                 // the blob is a local
   vm_launch L;
   L.prog = parts[0].prog; L.n_insns = parts[0].n_insns; L.result_reg = parts[0].result_reg;
   L.cols = (const uint32_t* const*)(d + o_cols);

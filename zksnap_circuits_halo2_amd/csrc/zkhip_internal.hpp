@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstddef>
 #include <cstdint>
+#include <cstring>
 #include "../../include/zkhip.h"
 
 namespace zkhip {
@@ -92,22 +93,60 @@ int fr_mul_periodic_device(uint32_t* d_a, size_t n, const uint32_t* d_table_ext,
 int fr_scale_device(uint32_t* d_a, size_t n, const uint32_t scale_ext[8], hipStream_t stream);
 void ntt_clear_cache();
 
+// Small host arrays of a `_device` call (lists of column addresses, coefficients) on their way to device memory WITHOUT waiting for the stream:
+// copied into a pinned slot first (the caller's memory is free when the call returns), then from there with hipMemcpyAsync.  Eight slots used in
+// turn, an event per slot: the host runs up to eight uploads ahead of the stream before it has to wait for the oldest.  Owned by the caller's
+// scratch set.  Anything larger than a slot -- or a null ring -- takes the plain path: copy from the caller's memory and synchronise the stream.
+struct arg_ring {
+  static constexpr int SLOTS = 8;
+  static constexpr size_t SLOT_BYTES = 32768;
+  void* host = nullptr;
+  hipEvent_t ev[SLOTS] = {};
+  bool used[SLOTS] = {};
+  int turn = 0;
+  int upload(void* dst, const void* src, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return ZKHIP_OK;
+    if (bytes > SLOT_BYTES) return plain(dst, src, bytes, stream);
+    if (!host && hipHostMalloc(&host, SLOTS * SLOT_BYTES, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); host = nullptr; return plain(dst, src, bytes, stream); }
+    const int s = turn;
+    turn = (turn + 1) % SLOTS;
+    if (!ev[s] && hipEventCreateWithFlags(&ev[s], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ev[s] = nullptr; return plain(dst, src, bytes, stream); }
+    if (used[s] && hipEventSynchronize(ev[s]) != hipSuccess) { set_error("arg_ring: event wait failed"); return ZKHIP_EHIP; }
+    void* slot = (char*)host + (size_t)s * SLOT_BYTES;
+    std::memcpy(slot, src, bytes);
+    if (hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, stream) != hipSuccess || hipEventRecord(ev[s], stream) != hipSuccess) { set_error("arg_ring: copy failed"); return ZKHIP_EHIP; }
+    used[s] = true;
+    return ZKHIP_OK;
+  }
+  static int plain(void* dst, const void* src, size_t bytes, hipStream_t stream) {
+    if (hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) { set_error("upload of call arguments failed"); return ZKHIP_EHIP; }
+    return ZKHIP_OK;
+  }
+  void release() {
+    for (int i = 0; i < SLOTS; i++) if (ev[i]) { if (used[i]) (void)hipEventSynchronize(ev[i]); (void)hipEventDestroy(ev[i]); ev[i] = nullptr; used[i] = false; }
+    if (host) { (void)hipHostFree(host); host = nullptr; }
+  }
+};
+static inline int upload_args(arg_ring* ring, void* dst, const void* src, size_t bytes, hipStream_t stream) {
+  return ring ? ring->upload(dst, src, bytes, stream) : arg_ring::plain(dst, src, bytes, stream);
+}
+
 // poly.hip
 size_t poly_workspace_bytes(size_t n);
 int fr_eval_polynomial_device(const uint32_t* d_a, size_t n, const uint32_t x_host[8], uint32_t* d_result, void* ws, size_t ws_bytes, hipStream_t stream);
 size_t poly_batch_workspace_bytes(size_t n, size_t count);
 int fr_eval_polynomial_batch_device(const void* const* d_polys_host, size_t count, size_t n, const uint32_t x_host[8], uint32_t* d_results,
-                                    void* ws, size_t ws_bytes, hipStream_t stream);
+                                    void* ws, size_t ws_bytes, hipStream_t stream, arg_ring* ring = nullptr);
 int fr_kate_division_device(const uint32_t* d_a, size_t n, const uint32_t b_host[8], uint32_t* d_q, void* ws, size_t ws_bytes, hipStream_t stream);
 int fr_prefix_product_device(const uint32_t* d_v, size_t n, uint32_t* d_out, void* ws, size_t ws_bytes, hipStream_t stream);
 int fr_batch_invert_device(uint32_t* d_a, size_t n, void* ws, size_t ws_bytes, hipStream_t stream);
 size_t lincomb_workspace_bytes(size_t count, size_t n);
 int fr_linear_combination_device(const void* const* d_cols_host, const uint32_t* coeffs_host, size_t count, size_t n, uint32_t* d_out, void* ws, size_t ws_bytes,
-                                 hipStream_t stream);
+                                 hipStream_t stream, arg_ring* ring = nullptr);
 size_t perm_workspace_bytes(uint32_t nperm, uint32_t chunk, uint32_t log_n);
 int fr_permutation_products_device(const void* const* d_values_host, const void* const* d_sigmas_host, uint32_t nperm, uint32_t chunk, uint32_t log_n,
                                    size_t usable, const uint32_t beta[8], const uint32_t gamma[8], const uint32_t delta[8], const uint32_t omega[8],
-                                   uint32_t* d_z, void* ws, size_t ws_bytes, hipStream_t stream);
+                                   uint32_t* d_z, void* ws, size_t ws_bytes, hipStream_t stream, arg_ring* ring = nullptr);
 
 // rowvm.hip
 int row_vm_validate(const zkhip_vm_program* p, uint32_t n_columns, uint32_t log_rows, int accumulate);
@@ -124,7 +163,7 @@ struct vm_staging {
 };
 size_t row_vm_multi_workspace_bytes(const zkhip_vm_program* progs, uint32_t n_progs, uint32_t n_columns, uint32_t log_rows);
 int row_vm_device_multi(const zkhip_vm_program* progs, uint32_t n_progs, const void* const* d_columns, uint32_t n_columns, uint32_t log_rows, uint32_t* const* d_outs,
-                        void* ws, size_t ws_bytes, hipStream_t stream);
+                        void* ws, size_t ws_bytes, hipStream_t stream, vm_staging* staging = nullptr);
 // rowvm_jit.hip: row programs compiled at run time with hiprtc (straight-line code per program shape, cached per device); row_vm_device
 // tries it first for short programs over many rows and runs the interpreter otherwise
 bool row_vm_jit_wanted(const zkhip_vm_program* p, uint32_t n_columns, uint32_t log_rows);
