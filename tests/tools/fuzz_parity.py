@@ -290,7 +290,54 @@ def fuzz_perm(seed):
     _lib.check(lib.zkhip_permutation_products(vp, sp, nperm, chunk, k, usable, *[c.ctypes.data for c in consts], z.ctypes.data))
     assert F.fr_decode(z) == exp, f"permutation products k={k} columns={nperm} chunk={chunk} usable={usable}"
 
-fns = [fuzz_msm, fuzz_host_chunked] if LARGE else [fuzz_msm, fuzz_ntt, fuzz_poly, fuzz_rows, fuzz_lookup, fuzz_batched, fuzz_sharded, fuzz_g2, fuzz_perm]
+def fuzz_lincomb(seed):
+    """zkhip_fr_linear_combination_device (one group, several groups, more than 64 groups) against big integers; the output may be a column"""
+    log_n = rng.randint(0, 9); n = 1 << log_n
+    count = rng.choice([rng.randint(0, 3), rng.randint(4, 70), rng.randint(70, 2200)])
+    base = [[rng.randrange(R) if rng.random() < 0.9 else rng.choice([0, 1, R - 1]) for _ in range(n)] for _ in range(min(max(count, 1), 12))]
+    pick = [rng.randrange(len(base)) for _ in range(count)]
+    coeffs = [rng.choice([0, 1, R - 1, rng.randrange(R)]) for _ in range(count)]
+    d_base = [torch.from_numpy(F.fr_encode(c).view(np.int64)).cuda() for c in base]
+    alias = count > 0 and rng.random() < 0.3
+    out = d_base[pick[0]] if alias else torch.full((n, 4), -1, dtype=torch.int64, device="cuda")
+    ptrs = (C.c_void_p * max(count, 1))(*[d_base[j].data_ptr() for j in pick])
+    cw = F.fr_encode(coeffs) if count else np.zeros((1, 4), dtype=np.uint64)
+    _lib.check(lib.zkhip_fr_linear_combination_device(ptrs, cw.ctypes.data, count, n, out.data_ptr(), None))
+    torch.cuda.synchronize()
+    exp = [sum(c * base[j][i] for c, j in zip(coeffs, pick)) % R for i in range(n)]
+    assert F.fr_decode(out.cpu().numpy().view(np.uint64)) == exp, f"linear combination n={n} count={count} alias={alias}"
+
+def fuzz_rows_sum(seed):
+    """zkhip_fr_eval_rows_sum_device: sum_p w_p program_p(row) for 1 .. 6 random programs over shared columns against the oracle's interpreter"""
+    log_rows = rng.randint(0, 7); rows = 1 << log_rows; n_cols = rng.randint(1, 4)
+    cols = [[rng.randrange(R) for _ in range(rows)] for _ in range(n_cols)]
+    omega = O.omega_for(log_rows) if rng.random() < 0.5 else None
+    progs, exp = [], [0] * rows
+    weights = [rng.choice([0, 1, R - 1, rng.randrange(R)]) for _ in range(rng.randint(1, 6))]
+    for wgt in weights:
+        p = E.RowProgram(rot_scale=rng.choice([1, 2]), omega=omega)
+        written = []
+        def operand():
+            kinds = ["const", "col"] + (["reg"] if written else []) + (["rowpow"] if omega else [])
+            k = rng.choice(kinds)
+            if k == "const": return p.constant(rng.choice([0, 1, R - 1, rng.randrange(R)]))
+            if k == "col": return p.column(rng.randrange(n_cols), rng.choice([0, 1, -1, 3]))
+            return E.RowProgram.reg(rng.choice(written)) if k == "reg" else E.RowProgram.ROWPOW
+        n_regs = rng.choice([6, 8, 12, 16])
+        for _ in range(rng.randint(1, 40)):
+            dst = rng.randrange(n_regs); p.emit(rng.randrange(8), dst, operand(), operand(), operand())
+            if dst not in written: written.append(dst)
+        p.result_reg = rng.choice(written)
+        progs.append(p)
+        val = O.row_program_run(p.insns, p.constants, p.rotations, p.rot_scale, p.result_reg, cols + [cols[0]] * 8, log_rows, omega=omega)
+        exp = [(e + wgt * v) % R for e, v in zip(exp, val)]
+    d_cols = [torch.from_numpy(F.fr_encode(c).view(np.int64)).cuda() for c in cols]
+    out = torch.full((rows, 4), -1, dtype=torch.int64, device="cuda")
+    E.run_programs_sum_device(progs, weights, [t.data_ptr() for t in d_cols], log_rows, out.data_ptr())
+    torch.cuda.synchronize()
+    assert F.fr_decode(out.cpu().numpy().view(np.uint64)) == exp, f"sum of row programs rows={rows} programs={len(progs)}"
+
+fns = [fuzz_msm, fuzz_host_chunked] if LARGE else [fuzz_msm, fuzz_ntt, fuzz_poly, fuzz_rows, fuzz_lookup, fuzz_batched, fuzz_sharded, fuzz_g2, fuzz_perm, fuzz_lincomb, fuzz_rows_sum]
 t_end = time.time() + budget
 it = 0
 while time.time() < t_end:

@@ -59,20 +59,6 @@ __global__ void __launch_bounds__(256) k_horner_apply(const uint32_t* __restrict
   }
 }
 
-// b^CH for the next recursion level (single thread)
-__global__ void k_pow_const(const fe_arg* __restrict__ b_dev, uint32_t e, uint32_t* __restrict__ out_ext) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const fe_arg b_ext = *b_dev;
-  fe r = fr_pow_u32(fr_const_internal(b_ext), e);             // b^e * 2^261
-  fe k;
-#pragma unroll
-  for (int i = 0; i < NL; i++) k.l[i] = Fr::TO_EXT[i];
-  uint32_t w[8];
-  fe_pack(fe_canon_lt2p<Fr>(fe_mul<Fr>(k, r)), w);             // b^e * 2^256
-#pragma unroll
-  for (int i = 0; i < 8; i++) out_ext[i] = w[i];
-}
-
 // batched form of pass A for many polynomials of one length evaluated at one point (multiopen: every advice / fixed / permutation
 // polynomial at x): blockIdx.y = polynomial; level 0 reads through a pointer table, deeper levels a dense [count][n] array.
 // The last level (n <= CH) is the evaluation itself.
@@ -201,12 +187,11 @@ static int horner_scan(const uint32_t* d_a, size_t n, const fe_arg* b, uint32_t*
   const size_t m = chunks_of(n);
   uint32_t* agg = (uint32_t*)ws;
   char* next_ws = ws + ((m * 32 + 255) / 256) * 256;
-  fe_arg* bpow = (fe_arg*)next_ws;
-  next_ws += 256;
   hipLaunchKernelGGL(k_horner_agg, grid_for(m, 256), dim3(256), 0, stream, d_a, n, b, agg);
-  hipLaunchKernelGGL(k_pow_const, dim3(1), dim3(64), 0, stream, b, POLY_CH, (uint32_t*)bpow);
-  // recursion: scan the aggregates in place with multiplier b^CH; its value at index 0 is the overall result
-  int rc = horner_scan(agg, m, bpow, d_out ? agg : nullptr, 0, d_result, next_ws, stream);
+  // recursion: scan the aggregates in place with multiplier b^CH -- the next entry of the power array the caller parked (stage_const: b,
+  // b^CH, b^(CH^2), ... computed by ONE thread up front; a launch per level for one power each cost 11 us apiece in the dependent chain);
+  // the scan's value at index 0 is the overall result
+  int rc = horner_scan(agg, m, b + 1, d_out ? agg : nullptr, 0, d_result, next_ws, stream);
   if (rc != ZKHIP_OK) return rc;
   if (d_out) hipLaunchKernelGGL(k_horner_apply, grid_for(m, 256), dim3(256), 0, stream, d_a, n, b, (const uint32_t*)agg, m, d_out, out_shift);
   HIPCHK(hipGetLastError());
@@ -215,21 +200,43 @@ static int horner_scan(const uint32_t* d_a, size_t n, const fe_arg* b, uint32_t*
 
 // a constant that arrives from the host travels as a kernel argument (by value: the caller's memory is free when the launch returns, and
 // nothing waits for the stream -- a copy from the caller's memory would need a synchronisation) and is parked in device memory by one thread
-__global__ void k_store_const(fe_arg v, fe_arg* __restrict__ out) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) *out = v;
+// out[0] = v, out[l] = out[l - 1]^CH for l <= levels: the multipliers of every recursion level of a scan
+constexpr uint32_t POW_LEVELS = 7;        // 16^7 = 2^28 elements; 8 constants = the 256 bytes the scans reserve
+__global__ void k_store_const(fe_arg v, fe_arg* __restrict__ out, uint32_t levels) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  out[0] = v;
+  if (levels == 0) return;
+  fe r = fr_const_internal(v);
+  fe k;
+#pragma unroll
+  for (int i = 0; i < NL; i++) k.l[i] = Fr::TO_EXT[i];
+#pragma unroll 1
+  for (uint32_t l = 1; l <= levels; l++) {
+    r = fr_pow_u32(r, POLY_CH);                                 // (reduced: fr_pow_u32's products are < 2p)
+    uint32_t w[8];
+    fe_pack(fe_canon_lt2p<Fr>(fe_mul<Fr>(k, r)), w);
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[l].w[i] = w[i];
+  }
 }
-static int store_const(const uint32_t host[8], fe_arg* d, hipStream_t stream) {
+static int store_const(const uint32_t host[8], fe_arg* d, hipStream_t stream, uint32_t levels = 0) {
   fe_arg v;
   memcpy(v.w, host, 32);
-  hipLaunchKernelGGL(k_store_const, dim3(1), dim3(64), 0, stream, v, d);
+  hipLaunchKernelGGL(k_store_const, dim3(1), dim3(64), 0, stream, v, d, levels);
   HIPCHK(hipGetLastError());
   return ZKHIP_OK;
 }
-// the multiplier of a scan: parked in the last 256 bytes of the workspace
-static int stage_const(const uint32_t host[8], char* ws, size_t ws_bytes, hipStream_t stream, fe_arg** out) {
+// recursion levels below the top one of a scan over n elements (= how many powers of the multiplier it needs)
+static uint32_t scan_levels(size_t n) {
+  uint32_t levels = 0;
+  while (n > POLY_CH) { n = (n + POLY_CH - 1) / POLY_CH; levels++; }
+  return levels < POW_LEVELS ? levels : POW_LEVELS;
+}
+// the multiplier of a scan over n elements and its powers: parked in the last 256 bytes of the workspace
+static int stage_const(const uint32_t host[8], size_t n, char* ws, size_t ws_bytes, hipStream_t stream, fe_arg** out) {
   fe_arg* d = (fe_arg*)(ws + ws_bytes - 256);
   *out = d;
-  return store_const(host, d, stream);
+  return store_const(host, d, stream, scan_levels(n));
 }
 
 // eval_polynomial: result (8 words, device) = sum a[i] x^i
@@ -238,7 +245,7 @@ int fr_eval_polynomial_device(const uint32_t* d_a, size_t n, const uint32_t x_ho
   if (n == 0) { HIPCHK(hipMemsetAsync(d_result, 0, 32, stream)); return ZKHIP_OK; }
   if (ws_bytes < poly_workspace_bytes(n)) { set_error("eval_polynomial: workspace too small"); return ZKHIP_EINVAL; }
   fe_arg* b = nullptr;
-  int rc = stage_const(x_host, (char*)ws, ws_bytes, stream, &b);
+  int rc = stage_const(x_host, n, (char*)ws, ws_bytes, stream, &b);
   if (rc != ZKHIP_OK) return rc;
   return horner_scan(d_a, n, b, nullptr, 0, d_result, (char*)ws, stream);
 }
@@ -263,7 +270,7 @@ int fr_eval_polynomial_batch_device(const void* const* d_polys_host, size_t coun
   fe_arg* b = (fe_arg*)p;
   p += 256;
   int rc = upload_args(ring, d_ptrs, d_polys_host, count * 8, stream);        // caller memory: through the pinned ring, no wait for the stream
-  if (rc == ZKHIP_OK) rc = store_const(x_host, b, stream);
+  if (rc == ZKHIP_OK) rc = store_const(x_host, b, stream, scan_levels(n));   // b, b^CH, b^(CH^2), ...: the multiplier of every level, one thread, once
   if (rc != ZKHIP_OK) return rc;
   const uint32_t* cur = nullptr;                            // level 0 reads through d_ptrs
   size_t cur_n = n;
@@ -273,11 +280,8 @@ int fr_eval_polynomial_batch_device(const void* const* d_polys_host, size_t coun
     hipLaunchKernelGGL(k_horner_agg_batch, dim3((unsigned)((m + 255) / 256), (unsigned)count), dim3(256), 0, stream,
                        cur ? (const uint32_t* const*)nullptr : (const uint32_t* const*)d_ptrs, cur, cur_n, (const fe_arg*)b, agg, m);
     if (m == 1) break;
-    p += ((count * m * 32 + 255) / 256) * 256;
-    fe_arg* bpow = (fe_arg*)p;
-    p += 256;
-    hipLaunchKernelGGL(k_pow_const, dim3(1), dim3(64), 0, stream, (const fe_arg*)b, POLY_CH, (uint32_t*)bpow);
-    b = bpow;
+    p += ((count * m * 32 + 255) / 256) * 256 + 256;
+    b = b + 1;
     cur = agg;
     cur_n = m;
   }
@@ -291,7 +295,7 @@ int fr_kate_division_device(const uint32_t* d_a, size_t n, const uint32_t b_host
   if (n < 2) return ZKHIP_OK;
   if (ws_bytes < poly_workspace_bytes(n)) { set_error("kate_division: workspace too small"); return ZKHIP_EINVAL; }
   fe_arg* b = nullptr;
-  int rc = stage_const(b_host, (char*)ws, ws_bytes, stream, &b);
+  int rc = stage_const(b_host, n, (char*)ws, ws_bytes, stream, &b);
   if (rc != ZKHIP_OK) return rc;
   // the suffix Horner scan of a at index i+1 is q[i]: scan everything, drop index 0
   return horner_scan(d_a, n, b, d_q, 1, nullptr, (char*)ws, stream);
