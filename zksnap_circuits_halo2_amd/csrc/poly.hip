@@ -38,7 +38,18 @@ __global__ void __launch_bounds__(256) k_horner_agg(const uint32_t* __restrict__
   const size_t hi = lo + POLY_CH < n ? lo + POLY_CH : n;
   const fe b = fr_const_internal(b_ext);
   fe q = fe_zero();
-  for (size_t i = hi; i-- > lo;) q = fe_norm(fe_add(load_ext(a, i), fe_mul<Fr>(b, q)));   // < 3p, N
+  size_t i = hi;
+  // full blocks of four elements = one 128-byte line per lane: the eight loads of a block are issued together and the line is consumed at
+  // once (element by element the same line was touched in four separate iterations, 64 lanes x 64 lines apart, and had to survive in L1)
+  for (; i >= lo + 4 && ((i & 3) == 0); i -= 4) {
+    uint32_t w0[8], w1[8], w2[8], w3[8];
+    load_words(a + (i - 1) * 8, w3); load_words(a + (i - 2) * 8, w2); load_words(a + (i - 3) * 8, w1); load_words(a + (i - 4) * 8, w0);
+    q = fe_norm(fe_add(fe_unpack<0>(w3), fe_mul<Fr>(b, q)));
+    q = fe_norm(fe_add(fe_unpack<0>(w2), fe_mul<Fr>(b, q)));
+    q = fe_norm(fe_add(fe_unpack<0>(w1), fe_mul<Fr>(b, q)));
+    q = fe_norm(fe_add(fe_unpack<0>(w0), fe_mul<Fr>(b, q)));
+  }
+  for (; i-- > lo;) q = fe_norm(fe_add(load_ext(a, i), fe_mul<Fr>(b, q)));   // < 3p, N
   store_canon(agg, t, q);
 }
 
@@ -53,9 +64,20 @@ __global__ void __launch_bounds__(256) k_horner_apply(const uint32_t* __restrict
   const size_t hi = lo + POLY_CH < n ? lo + POLY_CH : n;
   const fe b = fr_const_internal(b_ext);
   fe q = (carry != nullptr && t + 1 < ncarry) ? load_ext(carry, t + 1) : fe_zero();
-  for (size_t i = hi; i-- > lo;) {
+  size_t i = hi;
+  for (; i >= lo + 4 && ((i & 3) == 0); i -= 4) {               // four elements = one 128-byte line per lane, loaded together (see k_horner_agg)
+    uint32_t w[4][8];
+#pragma unroll
+    for (int e = 0; e < 4; e++) load_words(a + (i - 4 + e) * 8, w[e]);
+#pragma unroll
+    for (int e = 3; e >= 0; e--) {
+      q = fe_norm(fe_add(fe_unpack<0>(w[e]), fe_mul<Fr>(b, q)));
+      if (i - 4 + e >= out_shift) store_canon(out, i - 4 + e - out_shift, q);     // kate_division drops the scan value at index 0
+    }
+  }
+  for (; i-- > lo;) {
     q = fe_norm(fe_add(load_ext(a, i), fe_mul<Fr>(b, q)));
-    if (i >= out_shift) store_canon(out, i - out_shift, q);     // kate_division drops the scan value at index 0
+    if (i >= out_shift) store_canon(out, i - out_shift, q);
   }
 }
 
@@ -72,7 +94,15 @@ __global__ void __launch_bounds__(256) k_horner_agg_batch(const uint32_t* const*
   const fe_arg b_ext = *b_dev;
   const fe b = fr_const_internal(b_ext);
   fe q = fe_zero();
-  for (size_t i = hi; i-- > lo;) q = fe_norm(fe_add(load_ext(a, i), fe_mul<Fr>(b, q)));
+  size_t i = hi;
+  for (; i >= lo + 4 && ((i & 3) == 0); i -= 4) {               // four elements = one 128-byte line per lane, loaded together (see k_horner_agg)
+    uint32_t w[4][8];
+#pragma unroll
+    for (int e = 0; e < 4; e++) load_words(a + (i - 4 + e) * 8, w[e]);
+#pragma unroll
+    for (int e = 3; e >= 0; e--) q = fe_norm(fe_add(fe_unpack<0>(w[e]), fe_mul<Fr>(b, q)));
+  }
+  for (; i-- > lo;) q = fe_norm(fe_add(load_ext(a, i), fe_mul<Fr>(b, q)));
   store_canon(agg + (size_t)blockIdx.y * m * 8, t, q);
 }
 
@@ -85,9 +115,21 @@ __global__ void __launch_bounds__(256) k_prod_agg(const uint32_t* __restrict__ v
   uint32_t w[8];
   load_words(v + lo * 8, w);
   fe acc = fe_unpack<0>(w);                                   // x * 2^256 (external domain)
-  for (size_t i = lo + 1; i < hi; i++) {
+  size_t i = lo + 1;
+  for (; i < hi && (i & 3) != 0; i++) {                       // up to the next 128-byte line
     load_words(v + i * 8, w);
     acc = fe_mul<Fr>(acc, fe_from_ext_lazy(w));               // ext-domain value times internal-form factor stays in the ext domain
+  }
+  for (; i + 4 <= hi; i += 4) {                               // four elements = one line per lane, loaded together (see k_horner_agg)
+    uint32_t ww[4][8];
+#pragma unroll
+    for (int e = 0; e < 4; e++) load_words(v + (i + e) * 8, ww[e]);
+#pragma unroll
+    for (int e = 0; e < 4; e++) acc = fe_mul<Fr>(acc, fe_from_ext_lazy(ww[e]));
+  }
+  for (; i < hi; i++) {
+    load_words(v + i * 8, w);
+    acc = fe_mul<Fr>(acc, fe_from_ext_lazy(w));
   }
   store_canon(agg, t, acc);
 }
@@ -106,7 +148,18 @@ __global__ void __launch_bounds__(256) k_prod_apply(const uint32_t* __restrict__
     for (int i = 0; i < NL; i++) cur.l[i] = Fr::TO_EXT[i];
   }
   uint32_t w[8];
-  for (size_t i = lo; i < hi; i++) {
+  size_t i = lo;
+  for (; i + 4 <= hi && (i & 3) == 0; i += 4) {               // four elements = one line per lane, loaded together (see k_horner_agg); all four
+    uint32_t ww[4][8];                                        // are read before any of them is stored: v and out may alias
+#pragma unroll
+    for (int e = 0; e < 4; e++) load_words(v + (i + e) * 8, ww[e]);
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      store_canon(out, i + e, cur);
+      cur = fe_mul<Fr>(cur, fe_from_ext_lazy(ww[e]));
+    }
+  }
+  for (; i < hi; i++) {
     load_words(v + i * 8, w);                                 // read before the store: v and out may alias
     const fe f = fe_from_ext_lazy(w);
     store_canon(out, i, cur);
