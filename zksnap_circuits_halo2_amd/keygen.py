@@ -452,6 +452,15 @@ def _copy_device(dst: int, src: int, log_rows: int) -> None:
     prog.run_device([src], log_rows, dst)
 
 
+def _copy_device_range(dst: int, src: int, elements: int) -> None:
+    """`elements` field elements, device to device, as power-of-two pieces (largest first): one launch per set bit instead of one per column"""
+    off = 0
+    for bit in range(elements.bit_length() - 1, -1, -1):
+        if elements >> bit & 1:
+            _copy_device(dst + off * 32, src + off * 32, bit)
+            off += 1 << bit
+
+
 def _sigma_to_device(assembly: Assembly, k: int, d_out: int) -> None:
     """the sigma columns (Lagrange basis) written to d_out, column after column: omega^row from a row program, then one gather-multiply
     per column (`zkhip_fr_gather_mul_device`); the mapping travels as 2 x 4 bytes per cell instead of 32"""
@@ -459,30 +468,30 @@ def _sigma_to_device(assembly: Assembly, k: int, d_out: int) -> None:
     n, ncol = 1 << k, assembly.n_columns
     if ncol == 0:
         return
-    with _DeviceBuffer(n * 32) as d_pow, _DeviceBuffer(ncol * 32) as d_delta, _DeviceBuffer(2 * n * 4) as d_idx:
+    with _DeviceBuffer(n * 32) as d_pow, _DeviceBuffer(ncol * 32) as d_delta, _DeviceBuffer(2 * ncol * n * 4) as d_idx:
         powers = E.RowProgram(omega=_omega(k))
         powers.emit(E.OP_MOV, 0, E.RowProgram.ROWPOW)
         powers.run_device([], k, d_pow.ptr.value)
         d_delta.upload(fr_encode([pow(E.DELTA, c, R_MOD) for c in range(ncol)]))
+        # the whole mapping in two uploads ([column][row] u32 each), then one gather-multiply per column
+        d_idx.upload(np.ascontiguousarray(np.stack([np.asarray(assembly.map_row[c], dtype=np.uint32) for c in range(ncol)])))
+        d_idx.upload(np.ascontiguousarray(np.stack([np.asarray(assembly.map_col[c], dtype=np.uint32) for c in range(ncol)])), ncol * n * 4)
         for c in range(ncol):
-            d_idx.upload(np.ascontiguousarray(assembly.map_row[c], dtype=np.uint32))
-            d_idx.upload(np.ascontiguousarray(assembly.map_col[c], dtype=np.uint32), n * 4)
-            _lib.check(lib.zkhip_fr_gather_mul_device(d_pow.ptr, n, d_idx.ptr, d_delta.ptr, ncol, C.c_void_p(d_idx.ptr.value + n * 4), n,
-                                                      C.c_void_p(d_out + c * n * 32), None))
-        _lib.check(lib.zkhip_sync())                      # the index buffer is reused per column and freed on return
+            _lib.check(lib.zkhip_fr_gather_mul_device(d_pow.ptr, n, C.c_void_p(d_idx.ptr.value + c * n * 4), d_delta.ptr, ncol,
+                                                      C.c_void_p(d_idx.ptr.value + (ncol + c) * n * 4), n, C.c_void_p(d_out + c * n * 32), None))
+        _lib.check(lib.zkhip_sync())                      # the buffers are freed on return
 
 
 def _commit_lagrange_device(params, d_columns: int, count: int) -> np.ndarray:
     """commit_lagrange of `count` device-resident columns (n elements each, back to back) -> affine points: MSMs against the registered
-    g_lagrange (`zkhip_msm_g1_registered_device`), normalised together"""
+    g_lagrange (`zkhip_msm_g1_registered_batch_device`), normalised together"""
     lib = _lib.load()
     if count == 0:
         return np.zeros((0, 8), dtype=np.uint64)
     n = 1 << params.k
     with _DeviceBuffer(count * (96 + 64)) as d_out:
-        for i in range(count):
-            _lib.check(lib.zkhip_msm_g1_registered_device(params.g_lagrange.ctypes.data, C.c_void_p(d_columns + i * n * 32), n,
-                                                          C.c_void_p(d_out.ptr.value + i * 96), None))
+        # the columns lie back to back: ONE batched call (a launch set for all of them when they are small, overlapped pairs when they are large)
+        _lib.check(lib.zkhip_msm_g1_registered_batch_device(params.g_lagrange.ctypes.data, C.c_void_p(d_columns), n, count, n, d_out.ptr, None))
         _lib.check(lib.zkhip_g1_batch_normalize_device(d_out.ptr, count, C.c_void_p(d_out.ptr.value + count * 96), None))
         return d_out.download((count, 8), count * 96)
 
@@ -509,8 +518,7 @@ def keygen_device(params, cs: E.ConstraintSystem, fixed: Sequence[np.ndarray], a
         commits = _commit_lagrange_device(params, pk.fixed_values(0), cols)
         pk.vk.fixed_commitments, pk.vk.permutation_commitments = commits[:nf], commits[nf:]
         # values -> coefficients (copy, then the batched inverse transform in place) -> extended cosets
-        for i in range(cols):
-            _copy_device(pk._b(cols + i), pk._b(i), k)
+        _copy_device_range(pk._b(cols), pk._b(0), cols * n)
         if cols:
             _lib.check(lib.zkhip_ifft_scaled_batch_device(C.c_void_p(pk._b(cols)), dom.omega_inv.ctypes.data, k, dom.ifft_divisor.ctypes.data, cols, n, None))
             _lib.check(lib.zkhip_coeff_to_extended_device(C.c_void_p(pk._b(cols)), n, k, C.c_void_p(pk._e(3)), en, dom.extended_k, cols, dom.extended_omega.ctypes.data,
