@@ -265,7 +265,9 @@ __global__ void k_store_const(fe_arg v, fe_arg* __restrict__ out, uint32_t level
   for (int i = 0; i < NL; i++) k.l[i] = Fr::TO_EXT[i];
 #pragma unroll 1
   for (uint32_t l = 1; l <= levels; l++) {
-    r = fr_pow_u32(r, POLY_CH);                                 // (reduced: fr_pow_u32's products are < 2p)
+    static_assert(POLY_CH == 16, "b^CH below is four squarings");
+#pragma unroll
+    for (int q = 0; q < 4; q++) r = fe_sqr<Fr>(r);              // b^16 (products of values < 2p stay < 2p)
     uint32_t w[8];
     fe_pack(fe_canon_lt2p<Fr>(fe_mul<Fr>(k, r)), w);
 #pragma unroll
