@@ -10,7 +10,7 @@ TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-BENCH_MSM="python3 $R/bench.py --steps 10 --warmup 2 --no-extras --no-cpu-baseline --no-general-path"
+BENCH_MSM="python3 $R/bench.py --steps 50 --warmup 5 --no-extras --no-cpu-baseline --no-general-path"     # the bench line's own steps / warm-up
 BENCH_PMC="python3 $R/bench.py --steps 3 --warmup 1 --no-extras --no-cpu-baseline --no-general-path"
 S="python3 $R/tools/summarize_prof.py"
 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof_msm -- $BENCH_MSM > $O/${TAG}_prof_msm.log 2>&1
