@@ -85,6 +85,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the NTT / wrapper-replay extras")
     ap.add_argument("--no-general-path", action="store_true", help="skip the unregistered-bases MSM (rocprofv3 runs: keeps per-kernel averages to the headline path)")
+    ap.add_argument("--c-abi-config4", type=int, default=0, metavar="NDEV",
+                    help="internal: run ONLY the single-process C-ABI leg of configs[4] over devices 0 .. NDEV-1 and print its dict as one JSON line (the N > 1 "
+                         "run starts this in a child process: the leg drives several cards from one process -- peer access, peer copies -- which has never "
+                         "run on real multi-GPU hardware, and a fault there must not take the bench line with it)")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="CPU rehearsal of the --gpus N launcher: the ranks rendezvous over gloo, time an empty step and rank 0 prints a line that is "
                          "marked as a self-test (no GPU work, no metric)")
@@ -259,6 +263,19 @@ def main() -> None:
     # ---- who starts the ranks ---------------------------------------------------------------------------------------------------------
     # The metric is "Mpoints/sec at 1/2/4/8 MI355X": --gpus N must mean N ranks on N GPUs or no number at all.  Under torchrun (the driver's
     # form for N > 1) WORLD_SIZE is set and must equal --gpus; without it, N > 1 starts the ranks here, before anything touches the GPU.
+    if args.c_abi_config4 > 0:
+        import torch
+
+        from zksnap_circuits_halo2_amd import _lib, fields as F
+
+        torch.cuda.set_device(0)
+        dev0 = torch.device("cuda", 0)
+        try:
+            out = c_abi_config4(_lib.load(), _lib, F, torch, dev0, torch.cuda.current_stream().cuda_stream, devices=list(range(args.c_abi_config4)), shards=args.c_abi_config4)
+        except Exception as exc:
+            out = {"error": repr(exc)}
+        print(json.dumps(out), flush=True)
+        return
     env_world = os.environ.get("WORLD_SIZE")
     if args.gpus < 1:
         fail(f"--gpus {args.gpus}: need at least one GPU")
@@ -566,8 +583,19 @@ def main() -> None:
         torch.cuda.empty_cache()
         dist.barrier(group=cpu_group)
         if rank == 0:
+            # in a CHILD process: one process driving several cards (peer access, peer copies, cross-device events) has only ever run as several
+            # contexts on one card -- a fault there must not take this process, and with it the N-GPU line, down
             try:
-                result["config4_wrapper_k24_msm"]["single_process_c_abi"] = c_abi_config4(lib, _lib, F, torch, dev, stream, devices=list(range(world)), shards=world)
+                import subprocess
+
+                lib.zkhip_shutdown()
+                torch.cuda.empty_cache()
+                env = {k_: v_ for k_, v_ in os.environ.items() if k_ not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
+                                                                             "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+                child = subprocess.run([sys.executable, os.path.abspath(__file__), "--c-abi-config4", str(world)], capture_output=True, text=True, timeout=600, env=env)
+                last = [ln for ln in child.stdout.splitlines() if ln.startswith("{")]
+                result["config4_wrapper_k24_msm"]["single_process_c_abi"] = (json.loads(last[-1]) if child.returncode == 0 and last else
+                                                                             {"error": f"child exited with {child.returncode}: {(child.stdout + child.stderr)[-300:]}"})
             except Exception as exc:   # an extra: never fail the bench line
                 result["config4_wrapper_k24_msm"]["single_process_c_abi"] = {"error": repr(exc)}
         dist.barrier(group=cpu_group)
